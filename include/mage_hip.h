@@ -1,0 +1,206 @@
+/*
+ * mage_hip.h -- C ABI of libmage_hip.so: hand-written HIP (gfx950 / CDNA4) kernels for
+ * the MAGE autoregressive video-token generation path.
+ *
+ * The reference (Youncy-Hu/MAGE) is pure PyTorch: it has NO FFI today.  Each entry
+ * point below replaces the torch-op arithmetic at the cited reference site; the only
+ * caller is the host-side mirror in mage_amd/modules/ (same class names and forward()
+ * signatures as modules/mage_model.py / modules/vqvae_model.py), through ctypes
+ * (mage_amd/_lib.py).  See INTEGRATION.md for the binding a reference maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (a torch tensor kept alive by
+ *     the Python caller for the duration of the asynchronous call);
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     kernels are enqueued on it and the call returns without synchronising;
+ *   - return value: 0 on success, negative MAGE_E* code otherwise; mage_last_error()
+ *     gives a thread-local message.  The ctypes shim maps codes to RuntimeError/ValueError;
+ *   - activations are channels-last: a [.., C] tensor is a row-major [rows, C] matrix;
+ *   - dtype tags: MAGE_F32 = IEEE fp32 (GEMMs run on v_mfma_f32_16x16x4_f32: exact fp32
+ *     fma chains -- the parity mode), MAGE_BF16 = bf16 storage + v_mfma_f32_16x16x32_bf16
+ *     with fp32 accumulation (the performance mode).  The residual stream, LayerNorm
+ *     statistics, softmax, logits and all VQ arithmetic are fp32 in both modes.
+ */
+#ifndef MAGE_HIP_H
+#define MAGE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAGE_ABI_VERSION 1
+
+enum { MAGE_F32 = 0, MAGE_BF16 = 1 };
+enum { MAGE_OK = 0, MAGE_EINVAL = -1, MAGE_EHIP = -2, MAGE_EUNSUPPORTED = -3 };
+enum { MAGE_ACT_NONE = 0, MAGE_ACT_RELU = 1, MAGE_ACT_QUICKGELU = 2, MAGE_ACT_GELU_ERF = 3, MAGE_ACT_TANH = 4 };
+
+int mage_abi_version(void);
+const char* mage_last_error(void);
+/* One-time per-device setup (allocates the 4 KiB zero page the gather loads use for padding).
+ * Must be called once per process+device before any other call, outside stream capture. */
+int mage_init(int device);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused GEMM / implicit-GEMM convolution on MFMA:   Y[yrow(m), n] = epi( sum_k A[arow(m,k), .] * W[n, k] )
+ *
+ * Replaces: every nn.Linear on the path (mage_model.py:22-26,332-335,348,375-376,385; the MHA
+ * in/out projections inside nn.MultiheadAttention :20,:75; text encoder :193-207), the frame
+ * conv3x3 (mage_model.py:485-488,587,648,675) and every Conv2d/ConvTranspose2d with C_in >= 8
+ * of the VQ-VAE (vqvae_model.py:111-214), with BatchNorm(eval), bias, activation, positional
+ * tables and the residual add fused into the epilogue.
+ *
+ * Row geometry.  A GEMM row m in [0, M) is decoded as img = m / (out_h*out_w),
+ * oy = (m / out_w) % out_h, ox = m % out_w.  K = taps_h*taps_w*cin; k -> (ky, kx, ci), ci fastest:
+ *     iy = oy*stride + dy0 + ky*dys,   ix = ox*stride + dx0 + kx*dxs      (zero outside [0,in_h)x[0,in_w))
+ *     arow = img*a_img_stride + iy*in_w + ix + a_off
+ *     yrow = img*y_img_stride + oy*y_mul_y + ox*y_mul_x + y_off
+ * A plain Linear is taps_h=taps_w=1, out_h=in_h=1, out_w=in_w=P: rows are then regrouped P at a
+ * time (x[:, 1:] views, writing frames into slots 1.. of the decoder input) without copies.
+ *
+ * Epilogue, in this order:  v = acc + bias[n];  v = v*scale[n] + shift[n] (BatchNorm eval);
+ * v = act(v);  v += rowadd[((yrow / rowadd_div) % rowadd_mod), n];  v += residual[yrow, n];
+ * v = relu(v) if post_relu;  store as y_dtype.  Null pointers skip a stage.  Y may alias residual.
+ *
+ * Requirements: lda/ldy/ldr and cin multiples of 8 (bf16) / 4 (f32); N multiple of 4; A, W, Y 16-byte
+ * aligned; W is [N][K] row-major in `dtype`.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mage_gemm_desc {
+    int32_t dtype;                     /* MAGE_F32 | MAGE_BF16: type of A and W and of the MFMA */
+    int32_t M, N, K;
+    const void* A;
+    const void* W;
+    void* Y;
+    int32_t lda, ldy;                  /* in elements */
+    int32_t y_dtype;                   /* MAGE_F32 | MAGE_BF16 */
+    int32_t out_h, out_w, in_h, in_w;
+    int32_t a_img_stride, a_off;
+    int32_t taps_h, taps_w, cin, stride;
+    int32_t dy0, dx0, dys, dxs;
+    int32_t y_img_stride, y_mul_y, y_mul_x, y_off;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    int32_t act;
+    const float* rowadd;
+    int32_t rowadd_div, rowadd_mod;
+    const void* residual;
+    int32_t ldr, res_dtype;
+    int32_t post_relu;
+    int32_t reserved;
+} mage_gemm_desc;
+
+int mage_gemm(const mage_gemm_desc* desc, void* stream);
+
+/* LayerNorm over the last dim of fp32 rows; y may be fp32 (may alias x) or bf16.
+ * Replaces nn.LayerNorm at mage_model.py:21,27,84,204,206 and inside nn.TransformerEncoderLayer. */
+int mage_layernorm(const float* x, const float* gamma, const float* beta, void* y, int32_t y_dtype,
+                   int64_t rows, int32_t C, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-head attention core softmax(q k^T * scale + mask) v for SHORT key sets (nk <= 64),
+ * head_dim = 32, fp32 arithmetic, no permute copies: sequences are strided row sets.
+ * Replaces the scaled-dot-product inside nn.MultiheadAttention for the axial blocks
+ * (mage_model.py:31-33,47-52: axis L with the causal mask :367-372, axes H and W), the text
+ * encoder self-attention with key padding (:237-244) and the motion-anchor cross-attention (:87-92).
+ *
+ * Sequence s in [0, n_seq): outer = s / inner, in = s % inner.
+ *   query i  -> row  outer*q_outer_stride  + in + i*q_axis_stride     of q  (and of out)
+ *   key   j  -> row  outer*kv_outer_stride + in + j*kv_axis_stride    of k, v
+ * Head h uses columns [h*32, h*32+32).  causal: key j visible to query i iff j <= i.
+ * kv_len (optional, int32 [ceil(n_seq / kv_len_div)]): only keys j < kv_len[s / kv_len_div] are visible.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mage_attn_desc {
+    int32_t dtype;                     /* element type of q, k, v and out */
+    const void* q;
+    const void* k;
+    const void* v;
+    void* out;
+    int32_t ldq, ldk, ldv, ldo;
+    int32_t n_seq, inner;
+    int32_t nq, nk, n_head;
+    int32_t q_outer_stride, q_axis_stride;
+    int32_t kv_outer_stride, kv_axis_stride;
+    int32_t causal;
+    const int32_t* kv_len;
+    int32_t kv_len_div;
+    float scale;
+} mage_attn_desc;
+
+int mage_attention(const mage_attn_desc* desc, void* stream);
+
+/* out[orow(i), :] = act(table[ids[i], :]),  orow(i) = (i / group)*group_stride + i % group + off.
+ * Replaces nn.Embedding lookups: visual_token_embedding (mage_model.py:581,644,682), the codebook
+ * gather of VectorQuantizedVAE.decode (vqvae_model.py:240; relu=1 folds the in-place ReLU that
+ * opens the first decoder ResBlock :113), text token embedding (:226).  Out-of-range ids -> MAGE_EINVAL
+ * is NOT checked on device; ids are clamped to [0, n_table). */
+int mage_embedding(const int64_t* ids, const float* table, void* out, int32_t out_dtype, int64_t n,
+                   int32_t C, int32_t n_table, int32_t relu, int64_t group, int64_t group_stride, int64_t off,
+                   void* stream);
+
+/* Nearest codebook entry, reference formula and tie-break (vqvae_model.py:8-25):
+ *   dist[m,k] = (|c_k|^2 + |z_m|^2) - 2 * <z_m, c_k>,  idx[m] = first k attaining the minimum.
+ * z [M, D] fp32 rows (channels-last encoder output), codebook_t [D, K] fp32 (transposed copy),
+ * c2 [K] = row sums of squares.  margin (optional, [M] fp32) receives second-best minus best. */
+int mage_vq_nearest(const float* z, const float* codebook_t, const float* c2, int64_t M, int32_t D, int32_t K,
+                    int64_t* idx, float* margin, void* stream);
+/* c2[k] = sum_d codebook[k, d]^2 and codebook_t = codebook^T (derived caches of the codebook). */
+int mage_vq_prepare(const float* codebook, int32_t K, int32_t D, float* codebook_t, float* c2, void* stream);
+
+/* Row argmax with first-maximum tie-break (torch.max(prediction, -1)[1], mage_model.py:681,687).
+ * Row i in [0, rows) is read from logits row  (i / group)*in_group_stride + i % group + in_off  (fp32, leading
+ * dim ld) and its index written to out[(i / group)*out_group_stride + i % group + out_off] (int64): this is how
+ * frame i of every clip is picked out of [B, L-1, hw, K] logits and written into slot i+1 of the token buffer
+ * without copies.  margin (optional, [rows] fp32) receives best minus second-best. */
+int mage_argmax(const float* logits, int64_t rows, int32_t K, int64_t ld, int64_t group, int64_t in_group_stride,
+                int64_t in_off, int64_t* out, int64_t out_group_stride, int64_t out_off, float* margin, void* stream);
+
+/* Mean cross entropy over rows (F.cross_entropy, mage_model.py:618): row_loss[i] = logsumexp(logits[i]) -
+ * logits[i, target[i]] (workspace, [rows] fp32), loss_mean[0] = mean_i row_loss[i] (fixed-order fp64 sum:
+ * deterministic). */
+int mage_cross_entropy(const float* logits, const int64_t* target, int64_t rows, int32_t K, float* row_loss,
+                       float* loss_mean, void* stream);
+
+/* ------------------------------------------------------------------------------------- direct convs
+ * Small-channel ends of the VQ-VAE that are HBM-bound, not GEMMs.
+ * mage_conv_in:  NCHW fp32 image [N, cin<=4, H, W] -> channels-last [N, OH, OW, cout] (y_dtype),
+ *   y = act((conv(x) + bias) * scale + shift).  f4 stem Conv2d(1,dim,4,2,1)+BN+ReLU (vqvae_model.py:173-175),
+ *   f8 stem Conv2d(3,dim,7,padding=3) (:193).  weight_t is the transposed copy [cin, kh, kw, cout] fp32
+ *   (lanes = output channels read it coalesced).
+ * mage_conv_out: channels-last [N, IH, IW, cin] (x_dtype) -> NCHW fp32 [N, cout<=4, OH, OW], y = tanh(.):
+ *   transposed=1: ConvTranspose2d(dim, cout, 4, 2, 1) (vqvae_model.py:187-188), weight_t [4, 4, cout, cin]
+ *   (= torch weight [cin, cout, ky, kx] permuted to ky, kx, cout, cin);
+ *   transposed=0: Conv2d(dim, cout, 1) (:212-213), weight_t [cout, cin]. */
+int mage_conv_in(const float* x, const float* weight_t, const float* bias, const float* scale, const float* shift,
+                 void* y, int32_t y_dtype, int32_t N, int32_t cin, int32_t H, int32_t W, int32_t cout,
+                 int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t act, void* stream);
+int mage_conv_out(const void* x, int32_t x_dtype, const float* weight_t, const float* bias, float* y,
+                  int32_t N, int32_t IH, int32_t IW, int32_t cin, int32_t cout, int32_t transposed, void* stream);
+
+/* Channels-last elementwise helpers of the f8 stack (vqvae_model.py:194-210): 2x2 max-pool,
+ * nearest 2x upsample, and a ReLU'd copy (the non-in-place ReLU that opens every Encoder/DecoderBlock). */
+int mage_maxpool2(const void* x, void* y, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t relu,
+                  void* stream);
+int mage_upsample2(const void* x, void* y, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int mage_relu(const void* x, void* y, int32_t dtype, int64_t n, void* stream);
+/* y = x converted between fp32 and bf16 (n elements). */
+int mage_cast(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, int64_t n, void* stream);
+
+/* ADAIN2D (mage_model.py:299-314): out[b,p,c] = gamma[b,p,c] * (x[b,p,c]-mean[b,c])*rstd[b,c] + beta[b,p,c]
+ * with InstanceNorm2d statistics over the P = H*W positions (biased variance, eps 1e-5). fp32, channels-last. */
+int mage_adain(const float* x, const float* gamma, const float* beta, float* out, int32_t B, int32_t P, int32_t C,
+               float eps, void* stream);
+
+/* x[b, p, :] += s[b] * vec[:]   (speed embedding, mage_model.py:666-668). fp32. */
+int mage_add_scaled_rowvec(float* x, const float* s, const float* vec, int32_t B, int32_t P, int32_t C, void* stream);
+
+/* x[r, :] = x[r, :] * rs[r] + table[(r / div) % mod, :]   (rs and/or table may be null), fp32, in place.
+ * Text encoder: + positions (mage_model.py:227-228) and the padding-row zeroing (:233-235). */
+int mage_row_affine(float* x, const float* rs, const float* table, int64_t rows, int32_t C, int32_t div, int32_t mod,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGE_HIP_H */

@@ -1,0 +1,80 @@
+// Shared helpers for the libmage_hip.so kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/mage_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+void mage_set_error(const char* fmt, ...);
+const void* mage_zero_page();          // device pointer, >= 4096 zero bytes; null before mage_init
+
+#define MAGE_CHECK_ARG(cond, ...)                                   \
+    do {                                                            \
+        if (!(cond)) {                                              \
+            mage_set_error(__VA_ARGS__);                            \
+            return MAGE_EINVAL;                                     \
+        }                                                           \
+    } while (0)
+
+#define MAGE_CHECK_LAUNCH(name)                                                         \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) {                                                         \
+            mage_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));       \
+            return MAGE_EHIP;                                                           \
+        }                                                                               \
+    } while (0)
+
+// round-to-nearest-even fp32 -> bf16 (same rounding as torch's .to(torch.bfloat16))
+__device__ __forceinline__ unsigned short f2bf_bits(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf_bits2f(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<unsigned short>(unsigned short v) { return bf_bits2f(v); }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ unsigned short from_f32<unsigned short>(float v) { return f2bf_bits(v); }
+
+// load / store 4 consecutive elements as fp32
+__device__ __forceinline__ f32x4 load4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 load4(const unsigned short* p) {
+    uint2 r = *(const uint2*)p;
+    f32x4 o;
+    o[0] = __uint_as_float(r.x << 16);
+    o[1] = __uint_as_float(r.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.y << 16);
+    o[3] = __uint_as_float(r.y & 0xffff0000u);
+    return o;
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void store4(unsigned short* p, f32x4 v) {
+    uint2 r;
+    r.x = (unsigned int)f2bf_bits(v[0]) | ((unsigned int)f2bf_bits(v[1]) << 16);
+    r.y = (unsigned int)f2bf_bits(v[2]) | ((unsigned int)f2bf_bits(v[3]) << 16);
+    *(uint2*)p = r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

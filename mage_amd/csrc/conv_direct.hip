@@ -1,0 +1,233 @@
+// Small-channel ends of the VQ-VAE (image <-> channels-last features) and the channels-last elementwise
+// helpers of the f8 stack.  These are HBM/L2-bound integer-ish data movement, not GEMMs: coalesced
+// channel-fastest accesses, no matrix cores.
+#include "common.h"
+
+namespace {
+
+// y[n, oy, ox, co] = act((bias[co] + sum_{ci,ky,kx} x[n, ci, oy*s-p+ky, ox*s-p+kx] * wt[(ci,ky,kx), co]) * scale + shift)
+// One thread per (pixel, 4 consecutive co); the KH*KW*cin input taps are wave-uniform broadcast loads.
+template <typename OT>
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                      const float* __restrict__ bias, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, OT* __restrict__ y, int N, int cin,
+                                                      int H, int W, int cout, int kh, int kw, int stride, int pad, int OH,
+                                                      int OW, int act) {
+    const int cq = cout / 4;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)N * OH * OW * cq;
+    if (gid >= total) return;
+    const int co = (int)(gid % cq) * 4;
+    const long pix = gid / cq;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), n = (int)(pix / ((long)OW * OH));
+    f32x4 acc = bias ? *(const f32x4*)(bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ci = 0; ci < cin; ++ci) {
+        const float* xp = x + ((long)n * cin + ci) * H * W;
+        for (int ky = 0; ky < kh; ++ky) {
+            const int iy = oy * stride - pad + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int kx = 0; kx < kw; ++kx) {
+                const int ix = ox * stride - pad + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const float xv = xp[(long)iy * W + ix];
+                acc += xv * *(const f32x4*)(wt + ((long)(ci * kh + ky) * kw + kx) * cout + co);
+            }
+        }
+    }
+    if (scale) acc = acc * *(const f32x4*)(scale + co) + *(const f32x4*)(shift + co);
+    if (act == MAGE_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+    }
+    store4(y + pix * cout + co, acc);
+}
+
+// One wave per output pixel, lanes split the input channels, shuffle reduction, tanh, NCHW fp32 store.
+template <typename IT, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void conv_out_kernel(const IT* __restrict__ x, const float* __restrict__ wt,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int N,
+                                                       int IH, int IW, int cin, int cout, int OH, int OW) {
+    const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= (long)N * OH * OW) return;
+    const int lane = threadIdx.x & 63;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), n = (int)(pix / ((long)OW * OH));
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (TRANSPOSED) {
+        // oy = 2*iy - 1 + ky: the two contributing input rows are iy0 = (oy+1)>>1 (ky = oy+1-2*iy0) and iy0-1 (ky+2)
+        const int iy0 = (oy + 1) >> 1, ky0 = oy + 1 - 2 * iy0;
+        const int ix0 = (ox + 1) >> 1, kx0 = ox + 1 - 2 * ix0;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int iy = iy0 - a, ky = ky0 + 2 * a;
+            if ((unsigned)iy >= (unsigned)IH) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ix = ix0 - b, kx = kx0 + 2 * b;
+                if ((unsigned)ix >= (unsigned)IW) continue;
+                const IT* xp = x + (((long)n * IH + iy) * IW + ix) * cin;
+                for (int c = lane * 4; c < cin; c += 256) {
+                    const f32x4 xv = load4(xp + c);
+#pragma unroll
+                    for (int co = 0; co < 4; ++co) {
+                        if (co < cout) {
+                            const f32x4 wv = *(const f32x4*)(wt + ((long)((ky * 4 + kx) * cout + co)) * cin + c);
+                            acc[co] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        const IT* xp = x + (((long)n * IH + oy) * IW + ox) * cin;
+        for (int c = lane * 4; c < cin; c += 256) {
+            const f32x4 xv = load4(xp + c);
+#pragma unroll
+            for (int co = 0; co < 4; ++co) {
+                if (co < cout) {
+                    const f32x4 wv = *(const f32x4*)(wt + (long)co * cin + c);
+                    acc[co] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+        if (co < cout) {
+            const float s = wave_sum(acc[co]);
+            if (lane == 0) y[(((long)n * cout + co) * OH + oy) * OW + ox] = tanhf(s + (bias ? bias[co] : 0.f));
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
+                                                       int C, int relu) {
+    const int cq = C / 4, OH = H / 2, OW = W / 2;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)N * OH * OW * cq) return;
+    const int c = (int)(gid % cq) * 4;
+    const long pix = gid / cq;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), n = (int)(pix / ((long)OW * OH));
+    const T* p = x + (((long)n * H + oy * 2) * W + ox * 2) * C + c;
+    f32x4 a = load4(p), b = load4(p + C), cc = load4(p + (long)W * C), dd = load4(p + (long)W * C + C), o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(cc[e], dd[e]));
+        if (relu) o[e] = fmaxf(o[e], 0.f);
+    }
+    store4(y + pix * C + c, o);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C) {
+    const int cq = C / 4, OH = H * 2, OW = W * 2;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)N * OH * OW * cq) return;
+    const int c = (int)(gid % cq) * 4;
+    const long pix = gid / cq;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), n = (int)(pix / ((long)OW * OH));
+    store4(y + pix * C + c, load4(x + (((long)n * H + (oy >> 1)) * W + (ox >> 1)) * C + c));
+}
+
+template <typename IT, typename OT, bool RELU>
+__global__ __launch_bounds__(256) void map_kernel(const IT* __restrict__ x, OT* __restrict__ y, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 v = load4(x + i);
+    if (RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    store4(y + i, v);
+}
+
+inline dim3 grid1(long items) { return dim3((unsigned)((items + 255) / 256)); }
+
+}  // namespace
+
+extern "C" int mage_conv_in(const float* x, const float* weight_t, const float* bias, const float* scale, const float* shift,
+                            void* y, int32_t y_dtype, int32_t N, int32_t cin, int32_t H, int32_t W, int32_t cout, int32_t kh,
+                            int32_t kw, int32_t stride, int32_t pad, int32_t act, void* stream) {
+    MAGE_CHECK_ARG(x && weight_t && y, "mage_conv_in: null pointer");
+    MAGE_CHECK_ARG(N > 0 && cin > 0 && cin <= 4 && cout % 4 == 0 && stride >= 1, "mage_conv_in: cin=%d cout=%d unsupported", cin, cout);
+    MAGE_CHECK_ARG(!scale == !shift, "mage_conv_in: scale and shift must be given together");
+    MAGE_CHECK_ARG(act == MAGE_ACT_NONE || act == MAGE_ACT_RELU, "mage_conv_in: act %d unsupported", act);
+    const int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1;
+    const long items = (long)N * OH * OW * (cout / 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (y_dtype == MAGE_F32)
+        hipLaunchKernelGGL((conv_in_kernel<float>), grid1(items), dim3(256), 0, s, x, weight_t, bias, scale, shift, (float*)y, N,
+                           cin, H, W, cout, kh, kw, stride, pad, OH, OW, act);
+    else if (y_dtype == MAGE_BF16)
+        hipLaunchKernelGGL((conv_in_kernel<unsigned short>), grid1(items), dim3(256), 0, s, x, weight_t, bias, scale, shift,
+                           (unsigned short*)y, N, cin, H, W, cout, kh, kw, stride, pad, OH, OW, act);
+    else {
+        mage_set_error("mage_conv_in: bad y_dtype %d", y_dtype);
+        return MAGE_EINVAL;
+    }
+    MAGE_CHECK_LAUNCH("mage_conv_in");
+    return MAGE_OK;
+}
+
+extern "C" int mage_conv_out(const void* x, int32_t x_dtype, const float* weight_t, const float* bias, float* y, int32_t N,
+                             int32_t IH, int32_t IW, int32_t cin, int32_t cout, int32_t transposed, void* stream) {
+    MAGE_CHECK_ARG(x && weight_t && y, "mage_conv_out: null pointer");
+    MAGE_CHECK_ARG(N > 0 && cin % 4 == 0 && cout >= 1 && cout <= 4, "mage_conv_out: cin=%d cout=%d unsupported", cin, cout);
+    const int OH = transposed ? IH * 2 : IH, OW = transposed ? IW * 2 : IW;
+    const dim3 grid((unsigned)(((long)N * OH * OW + 3) / 4)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+#define CO_LAUNCH(IT, TR) hipLaunchKernelGGL((conv_out_kernel<IT, TR>), grid, blk, 0, s, (const IT*)x, weight_t, bias, y, N, IH, IW, cin, cout, OH, OW)
+    if (x_dtype == MAGE_F32) { if (transposed) CO_LAUNCH(float, true); else CO_LAUNCH(float, false); }
+    else if (x_dtype == MAGE_BF16) { if (transposed) CO_LAUNCH(unsigned short, true); else CO_LAUNCH(unsigned short, false); }
+    else { mage_set_error("mage_conv_out: bad x_dtype %d", x_dtype); return MAGE_EINVAL; }
+#undef CO_LAUNCH
+    MAGE_CHECK_LAUNCH("mage_conv_out");
+    return MAGE_OK;
+}
+
+extern "C" int mage_maxpool2(const void* x, void* y, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t relu,
+                             void* stream) {
+    MAGE_CHECK_ARG(x && y && N > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "mage_maxpool2: bad arguments");
+    const long items = (long)N * (H / 2) * (W / 2) * (C / 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MAGE_F32) hipLaunchKernelGGL((maxpool2_kernel<float>), grid1(items), dim3(256), 0, s, (const float*)x, (float*)y, N, H, W, C, relu);
+    else if (dtype == MAGE_BF16) hipLaunchKernelGGL((maxpool2_kernel<unsigned short>), grid1(items), dim3(256), 0, s, (const unsigned short*)x, (unsigned short*)y, N, H, W, C, relu);
+    else { mage_set_error("mage_maxpool2: bad dtype %d", dtype); return MAGE_EINVAL; }
+    MAGE_CHECK_LAUNCH("mage_maxpool2");
+    return MAGE_OK;
+}
+
+extern "C" int mage_upsample2(const void* x, void* y, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    MAGE_CHECK_ARG(x && y && N > 0 && C % 4 == 0, "mage_upsample2: bad arguments");
+    const long items = (long)N * (H * 2) * (W * 2) * (C / 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MAGE_F32) hipLaunchKernelGGL((upsample2_kernel<float>), grid1(items), dim3(256), 0, s, (const float*)x, (float*)y, N, H, W, C);
+    else if (dtype == MAGE_BF16) hipLaunchKernelGGL((upsample2_kernel<unsigned short>), grid1(items), dim3(256), 0, s, (const unsigned short*)x, (unsigned short*)y, N, H, W, C);
+    else { mage_set_error("mage_upsample2: bad dtype %d", dtype); return MAGE_EINVAL; }
+    MAGE_CHECK_LAUNCH("mage_upsample2");
+    return MAGE_OK;
+}
+
+extern "C" int mage_relu(const void* x, void* y, int32_t dtype, int64_t n, void* stream) {
+    MAGE_CHECK_ARG(x && y && n > 0 && n % 4 == 0, "mage_relu: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MAGE_F32) hipLaunchKernelGGL((map_kernel<float, float, true>), grid1(n / 4), dim3(256), 0, s, (const float*)x, (float*)y, (long)n);
+    else if (dtype == MAGE_BF16) hipLaunchKernelGGL((map_kernel<unsigned short, unsigned short, true>), grid1(n / 4), dim3(256), 0, s, (const unsigned short*)x, (unsigned short*)y, (long)n);
+    else { mage_set_error("mage_relu: bad dtype %d", dtype); return MAGE_EINVAL; }
+    MAGE_CHECK_LAUNCH("mage_relu");
+    return MAGE_OK;
+}
+
+extern "C" int mage_cast(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, int64_t n, void* stream) {
+    MAGE_CHECK_ARG(x && y && n > 0 && n % 4 == 0, "mage_cast: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == MAGE_F32 && y_dtype == MAGE_BF16)
+        hipLaunchKernelGGL((map_kernel<float, unsigned short, false>), grid1(n / 4), dim3(256), 0, s, (const float*)x, (unsigned short*)y, (long)n);
+    else if (x_dtype == MAGE_BF16 && y_dtype == MAGE_F32)
+        hipLaunchKernelGGL((map_kernel<unsigned short, float, false>), grid1(n / 4), dim3(256), 0, s, (const unsigned short*)x, (float*)y, (long)n);
+    else if (x_dtype == MAGE_F32 && y_dtype == MAGE_F32)
+        hipLaunchKernelGGL((map_kernel<float, float, false>), grid1(n / 4), dim3(256), 0, s, (const float*)x, (float*)y, (long)n);
+    else { mage_set_error("mage_cast: unsupported %d -> %d", x_dtype, y_dtype); return MAGE_EINVAL; }
+    MAGE_CHECK_LAUNCH("mage_cast");
+    return MAGE_OK;
+}

@@ -1,0 +1,265 @@
+// LayerNorm, short-sequence multi-head attention (axial / text / cross), ADAIN, speed-embedding add.
+// All HBM-bound: one pass over the data, 16-byte vector accesses, fp32 arithmetic.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------ LayerNorm
+// One wave per row; two-pass (mean, then centred variance) entirely in registers.
+template <typename OT, int VPL>   // VPL = float4 vectors per lane (C <= 256*VPL)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, OT* __restrict__ y, long rows,
+                                                        int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    f32x4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int c = j * 256 + lane * 4;
+        v[j] = (c < C) ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int c = j * 256 + lane * 4;
+        if (c < C) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dlt = v[j][e] - mean;
+                q += dlt * dlt;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    OT* yr = y + row * C;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int c = j * 256 + lane * 4;
+        if (c < C) {
+            const f32x4 gm = *(const f32x4*)(gamma + c), bt = *(const f32x4*)(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gm[e] + bt[e];
+            store4(yr + c, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ attention
+// Workgroup = (sequence, head group).  K and V of the head group are staged once in LDS as fp32;
+// each thread then owns (query i, head h) pairs: q in registers, scores in registers (NK_MAX <= 64),
+// softmax in registers, output accumulated in registers.  Lanes of a wave that share h read the same
+// LDS address (broadcast), the (up to 4) distinct heads of a wave sit 128 B apart: conflict-free b128 reads.
+template <typename T, int NK_MAX>
+__global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, int hg) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* ks = (float*)smem_raw;                    // [nk][hg*32]
+    const int rowf = hg * 32;
+    float* vs = ks + (long)d.nk * rowf;
+    const int s = blockIdx.x;
+    const int h0 = blockIdx.y * hg;
+    const int outer = s / d.inner, in = s - outer * d.inner;
+    const long q_base = (long)outer * d.q_outer_stride + in;
+    const long kv_base = (long)outer * d.kv_outer_stride + in;
+    const T* kp = (const T*)d.k;
+    const T* vp = (const T*)d.v;
+    // stage K, V: nk rows x (hg*32) columns, 4 elements per thread-step
+    const int vec_per_row = rowf / 4;
+    for (int e = threadIdx.x; e < d.nk * vec_per_row; e += 256) {
+        const int j = e / vec_per_row, c = (e - j * vec_per_row) * 4;
+        const long row = kv_base + (long)j * d.kv_axis_stride;
+        *(f32x4*)(ks + j * rowf + c) = load4(kp + row * d.ldk + h0 * 32 + c);
+        *(f32x4*)(vs + j * rowf + c) = load4(vp + row * d.ldv + h0 * 32 + c);
+    }
+    __syncthreads();
+    int klen = d.nk;
+    if (d.kv_len) klen = min(klen, d.kv_len[s / d.kv_len_div]);
+    const T* qp = (const T*)d.q;
+    T* op = (T*)d.out;
+    for (int p = threadIdx.x; p < d.nq * hg; p += 256) {
+        const int hl = p / d.nq, i = p - hl * d.nq;
+        const long row = q_base + (long)i * d.q_axis_stride;
+        f32x4 q[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            q[c] = load4(qp + row * d.ldq + (h0 + hl) * 32 + c * 4);
+            q[c] *= d.scale;
+        }
+        const int jmax = d.causal ? min(klen, i + 1) : klen;
+        float sc[NK_MAX];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NK_MAX; ++j) {
+            float a = -INFINITY;
+            if (j < jmax) {
+                const float* kr = ks + j * rowf + hl * 32;
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; c += 2) {
+                    const f32x4 k0 = *(const f32x4*)(kr + c * 4), k1 = *(const f32x4*)(kr + c * 4 + 4);
+                    a0 += q[c][0] * k0[0] + q[c][1] * k0[1] + q[c][2] * k0[2] + q[c][3] * k0[3];
+                    a1 += q[c + 1][0] * k1[0] + q[c + 1][1] * k1[1] + q[c + 1][2] * k1[2] + q[c + 1][3] * k1[3];
+                }
+                a = a0 + a1;
+            }
+            sc[j] = a;
+            mx = fmaxf(mx, a);
+        }
+        float den = 0.f;
+        f32x4 o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NK_MAX; ++j) {
+            if (j < jmax) {
+                const float pj = expf(sc[j] - mx);
+                den += pj;
+                const float* vr = vs + j * rowf + hl * 32;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[c] += pj * *(const f32x4*)(vr + c * 4);
+            }
+        }
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) store4(op + row * d.ldo + (h0 + hl) * 32 + c * 4, o[c] * inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------ ADAIN
+// grid = (B, C/64); block 256 = 64 channels x 4 position phases.
+__global__ __launch_bounds__(256) void adain_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ out, int P,
+                                                    int C, float eps) {
+    __shared__ float red[2][4][64];
+    const int b = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    const long base = (long)b * P * C + c;
+    float s = 0.f;
+    for (int p = ph; p < P; p += 4) s += x[base + (long)p * C];
+    red[0][ph][threadIdx.x & 63] = s;
+    __syncthreads();
+    const float mean = (red[0][0][threadIdx.x & 63] + red[0][1][threadIdx.x & 63] + red[0][2][threadIdx.x & 63] +
+                        red[0][3][threadIdx.x & 63]) / (float)P;
+    float q = 0.f;
+    for (int p = ph; p < P; p += 4) {
+        const float dlt = x[base + (long)p * C] - mean;
+        q += dlt * dlt;
+    }
+    red[1][ph][threadIdx.x & 63] = q;
+    __syncthreads();
+    const float var = (red[1][0][threadIdx.x & 63] + red[1][1][threadIdx.x & 63] + red[1][2][threadIdx.x & 63] +
+                       red[1][3][threadIdx.x & 63]) / (float)P;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    for (int p = ph; p < P; p += 4) {
+        const long i = base + (long)p * C;
+        out[i] = gamma[i] * ((x[i] - mean) * rstd) + beta[i];
+    }
+}
+
+__global__ void add_scaled_rowvec_kernel(float* __restrict__ x, const float* __restrict__ s, const float* __restrict__ vec,
+                                         long per_b, int C, long total) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= total) return;
+    const long b = i / per_b;
+    const int c = (int)(i % C);
+    f32x4 v = *(f32x4*)(x + i);
+    v += s[b] * *(const f32x4*)(vec + c);
+    *(f32x4*)(x + i) = v;
+}
+
+__global__ void row_affine_kernel(float* __restrict__ x, const float* __restrict__ rs, const float* __restrict__ table,
+                                  long rows, int C, int div, int mod) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= rows * C) return;
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    f32x4 v = *(f32x4*)(x + i);
+    if (rs) v *= rs[r];
+    if (table) v += *(const f32x4*)(table + ((r / div) % mod) * (long)C + c);
+    *(f32x4*)(x + i) = v;
+}
+
+template <typename OT>
+int ln_launch(const float* x, const float* g, const float* b, void* y, int64_t rows, int C, float eps, hipStream_t s) {
+    const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
+    if (C <= 256) hipLaunchKernelGGL((layernorm_kernel<OT, 1>), grid, blk, 0, s, x, g, b, (OT*)y, (long)rows, C, eps);
+    else if (C <= 512) hipLaunchKernelGGL((layernorm_kernel<OT, 2>), grid, blk, 0, s, x, g, b, (OT*)y, (long)rows, C, eps);
+    else if (C <= 1024) hipLaunchKernelGGL((layernorm_kernel<OT, 4>), grid, blk, 0, s, x, g, b, (OT*)y, (long)rows, C, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<OT, 8>), grid, blk, 0, s, x, g, b, (OT*)y, (long)rows, C, eps);
+    MAGE_CHECK_LAUNCH("mage_layernorm");
+    return MAGE_OK;
+}
+
+template <typename T>
+int attn_launch(const mage_attn_desc* d, hipStream_t s) {
+    // heads per workgroup: all of them if K,V fit 64 KiB of LDS, else the largest power of two that does
+    int hg = d->n_head;
+    while ((long)d->nk * hg * 32 * 8 > 64 * 1024 && hg > 1 && hg % 2 == 0) hg /= 2;
+    const size_t lds = (size_t)d->nk * hg * 32 * 8;
+    MAGE_CHECK_ARG(lds <= 64 * 1024 && d->n_head % hg == 0, "mage_attention: nk=%d too large for LDS staging", d->nk);
+    const dim3 grid(d->n_seq, d->n_head / hg), blk(256);
+    if (d->nk <= 16) hipLaunchKernelGGL((attention_kernel<T, 16>), grid, blk, lds, s, *d, hg);
+    else if (d->nk <= 32) hipLaunchKernelGGL((attention_kernel<T, 32>), grid, blk, lds, s, *d, hg);
+    else hipLaunchKernelGGL((attention_kernel<T, 64>), grid, blk, lds, s, *d, hg);
+    MAGE_CHECK_LAUNCH("mage_attention");
+    return MAGE_OK;
+}
+
+}  // namespace
+
+extern "C" int mage_layernorm(const float* x, const float* gamma, const float* beta, void* y, int32_t y_dtype,
+                              int64_t rows, int32_t C, float eps, void* stream) {
+    MAGE_CHECK_ARG(x && gamma && beta && y, "mage_layernorm: null pointer");
+    MAGE_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, "mage_layernorm: rows=%ld C=%d unsupported", (long)rows, C);
+    if (y_dtype == MAGE_F32) return ln_launch<float>(x, gamma, beta, y, rows, C, eps, (hipStream_t)stream);
+    if (y_dtype == MAGE_BF16) return ln_launch<unsigned short>(x, gamma, beta, y, rows, C, eps, (hipStream_t)stream);
+    mage_set_error("mage_layernorm: bad y_dtype %d", y_dtype);
+    return MAGE_EINVAL;
+}
+
+extern "C" int mage_attention(const mage_attn_desc* d, void* stream) {
+    MAGE_CHECK_ARG(d && d->q && d->k && d->v && d->out, "mage_attention: null pointer");
+    MAGE_CHECK_ARG(d->nk >= 1 && d->nk <= 64, "mage_attention: nk=%d outside [1, 64]", d->nk);
+    MAGE_CHECK_ARG(d->nq >= 1 && d->n_seq >= 1 && d->n_head >= 1 && d->inner >= 1, "mage_attention: bad sizes");
+    MAGE_CHECK_ARG((d->ldq | d->ldk | d->ldv | d->ldo) % 4 == 0, "mage_attention: leading dims must be multiples of 4");
+    MAGE_CHECK_ARG(!d->kv_len || d->kv_len_div >= 1, "mage_attention: kv_len_div must be >= 1");
+    if (d->dtype == MAGE_F32) return attn_launch<float>(d, (hipStream_t)stream);
+    if (d->dtype == MAGE_BF16) return attn_launch<unsigned short>(d, (hipStream_t)stream);
+    mage_set_error("mage_attention: bad dtype %d", d->dtype);
+    return MAGE_EINVAL;
+}
+
+extern "C" int mage_adain(const float* x, const float* gamma, const float* beta, float* out, int32_t B, int32_t P,
+                          int32_t C, float eps, void* stream) {
+    MAGE_CHECK_ARG(x && gamma && beta && out, "mage_adain: null pointer");
+    MAGE_CHECK_ARG(B > 0 && P > 0 && C > 0 && C % 64 == 0, "mage_adain: C=%d must be a multiple of 64", C);
+    hipLaunchKernelGGL(adain_kernel, dim3(B, C / 64), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, out, P, C, eps);
+    MAGE_CHECK_LAUNCH("mage_adain");
+    return MAGE_OK;
+}
+
+extern "C" int mage_add_scaled_rowvec(float* x, const float* s, const float* vec, int32_t B, int32_t P, int32_t C,
+                                      void* stream) {
+    MAGE_CHECK_ARG(x && s && vec, "mage_add_scaled_rowvec: null pointer");
+    MAGE_CHECK_ARG(B > 0 && P > 0 && C > 0 && C % 4 == 0, "mage_add_scaled_rowvec: C=%d must be a multiple of 4", C);
+    const long total = (long)B * P * C;
+    hipLaunchKernelGGL(add_scaled_rowvec_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, s, vec, (long)P * C, C, total);
+    MAGE_CHECK_LAUNCH("mage_add_scaled_rowvec");
+    return MAGE_OK;
+}
+
+extern "C" int mage_row_affine(float* x, const float* rs, const float* table, int64_t rows, int32_t C, int32_t div, int32_t mod,
+                               void* stream) {
+    MAGE_CHECK_ARG(x && rows > 0 && C > 0 && C % 4 == 0, "mage_row_affine: bad arguments");
+    MAGE_CHECK_ARG(!table || (div >= 1 && mod >= 1), "mage_row_affine: bad div/mod");
+    const long total = (long)rows * C;
+    hipLaunchKernelGGL(row_affine_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rs,
+                       table, (long)rows, C, div, mod);
+    MAGE_CHECK_LAUNCH("mage_row_affine");
+    return MAGE_OK;
+}

@@ -1,0 +1,257 @@
+// Codebook quantiser (nearest neighbour), embedding gathers, row argmax and cross entropy.
+// Integer/index outputs here must be bit-exact against the reference, so the distance follows the
+// reference FORMULA (vqvae_model.py:14-21): fl32(fl32(|c|^2 + |z|^2) - 2*<z,c>), first minimum wins.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void vq_prepare_kernel(const float* __restrict__ cb, int K, int D,
+                                                         float* __restrict__ cbt, float* __restrict__ c2) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    double s = 0.0;
+    for (int d = 0; d < D; ++d) {
+        const float v = cb[(long)k * D + d];
+        cbt[(long)d * K + k] = v;
+        s += (double)v * (double)v;
+    }
+    c2[k] = (float)s;
+}
+
+struct Best {
+    float d0; int i0; float d1;     // best distance, its index, second-best distance
+};
+__device__ __forceinline__ void best_push(Best& b, float d, int i) {
+    if (d < b.d0 || (d == b.d0 && i < b.i0)) { b.d1 = b.d0; b.d0 = d; b.i0 = i; }
+    else if (d < b.d1) b.d1 = d;
+}
+__device__ __forceinline__ Best best_wave_reduce(Best b) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float od0 = __shfl_xor(b.d0, o, 64), od1 = __shfl_xor(b.d1, o, 64);
+        const int oi0 = __shfl_xor(b.i0, o, 64);
+        if (od0 < b.d0 || (od0 == b.d0 && oi0 < b.i0)) { b.d1 = fminf(b.d0, od1); b.d0 = od0; b.i0 = oi0; }
+        else b.d1 = fminf(b.d1, od0);
+    }
+    return b;
+}
+
+// 16 rows of z per workgroup; every thread owns KPT codes (k = tid + 256*kk) for all 16 rows.
+// Dot products are accumulated in fp64 (FP64 vector rate on CDNA4 is half the fp32 rate; this kernel is
+// tiny) and rounded once, so the only fp32 roundings left are the ones the reference formula itself has.
+template <int KPT>
+__global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict__ z, const float* __restrict__ cbt,
+                                                         const float* __restrict__ c2, long M, int D, int K,
+                                                         int64_t* __restrict__ idx, float* __restrict__ margin) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* zs = (float*)smem_raw;                    // [16][D]
+    float* x2s = zs + 16 * D;                        // [16]
+    float* ds = x2s + 16;                            // [16][K]
+    const long r0 = (long)blockIdx.x * 16;
+    for (int e = threadIdx.x; e < 16 * D / 4; e += 256) {
+        const int r = e / (D / 4), c = (e - r * (D / 4)) * 4;
+        *(f32x4*)(zs + r * D + c) = (r0 + r < M) ? *(const f32x4*)(z + (r0 + r) * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double s = 0.0;
+        for (int d = 0; d < D; ++d) s += (double)zs[threadIdx.x * D + d] * (double)zs[threadIdx.x * D + d];
+        x2s[threadIdx.x] = (float)s;
+    }
+    double acc[KPT][16];
+#pragma unroll
+    for (int kk = 0; kk < KPT; ++kk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[kk][r] = 0.0;
+    for (int d = 0; d < D; d += 4) {
+        float c[KPT][4];
+#pragma unroll
+        for (int kk = 0; kk < KPT; ++kk) {
+            const int k = threadIdx.x + 256 * kk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[kk][e] = (k < K) ? cbt[(long)(d + e) * K + k] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const f32x4 zv = *(const f32x4*)(zs + r * D + d);
+#pragma unroll
+            for (int kk = 0; kk < KPT; ++kk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[kk][r] = fma((double)zv[e], (double)c[kk][e], acc[kk][r]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KPT; ++kk) {
+        const int k = threadIdx.x + 256 * kk;
+        if (k < K) {
+            const float ck = c2[k];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float s = ck + x2s[r];                       // fl32(|c|^2 + |z|^2)
+                ds[r * K + k] = fmaf(-2.0f, (float)acc[kk][r], s); // fl32(s - 2*dot)
+            }
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = wave; r < 16; r += 4) {
+        if (r0 + r >= M) break;
+        Best b{INFINITY, 0x7fffffff, INFINITY};
+        for (int k = lane; k < K; k += 64) best_push(b, ds[r * K + k], k);
+        b = best_wave_reduce(b);
+        if (lane == 0) {
+            idx[r0 + r] = b.i0;
+            if (margin) margin[r0 + r] = b.d1 - b.d0;
+        }
+    }
+}
+
+template <typename OT>
+__global__ __launch_bounds__(256) void embedding_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                        OT* __restrict__ out, long n, int C, int n_table, int relu,
+                                                        long group, long group_stride, long off) {
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    long id = ids[i];
+    id = id < 0 ? 0 : (id >= n_table ? n_table - 1 : id);
+    const long orow = (i / group) * group_stride + (i % group) + off;
+    const float* src = table + id * C;
+    OT* dst = out + orow * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        f32x4 v = *(const f32x4*)(src + c);
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        store4(dst + c, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, long rows, int K, long ld, long group,
+                                                     long in_stride, long in_off, int64_t* __restrict__ out,
+                                                     long out_stride, long out_off, float* __restrict__ margin) {
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const long gi = i / group, gr = i - gi * group;
+    const float* p = logits + (gi * in_stride + gr + in_off) * ld;
+    Best b{INFINITY, 0x7fffffff, INFINITY};          // minimise the negated logit: first maximum wins
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 v = *(const f32x4*)(p + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (k + e < K) best_push(b, -v[e], k + e);
+    }
+    b = best_wave_reduce(b);
+    if (lane == 0) {
+        out[gi * out_stride + gr + out_off] = b.i0;
+        if (margin) margin[i] = b.d1 - b.d0;
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                      long rows, int K, float* __restrict__ row_loss) {
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = logits + i * K;
+    float mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, p[k]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += expf(p[k] - mx);
+    s = wave_sum(s);
+    if (lane == 0) row_loss[i] = (logf(s) + mx) - p[target[i]];
+}
+
+__global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ v, long n, float* __restrict__ out, double inv) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) s += (double)v[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        out[0] = (float)(t * inv);
+    }
+}
+
+}  // namespace
+
+extern "C" int mage_vq_prepare(const float* codebook, int32_t K, int32_t D, float* codebook_t, float* c2, void* stream) {
+    MAGE_CHECK_ARG(codebook && codebook_t && c2 && K > 0 && D > 0, "mage_vq_prepare: bad arguments");
+    hipLaunchKernelGGL(vq_prepare_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, codebook, K, D,
+                       codebook_t, c2);
+    MAGE_CHECK_LAUNCH("mage_vq_prepare");
+    return MAGE_OK;
+}
+
+extern "C" int mage_vq_nearest(const float* z, const float* codebook_t, const float* c2, int64_t M, int32_t D, int32_t K,
+                               int64_t* idx, float* margin, void* stream) {
+    MAGE_CHECK_ARG(z && codebook_t && c2 && idx, "mage_vq_nearest: null pointer");
+    MAGE_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && K > 0 && K <= 1024, "mage_vq_nearest: M=%ld D=%d K=%d unsupported", (long)M, D, K);
+    const size_t lds = (size_t)(16 * D + 16 + 16 * K) * 4;
+    MAGE_CHECK_ARG(lds <= 144 * 1024, "mage_vq_nearest: D=%d K=%d exceed the LDS budget", D, K);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)vq_nearest_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipFuncSetAttribute((const void*)vq_nearest_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipFuncSetAttribute((const void*)vq_nearest_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)((M + 15) / 16)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (K <= 256) hipLaunchKernelGGL((vq_nearest_kernel<1>), grid, blk, lds, s, z, codebook_t, c2, (long)M, D, K, idx, margin);
+    else if (K <= 512) hipLaunchKernelGGL((vq_nearest_kernel<2>), grid, blk, lds, s, z, codebook_t, c2, (long)M, D, K, idx, margin);
+    else hipLaunchKernelGGL((vq_nearest_kernel<4>), grid, blk, lds, s, z, codebook_t, c2, (long)M, D, K, idx, margin);
+    MAGE_CHECK_LAUNCH("mage_vq_nearest");
+    return MAGE_OK;
+}
+
+extern "C" int mage_embedding(const int64_t* ids, const float* table, void* out, int32_t out_dtype, int64_t n, int32_t C,
+                              int32_t n_table, int32_t relu, int64_t group, int64_t group_stride, int64_t off, void* stream) {
+    MAGE_CHECK_ARG(ids && table && out, "mage_embedding: null pointer");
+    MAGE_CHECK_ARG(n > 0 && C > 0 && C % 4 == 0 && n_table > 0 && group > 0, "mage_embedding: bad sizes n=%ld C=%d", (long)n, C);
+    const dim3 grid((unsigned)((n + 3) / 4)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == MAGE_F32)
+        hipLaunchKernelGGL((embedding_kernel<float>), grid, blk, 0, s, ids, table, (float*)out, (long)n, C, n_table, relu,
+                           (long)group, (long)group_stride, (long)off);
+    else if (out_dtype == MAGE_BF16)
+        hipLaunchKernelGGL((embedding_kernel<unsigned short>), grid, blk, 0, s, ids, table, (unsigned short*)out, (long)n, C,
+                           n_table, relu, (long)group, (long)group_stride, (long)off);
+    else {
+        mage_set_error("mage_embedding: bad out_dtype %d", out_dtype);
+        return MAGE_EINVAL;
+    }
+    MAGE_CHECK_LAUNCH("mage_embedding");
+    return MAGE_OK;
+}
+
+extern "C" int mage_argmax(const float* logits, int64_t rows, int32_t K, int64_t ld, int64_t group, int64_t in_group_stride,
+                           int64_t in_off, int64_t* out, int64_t out_group_stride, int64_t out_off, float* margin,
+                           void* stream) {
+    MAGE_CHECK_ARG(logits && out, "mage_argmax: null pointer");
+    MAGE_CHECK_ARG(rows > 0 && K > 0 && K % 4 == 0 && ld % 4 == 0 && group > 0, "mage_argmax: bad sizes rows=%ld K=%d", (long)rows, K);
+    hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, (long)rows,
+                       K, (long)ld, (long)group, (long)in_group_stride, (long)in_off, out, (long)out_group_stride,
+                       (long)out_off, margin);
+    MAGE_CHECK_LAUNCH("mage_argmax");
+    return MAGE_OK;
+}
+
+extern "C" int mage_cross_entropy(const float* logits, const int64_t* target, int64_t rows, int32_t K, float* row_loss,
+                                  float* loss_mean, void* stream) {
+    MAGE_CHECK_ARG(logits && target && row_loss && loss_mean, "mage_cross_entropy: null pointer");
+    MAGE_CHECK_ARG(rows > 0 && K > 0, "mage_cross_entropy: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, target, (long)rows, K, row_loss);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, row_loss, (long)rows, loss_mean, 1.0 / (double)rows);
+    MAGE_CHECK_LAUNCH("mage_cross_entropy");
+    return MAGE_OK;
+}

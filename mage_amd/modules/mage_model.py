@@ -1,0 +1,633 @@
+"""MI355X-native MAGE (drop-in for the reference's modules/mage_model.py).
+
+Same class names, constructor kwargs, ``forward`` / ``autoregressive_generate`` signatures and
+state_dict layout as the reference (mage_model.py:15-693).  ``nn.Linear`` /
+``nn.MultiheadAttention`` / ``nn.LayerNorm`` objects are parameter containers only; all arithmetic is
+libmage_hip.so: channels-last activations ([B, L, H, W, C] is a row-major [tokens, C] matrix), axial
+attention over strided row sets (no permute/contiguous copies -- the reference spends 19 % of its time
+there), LayerNorm / bias / QuickGELU / residual / positional tables fused around MFMA GEMMs.
+
+Precision: ``set_precision('fp32')`` (default; exact-fp32 MFMA, the parity mode) or ``'bf16'``
+(bf16 MFMA with fp32 accumulation for the decoder stack and VQ-VAE decode; the residual stream,
+LayerNorm, softmax, logits, the once-per-clip prologue and the VQ-VAE encode + quantiser stay fp32).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from math import exp
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..utils.util import default, instantiate_from_config, zero_module
+from .vqvae_model import VectorQuantizedVAE, _Derived, _conv_w, _no_torch_forward
+
+__all__ = ["QuickGELU", "AxialAttentionBlock", "TransformerBlock", "MAEncoder", "TransformerTextEncoder", "BasicBlock",
+           "ADAIN2D", "FlatAxialDecoder", "PIDControl", "MAGE"]
+
+F32 = torch.float32
+BF16 = torch.bfloat16
+
+
+def _sfx(dt: torch.dtype) -> str:
+    return ".f32" if dt == F32 else ".bf16"
+
+
+def _need_gpu(t: torch.Tensor, who: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{who} runs on libmage_hip.so kernels: move the model and the batch to a ROCm GPU "
+                           "(there is no CPU / PyTorch fallback)")
+
+
+def _pack_linear(d: Dict[str, torch.Tensor], name: str, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> None:
+    w = weight.float().contiguous()
+    d[name + ".f32"] = w
+    d[name + ".bf16"] = w.to(BF16)
+    if bias is not None:
+        d[name + ".b"] = bias.float().contiguous()
+
+
+def _linear(a, d, name, y, dt, *, M, N, K, **kw):
+    return ops.gemm(a, d[name + _sfx(dt)], y, M=M, N=N, K=K, lda=kw.pop("lda", K), ldy=kw.pop("ldy", N),
+                    bias=d.get(name + ".b"), **kw)
+
+
+class QuickGELU(nn.Module):
+    """x * sigmoid(1.702 x) (mage_model.py:11-13); fused into the c_fc GEMM epilogue on the GPU path."""
+
+    forward = _no_torch_forward
+
+
+def _mlp(d_model: int) -> nn.Sequential:
+    return nn.Sequential(OrderedDict([("c_fc", nn.Linear(d_model, d_model * 4)), ("gelu", QuickGELU()),
+                                      ("c_proj", nn.Linear(d_model * 4, d_model))]))
+
+
+class AxialAttentionBlock(nn.Module):
+    """Parameter container with the reference's keys (mage_model.py:15-29)."""
+
+    def __init__(self, d_model: int, n_head: int, dropout: float = 0.1, axial_dim: int = 1):
+        super().__init__()
+        self.d_model, self.n_head, self.axial_dim = d_model, n_head, axial_dim
+        self.attn = nn.MultiheadAttention(d_model, n_head)
+        self.ln_1 = nn.LayerNorm(d_model)
+        self.mlp = _mlp(d_model)
+        self.ln_2 = nn.LayerNorm(d_model)
+        self.dropout = nn.Dropout(dropout)
+
+    forward = _no_torch_forward
+
+
+class TransformerBlock(nn.Module):
+    """Parameter container (mage_model.py:72-85); ln_q / ln_kv exist in checkpoints but MAGE never applies them (:92)."""
+
+    def __init__(self, d_model: int, n_head: int, dropout: float = 0.1):
+        super().__init__()
+        self.d_model, self.n_head = d_model, n_head
+        self.attn = nn.MultiheadAttention(d_model, n_head)
+        self.ln_q = nn.LayerNorm(d_model)
+        self.ln_kv = nn.LayerNorm(d_model)
+        self.mlp = _mlp(d_model)
+        self.ln_2 = nn.LayerNorm(d_model)
+        self.dropout = nn.Dropout(dropout)
+
+    forward = _no_torch_forward
+
+
+def _pack_block(d: Dict[str, torch.Tensor], p: str, blk) -> None:
+    _pack_linear(d, p + ".in_proj", blk.attn.in_proj_weight, blk.attn.in_proj_bias)
+    _pack_linear(d, p + ".out_proj", blk.attn.out_proj.weight, blk.attn.out_proj.bias)
+    _pack_linear(d, p + ".c_fc", blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
+    _pack_linear(d, p + ".c_proj", blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
+    for ln in ("ln_1", "ln_2", "ln_q", "ln_kv"):
+        if hasattr(blk, ln):
+            d[f"{p}.{ln}.w"] = getattr(blk, ln).weight.float().contiguous()
+            d[f"{p}.{ln}.b"] = getattr(blk, ln).bias.float().contiguous()
+
+
+class MAEncoder(nn.Module):
+    """Motion-anchor cross-attention encoder (mage_model.py:104-117).  ``forward(x, kv)`` keeps the reference's
+    sequence-first convention: x [Tq, B, C], kv [Tk, B, C] -> [Tq, B, C]; rows are addressed by stride, not permuted."""
+
+    def __init__(self, layers: int, d_model: int, dropout: float = 0.1):
+        super().__init__()
+        self.d_model, self.layers = d_model, layers
+        self.blocks = nn.ModuleList([TransformerBlock(d_model, d_model // 32, dropout) for _ in range(layers)])
+        self.mage_plus = False          # True = the ln_q/ln_kv variant of mage_model.py:93 (MAGE+)
+        self._derived = _Derived(self)
+
+    def _build(self):
+        d: Dict[str, torch.Tensor] = {}
+        for i, blk in enumerate(self.blocks):
+            _pack_block(d, f"b{i}", blk)
+        return d
+
+    @torch.no_grad()
+    def _run(self, q: torch.Tensor, kv: torch.Tensor, *, B: int, nq: int, nk: int, seq_first: bool) -> torch.Tensor:
+        """q [B*nq, C] / kv [B*nk, C] fp32 rows (batch-first: row = b*n + i; seq-first: row = i*B + b)."""
+        d = self._derived.get(self._build)
+        Cc, dev, H = self.d_model, q.device, self.d_model // 32
+        x = q.float().contiguous().clone()
+        kv = kv.float().contiguous()
+        inner, qo, qa, ko, ka = (B, 0, B, 0, B) if seq_first else (1, nq, 1, nk, 1)
+        for i in range(self.layers):
+            p = f"b{i}"
+            qin, kvin = x, kv
+            if self.mage_plus:
+                qin = ops.layernorm(x, d[p + ".ln_q.w"], d[p + ".ln_q.b"], torch.empty_like(x), 1e-5)
+                kvin = ops.layernorm(kv, d[p + ".ln_kv.w"], d[p + ".ln_kv.b"], torch.empty_like(kv), 1e-5)
+            w, b = d[p + ".in_proj.f32"], d[p + ".in_proj.b"]
+            qp = ops.gemm(qin, w[:Cc], torch.empty(B * nq, Cc, device=dev, dtype=F32), M=B * nq, N=Cc, K=Cc, lda=Cc, ldy=Cc,
+                          bias=b[:Cc])
+            kvp = ops.gemm(kvin, w[Cc:], torch.empty(B * nk, 2 * Cc, device=dev, dtype=F32), M=B * nk, N=2 * Cc, K=Cc, lda=Cc,
+                           ldy=2 * Cc, bias=b[Cc:])
+            ao = torch.empty(B * nq, Cc, device=dev, dtype=F32)
+            ops.attention(qp, kvp[:, :Cc], kvp[:, Cc:], ao, ldq=Cc, ldk=2 * Cc, ldv=2 * Cc, ldo=Cc, n_seq=B, inner=inner,
+                          nq=nq, nk=nk, n_head=H, q_outer_stride=qo, q_axis_stride=qa, kv_outer_stride=ko, kv_axis_stride=ka)
+            _linear(ao, d, p + ".out_proj", x, F32, M=B * nq, N=Cc, K=Cc, residual=x, ldr=Cc)
+            xn = ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], torch.empty_like(x), 1e-5)
+            hdn = _linear(xn, d, p + ".c_fc", torch.empty(B * nq, 4 * Cc, device=dev, dtype=F32), F32, M=B * nq, N=4 * Cc, K=Cc,
+                          act=ops.ACT_QUICKGELU)
+            _linear(hdn, d, p + ".c_proj", x, F32, M=B * nq, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
+        return x
+
+    def forward(self, x: torch.Tensor, kv: torch.Tensor, key_mask=None, need_weights=False):
+        _need_gpu(x, "MAEncoder")
+        if key_mask is not None:
+            raise NotImplementedError("key_mask is never passed by MAGE (mage_model.py:596,657)")
+        Tq, B, Cc = x.shape
+        return self._run(x.reshape(Tq * B, Cc), kv.reshape(-1, Cc), B=B, nq=Tq, nk=kv.shape[0], seq_first=True).view(Tq, B, Cc)
+
+
+class TransformerTextEncoder(nn.Module):
+    """Text encoder (mage_model.py:180-250): token+position embedding -> LN(eps 1e-8) -> zero padded rows ->
+    post-norm encoder layers (erf-GELU, key-padding mask) -> LN -> Linear.  forward(text int64 [B,S]) -> [B,S,out]."""
+
+    def __init__(self, vocab_size: int, transformer_width: int, transformer_layers: int, output_dim: int,
+                 context_length: int, padding_idx: int = 0, dropout: float = 0.1):
+        super().__init__()
+        self.vocab_size, self.padding_idx = vocab_size, padding_idx
+        self.transformer_width, self.context_length = transformer_width, context_length
+        self.transformer_layers, self.output_dim = transformer_layers, output_dim
+        layer = nn.TransformerEncoderLayer(transformer_width, transformer_width // 32, dim_feedforward=transformer_width * 4,
+                                           dropout=dropout, activation="gelu")
+        self.transformer = nn.TransformerEncoder(layer, transformer_layers, enable_nested_tensor=False)
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width, padding_idx=padding_idx)
+        self.positions = nn.Embedding(context_length, transformer_width)
+        self.layer_norm = nn.LayerNorm(transformer_width, eps=1e-8, elementwise_affine=True)
+        self.dropout = nn.Dropout(p=dropout)
+        self.ln_text_final = nn.LayerNorm(transformer_width)
+        self.text_projection = nn.Linear(transformer_width, output_dim)
+        self.apply(self._init_weights)
+        self._derived = _Derived(self)
+
+    @staticmethod
+    def _init_weights(module):
+        """mage_model.py:211-221."""
+        if isinstance(module, nn.Linear):
+            module.weight.data.normal_(mean=0.0, std=0.02)
+        elif isinstance(module, nn.MultiheadAttention):
+            module.in_proj_weight.data.normal_(mean=0.0, std=0.02)
+            module.out_proj.weight.data.normal_(mean=0.0, std=0.02)
+        elif isinstance(module, nn.Embedding):
+            module.weight.data.normal_(mean=0.0, std=0.02)
+            if module.padding_idx is not None:
+                module.weight.data[module.padding_idx].zero_()
+
+    def _build(self):
+        d: Dict[str, torch.Tensor] = {"tok": self.token_embedding.weight.float().contiguous(),
+                                      "pos": self.positions.weight.float().contiguous()}
+        for n in ("layer_norm", "ln_text_final"):
+            d[n + ".w"], d[n + ".b"] = getattr(self, n).weight.float().contiguous(), getattr(self, n).bias.float().contiguous()
+        _pack_linear(d, "proj", self.text_projection.weight, self.text_projection.bias)
+        for i, l in enumerate(self.transformer.layers):
+            _pack_linear(d, f"l{i}.in_proj", l.self_attn.in_proj_weight, l.self_attn.in_proj_bias)
+            _pack_linear(d, f"l{i}.out_proj", l.self_attn.out_proj.weight, l.self_attn.out_proj.bias)
+            _pack_linear(d, f"l{i}.fc1", l.linear1.weight, l.linear1.bias)
+            _pack_linear(d, f"l{i}.fc2", l.linear2.weight, l.linear2.bias)
+            for n in ("norm1", "norm2"):
+                d[f"l{i}.{n}.w"], d[f"l{i}.{n}.b"] = getattr(l, n).weight.float().contiguous(), getattr(l, n).bias.float().contiguous()
+                d[f"l{i}.{n}.eps"] = getattr(l, n).eps
+        return d
+
+    @torch.no_grad()
+    def forward(self, text: torch.Tensor) -> torch.Tensor:
+        _need_gpu(text, "TransformerTextEncoder")
+        d = self._derived.get(self._build)
+        B, S = text.shape
+        if S > 64 or S > self.context_length:
+            raise ValueError(f"caption length {S} exceeds context_length {self.context_length} (kernel limit 64)")
+        Wd, dev, H = self.transformer_width, text.device, self.transformer_width // 32
+        ids = text.to(torch.int64).contiguous()
+        keep = ids != self.padding_idx                                   # index plumbing (masks / lengths), not arithmetic
+        kv_len = keep.sum(-1).to(torch.int32).contiguous()
+        x = ops.embedding(ids, d["tok"], torch.empty(B * S, Wd, device=dev, dtype=F32))
+        ops.row_affine(x, None, d["pos"], div=1, mod=S)                  # + positions[0..S)       (:227-228)
+        ops.layernorm(x, d["layer_norm.w"], d["layer_norm.b"], x, self.layer_norm.eps)
+        ops.row_affine(x, keep.reshape(-1).to(F32).contiguous(), None)   # zero padded rows          (:233-235)
+        for i in range(self.transformer_layers):
+            p = f"l{i}"
+            qkv = _linear(x, d, p + ".in_proj", torch.empty(B * S, 3 * Wd, device=dev, dtype=F32), F32, M=B * S, N=3 * Wd, K=Wd)
+            ao = torch.empty(B * S, Wd, device=dev, dtype=F32)
+            ops.attention(qkv, qkv[:, Wd:], qkv[:, 2 * Wd:], ao, ldq=3 * Wd, ldk=3 * Wd, ldv=3 * Wd, ldo=Wd, n_seq=B, inner=1,
+                          nq=S, nk=S, n_head=H, q_outer_stride=S, q_axis_stride=1, kv_outer_stride=S, kv_axis_stride=1,
+                          kv_len=kv_len, kv_len_div=1)
+            _linear(ao, d, p + ".out_proj", x, F32, M=B * S, N=Wd, K=Wd, residual=x, ldr=Wd)
+            ops.layernorm(x, d[p + ".norm1.w"], d[p + ".norm1.b"], x, d[p + ".norm1.eps"])
+            hdn = _linear(x, d, p + ".fc1", torch.empty(B * S, 4 * Wd, device=dev, dtype=F32), F32, M=B * S, N=4 * Wd, K=Wd,
+                          act=ops.ACT_GELU_ERF)
+            _linear(hdn, d, p + ".fc2", x, F32, M=B * S, N=Wd, K=4 * Wd, residual=x, ldr=Wd)
+            ops.layernorm(x, d[p + ".norm2.w"], d[p + ".norm2.b"], x, d[p + ".norm2.eps"])
+        ops.layernorm(x, d["ln_text_final.w"], d["ln_text_final.b"], x, self.ln_text_final.eps)
+        out = _linear(x, d, "proj", torch.empty(B * S, self.output_dim, device=dev, dtype=F32), F32, M=B * S, N=self.output_dim,
+                      K=Wd)
+        return out.view(B, S, self.output_dim)
+
+
+class BasicBlock(nn.Module):
+    """Conv3d + GroupNorm video-prior block (mage_model.py:264-297): TRAINING-ONLY (MAGE.forward with
+    randomness=True); kept as a parameter container so checkpoints load.  'next' row, SURVEY.md 8f-3."""
+
+    def __init__(self, in_planes, out_planes, stride=1, stride_t=1, downsample=False, spectral=False):
+        super().__init__()
+        st = [stride_t, stride, stride]
+        self.conv1 = nn.Conv3d(in_planes, out_planes, kernel_size=(3, 3, 3), stride=st, padding=1, bias=False)
+        self.bn1 = nn.GroupNorm(num_groups=16, num_channels=out_planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv3d(out_planes, out_planes, kernel_size=(3, 3, 3), stride=[1, 1, 1], padding=1, bias=False)
+        self.bn2 = nn.GroupNorm(num_groups=16, num_channels=out_planes)
+        self.downsample = nn.Sequential(nn.Conv3d(in_planes, out_planes, kernel_size=(3, 3, 3), stride=st, padding=[1, 1, 1],
+                                                  bias=False),
+                                        nn.GroupNorm(num_channels=out_planes, num_groups=16)) if downsample else None
+        self.stride = stride
+        if spectral:
+            self.conv1 = torch.nn.utils.spectral_norm(self.conv1)
+            self.conv2 = torch.nn.utils.spectral_norm(self.conv2)
+
+    forward = _no_torch_forward
+
+
+class ADAIN2D(nn.Module):
+    """InstanceNorm2d(x) * conv_mu(y) + conv_var(y) (mage_model.py:299-314).  forward(x, y) takes the reference's
+    NCHW tensors; the GPU path runs channels-last."""
+
+    def __init__(self, num_features, z_dim):
+        super().__init__()
+        self.num_features = num_features
+        self.norm = nn.InstanceNorm2d(num_features, affine=False, track_running_stats=False)
+        self.conv_mu = nn.Sequential(nn.Conv2d(z_dim, num_features, 3, 1, 1), nn.Conv2d(num_features, num_features, 3, 1, 1))
+        self.conv_var = nn.Sequential(nn.Conv2d(z_dim, num_features, 3, 1, 1), nn.Conv2d(num_features, num_features, 3, 1, 1))
+        self._derived = _Derived(self)
+
+    def _build(self):
+        d: Dict[str, torch.Tensor] = {}
+        for n, seq in (("mu", self.conv_mu), ("var", self.conv_var)):
+            for j in range(2):
+                d[f"{n}{j}.w"] = _conv_w(seq[j])
+                d[f"{n}{j}.b"] = seq[j].bias.float().contiguous()
+        return d
+
+    @torch.no_grad()
+    def _run(self, x_rows: torch.Tensor, y_rows: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+        """x_rows [B*H*W, C] fp32 (motion anchor), y_rows [B*H*W, z] fp32 -> [B*H*W, C]."""
+        d = self._derived.get(self._build)
+        Cc, z, dev = self.num_features, y_rows.shape[1], x_rows.device
+        outs = []
+        for n in ("mu", "var"):
+            t = VectorQuantizedVAE._conv(y_rows, d[n + "0.w"], torch.empty(B * H * W, Cc, device=dev, dtype=F32), n_img=B, H=H,
+                                         W=W, cin=z, cout=Cc, k=3, bias=d[n + "0.b"])
+            outs.append(VectorQuantizedVAE._conv(t, d[n + "1.w"], torch.empty(B * H * W, Cc, device=dev, dtype=F32), n_img=B,
+                                                 H=H, W=W, cin=Cc, cout=Cc, k=3, bias=d[n + "1.b"]))
+        return ops.adain(x_rows, outs[0], outs[1], torch.empty_like(x_rows), B=B, P=H * W, Cc=Cc, eps=self.norm.eps)
+
+    def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        _need_gpu(x, "ADAIN2D")
+        B, Cc, H, W = x.shape
+        xr = x.permute(0, 2, 3, 1).reshape(B * H * W, Cc).float().contiguous()
+        yr = y.permute(0, 2, 3, 1).reshape(B * H * W, -1).float().contiguous()
+        return self._run(xr, yr, B, H, W).view(B, H, W, Cc).permute(0, 3, 1, 2)
+
+
+class FlatAxialDecoder(nn.Module):
+    """Axial-attention AR decoder (mage_model.py:317-390): in/context Linear -> concat along L -> + T positions ->
+    `layers` blocks attending along L (causal), H, W in turn -> Linear head on x[:, 1:]."""
+
+    def __init__(self, in_channels, model_channels, out_channels, frames_length, layers, context_channels=None, use_cids=True,
+                 dropout=0.1):
+        super().__init__()
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.frames_length, self.layers = frames_length, layers
+        self.in_linear = nn.Linear(in_channels, model_channels)
+        context_channels = default(context_channels, in_channels)
+        self.context_channels = context_channels
+        self.context_linear = nn.Linear(context_channels, model_channels)
+        scale = model_channels ** -0.5
+        self.T_positional_embedding = nn.Parameter(scale * torch.randn(frames_length, 1, 1, model_channels))
+        num_heads = model_channels // 32
+        self.blocks = nn.ModuleList([AxialAttentionBlock(model_channels, num_heads, axial_dim=i % 3 + 1, dropout=dropout)
+                                     for i in range(layers)])
+        self.use_cids = use_cids
+        if use_cids:
+            self.out = nn.Linear(model_channels, out_channels)
+        else:
+            self.out = nn.Sequential(nn.GroupNorm(32, model_channels), nn.SiLU(),
+                                     zero_module(nn.Conv3d(model_channels, out_channels, 1)))
+        self.initialize_parameters()
+        self.compute_dtype = F32
+        self._derived = _Derived(self)
+
+    def initialize_parameters(self):
+        """mage_model.py:357-365."""
+        proj_std = (self.model_channels ** -0.5) * ((2 * self.layers) ** -0.5)
+        attn_std = self.model_channels ** -0.5
+        fc_std = (2 * self.model_channels) ** -0.5
+        for block in self.blocks:
+            nn.init.normal_(block.attn.in_proj_weight, std=attn_std)
+            nn.init.normal_(block.attn.out_proj.weight, std=proj_std)
+            nn.init.normal_(block.mlp.c_fc.weight, std=fc_std)
+            nn.init.normal_(block.mlp.c_proj.weight, std=proj_std)
+
+    def build_casual_attention_mask(self):
+        """Kept for API parity (mage_model.py:367-372); the GPU attention kernel applies j <= i directly."""
+        mask = torch.empty(self.frames_length, self.frames_length)
+        mask.fill_(float("-inf"))
+        mask.triu_(1)
+        return mask
+
+    def _build(self):
+        d: Dict[str, torch.Tensor] = {}
+        _pack_linear(d, "in_linear", self.in_linear.weight, self.in_linear.bias)
+        _pack_linear(d, "context_linear", self.context_linear.weight, self.context_linear.bias)
+        if self.use_cids:
+            _pack_linear(d, "out", self.out.weight, self.out.bias)
+        d["tpos"] = self.T_positional_embedding.float().reshape(self.frames_length, self.model_channels).contiguous()
+        for i, blk in enumerate(self.blocks):
+            _pack_block(d, f"b{i}", blk)
+        return d
+
+    @torch.no_grad()
+    def _run(self, motion: torch.Tensor, imgs: torch.Tensor, *, B: int, hh: int, ww: int) -> torch.Tensor:
+        """motion [B*hw, Cc], imgs [B*(L-1)*hw, Ci] in the compute dtype -> logits [B*(L-1)*hw, K] fp32."""
+        if not self.use_cids:
+            raise NotImplementedError("use_cids=False (MAGE+ GroupNorm/SiLU/Conv3d head) is a 'next' row (SURVEY.md 8f-3)")
+        d = self._derived.get(self._build)
+        dt, Cc, L, dev = self.compute_dtype, self.model_channels, self.frames_length, motion.device
+        hw = hh * ww
+        M = B * L * hw
+        H = Cc // 32
+        x = torch.empty(M, Cc, device=dev, dtype=F32)                              # residual stream, fp32
+        # context_linear -> slot 0, in_linear -> slots 1..L-1, + T_positional_embedding, no concat copy (:375-378)
+        _linear(motion, d, "context_linear", x, dt, M=B * hw, N=Cc, K=self.context_channels, out_w=hw, y_img_stride=L * hw,
+                rowadd=d["tpos"], rowadd_div=hw, rowadd_mod=L)
+        _linear(imgs, d, "in_linear", x, dt, M=B * (L - 1) * hw, N=Cc, K=self.in_channels, out_w=(L - 1) * hw,
+                y_img_stride=L * hw, y_off=hw, rowadd=d["tpos"], rowadd_div=hw, rowadd_mod=L)
+        xn = torch.empty(M, Cc, device=dev, dtype=dt)
+        qkv = torch.empty(M, 3 * Cc, device=dev, dtype=dt)
+        ao = torch.empty(M, Cc, device=dev, dtype=dt)
+        hdn = torch.empty(M, 4 * Cc, device=dev, dtype=dt)
+        for i in range(self.layers):
+            p = f"b{i}"
+            axis = i % 3                                                            # 0: L (causal), 1: H, 2: W  (:344,:382)
+            if axis == 0:
+                geo = dict(n_seq=B * hw, inner=hw, nq=L, nk=L, q_outer_stride=L * hw, q_axis_stride=hw, causal=True)
+            elif axis == 1:
+                geo = dict(n_seq=B * L * ww, inner=ww, nq=hh, nk=hh, q_outer_stride=hw, q_axis_stride=ww, causal=False)
+            else:
+                geo = dict(n_seq=B * L * hh, inner=1, nq=ww, nk=ww, q_outer_stride=ww, q_axis_stride=1, causal=False)
+            ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], xn, 1e-5)
+            _linear(xn, d, p + ".in_proj", qkv, dt, M=M, N=3 * Cc, K=Cc)
+            ops.attention(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], ao, ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=Cc, n_head=H,
+                          kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], **geo)
+            _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc)
+            ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5)
+            _linear(xn, d, p + ".c_fc", hdn, dt, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU)
+            _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
+        xa = x if dt == F32 else ops.cast(x, xn)
+        logits = torch.empty(B * (L - 1) * hw, self.out_channels, device=dev, dtype=F32)
+        _linear(xa, d, "out", logits, dt, M=B * (L - 1) * hw, N=self.out_channels, K=Cc, out_w=(L - 1) * hw,
+                a_img_stride=L * hw, a_off=hw)                                      # head on x[:, 1:]  (:385)
+        return logits
+
+    def forward(self, motion: torch.Tensor, imgs: torch.Tensor) -> torch.Tensor:
+        """motion [B,H,W,Cc], imgs [B,L-1,H,W,Ci] -> logits [B,L-1,H,W,out] fp32."""
+        _need_gpu(motion, "FlatAxialDecoder")
+        B, hh, ww, _ = motion.shape
+        dt = self.compute_dtype
+        m = motion.reshape(B * hh * ww, -1).to(dt).contiguous()
+        im = imgs.reshape(-1, imgs.shape[-1]).to(dt).contiguous()
+        return self._run(m, im, B=B, hh=hh, ww=ww).view(B, self.frames_length - 1, hh, ww, self.out_channels)
+
+
+class PIDControl:
+    """KL-weight PI controller (mage_model.py:394-434); host-side scalar bookkeeping, training only."""
+
+    def __init__(self):
+        self.I_k1 = 0.0
+        self.W_k1 = 0.0
+        self.e_k1 = 0.0
+
+    def _Kp_fun(self, Err, scale=1):
+        return 1.0 / (1.0 + float(scale) * exp(Err))
+
+    def pid(self, exp_KL, KL_loss, Kp=0.01, Ki=-0.0001, Kd=0.0):
+        error_k = exp_KL - KL_loss
+        Pk = Kp * self._Kp_fun(error_k)
+        Ik = self.I_k1 + Ki * error_k
+        if self.W_k1 < 0 and self.W_k1 >= 1:      # (sic) never true in the reference either
+            Ik = self.I_k1
+        Wk = Pk + Ik
+        self.W_k1, self.I_k1, self.e_k1 = Wk, Ik, error_k
+        return min(max(Wk, 0.0), 1.0), error_k
+
+
+def disabled_train(self, mode=True):
+    return self
+
+
+class MAGE(nn.Module):
+    def __init__(self, first_stage_config, text_encoder_config, ma_config, generate_decoder_config, codebook_size: int,
+                 frames_length: int, image_resolution: int, vision_width: int, dropout: float = 0.1, use_cids=False,
+                 randomness=False, alpha=0., beta=1., v_kl=0., auto_beta=False):
+        super().__init__()
+        self.instantiate_first_stage(first_stage_config)
+        self.frames_length, self.image_resolution, self.vision_width = frames_length, image_resolution, vision_width
+        self.dropout, self.use_cids, self.auto_beta = dropout, use_cids, auto_beta
+        self.text_encoder = instantiate_from_config(text_encoder_config)
+        self.ma_encoder = instantiate_from_config(ma_config, {"dropout": dropout})
+        self.generate_model = instantiate_from_config(
+            generate_decoder_config, {"use_cids": use_cids, "dropout": dropout, "context_channels": ma_config["params"]["d_model"]})
+        self.codebook_size = codebook_size
+        if use_cids:
+            self.visual_token_embedding = nn.Embedding(codebook_size, vision_width)
+        else:
+            self.visual_token_embedding = nn.Linear(self.first_stage_model.embed_dim, vision_width)
+        self.conv = nn.Sequential(nn.Conv2d(vision_width, vision_width, kernel_size=3, stride=1, padding=1, bias=False))
+        scale = vision_width ** -0.5
+        self.speed_embedding = nn.Parameter(scale * torch.randn(1, vision_width))
+        self.H_positional_embedding = nn.Parameter(scale * torch.randn(1, image_resolution, 1, vision_width))
+        self.W_positional_embedding = nn.Parameter(scale * torch.randn(1, 1, image_resolution, vision_width))
+        self.randomness = randomness
+        if randomness:
+            dm = ma_config["params"]["d_model"]
+            self.conv3d = nn.Sequential(*[BasicBlock(vision_width, vision_width if i < 3 else dm, stride=1, stride_t=2,
+                                                     downsample=True) for i in range(4)])
+            self.conv_mu2 = nn.Conv2d(vision_width, 64, 3, 1, 1)
+            self.conv_var2 = nn.Conv2d(vision_width, 64, 3, 1, 1)
+            self.conv_d2 = nn.Conv2d(64, vision_width, kernel_size=3, stride=1, padding=1, bias=False)
+            self.adain = ADAIN2D(vision_width, vision_width)
+            if auto_beta:
+                self.PID = PIDControl()
+                self.KL_loss = v_kl
+            else:
+                self.alpha, self.beta = alpha, beta
+        self.initialize_parameters()
+        self.precision = "fp32"
+        self.ar_mode = "full"          # 'full' = the reference's per-iteration full recompute (mage_model.py:673-684)
+        self._derived = _Derived(self)
+        self.last_tokens: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ construction helpers
+    def instantiate_first_stage(self, config):
+        """Frozen, eval, train() disabled (mage_model.py:516-521)."""
+        model = instantiate_from_config(config)
+        self.first_stage_model = model.eval()
+        self.first_stage_model.train = disabled_train.__get__(self.first_stage_model)
+        for p in self.first_stage_model.parameters():
+            p.requires_grad = False
+
+    def initialize_parameters(self):
+        nn.init.normal_(self.visual_token_embedding.weight, std=0.02)            # mage_model.py:524
+
+    def set_precision(self, precision: str) -> "MAGE":
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
+        self.generate_model.compute_dtype = F32 if precision == "fp32" else BF16
+        self.first_stage_model.set_precision(precision)
+        return self
+
+    def _dt(self) -> torch.dtype:
+        return F32 if self.precision == "fp32" else BF16
+
+    def _build(self):
+        d: Dict[str, torch.Tensor] = {}
+        if self.use_cids:
+            d["emb"] = self.visual_token_embedding.weight.float().contiguous()
+        cw = _conv_w(self.conv[0])
+        d["conv.f32"], d["conv.bf16"] = cw, cw.to(BF16)
+        R, Cc = self.image_resolution, self.vision_width
+        d["hwpos"] = (self.H_positional_embedding.float() + self.W_positional_embedding.float()).reshape(R * R, Cc).contiguous()
+        d["speed"] = self.speed_embedding.float().reshape(-1).contiguous()
+        if self.randomness:
+            d["conv_d2"] = _conv_w(self.conv_d2)
+        return d
+
+    # ------------------------------------------------------------------ first stage wrappers (mage_model.py:530-567)
+    @torch.no_grad()
+    def first_stage_encode(self, x):
+        """[B, T, C, H, W] -> token ids int64 [B, T, h, w]."""
+        out = self.first_stage_model.encode(x.reshape(-1, *x.shape[-3:]))
+        return self.get_first_stage_encoding(out).view(*x.shape[:-3], *out.shape[1:]).contiguous()
+
+    def get_first_stage_encoding(self, encoder_posterior):
+        if isinstance(encoder_posterior, torch.Tensor):
+            return encoder_posterior
+        raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
+
+    @torch.no_grad()
+    def first_stage_decode(self, x):
+        """[B, T, h, w] ids -> [B, T, C, H, W]."""
+        out = self.first_stage_model.decode(x.reshape(-1, *x.shape[-2:]) if self.use_cids else x.reshape(-1, *x.shape[-3:]))
+        return out.view(*x.shape[:2], *out.shape[1:]).contiguous()
+
+    # ------------------------------------------------------------------ shared pieces
+    def _frame_features(self, tokens: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+        """ids [n, hw] -> conv3x3(embedding) + (H_pos + W_pos) as rows [n*hw, C] (mage_model.py:581,586-588,674-676)."""
+        d = self._derived.get(self._build)
+        R, Cc = self.image_resolution, self.vision_width
+        n = tokens.numel() // (R * R)
+        emb = ops.embedding(tokens.reshape(-1), d["emb"], torch.empty(n * R * R, Cc, device=tokens.device, dtype=dt))
+        return VectorQuantizedVAE._conv(emb, d["conv" + _sfx(dt)], torch.empty_like(emb), n_img=n, H=R, W=R, cin=Cc, cout=Cc,
+                                        k=3, rowadd=d["hwpos"], rowadd_div=1, rowadd_mod=R * R)
+
+    def _motion_anchor(self, tok0: torch.Tensor, batch, noise: Optional[torch.Tensor]) -> torch.Tensor:
+        """Once-per-clip prologue, fp32 (mage_model.py:648-668): rows [B*hw, C]."""
+        d = self._derived.get(self._build)
+        B = tok0.shape[0]
+        R, Cc = self.image_resolution, self.vision_width
+        first = self._frame_features(tok0, F32)                                               # [B*hw, C]
+        txt = self.text_encoder(batch["text"])                                                # [B, S, C]
+        S = txt.shape[1]
+        ma = self.ma_encoder._run(first, txt.reshape(B * S, -1), B=B, nq=R * R, nk=S, seq_first=False)
+        if self.randomness:
+            if noise is None:
+                noise = torch.randn([B, 64, R, R], device=ma.device)                          # mage_model.py:661
+            nz = noise.float().permute(0, 2, 3, 1).reshape(B * R * R, 64).contiguous()
+            y = VectorQuantizedVAE._conv(nz, d["conv_d2"], torch.empty(B * R * R, Cc, device=ma.device, dtype=F32), n_img=B,
+                                         H=R, W=R, cin=64, cout=Cc, k=3)
+            ma = self.adain._run(ma, y, B, R, R)
+        if "speed" in batch:
+            ops.add_scaled_rowvec(ma, batch["speed"].float().contiguous(), d["speed"], B=B, P=R * R, Cc=Cc)
+        return ma
+
+    # ------------------------------------------------------------------ sampling (mage_model.py:641-693)
+    @torch.no_grad()
+    def autoregressive_generate(self, batch):
+        """batch {'images' [B,L,C,H,W] (only frame 0 is read), 'text' int64 [B,S], 'speed' [B] optional,
+        'video_noise' [B,64,h,w] optional (injects the randomness-branch noise instead of torch.randn)} -> [B,L,C,H,W]."""
+        images = batch["images"]
+        _need_gpu(images, "MAGE.autoregressive_generate")
+        if not self.use_cids:
+            raise NotImplementedError("use_cids=False (MAGE+ over an ldm AutoencoderKL) is a 'next' row (SURVEY.md 8f-3)")
+        B = images.shape[0]
+        R, L, K = self.image_resolution, self.frames_length, self.codebook_size
+        hw, Lm1 = R * R, self.frames_length - 1
+        dt = self._dt()
+        tok0 = self.first_stage_encode(images[:, 0:1])[:, 0].reshape(B, hw)                   # :642
+        ma = self._motion_anchor(tok0, batch, batch.get("video_noise"))
+        ma_dt = ma if dt == F32 else ma.to(dt)                                                # dtype plumbing of a [B*hw, C] tensor
+        cur = tok0[:, None, :].repeat(1, Lm1, 1).contiguous()                                 # :670 future slots hold frame 0
+        logits = None
+        for i in range(Lm1):                                                                  # :673-684
+            feats = self._frame_features(cur, dt)
+            logits = self.generate_model._run(ma_dt, feats, B=B, hh=R, ww=R)                  # [B*(L-1)*hw, K]
+            if i != Lm1 - 1:                                                                  # argmax of frame i -> slot i+1
+                ops.argmax(logits, cur, rows=B * hw, K=K, group=hw, in_group_stride=Lm1 * hw, in_off=i * hw,
+                           out_group_stride=Lm1 * hw, out_off=(i + 1) * hw)
+        gen = torch.empty(B, Lm1, R, R, device=images.device, dtype=torch.int64)
+        ops.argmax(logits, gen, rows=B * Lm1 * hw, K=K)                                       # :687
+        self.last_tokens, self.last_logits = gen, logits.view(B, Lm1, R, R, K)
+        video = self.first_stage_decode(gen)                                                  # :690
+        return torch.cat([images[:, 0:1].to(video.dtype), video], 1)                         # :691
+
+    # ------------------------------------------------------------------ teacher-forced pass (mage_model.py:575-639)
+    @torch.no_grad()
+    def teacher_forced_logits(self, batch):
+        """tokens [B, L, h, w] and logits [B, L-1, h, w, K] of one teacher-forced decoder pass."""
+        images = batch["images"]
+        _need_gpu(images, "MAGE.forward")
+        if not self.use_cids:
+            raise NotImplementedError("use_cids=False is a 'next' row (SURVEY.md 8f-3)")
+        if self.randomness:
+            raise NotImplementedError("MAGE.forward with randomness=True needs the Conv3d video prior (training-only, "
+                                      "SURVEY.md 8f-3); sampling with randomness=True is supported")
+        B = images.shape[0]
+        R, L = self.image_resolution, self.frames_length
+        dt = self._dt()
+        tok = self.first_stage_encode(images).reshape(B, -1, R * R)                          # :579
+        ma = self._motion_anchor(tok[:, 0].contiguous(), batch, None)
+        feats = self._frame_features(tok[:, :L - 1].contiguous(), dt)
+        logits = self.generate_model._run(ma if dt == F32 else ma.to(dt), feats, B=B, hh=R, ww=R)
+        return tok.view(B, -1, R, R), logits.view(B, L - 1, R, R, self.codebook_size)
+
+    def forward(self, batch, test_flag=False):
+        """(loss, loss_dict) of the teacher-forced pass.  Values only: the HIP path builds no autograd graph yet
+        (backward kernels are a 'next' row), so ``loss.backward()`` raises."""
+        tok, logits = self.teacher_forced_logits(batch)
+        L = self.frames_length
+        loss = ops.cross_entropy(logits.reshape(-1, self.codebook_size), tok[:, 1:L].reshape(-1).contiguous())   # :618
+        prefix = "train" if self.training else "val"
+        val = loss.item()
+        return loss, {f"{prefix}/prediction": val, f"{prefix}/final_loss": val}

@@ -1,0 +1,386 @@
+"""MI355X-native VQ-VAE first stage (drop-in for the reference's modules/vqvae_model.py).
+
+Same public surface -- ``VectorQuantizedVAE(input_dim, down_ratio, dim, K=512, ckpt_path=None,
+ignore_keys=[])``, ``.encode(x) -> int64 [N,h,w]``, ``.decode(latents) -> f32 [N,C,H,W]``,
+``.forward(x) -> (x_tilde, z_e_x, z_q_x)`` -- and the same state_dict keys/shapes
+(vqvae_model.py:168-248), but nothing below runs a torch op on the data:
+``nn.Conv2d`` / ``nn.BatchNorm2d`` objects are only parameter containers that give the reference's
+key names; the arithmetic is libmage_hip.so (channels-last activations, BatchNorm(eval) + bias +
+ReLU + residual fused into the implicit-GEMM epilogues, ConvTranspose as 4 sub-pixel GEMMs).
+
+Inference only (this is how MAGE uses it: frozen + eval, mage_model.py:516-521).  Training-mode
+BatchNorm and the straight-through backward (vqvae_model.py:34-65) are not built yet and raise.
+"""
+from __future__ import annotations
+
+from itertools import chain
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from .. import ops
+
+__all__ = ["VectorQuantizedVAE", "VQEmbedding", "ResBlock", "EncoderBlock", "DecoderBlock", "weights_init"]
+
+
+def weights_init(m: nn.Module) -> None:
+    """xavier-uniform conv weights, zero bias (reference vqvae_model.py:77-84)."""
+    if "Conv" in m.__class__.__name__ and hasattr(m, "weight"):
+        nn.init.xavier_uniform_(m.weight.data)
+        if getattr(m, "bias", None) is not None:
+            m.bias.data.zero_()
+
+
+def _no_torch_forward(self, *a, **k):
+    raise RuntimeError(f"{type(self).__name__} is a parameter container; the arithmetic runs in libmage_hip.so "
+                       "through VectorQuantizedVAE.encode/decode/forward")
+
+
+class VQEmbedding(nn.Module):
+    """Codebook holder: ``embedding.weight`` [K, D] ~ U(-1/K, 1/K) (vqvae_model.py:87-91)."""
+
+    def __init__(self, K: int, D: int):
+        super().__init__()
+        self.embedding = nn.Embedding(K, D)
+        self.embedding.weight.data.uniform_(-1.0 / K, 1.0 / K)
+
+    forward = _no_torch_forward
+
+
+class ResBlock(nn.Module):
+    """Keys block.{1,2,4,5}.* (vqvae_model.py:111-124)."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.block = nn.Sequential(nn.ReLU(True), nn.Conv2d(dim, dim, 3, 1, 1), nn.BatchNorm2d(dim), nn.ReLU(True),
+                                   nn.Conv2d(dim, dim, 1), nn.BatchNorm2d(dim))
+
+    forward = _no_torch_forward
+
+
+def _bottleneck(dim_in: int, dim_out: int, first_k: int, last_k: int) -> nn.Sequential:
+    hid = dim_out // 4
+    ks = [first_k, 3, 3, last_k]
+    chans = [dim_in, hid, hid, hid, dim_out]
+    layers: List[nn.Module] = []
+    for i, k in enumerate(ks):
+        layers += [nn.ReLU(), nn.Conv2d(chans[i], chans[i + 1], k, 1, k // 2)]
+    return nn.Sequential(*layers)
+
+
+class EncoderBlock(nn.Module):
+    """3x3,3x3,3x3,1x1 bottleneck + id path (vqvae_model.py:126-145)."""
+
+    def __init__(self, dim_in: int, dim_out: int):
+        super().__init__()
+        self.dim_in, self.dim_out, self.dim_hid = dim_in, dim_out, dim_out // 4
+        self.id_path = nn.Conv2d(dim_in, dim_out, 1) if dim_in != dim_out else nn.Identity()
+        self.block = _bottleneck(dim_in, dim_out, 3, 1)
+
+    forward = _no_torch_forward
+
+
+class DecoderBlock(nn.Module):
+    """1x1,3x3,3x3,3x3 bottleneck + id path (vqvae_model.py:147-166)."""
+
+    def __init__(self, dim_in: int, dim_out: int):
+        super().__init__()
+        self.dim_in, self.dim_out, self.dim_hid = dim_in, dim_out, dim_out // 4
+        self.id_path = nn.Conv2d(dim_in, dim_out, 1) if dim_in != dim_out else nn.Identity()
+        self.block = _bottleneck(dim_in, dim_out, 1, 3)
+
+    forward = _no_torch_forward
+
+
+class _Derived:
+    """Device-side derived caches (channels-last / transposed / bf16 weight copies, folded BN vectors).
+    Rebuilt whenever a parameter or buffer is replaced or modified in place (load_state_dict, .to())."""
+
+    def __init__(self, module: nn.Module):
+        self._m = module
+        self._sig = None
+        self._store: Dict[str, torch.Tensor] = {}
+
+    def get(self, builder) -> Dict[str, torch.Tensor]:
+        sig = tuple((t.data_ptr(), t._version, t.device) for t in chain(self._m.parameters(), self._m.buffers()))
+        if sig != self._sig:
+            with torch.no_grad():
+                self._store = builder()
+            self._sig = sig
+        return self._store
+
+
+def _bn_vectors(bn: nn.BatchNorm2d):
+    """eval BatchNorm as y = x*alpha + beta  (alpha = w/sqrt(var+eps), beta = b - mean*alpha)."""
+    alpha = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+    return alpha.contiguous(), (bn.bias.float() - bn.running_mean.float() * alpha).contiguous()
+
+
+def _conv_w(conv: nn.Conv2d) -> torch.Tensor:
+    """[Cout, Cin, kh, kw] -> GEMM weight [Cout, kh*kw*Cin] (ci fastest)."""
+    w = conv.weight.float()
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+class VectorQuantizedVAE(nn.Module):
+    def __init__(self, input_dim, down_ratio, dim, K=512, ckpt_path=None, ignore_keys=[]):
+        super().__init__()
+        self.input_dim, self.down_ratio, self.dim, self.K = input_dim, down_ratio, dim, K
+        if down_ratio == 4:                                           # vqvae_model.py:171-190
+            self.encoder = nn.Sequential(nn.Conv2d(input_dim, dim, 4, 2, 1), nn.BatchNorm2d(dim), nn.ReLU(True),
+                                         nn.Conv2d(dim, dim, 4, 2, 1), ResBlock(dim), ResBlock(dim))
+            self.decoder = nn.Sequential(ResBlock(dim), ResBlock(dim), nn.ReLU(True), nn.ConvTranspose2d(dim, dim, 4, 2, 1),
+                                         nn.BatchNorm2d(dim), nn.ReLU(True), nn.ConvTranspose2d(dim, input_dim, 4, 2, 1),
+                                         nn.Tanh())
+            self.codebook = VQEmbedding(K, dim)
+        elif down_ratio == 8:                                         # vqvae_model.py:191-215
+            self.encoder = nn.Sequential(nn.Conv2d(input_dim, dim, 7, padding=3), EncoderBlock(dim, dim), nn.MaxPool2d(2),
+                                         EncoderBlock(dim, dim), nn.MaxPool2d(2), EncoderBlock(dim, 2 * dim),
+                                         nn.MaxPool2d(2), EncoderBlock(2 * dim, 4 * dim), nn.ReLU())
+            self.decoder = nn.Sequential(DecoderBlock(4 * dim, 2 * dim), nn.Upsample(scale_factor=2, mode="nearest"),
+                                         DecoderBlock(2 * dim, dim), nn.Upsample(scale_factor=2, mode="nearest"),
+                                         DecoderBlock(dim, dim), nn.Upsample(scale_factor=2, mode="nearest"),
+                                         DecoderBlock(dim, dim), nn.ReLU(), nn.Conv2d(dim, input_dim, 1), nn.Tanh())
+            self.codebook = VQEmbedding(K, 4 * dim)
+        else:
+            raise ValueError(f"down_ratio must be 4 or 8, got {down_ratio}")
+        self.apply(weights_init)
+        self.decode_dtype = torch.float32          # torch.bfloat16 = MFMA-bf16 performance mode for decode
+        self.decode_chunk = 256                    # frames per decode launch group (bounds workspace)
+        self._derived = _Derived(self)
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
+
+    # ------------------------------------------------------------------ checkpoint (vqvae_model.py:222-231)
+    def init_from_ckpt(self, path, ignore_keys=list()):
+        sd = torch.load(path, map_location="cpu")
+        for k in list(sd.keys()):
+            if any(k.startswith(ik) for ik in ignore_keys):
+                print("Deleting key {} from state_dict.".format(k))
+                del sd[k]
+        self.load_state_dict(sd, strict=False)
+        print(f"Restored from {path}")
+
+    def set_precision(self, precision: str) -> "VectorQuantizedVAE":
+        """'fp32' (parity: exact-fp32 MFMA) or 'bf16' (decode stack on bf16 MFMA; encode + VQ stay fp32
+        so token indices stay bit-exact)."""
+        self.decode_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[precision]
+        return self
+
+    # ------------------------------------------------------------------ derived weights
+    def _build(self) -> Dict[str, torch.Tensor]:
+        d: Dict[str, torch.Tensor] = {}
+        cb = self.codebook.embedding.weight.float().contiguous()
+        d["cb"] = cb
+        d["cbt"], d["c2"] = ops.vq_prepare(cb)
+
+        def both(name, w):
+            d[name + ".f32"] = w
+            d[name + ".bf16"] = w.to(torch.bfloat16)
+
+        def res(prefix, rb: ResBlock):
+            both(prefix + ".w3", _conv_w(rb.block[1]))
+            d[prefix + ".b3"] = rb.block[1].bias.float().contiguous()
+            d[prefix + ".s3"], d[prefix + ".t3"] = _bn_vectors(rb.block[2])
+            both(prefix + ".w1", _conv_w(rb.block[4]))
+            d[prefix + ".b1"] = rb.block[4].bias.float().contiguous()
+            d[prefix + ".s1"], d[prefix + ".t1"] = _bn_vectors(rb.block[5])
+
+        def bott(prefix, blk):
+            if isinstance(blk.id_path, nn.Conv2d):
+                both(prefix + ".wid", _conv_w(blk.id_path))
+                d[prefix + ".bid"] = blk.id_path.bias.float().contiguous()
+            for j in (1, 3, 5, 7):
+                both(f"{prefix}.w{j}", _conv_w(blk.block[j]))
+                d[f"{prefix}.b{j}"] = blk.block[j].bias.float().contiguous()
+
+        enc, dec = self.encoder, self.decoder
+        if self.down_ratio == 4:
+            d["e0.wt"] = enc[0].weight.float().permute(1, 2, 3, 0).contiguous()       # [cin,kh,kw,cout]
+            d["e0.b"] = enc[0].bias.float().contiguous()
+            d["e0.s"], d["e0.t"] = _bn_vectors(enc[1])
+            both("e3.w", _conv_w(enc[3]))
+            d["e3.b"] = enc[3].bias.float().contiguous()
+            res("e4", enc[4]); res("e5", enc[5]); res("d0", dec[0]); res("d1", dec[1])
+            # ConvTranspose2d(dim, dim, 4, 2, 1) as 4 sub-pixel 2x2 convolutions: output pixel (2*oy+py, 2*ox+px) reads
+            # input (oy+dy, ox+dx) through kernel tap ky = py + 1 - 2*dy (dy = -ky2 for py = 0, 1 - ky2 for py = 1).
+            wt = dec[3].weight.float()                                                  # [cin, cout, 4, 4]
+            for py in range(2):
+                for px in range(2):
+                    kys = [py + 1 - 2 * (py - k2) for k2 in range(2)]
+                    kxs = [px + 1 - 2 * (px - k2) for k2 in range(2)]
+                    sub = wt[:, :, kys][:, :, :, kxs]                                   # [cin, cout, 2, 2]
+                    both(f"d3.w{py}{px}", sub.permute(1, 2, 3, 0).reshape(wt.shape[1], -1).contiguous())
+            d["d3.b"] = dec[3].bias.float().contiguous()
+            d["d3.s"], d["d3.t"] = _bn_vectors(dec[4])
+            d["d6.wt"] = dec[6].weight.float().permute(2, 3, 1, 0).contiguous()         # [4,4,cout,cin]
+            d["d6.b"] = dec[6].bias.float().contiguous()
+        else:
+            d["e0.wt"] = enc[0].weight.float().permute(1, 2, 3, 0).contiguous()
+            d["e0.b"] = enc[0].bias.float().contiguous()
+            for i in (1, 3, 5, 7):
+                bott(f"e{i}", enc[i])
+            for i in (0, 2, 4, 6):
+                bott(f"d{i}", dec[i])
+            d["d8.wt"] = dec[8].weight.float().reshape(dec[8].weight.shape[0], -1).contiguous()   # [cout, cin]
+            d["d8.b"] = dec[8].bias.float().contiguous()
+        return d
+
+    def _weights(self) -> Dict[str, torch.Tensor]:
+        return self._derived.get(self._build)
+
+    def _check_input(self, x: torch.Tensor) -> None:
+        if not x.is_cuda:
+            raise RuntimeError("VectorQuantizedVAE runs on libmage_hip.so kernels: move the model and inputs to a ROCm GPU "
+                               "(there is no CPU fallback)")
+        if any(isinstance(m, nn.BatchNorm2d) and m.training for m in self.modules()):
+            raise NotImplementedError("training-mode BatchNorm (batch statistics) is not built yet; call .eval() "
+                                      "(MAGE freezes the first stage: mage_model.py:516-521)")
+
+    # ------------------------------------------------------------------ kernels: conv helpers
+    @staticmethod
+    def _conv(a, w, y, *, n_img, H, W, cin, cout, k, stride=1, pad=None, OH=None, OW=None, **epi):
+        """Conv2d(cin, cout, k, stride, pad) on channels-last [n_img, H, W, cin] as one implicit GEMM."""
+        pad = k // 2 if pad is None else pad
+        OH = H if OH is None else OH
+        OW = W if OW is None else OW
+        return ops.gemm(a, w, y, M=n_img * OH * OW, N=cout, K=k * k * cin, lda=cin, ldy=cout, out_h=OH, out_w=OW, in_h=H,
+                        in_w=W, taps_h=k, taps_w=k, cin=cin, stride=stride, dy0=-pad, dx0=-pad, **epi)
+
+    def _resblock(self, w, p, r, dt, n_img, post_relu):
+        """r = relu(x) already (in-place-ReLU quirk, vqvae_model.py:113): out = r + BN(conv1(relu(BN(conv3(r)))))."""
+        dim, s = self.dim, "." + ("f32" if dt == torch.float32 else "bf16")
+        t = torch.empty_like(r)
+        self._conv(r, w[p + ".w3" + s], t, n_img=n_img, H=16, W=16, cin=dim, cout=dim, k=3, bias=w[p + ".b3"],
+                   scale=w[p + ".s3"], shift=w[p + ".t3"], act=ops.ACT_RELU)
+        out = torch.empty_like(r)
+        self._conv(t, w[p + ".w1" + s], out, n_img=n_img, H=16, W=16, cin=dim, cout=dim, k=1, bias=w[p + ".b1"],
+                   scale=w[p + ".s1"], shift=w[p + ".t1"], residual=r, ldr=dim, post_relu=post_relu)
+        return out
+
+    def _bottleneck(self, w, p, x, dt, n_img, H, W, cin, cout, first_k, last_k, post_relu):
+        s = "." + ("f32" if dt == torch.float32 else "bf16")
+        hid = cout // 4
+        dev = x.device
+        xr = ops.relu(x, torch.empty_like(x))
+        if (p + ".wid" + s) in w:
+            idp = torch.empty(n_img * H * W, cout, device=dev, dtype=dt)
+            self._conv(x, w[p + ".wid" + s], idp, n_img=n_img, H=H, W=W, cin=cin, cout=cout, k=1, bias=w[p + ".bid"])
+        else:
+            idp = x
+        ks = [first_k, 3, 3, last_k]
+        chans = [cin, hid, hid, hid, cout]
+        h = xr
+        for j in range(3):
+            nh = torch.empty(n_img * H * W, chans[j + 1], device=dev, dtype=dt)
+            self._conv(h, w[f"{p}.w{2 * j + 1}{s}"], nh, n_img=n_img, H=H, W=W, cin=chans[j], cout=chans[j + 1], k=ks[j],
+                       bias=w[f"{p}.b{2 * j + 1}"], act=ops.ACT_RELU)
+            h = nh
+        out = torch.empty(n_img * H * W, cout, device=dev, dtype=dt)
+        self._conv(h, w[p + ".w7" + s], out, n_img=n_img, H=H, W=W, cin=hid, cout=cout, k=ks[3], bias=w[p + ".b7"],
+                   residual=idp, ldr=cout, post_relu=post_relu)
+        return out
+
+    # ------------------------------------------------------------------ encoder (always fp32: bit-exact tokens)
+    @torch.no_grad()
+    def _encode_features(self, x: torch.Tensor) -> torch.Tensor:
+        """z_e as channels-last rows [N*h*w, D] fp32."""
+        self._check_input(x)
+        w = self._weights()
+        x = x.float().contiguous()
+        N, dev, dim, f = x.shape[0], x.device, self.dim, torch.float32
+        if self.down_ratio == 4:
+            H, W = x.shape[2], x.shape[3]
+            h0 = torch.empty(N * (H // 2) * (W // 2), dim, device=dev, dtype=f)
+            ops.conv_in(x, w["e0.wt"], w["e0.b"], w["e0.s"], w["e0.t"], h0, cin=self.input_dim, H=H, W=W, cout=dim, kh=4,
+                        kw=4, stride=2, pad=1, act=ops.ACT_RELU)
+            h1 = torch.empty(N * (H // 4) * (W // 4), dim, device=dev, dtype=f)
+            # relu folded: the only consumers of conv3's output are ResBlock e4's skip and body, both behind its in-place ReLU
+            self._conv(h0, w["e3.w.f32"], h1, n_img=N, H=H // 2, W=W // 2, cin=dim, cout=dim, k=4, stride=2, pad=1,
+                       OH=H // 4, OW=W // 4, bias=w["e3.b"], act=ops.ACT_RELU)
+            assert H // 4 == 16 and W // 4 == 16, "f4 VQ-VAE kernels are specialised for 64x64 inputs"
+            h2 = self._resblock(w, "e4", h1, f, N, post_relu=True)
+            return self._resblock(w, "e5", h2, f, N, post_relu=False)
+        H, W = x.shape[2], x.shape[3]
+        h = torch.empty(N * H * W, dim, device=dev, dtype=f)
+        ops.conv_in(x, w["e0.wt"], w["e0.b"], None, None, h, cin=self.input_dim, H=H, W=W, cout=dim, kh=7, kw=7, stride=1,
+                    pad=3)
+        chans = [(dim, dim), (dim, dim), (dim, 2 * dim), (2 * dim, 4 * dim)]
+        for bi, (ci, co) in zip((1, 3, 5, 7), chans):
+            last = bi == 7
+            h = self._bottleneck(w, f"e{bi}", h, f, N, H, W, ci, co, 3, 1, post_relu=last)   # trailing nn.ReLU (:201)
+            if not last:
+                p = torch.empty(N * (H // 2) * (W // 2), co, device=dev, dtype=f)
+                ops.maxpool2(h, p, N=N, H=H, W=W, Cc=co)
+                h, H, W = p, H // 2, W // 2
+        return h
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor) -> torch.Tensor:
+        """vqvae_model.py:233-237 -> int64 [N, h, w]."""
+        z = self._encode_features(x)
+        w = self._weights()
+        hw = x.shape[2] // self.down_ratio
+        return ops.vq_nearest(z, w["cbt"], w["c2"]).view(x.shape[0], hw, x.shape[3] // self.down_ratio)
+
+    # ------------------------------------------------------------------ decoder
+    @torch.no_grad()
+    def decode(self, latents: torch.Tensor = None) -> torch.Tensor:
+        """vqvae_model.py:239-242: int64 [N, h, w] -> fp32 [N, C, H, W] in (-1, 1)."""
+        self._check_input(latents)
+        N = latents.shape[0]
+        out = torch.empty(N, self.input_dim, latents.shape[1] * self.down_ratio, latents.shape[2] * self.down_ratio,
+                          device=latents.device, dtype=torch.float32)
+        ids = latents.to(torch.int64).contiguous()
+        for s in range(0, N, self.decode_chunk):
+            e = min(N, s + self.decode_chunk)
+            self._decode_chunk(ids[s:e], out[s:e])
+        return out
+
+    def _decode_chunk(self, ids: torch.Tensor, out: torch.Tensor) -> None:
+        w = self._weights()
+        dt = self.decode_dtype
+        s = "." + ("f32" if dt == torch.float32 else "bf16")
+        N, dev, dim = ids.shape[0], ids.device, self.dim
+        h, wd = ids.shape[1], ids.shape[2]
+        if self.down_ratio == 4:
+            assert h == 16 and wd == 16, "f4 VQ-VAE kernels are specialised for 16x16 latents"
+            r = ops.embedding(ids, w["cb"], torch.empty(N * 256, dim, device=dev, dtype=dt), relu=True)
+            r = self._resblock(w, "d0", r, dt, N, post_relu=True)
+            r = self._resblock(w, "d1", r, dt, N, post_relu=True)           # decoder[2] ReLU folded
+            up = torch.empty(N * 1024, dim, device=dev, dtype=dt)
+            for py in range(2):
+                for px in range(2):
+                    ops.gemm(r, w[f"d3.w{py}{px}{s}"], up, M=N * 256, N=dim, K=4 * dim, lda=dim, ldy=dim, out_h=16, out_w=16,
+                             in_h=16, in_w=16, taps_h=2, taps_w=2, cin=dim, stride=1, dy0=py, dx0=px, dys=-1, dxs=-1,
+                             y_img_stride=1024, y_mul_y=64, y_mul_x=2, y_off=py * 32 + px, bias=w["d3.b"], scale=w["d3.s"],
+                             shift=w["d3.t"], act=ops.ACT_RELU)
+            ops.conv_out(up, w["d6.wt"], w["d6.b"], out, N=N, IH=32, IW=32, cin=dim, cout=self.input_dim, transposed=True)
+            return
+        H, W = h, wd
+        x = ops.embedding(ids, w["cb"], torch.empty(N * H * W, 4 * dim, device=dev, dtype=dt))
+        chans = [(4 * dim, 2 * dim), (2 * dim, dim), (dim, dim), (dim, dim)]
+        for bi, (ci, co) in zip((0, 2, 4, 6), chans):
+            last = bi == 6
+            x = self._bottleneck(w, f"d{bi}", x, dt, N, H, W, ci, co, 1, 3, post_relu=last)    # decoder[7] ReLU folded
+            if not last:
+                u = torch.empty(N * H * W * 4, co, device=dev, dtype=dt)
+                ops.upsample2(x, u, N=N, H=H, W=W, Cc=co)
+                x, H, W = u, H * 2, W * 2
+        ops.conv_out(x, w["d8.wt"], w["d8.b"], out, N=N, IH=H, IW=W, cin=dim, cout=self.input_dim, transposed=False)
+
+    # ------------------------------------------------------------------ forward (values only)
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor):
+        """vqvae_model.py:244-248 values: (x_tilde, z_e_x, z_q_x), NCHW.  No autograd graph: the straight-through
+        backward is a 'next' row."""
+        z = self._encode_features(x)
+        w = self._weights()
+        N = x.shape[0]
+        hh, ww = x.shape[2] // self.down_ratio, x.shape[3] // self.down_ratio
+        ids = ops.vq_nearest(z, w["cbt"], w["c2"]).view(N, hh, ww)
+        D = z.shape[1]
+        z_q = ops.embedding(ids, w["cb"], torch.empty(N * hh * ww, D, device=x.device, dtype=torch.float32))
+        x_tilde = self.decode(ids)
+        return x_tilde, z.view(N, hh, ww, D).permute(0, 3, 1, 2), z_q.view(N, hh, ww, D).permute(0, 3, 1, 2)

@@ -1,0 +1,217 @@
+"""Thin tensor-level wrappers over the C ABI (include/mage_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every arithmetic
+op below is one libmage_hip.so call on ``torch.cuda.current_stream()``.
+All wrappers raise if a tensor is not on a CUDA (ROCm) device -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc
+
+__all__ = ["gemm", "layernorm", "attention", "embedding", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
+           "conv_in", "conv_out", "row_affine", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
+           "F32", "BF16", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
+
+
+def code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def tdtype(c: int) -> torch.dtype:
+    return torch.float32 if c == F32 else torch.bfloat16
+
+
+def _dev(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("mage_amd ops need tensors on a ROCm GPU (cuda device); there is no CPU fallback")
+    return _lib.lib(t.device.index or 0), torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldy: int,
+         out_h: int = 1, out_w: Optional[int] = None, in_h: Optional[int] = None, in_w: Optional[int] = None,
+         a_img_stride: Optional[int] = None, a_off: int = 0, taps_h: int = 1, taps_w: int = 1, cin: Optional[int] = None,
+         stride: int = 1, dy0: int = 0, dx0: int = 0, dys: int = 1, dxs: int = 1,
+         y_img_stride: Optional[int] = None, y_mul_y: Optional[int] = None, y_mul_x: int = 1, y_off: int = 0,
+         bias=None, scale=None, shift=None, act: int = ACT_NONE, rowadd=None, rowadd_div: int = 1, rowadd_mod: int = 1,
+         residual=None, ldr: int = 0, post_relu: bool = False) -> torch.Tensor:
+    """Y = epilogue(A (*) W^T); see mage_gemm in include/mage_hip.h for the geometry fields."""
+    l, s = _dev(a)
+    out_w = M if out_w is None else out_w
+    in_h = out_h if in_h is None else in_h
+    in_w = out_w if in_w is None else in_w
+    d = GemmDesc()
+    d.dtype, d.M, d.N, d.K = code(a), M, N, K
+    assert w.dtype == a.dtype, (w.dtype, a.dtype)
+    d.A, d.W, d.Y = a.data_ptr(), w.data_ptr(), y.data_ptr()
+    d.lda, d.ldy, d.y_dtype = lda, ldy, code(y)
+    d.out_h, d.out_w, d.in_h, d.in_w = out_h, out_w, in_h, in_w
+    d.a_img_stride = in_h * in_w if a_img_stride is None else a_img_stride
+    d.a_off = a_off
+    d.taps_h, d.taps_w, d.cin, d.stride = taps_h, taps_w, (K // (taps_h * taps_w) if cin is None else cin), stride
+    d.dy0, d.dx0, d.dys, d.dxs = dy0, dx0, dys, dxs
+    d.y_img_stride = out_h * out_w if y_img_stride is None else y_img_stride
+    d.y_mul_y = out_w if y_mul_y is None else y_mul_y
+    d.y_mul_x, d.y_off = y_mul_x, y_off
+    d.bias, d.scale, d.shift = _p(bias), _p(scale), _p(shift)
+    d.act = act
+    d.rowadd, d.rowadd_div, d.rowadd_mod = _p(rowadd), rowadd_div, rowadd_mod
+    d.residual, d.ldr, d.res_dtype = _p(residual), ldr, (code(residual) if residual is not None else 0)
+    d.post_relu = int(post_relu)
+    _lib.check(l.mage_gemm(C.byref(d), s), l)
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch.Tensor, eps: float) -> torch.Tensor:
+    l, s = _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous()
+    Cc = x.shape[-1]
+    _lib.check(l.mage_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), code(y),
+                                x.numel() // Cc, Cc, float(eps), s), l)
+    return y
+
+
+def attention(q, k, v, out, *, ldq, ldk, ldv, ldo, n_seq, inner, nq, nk, n_head, q_outer_stride, q_axis_stride,
+              kv_outer_stride, kv_axis_stride, causal=False, kv_len=None, kv_len_div=1, scale=None):
+    l, s = _dev(q)
+    d = AttnDesc()
+    d.dtype = code(q)
+    d.q, d.k, d.v, d.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    d.ldq, d.ldk, d.ldv, d.ldo = ldq, ldk, ldv, ldo
+    d.n_seq, d.inner, d.nq, d.nk, d.n_head = n_seq, inner, nq, nk, n_head
+    d.q_outer_stride, d.q_axis_stride = q_outer_stride, q_axis_stride
+    d.kv_outer_stride, d.kv_axis_stride = kv_outer_stride, kv_axis_stride
+    d.causal = int(causal)
+    d.kv_len, d.kv_len_div = _p(kv_len), kv_len_div
+    d.scale = float(32 ** -0.5 if scale is None else scale)
+    _lib.check(l.mage_attention(C.byref(d), s), l)
+    return out
+
+
+def embedding(ids: torch.Tensor, table: torch.Tensor, out: torch.Tensor, *, relu: bool = False, group: Optional[int] = None,
+              group_stride: Optional[int] = None, off: int = 0) -> torch.Tensor:
+    l, s = _dev(table)
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and table.dtype == torch.float32 and table.is_contiguous()
+    n = ids.numel()
+    group = n if group is None else group
+    group_stride = group if group_stride is None else group_stride
+    _lib.check(l.mage_embedding(ids.data_ptr(), table.data_ptr(), out.data_ptr(), code(out), n, table.shape[1],
+                                table.shape[0], int(relu), group, group_stride, off, s), l)
+    return out
+
+
+def vq_prepare(codebook: torch.Tensor):
+    l, s = _dev(codebook)
+    K, D = codebook.shape
+    cbt = torch.empty(D, K, device=codebook.device, dtype=torch.float32)
+    c2 = torch.empty(K, device=codebook.device, dtype=torch.float32)
+    _lib.check(l.mage_vq_prepare(codebook.contiguous().data_ptr(), K, D, cbt.data_ptr(), c2.data_ptr(), s), l)
+    return cbt, c2
+
+
+def vq_nearest(z: torch.Tensor, cbt: torch.Tensor, c2: torch.Tensor, want_margin: bool = False):
+    l, s = _dev(z)
+    assert z.dtype == torch.float32 and z.is_contiguous()
+    D, K = cbt.shape
+    M = z.numel() // D
+    idx = torch.empty(M, device=z.device, dtype=torch.int64)
+    margin = torch.empty(M, device=z.device, dtype=torch.float32) if want_margin else None
+    _lib.check(l.mage_vq_nearest(z.data_ptr(), cbt.data_ptr(), c2.data_ptr(), M, D, K, idx.data_ptr(), _p(margin), s), l)
+    return (idx, margin) if want_margin else idx
+
+
+def argmax(logits: torch.Tensor, out: torch.Tensor, *, rows: int, K: int, ld: Optional[int] = None, group: Optional[int] = None,
+           in_group_stride: Optional[int] = None, in_off: int = 0, out_group_stride: Optional[int] = None, out_off: int = 0,
+           margin=None) -> torch.Tensor:
+    l, s = _dev(logits)
+    assert logits.dtype == torch.float32 and out.dtype == torch.int64
+    group = rows if group is None else group
+    in_group_stride = group if in_group_stride is None else in_group_stride
+    out_group_stride = group if out_group_stride is None else out_group_stride
+    _lib.check(l.mage_argmax(logits.data_ptr(), rows, K, K if ld is None else ld, group, in_group_stride, in_off,
+                             out.data_ptr(), out_group_stride, out_off, _p(margin), s), l)
+    return out
+
+
+def cross_entropy(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    l, s = _dev(logits)
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and target.dtype == torch.int64
+    K = logits.shape[-1]
+    rows = logits.numel() // K
+    row_loss = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    _lib.check(l.mage_cross_entropy(logits.data_ptr(), target.contiguous().data_ptr(), rows, K, row_loss.data_ptr(),
+                                    loss.data_ptr(), s), l)
+    return loss[0]
+
+
+def conv_in(x, weight_t, bias, scale, shift, y, *, cin, H, W, cout, kh, kw, stride, pad, act=ACT_NONE):
+    l, s = _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    _lib.check(l.mage_conv_in(x.data_ptr(), weight_t.data_ptr(), _p(bias), _p(scale), _p(shift), y.data_ptr(), code(y),
+                              x.shape[0], cin, H, W, cout, kh, kw, stride, pad, act, s), l)
+    return y
+
+
+def conv_out(x, weight_t, bias, y, *, N, IH, IW, cin, cout, transposed: bool):
+    l, s = _dev(x)
+    _lib.check(l.mage_conv_out(x.data_ptr(), code(x), weight_t.data_ptr(), _p(bias), y.data_ptr(), N, IH, IW, cin, cout,
+                               int(transposed), s), l)
+    return y
+
+
+def maxpool2(x, y, *, N, H, W, Cc, relu=False):
+    l, s = _dev(x)
+    _lib.check(l.mage_maxpool2(x.data_ptr(), y.data_ptr(), code(x), N, H, W, Cc, int(relu), s), l)
+    return y
+
+
+def upsample2(x, y, *, N, H, W, Cc):
+    l, s = _dev(x)
+    _lib.check(l.mage_upsample2(x.data_ptr(), y.data_ptr(), code(x), N, H, W, Cc, s), l)
+    return y
+
+
+def relu(x, y):
+    l, s = _dev(x)
+    _lib.check(l.mage_relu(x.data_ptr(), y.data_ptr(), code(x), x.numel(), s), l)
+    return y
+
+
+def cast(x, y):
+    l, s = _dev(x)
+    _lib.check(l.mage_cast(x.data_ptr(), code(x), y.data_ptr(), code(y), x.numel(), s), l)
+    return y
+
+
+def adain(x, gamma, beta, out, *, B, P, Cc, eps=1e-5):
+    l, s = _dev(x)
+    _lib.check(l.mage_adain(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), B, P, Cc, float(eps), s), l)
+    return out
+
+
+def add_scaled_rowvec(x, svec, vec, *, B, P, Cc):
+    l, s = _dev(x)
+    _lib.check(l.mage_add_scaled_rowvec(x.data_ptr(), svec.data_ptr(), vec.data_ptr(), B, P, Cc, s), l)
+    return x
+
+
+def row_affine(x, rs=None, table=None, *, div: int = 1, mod: int = 1):
+    l, s = _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    Cc = x.shape[-1]
+    _lib.check(l.mage_row_affine(x.data_ptr(), _p(rs), _p(table), x.numel() // Cc, Cc, div, mod, s), l)
+    return x

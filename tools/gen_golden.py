@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE (read-only, /root/reference)
+on portable synthetic weights + inputs.  Build container only: the reference never
+travels to the GPU box; only the small fixtures written here do.
+
+    python tools/gen_golden.py            # regenerate everything (about a minute)
+
+Every fixture stores inputs that cannot be regenerated from mage_amd.utils.synth,
+the reference's outputs (tokens, logit slices, frames), fp64 checksums of big
+tensors and per-position top-2 margins, so that a consumer can tell an argmin /
+argmax near-tie from a real mismatch.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mage_amd.utils import synth  # noqa: E402
+from tools._ref_import import import_reference, to_cfg  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()})
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def top2_margin(x, largest=True):
+    v = x.topk(2, dim=-1, largest=largest)[0]
+    return (v[..., 0] - v[..., 1]).abs().float()
+
+
+def chk(x):
+    x = x.double()
+    return np.array([x.sum().item(), x.abs().sum().item(), (x * x).sum().item()], np.float64)
+
+
+def build_ref_mage(ref_mage, cfg, seed):
+    p = cfg["params"]
+    width, layers = p["vision_width"], p["generate_decoder_config"]["params"]["layers"]
+    m = ref_mage.MAGE(**to_cfg(p)).eval()
+    synth.fill_state_dict(m, seed, d_model=width, n_layers=layers)
+    return m
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref_mage, ref_vq = import_reference()
+
+    # ---- 1. VQ unit: exact ties, near ties, reference-init regime --------------------------
+    print("vq unit")
+    g = synth.rng_for(7, "vq_unit")
+    K, D = 32, 16
+    cb = g.standard_normal((K, D)).astype(np.float32)
+    cb[5] = cb[2]                      # duplicate code: exact tie, first index (2) must win
+    cb[17] = cb[9]
+    z = g.standard_normal((96, D)).astype(np.float32)
+    z[0], z[1] = cb[2], cb[9]          # inputs sitting on duplicated codes
+    z[2] = 0.5 * (cb[3] + cb[4])       # equidistant in exact arithmetic
+    z[3] = 0.0
+    idx = ref_vq.vq(torch.from_numpy(z), torch.from_numpy(cb))
+    # reference-init regime: tiny codebook U(-1/K, 1/K) vs O(1) inputs (vqvae_model.py:91)
+    cb2 = (g.random((64, 32)) * 2 - 1).astype(np.float32) / 64
+    z2 = g.standard_normal((4, 8, 8, 32)).astype(np.float32)
+    idx2 = ref_vq.vq(torch.from_numpy(z2), torch.from_numpy(cb2))
+    from oracle import mage_oracle as O
+    d2 = O.vq_distances(torch.from_numpy(z2), torch.from_numpy(cb2))
+    save("vq_unit", cb=cb, z=z, idx=idx, cb2=cb2, z2=z2, idx2=idx2, margin2=top2_margin(d2, largest=False))
+
+    # ---- 2. f4 VQ-VAE (MNIST) ---------------------------------------------------------------
+    print("vqvae f4")
+    vq4 = ref_vq.VectorQuantizedVAE(1, 4, 256, 512).eval()
+    synth.fill_state_dict(vq4, 11)
+    x = synth.synth_batch_mnist(3, 2, seed=11)["images"][:, :, :].reshape(6, 1, 64, 64)[:4].contiguous()
+    with torch.no_grad():
+        z_e = vq4.encoder(x.clone())
+        ids = vq4.encode(x.clone())
+        dist = O.vq_distances(z_e.permute(0, 2, 3, 1).contiguous(), vq4.codebook.embedding.weight)
+        rec = vq4.decode(ids)
+        x_tilde, z_e2, z_q = vq4(x.clone())
+    save("vqvae_f4", seed=11, x=x, ids=ids.to(torch.int16), z_e_slice=z_e[:, :8], z_e_chk=chk(z_e),
+         margin=top2_margin(dist, largest=False).view(ids.shape), rec=rec, rec_chk=chk(rec),
+         fwd_x_tilde_chk=chk(x_tilde), z_q_chk=chk(z_q))
+
+    # ---- 3. f8 VQ-VAE (CATER) at reduced dim -------------------------------------------------
+    print("vqvae f8")
+    vq8 = ref_vq.VectorQuantizedVAE(3, 8, 32, 64).eval()
+    synth.fill_state_dict(vq8, 12)
+    x8 = synth.synth_batch_cater(2, 1, seed=12)["images"][:, 0].contiguous()
+    with torch.no_grad():
+        z_e8 = vq8.encoder(x8)
+        ids8 = vq8.encode(x8)
+        dist8 = O.vq_distances(z_e8.permute(0, 2, 3, 1).contiguous(), vq8.codebook.embedding.weight)
+        rec8 = vq8.decode(ids8)
+    save("vqvae_f8", seed=12, dim=32, K=64, ids=ids8.to(torch.int16), z_e_slice=z_e8[:, :8], z_e_chk=chk(z_e8),
+         margin=top2_margin(dist8, largest=False).view(ids8.shape), rec_sub=rec8[..., ::4, ::4].contiguous(),
+         rec_chk=chk(rec8))
+
+    # ---- 4. MAGE, MNIST cfg at full width, short clip: every stage ----------------------------
+    for tag, B, L, seed, ragged, digits, tl in (("mage_mnist_L4", 2, 4, 21, False, 1, 11),
+                                                ("mage_mnist_L6_ragged", 3, 6, 22, True, 2, 20)):
+        print(tag)
+        cfg = synth.mnist_model_config(frames_length=L)
+        m = build_ref_mage(ref_mage, cfg, seed)
+        batch = synth.synth_batch_mnist(B, L, seed=seed, digits=digits, text_len=tl, ragged_text=ragged)
+        trace = []
+        orig_gen = m.generate_model.forward
+
+        def spy(motion, imgs, _o=orig_gen, _t=trace):
+            out = _o(motion, imgs)
+            _t.append((motion.clone(), out.clone()))
+            return out
+        m.generate_model.forward = spy
+        with torch.no_grad():
+            txt = m.text_encoder(batch["text"])
+            video = m.autoregressive_generate({k: v.clone() for k, v in batch.items()})
+            tok0 = m.first_stage_encode(batch["images"][:, 0:1])[:, 0]
+        motion = trace[0][0]
+        step_logits = torch.stack([trace[i][1][:, i] for i in range(L - 1)], 1)      # [B,L-1,h,w,K]
+        gen_tok = trace[-1][1].max(-1)[1]
+        m.generate_model.forward = orig_gen
+        with torch.no_grad():
+            loss, ld = m({k: v.clone() for k, v in batch.items()})
+        save(tag, seed=seed, B=B, L=L, digits=digits, text_len=tl, ragged=ragged,
+             text=batch["text"], text_emb=txt, tok0=tok0.to(torch.int16), motion_sub=motion[:, ::4, ::4].contiguous(),
+             motion_chk=chk(motion), gen_tokens=gen_tok.to(torch.int16),
+             step_logits_sub=step_logits[:, :, ::4, ::4].contiguous(), step_logits_chk=chk(step_logits),
+             margin=top2_margin(step_logits), video=video, loss=np.float64(loss.item()),
+             loss_dict_keys=np.array(sorted(ld.keys())))
+
+    # ---- 5. cfg1 shape (L=16) tokens only ------------------------------------------------------
+    print("mage_mnist_L16")
+    cfg = synth.mnist_model_config(frames_length=16)
+    m = build_ref_mage(ref_mage, cfg, 0)
+    batch = synth.synth_batch_mnist(2, 16, seed=0)
+    trace = []
+    orig_gen = m.generate_model.forward
+
+    def spy16(motion, imgs):
+        out = orig_gen(motion, imgs)
+        i = len(trace)
+        trace.append(out[:, i].clone())
+        spy16.last = out
+        return out
+    m.generate_model.forward = spy16
+    with torch.no_grad():
+        video = m.autoregressive_generate({k: v.clone() for k, v in batch.items()})
+    step_logits = torch.stack(trace, 1)
+    save("mage_mnist_L16", seed=0, B=2, L=16, gen_tokens=spy16.last.max(-1)[1].to(torch.int16),
+         margin=top2_margin(step_logits), step_logits_sub=step_logits[:, :, ::8, ::8, ::4].contiguous(),
+         video_chk=chk(video), video_sub=video[:, :, :, ::2, ::2].contiguous())
+
+    # ---- 6. reduced-width model (d=64, 2 heads), exercises non-512 shapes ----------------------
+    print("mage_small_d64")
+    cfg = synth.mnist_model_config(frames_length=5, width=64, layers=3, vq_dim=32, K=64)
+    m = build_ref_mage(ref_mage, cfg, 31)
+    batch = synth.synth_batch_mnist(3, 5, seed=31, text_len=9, ragged_text=True)
+    trace = []
+    orig_gen = m.generate_model.forward
+
+    def spy64(motion, imgs):
+        out = orig_gen(motion, imgs)
+        trace.append(out.clone())
+        return out
+    m.generate_model.forward = spy64
+    with torch.no_grad():
+        video = m.autoregressive_generate({k: v.clone() for k, v in batch.items()})
+    step_logits = torch.stack([trace[i][:, i] for i in range(4)], 1)
+    save("mage_small_d64", seed=31, B=3, L=5, width=64, layers=3, vq_dim=32, K=64, text_len=9,
+         gen_tokens=trace[-1].max(-1)[1].to(torch.int16), margin=top2_margin(step_logits),
+         step_logits=step_logits, video=video)
+
+    # ---- 7. cfg4 shape at reduced size: f8 first stage + randomness (ADAIN) with injected noise -
+    print("mage_cater_small")
+    cfg = synth.cater_model_config(frames_length=4, width=64, layers=3, vq_dim=32, K=64)
+    m = build_ref_mage(ref_mage, cfg, 41)
+    batch = synth.synth_batch_cater(2, 4, seed=41, text_len=12)
+    noise = torch.from_numpy(synth.rng_for(41, "video_noise").standard_normal((2, 64, 16, 16)).astype(np.float32))
+    real_randn = torch.randn
+
+    def fake_randn(*a, **k):
+        shape = a[0] if len(a) == 1 and isinstance(a[0], (list, tuple)) else a
+        if tuple(shape) == tuple(noise.shape):
+            return noise.clone()
+        return real_randn(*a, **k)
+    trace = []
+    orig_gen = m.generate_model.forward
+
+    def spyc(motion, imgs):
+        out = orig_gen(motion, imgs)
+        trace.append((motion.clone(), out.clone()))
+        return out
+    m.generate_model.forward = spyc
+    torch.randn = fake_randn
+    try:
+        with torch.no_grad():
+            video = m.autoregressive_generate({k: v.clone() for k, v in batch.items()})
+    finally:
+        torch.randn = real_randn
+    step_logits = torch.stack([trace[i][1][:, i] for i in range(3)], 1)
+    save("mage_cater_small", seed=41, B=2, L=4, width=64, layers=3, vq_dim=32, K=64, text_len=12, noise=noise,
+         motion=trace[0][0], gen_tokens=trace[-1][1].max(-1)[1].to(torch.int16), margin=top2_margin(step_logits),
+         step_logits=step_logits, video_sub=video[..., ::4, ::4].contiguous(), video_chk=chk(video))
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
