@@ -1,0 +1,136 @@
+#!/usr/bin/env python
+"""Headline benchmark: generated frames/sec of MAGE.autoregressive_generate on synthetic Moving-MNIST-shaped
+clips (BASELINE.json: 64x64, 16-frame clips; cfg2 = MNIST f4 VQ-VAE + MAGE, batch 64 per GPU, bf16 MFMA).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--frames 16] [--precision bf16|fp32]
+
+One "step" = one autoregressive_generate(batch) call: VQ-VAE encode of the first frames + text encoder +
+motion-anchor encoder + the reference's L-1 full decoder recomputes + VQ-VAE decode of the L-1 generated
+frames (nothing skipped, inputs resident in HBM).  N > 1: one process per GPU (torchrun), clips sharded
+across ranks, no data-path collective (clips are independent), weak scaling.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3        # fp32-input MFMA = fp32 vector peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from mage_amd import ops
+    from mage_amd.utils import synth
+    from mage_amd.utils.util import instantiate_from_config
+
+    B, L = args.batch, args.frames
+    cfg = synth.mnist_model_config(frames_length=L)
+    model = instantiate_from_config(cfg).eval()
+    synth.fill_state_dict(model, 0)
+    cpu_sd = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 and not args.no_cpu_baseline else None
+    model = model.to(dev).set_precision(args.precision)
+    batch = {k: v.to(dev) for k, v in synth.synth_batch_mnist(B, L, seed=100 + rank).items()}
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.autoregressive_generate(batch)
+    sync_all()
+    ops.PROFILE.reset(enabled=True)          # HIP events around every GEMM launch, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model.autoregressive_generate(batch)
+    sync_all()
+    dt = time.perf_counter() - t0
+    ops.PROFILE.enabled = False
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    assert tuple(out.shape) == (B, L, 1, 64, 64)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * B * L * args.steps / dt
+        prof = ops.PROFILE.summary()
+        dom = prof.get("gemm/plain")
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        roofline = None
+        if dom:
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": f"gemm_kernel<{args.precision},plain> (all Linear layers of the decoder stack)",
+                        "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "traffic": None, "launches_per_step": dom["calls"] // args.steps,
+                        "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
+                        "flops_per_launch": dom["flops"] / dom["calls"]}
+        res = {
+            "metric": "generated frames/sec (64x64, 16-frame clips)", "value": round(value, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"cfg2: Single Moving MNIST 64x64, {L} frames, batch={B}/GPU, MNIST f4 VQ-VAE + MAGE "
+                                   f"(d=512, 6 axial blocks), reference AR loop with full recompute, random-init weights",
+                       "global_batch": world * B, "frames": L, "parallelism": f"clip-sharded x{world} (no collective)",
+                       "ar_mode": model.ar_mode},
+            "roofline": roofline,
+            "kernel_time_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items())},
+        }
+        if cpu_sd is not None:
+            res["cpu_baseline"] = cpu_baseline(cpu_sd, L, args.cpu_clips)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd, L, clips):
+    """The CPU oracle (validated against the reference's golden vectors) timed on this box's host cores on a
+    bounded sample of the same workload: `clips` clips of the cfg shape through the reference's full AR loop."""
+    from mage_amd.utils import synth
+    from oracle import mage_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    batch = synth.synth_batch_mnist(clips, L, seed=100)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        O.mage_generate(sd, batch, L)
+    dt = time.perf_counter() - t0
+    return {"value": round(clips * L / dt, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{clips} clips x {L} frames (same model, fp32, oracle/mage_oracle.py mage_generate, "
+                      f"torch {torch.__version__} CPU ops), {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

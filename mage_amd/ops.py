@@ -16,7 +16,7 @@ from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF1
 
 __all__ = ["gemm", "layernorm", "attention", "embedding", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
            "conv_in", "conv_out", "row_affine", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
-           "F32", "BF16", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
+           "PROFILE", "F32", "BF16", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
 
 
 def code(t: torch.Tensor) -> int:
@@ -39,6 +39,43 @@ def _dev(t: torch.Tensor):
 
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
+
+
+class _Profile:
+    """Optional per-launch timing with HIP events recorded on the launch stream (torch.cuda.Event on the
+    current stream IS a hipEvent on the stream the kernels are enqueued on).  Used by bench.py for the
+    roofline of the dominant kernel; off by default (zero overhead)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def reset(self, enabled: bool = False):
+        self.enabled, self.records = enabled, []
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, key: str, start, flops: float = 0.0, nbytes: float = 0.0):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.append((key, start, e, flops, nbytes))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, s, e, fl, nb in self.records:
+            d = out.setdefault(key, {"ms": 0.0, "calls": 0, "flops": 0.0, "bytes": 0.0})
+            d["ms"] += s.elapsed_time(e)
+            d["calls"] += 1
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
+
+PROFILE = _Profile()
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldy: int,
@@ -71,6 +108,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     d.rowadd, d.rowadd_div, d.rowadd_mod = _p(rowadd), rowadd_div, rowadd_mod
     d.residual, d.ldr, d.res_dtype = _p(residual), ldr, (code(residual) if residual is not None else 0)
     d.post_relu = int(post_relu)
+    if PROFILE.enabled:
+        gather = taps_h * taps_w > 1 or stride != 1 or d.in_h != d.out_h or d.in_w != d.out_w
+        ev = PROFILE.begin()
+        _lib.check(l.mage_gemm(C.byref(d), s), l)
+        PROFILE.end("gemm/conv" if gather else "gemm/plain", ev, 2.0 * M * N * K)
+        return y
     _lib.check(l.mage_gemm(C.byref(d), s), l)
     return y
 
@@ -79,8 +122,11 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch
     l, s = _dev(x)
     assert x.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous()
     Cc = x.shape[-1]
+    ev = PROFILE.begin() if PROFILE.enabled else None
     _lib.check(l.mage_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), code(y),
                                 x.numel() // Cc, Cc, float(eps), s), l)
+    if ev is not None:
+        PROFILE.end("layernorm", ev, 0.0, float(x.numel()) * (4 + y.element_size()))
     return y
 
 
@@ -97,7 +143,11 @@ def attention(q, k, v, out, *, ldq, ldk, ldv, ldo, n_seq, inner, nq, nk, n_head,
     d.causal = int(causal)
     d.kv_len, d.kv_len_div = _p(kv_len), kv_len_div
     d.scale = float(32 ** -0.5 if scale is None else scale)
+    ev = PROFILE.begin() if PROFILE.enabled else None
     _lib.check(l.mage_attention(C.byref(d), s), l)
+    if ev is not None:
+        es = q.element_size()
+        PROFILE.end("attention", ev, 4.0 * n_seq * nq * nk * n_head * 32, float(n_seq) * n_head * 32 * es * (2 * nq + 2 * nk))
     return out
 
 

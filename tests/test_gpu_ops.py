@@ -1,0 +1,289 @@
+"""GPU: every libmage_hip.so entry point against a plain PyTorch-CPU fp32 restatement of the same op
+(through the C ABI, on seeded inputs).  fp32 mode: 1e-4 class tolerances (exact-fp32 MFMA);
+bf16 mode: bf16-rounding class tolerances."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import golden, t
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def ops():
+    from mage_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def to_dev(x, dt):
+    return x.to(DEV).to(dt).contiguous()
+
+
+TOL = {torch.float32: dict(atol=2e-5, rtol=2e-5), torch.bfloat16: dict(atol=6e-2, rtol=3e-2)}
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (300, 132, 200), (33, 64, 2048), (1000, 1536, 512), (7, 4, 8)])
+def test_gemm_plain(dt, M, N, K):
+    o = ops()
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    if dt == torch.bfloat16:
+        a, w = a.bfloat16().float(), w.bfloat16().float()
+    want = a.double() @ w.double().t() + b.double()
+    y = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    o.gemm(to_dev(a, dt), to_dev(w, dt), y, M=M, N=N, K=K, lda=K, ldy=N, bias=b.to(DEV))
+    torch.testing.assert_close(y.cpu().double(), want, atol=2e-5 if dt == torch.float32 else 2e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_epilogue_full(dt):
+    """bias -> BN scale/shift -> QuickGELU -> row table -> residual (in place, fp32) -> relu, bf16/fp32 output."""
+    o = ops()
+    M, N, K, P = 512, 256, 128, 64
+    a, w = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=K ** -0.5)
+    if dt == torch.bfloat16:
+        a, w = a.bfloat16().float(), w.bfloat16().float()
+    b, sc, sh, tab, res = rnd(N, seed=6), rnd(N, seed=7).abs() + 0.5, rnd(N, seed=8), rnd(P, N, seed=9), rnd(M, N, seed=10)
+    v = (a @ w.t() + b) * sc + sh
+    v = v * torch.sigmoid(1.702 * v)
+    v = v + tab[torch.arange(M) % P] + res
+    want = torch.relu(v)
+    y = res.to(DEV).clone()
+    o.gemm(to_dev(a, dt), to_dev(w, dt), y, M=M, N=N, K=K, lda=K, ldy=N, bias=b.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV),
+           act=o.ACT_QUICKGELU, rowadd=tab.to(DEV), rowadd_div=1, rowadd_mod=P, residual=y, ldr=N, post_relu=True)
+    torch.testing.assert_close(y.cpu(), want, atol=2e-5 if dt == torch.float32 else 5e-3, rtol=1e-4)
+    yb = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    o.gemm(to_dev(a, dt), to_dev(w, dt), yb, M=M, N=N, K=K, lda=K, ldy=N, bias=b.to(DEV), act=o.ACT_GELU_ERF)
+    torch.testing.assert_close(yb.float().cpu(), F.gelu(a @ w.t() + b), atol=2e-2, rtol=2e-2)
+
+
+def test_gemm_row_regrouping():
+    """x[:, 1:] views and slot writes without copies (decoder in_linear / head geometry)."""
+    o = ops()
+    B, L, hw, Cc, N = 3, 5, 16, 64, 32
+    x = rnd(B * L * hw, Cc, seed=11)
+    w = rnd(N, Cc, seed=12, scale=0.1)
+    y = torch.empty(B * (L - 1) * hw, N, device=DEV)
+    o.gemm(x.to(DEV), w.to(DEV), y, M=B * (L - 1) * hw, N=N, K=Cc, lda=Cc, ldy=N, out_w=(L - 1) * hw, a_img_stride=L * hw, a_off=hw)
+    want = (x.view(B, L, hw, Cc)[:, 1:] @ w.t()).reshape(-1, N)
+    torch.testing.assert_close(y.cpu(), want, atol=2e-5, rtol=1e-5)
+    tpos = rnd(L, N, seed=13)
+    z = torch.zeros(B * L * hw, N, device=DEV)
+    imgs = rnd(B * (L - 1) * hw, Cc, seed=14)
+    o.gemm(imgs.to(DEV), w.to(DEV), z, M=B * (L - 1) * hw, N=N, K=Cc, lda=Cc, ldy=N, out_w=(L - 1) * hw, y_img_stride=L * hw,
+           y_off=hw, rowadd=tpos.to(DEV), rowadd_div=hw, rowadd_mod=L)
+    wz = torch.zeros(B, L, hw, N)
+    wz[:, 1:] = (imgs @ w.t()).view(B, L - 1, hw, N) + tpos[1:, None, :]
+    torch.testing.assert_close(z.cpu(), wz.view(-1, N), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,stride,pad,cin,cout,H", [(3, 1, 1, 64, 64, 16), (4, 2, 1, 32, 48, 32), (1, 1, 0, 40, 24, 8), (3, 1, 1, 8, 8, 16)])
+def test_conv_implicit_gemm(dt, k, stride, pad, cin, cout, H):
+    o = ops()
+    from mage_amd.modules.vqvae_model import VectorQuantizedVAE as V
+    n = 3
+    x, w, b = rnd(n, cin, H, H, seed=20), rnd(cout, cin, k, k, seed=21, scale=(cin * k * k) ** -0.5), rnd(cout, seed=22)
+    if dt == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    want = F.conv2d(x, w, b, stride=stride, padding=pad)
+    OH = want.shape[-1]
+    xr = x.permute(0, 2, 3, 1).reshape(-1, cin)
+    wp = w.permute(0, 2, 3, 1).reshape(cout, -1)
+    y = torch.empty(n * OH * OH, cout, device=DEV)
+    V._conv(to_dev(xr, dt), to_dev(wp, dt), y, n_img=n, H=H, W=H, cin=cin, cout=cout, k=k, stride=stride, pad=pad, OH=OH, OW=OH,
+            bias=b.to(DEV))
+    got = y.cpu().view(n, OH, OH, cout).permute(0, 3, 1, 2)
+    torch.testing.assert_close(got, want, atol=3e-5 if dt == torch.float32 else 3e-3, rtol=1e-4)
+
+
+def test_layernorm_both_eps():
+    o = ops()
+    for Cc, eps in ((512, 1e-5), (64, 1e-8), (1024, 1e-5)):
+        x, g, b = rnd(37, Cc, seed=30, scale=3.0) + 0.5, rnd(Cc, seed=31), rnd(Cc, seed=32)
+        want = F.layer_norm(x, (Cc,), g, b, eps)
+        y = torch.empty(37, Cc, device=DEV)
+        o.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), y, eps)
+        torch.testing.assert_close(y.cpu(), want, atol=2e-5, rtol=2e-5)
+        yb = torch.empty(37, Cc, device=DEV, dtype=torch.bfloat16)
+        o.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), yb, eps)
+        torch.testing.assert_close(yb.float().cpu(), want, atol=3e-2, rtol=2e-2)
+
+
+def _ref_attn(q, k, v, H, mask=None):
+    R, Tq, E = q.shape
+    hd = E // H
+    qh, kh, vh = (z.view(R, -1, H, hd).transpose(1, 2) for z in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) * hd ** -0.5
+    if mask is not None:
+        s = s + mask
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(R, Tq, E)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("L", [16, 10, 32, 5])
+def test_axial_attention_all_axes(dt, L):
+    o = ops()
+    B, hh, ww, Cc = 2, 16, 16, 64
+    H = Cc // 32
+    hw = hh * ww
+    M = B * L * hw
+    qkv = rnd(M, 3 * Cc, seed=40)
+    if dt == torch.bfloat16:
+        qkv = qkv.bfloat16().float()
+    x5 = qkv.view(B, L, hh, ww, 3 * Cc)
+    dq = to_dev(qkv, dt)
+    for axis, geo in ((1, dict(n_seq=B * hw, inner=hw, nq=L, nk=L, q_outer_stride=L * hw, q_axis_stride=hw, causal=True)),
+                      (2, dict(n_seq=B * L * ww, inner=ww, nq=hh, nk=hh, q_outer_stride=hw, q_axis_stride=ww, causal=False)),
+                      (3, dict(n_seq=B * L * hh, inner=1, nq=ww, nk=ww, q_outer_stride=ww, q_axis_stride=1, causal=False))):
+        out = torch.empty(M, Cc, device=DEV, dtype=dt)
+        o.attention(dq, dq[:, Cc:], dq[:, 2 * Cc:], out, ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=Cc, n_head=H,
+                    kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], **geo)
+        xt = x5.movedim(axis, -2)
+        rows = xt.reshape(-1, xt.shape[-2], 3 * Cc)
+        A = rows.shape[1]
+        mask = torch.full((A, A), float("-inf")).triu_(1) if axis == 1 else None
+        want = _ref_attn(rows[..., :Cc], rows[..., Cc:2 * Cc], rows[..., 2 * Cc:], H, mask)
+        want = want.view(*xt.shape[:-1], Cc).movedim(-2, axis).reshape(M, Cc)
+        torch.testing.assert_close(out.float().cpu(), want, atol=2e-5 if dt == torch.float32 else 2e-2, rtol=1e-4 if dt == torch.float32 else 2e-2)
+
+
+def test_attention_key_padding_and_cross():
+    o = ops()
+    B, S, Cc, H = 3, 38, 64, 2
+    qkv = rnd(B * S, 3 * Cc, seed=41)
+    lens = torch.tensor([38, 5, 20], dtype=torch.int32)
+    out = torch.empty(B * S, Cc, device=DEV)
+    dq = qkv.to(DEV)
+    o.attention(dq, dq[:, Cc:], dq[:, 2 * Cc:], out, ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=Cc, n_seq=B, inner=1, nq=S, nk=S,
+                n_head=H, q_outer_stride=S, q_axis_stride=1, kv_outer_stride=S, kv_axis_stride=1, kv_len=lens.to(DEV))
+    r = qkv.view(B, S, 3 * Cc)
+    mask = torch.zeros(B, 1, 1, S)
+    for b in range(B):
+        mask[b, ..., lens[b]:] = float("-inf")
+    want = _ref_attn(r[..., :Cc], r[..., Cc:2 * Cc], r[..., 2 * Cc:], H, mask).reshape(B * S, Cc)
+    torch.testing.assert_close(out.cpu(), want, atol=2e-5, rtol=1e-4)
+    # cross attention, sequence-first addressing (row = t*B + b), 256 queries x 11 keys, 512 channels
+    Cc, H, nq, nk = 512, 16, 256, 11
+    q, kv = rnd(nq * B, Cc, seed=42), rnd(nk * B, 2 * Cc, seed=43)
+    out = torch.empty(nq * B, Cc, device=DEV)
+    dkv = kv.to(DEV)
+    o.attention(q.to(DEV), dkv, dkv[:, Cc:], out, ldq=Cc, ldk=2 * Cc, ldv=2 * Cc, ldo=Cc, n_seq=B, inner=B, nq=nq, nk=nk, n_head=H,
+                q_outer_stride=0, q_axis_stride=B, kv_outer_stride=0, kv_axis_stride=B)
+    qb, kvb = q.view(nq, B, Cc).transpose(0, 1), kv.view(nk, B, 2 * Cc).transpose(0, 1)
+    want = _ref_attn(qb, kvb[..., :Cc], kvb[..., Cc:], H).transpose(0, 1).reshape(nq * B, Cc)
+    torch.testing.assert_close(out.cpu(), want, atol=2e-5, rtol=1e-4)
+
+
+def test_vq_nearest_golden_ties_and_margin():
+    o = ops()
+    g = golden("vq_unit")
+    for zk, ck, ik in (("z", "cb", "idx"), ("z2", "cb2", "idx2")):
+        z, cb = t(g[zk]).to(DEV), t(g[ck]).to(DEV)
+        cbt, c2 = o.vq_prepare(cb)
+        idx, margin = o.vq_nearest(z.reshape(-1, cb.shape[1]).contiguous(), cbt, c2, want_margin=True)
+        want = t(g[ik]).reshape(-1)
+        bad = idx.cpu() != want
+        if zk == "z":
+            assert not bad.any()                              # exact ties: lowest index wins, like torch.min
+            assert margin[0].item() == 0.0 and margin[1].item() == 0.0
+        else:                                                  # reference-init regime: distances quantised at ulp(|z|^2)
+            m = t(g["margin2"]).reshape(-1)
+            assert not (bad & (m > 1e-5)).any()
+
+
+def test_embedding_argmax_ce_rowaffine():
+    o = ops()
+    table = rnd(50, 64, seed=50)
+    ids = torch.randint(0, 50, (7, 9), generator=torch.Generator().manual_seed(1))
+    out = torch.empty(63, 64, device=DEV)
+    o.embedding(ids.to(DEV), table.to(DEV), out, relu=True)
+    torch.testing.assert_close(out.cpu(), torch.relu(table[ids.reshape(-1)]))
+    logits = rnd(40, 512, seed=51)
+    logits[3, 100] = logits[3, 7] = 9.0                       # tie: first maximum
+    tgt = torch.randint(0, 512, (40,), generator=torch.Generator().manual_seed(2))
+    am = torch.empty(40, device=DEV, dtype=torch.int64)
+    mg = torch.empty(40, device=DEV)
+    o.argmax(logits.to(DEV), am, rows=40, K=512, margin=mg)
+    assert torch.equal(am.cpu(), logits.max(-1)[1]) and am[3].item() == 7 and mg[3].item() == 0.0
+    # regrouped: pick frame 2 of [B=4, T=5, hw=2, K] and write into slot 3 of a [B, 5, hw] token buffer
+    lg = rnd(4 * 5 * 2, 512, seed=52)
+    buf = torch.full((4, 5, 2), -1, device=DEV, dtype=torch.int64)
+    o.argmax(lg.to(DEV), buf, rows=8, K=512, group=2, in_group_stride=10, in_off=4, out_group_stride=10, out_off=6)
+    wantb = torch.full((4, 5, 2), -1, dtype=torch.int64)
+    wantb[:, 3] = lg.view(4, 5, 2, 512)[:, 2].max(-1)[1]
+    assert torch.equal(buf.cpu(), wantb)
+    loss = o.cross_entropy(logits.to(DEV), tgt.to(DEV))
+    assert abs(loss.item() - F.cross_entropy(logits, tgt).item()) < 1e-5
+    x, rs, tab = rnd(24, 64, seed=53), rnd(24, seed=54), rnd(6, 64, seed=55)
+    dx = x.to(DEV).clone()
+    o.row_affine(dx, rs.to(DEV), tab.to(DEV), div=2, mod=6)
+    torch.testing.assert_close(dx.cpu(), x * rs[:, None] + tab[(torch.arange(24) // 2) % 6])
+
+
+def test_direct_convs_pool_upsample_adain():
+    o = ops()
+    # f4 stem: Conv2d(1, 64, 4, 2, 1) + BN + ReLU, NCHW image -> channels-last
+    x, w, b = rnd(2, 1, 64, 64, seed=60), rnd(64, 1, 4, 4, seed=61, scale=0.25), rnd(64, seed=62)
+    sc, sh = rnd(64, seed=63).abs() + 0.5, rnd(64, seed=64)
+    want = torch.relu((F.conv2d(x, w, b, stride=2, padding=1)) * sc[None, :, None, None] + sh[None, :, None, None])
+    y = torch.empty(2 * 32 * 32, 64, device=DEV)
+    o.conv_in(x.to(DEV), w.permute(1, 2, 3, 0).contiguous().to(DEV), b.to(DEV), sc.to(DEV), sh.to(DEV), y, cin=1, H=64, W=64,
+              cout=64, kh=4, kw=4, stride=2, pad=1, act=o.ACT_RELU)
+    torch.testing.assert_close(y.cpu().view(2, 32, 32, 64).permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5)
+    # f8 stem: Conv2d(3, 32, 7, padding=3)
+    x, w, b = rnd(1, 3, 32, 32, seed=65), rnd(32, 3, 7, 7, seed=66, scale=0.1), rnd(32, seed=67)
+    y = torch.empty(32 * 32, 32, device=DEV)
+    o.conv_in(x.to(DEV), w.permute(1, 2, 3, 0).contiguous().to(DEV), b.to(DEV), None, None, y, cin=3, H=32, W=32, cout=32, kh=7,
+              kw=7, stride=1, pad=3)
+    torch.testing.assert_close(y.cpu().view(1, 32, 32, 32).permute(0, 3, 1, 2), F.conv2d(x, w, b, padding=3), atol=3e-5, rtol=1e-5)
+    # ConvTranspose2d(64, 1, 4, 2, 1) + tanh and Conv2d(64, 3, 1) + tanh, channels-last -> NCHW
+    xi, wt, bt = rnd(2, 64, 8, 8, seed=68), rnd(64, 1, 4, 4, seed=69, scale=0.1), rnd(1, seed=70)
+    out = torch.empty(2, 1, 16, 16, device=DEV)
+    o.conv_out(xi.permute(0, 2, 3, 1).contiguous().to(DEV), wt.permute(2, 3, 1, 0).contiguous().to(DEV), bt.to(DEV), out, N=2, IH=8,
+               IW=8, cin=64, cout=1, transposed=True)
+    torch.testing.assert_close(out.cpu(), torch.tanh(F.conv_transpose2d(xi, wt, bt, stride=2, padding=1)), atol=2e-5, rtol=1e-5)
+    w1, b1 = rnd(3, 64, 1, 1, seed=71, scale=0.2), rnd(3, seed=72)
+    out = torch.empty(2, 3, 8, 8, device=DEV)
+    o.conv_out(xi.permute(0, 2, 3, 1).contiguous().to(DEV), w1.reshape(3, 64).contiguous().to(DEV), b1.to(DEV), out, N=2, IH=8, IW=8,
+               cin=64, cout=3, transposed=False)
+    torch.testing.assert_close(out.cpu(), torch.tanh(F.conv2d(xi, w1, b1)), atol=2e-5, rtol=1e-5)
+    # pool / upsample / relu / cast
+    xc = rnd(2, 8, 8, 16, seed=73)
+    p = torch.empty(2 * 4 * 4, 16, device=DEV)
+    o.maxpool2(xc.to(DEV), p, N=2, H=8, W=8, Cc=16)
+    torch.testing.assert_close(p.cpu().view(2, 4, 4, 16), F.max_pool2d(xc.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
+    u = torch.empty(2 * 16 * 16, 16, device=DEV)
+    o.upsample2(xc.to(DEV), u, N=2, H=8, W=8, Cc=16)
+    torch.testing.assert_close(u.cpu().view(2, 16, 16, 16), F.interpolate(xc.permute(0, 3, 1, 2), scale_factor=2).permute(0, 2, 3, 1))
+    r = o.relu(xc.to(DEV), torch.empty_like(xc, device=DEV))
+    torch.testing.assert_close(r.cpu(), torch.relu(xc))
+    cb = o.cast(xc.to(DEV), torch.empty(xc.shape, device=DEV, dtype=torch.bfloat16))
+    assert torch.equal(cb.cpu(), xc.bfloat16())
+    # ADAIN + speed add
+    B, P, Cc = 2, 256, 64
+    xm, gm, bt2 = rnd(B, P, Cc, seed=74, scale=2.0) + 1, rnd(B, P, Cc, seed=75), rnd(B, P, Cc, seed=76)
+    oa = o.adain(xm.to(DEV), gm.to(DEV), bt2.to(DEV), torch.empty(B, P, Cc, device=DEV), B=B, P=P, Cc=Cc)
+    want = gm * F.instance_norm(xm.permute(0, 2, 1)).permute(0, 2, 1) + bt2
+    torch.testing.assert_close(oa.cpu(), want, atol=2e-5, rtol=1e-4)
+    sp, vec = rnd(B, seed=77), rnd(Cc, seed=78)
+    xs = xm.to(DEV).clone()
+    o.add_scaled_rowvec(xs, sp.to(DEV), vec.to(DEV), B=B, P=P, Cc=Cc)
+    torch.testing.assert_close(xs.cpu(), xm + sp[:, None, None] * vec)
+
+
+def test_errors_are_loud():
+    o = ops()
+    a = torch.zeros(8, 8, device=DEV)
+    with pytest.raises(ValueError):
+        o.gemm(a, a, a, M=8, N=6, K=8, lda=8, ldy=6)           # N not a multiple of 4
+    with pytest.raises(RuntimeError):
+        o.layernorm(torch.zeros(4, 8), torch.zeros(8), torch.zeros(8), torch.zeros(4, 8), 1e-5)   # CPU tensors: no fallback
