@@ -88,6 +88,9 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         raise MageHipError(
             f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             f"(or `make -C mage_amd/csrc`). There is no CPU/PyTorch fallback for the MAGE product path.")
+    # torch bundles its own libamdhip64.so.7; import it FIRST so that this library binds to the HIP runtime
+    # that owns torch's streams and allocations (two HIP runtimes in one process do not see each other's devices).
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale / missing a symbol
