@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmage_hip.so")
+LIB_PATH = os.environ.get("MAGE_HIP_LIB", os.path.join(_HERE, "lib", "libmage_hip.so"))   # override: kernel-tuning builds only
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_QUICKGELU, ACT_GELU_ERF, ACT_TANH = 0, 1, 2, 3, 4

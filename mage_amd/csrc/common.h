@@ -61,12 +61,29 @@ __device__ __forceinline__ f32x4 load4(const unsigned short* p) {
     return o;
 }
 __device__ __forceinline__ void store4(float* p, f32x4 v) { *(f32x4*)p = v; }
+// two fp32 -> packed bf16x2 with the hardware converter (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN-safe)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ unsigned int pack_bf16x2(float a, float b) {
+    bf16x2_t v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned int, v);
+}
 __device__ __forceinline__ void store4(unsigned short* p, f32x4 v) {
     uint2 r;
-    r.x = (unsigned int)f2bf_bits(v[0]) | ((unsigned int)f2bf_bits(v[1]) << 16);
-    r.y = (unsigned int)f2bf_bits(v[2]) | ((unsigned int)f2bf_bits(v[3]) << 16);
+    r.x = pack_bf16x2(v[0], v[1]);
+    r.y = pack_bf16x2(v[2], v[3]);
     *(uint2*)p = r;
 }
+
+// 8 consecutive elements (16 bytes of bf16) in one store
+__device__ __forceinline__ void store8(unsigned short* p, f32x4 a, f32x4 b) {
+    uint4 r;
+    r.x = pack_bf16x2(a[0], a[1]);
+    r.y = pack_bf16x2(a[2], a[3]);
+    r.z = pack_bf16x2(b[0], b[1]);
+    r.w = pack_bf16x2(b[2], b[3]);
+    *(uint4*)p = r;
+}
+__device__ __forceinline__ void store8(float* p, f32x4 a, f32x4 b) { *(f32x4*)p = a; *(f32x4*)(p + 4) = b; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

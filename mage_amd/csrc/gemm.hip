@@ -17,6 +17,23 @@
 // byte-identical LDS image, loader and epilogue with the bf16 path: only the inner MFMA differs.
 #include "common.h"
 
+#ifndef MAGE_ABL
+#define MAGE_ABL 0
+#endif
+#ifndef MAGE_STAGGER
+#define MAGE_STAGGER 100          // x64 clocks
+#endif
+
+#if MAGE_ABL == 4
+__device__ unsigned long long mage_dbg[8 * 65536];
+extern "C" int mage_debug_read(void* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mage_dbg), bytes);
+}
+#define DBG_T(slot) do { if (lane == 0 && wave == 0 && blockIdx.x < 65536) mage_dbg[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DBG_T(slot)
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128;
@@ -39,17 +56,132 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ float act_apply(float v, int act) {
-    switch (act) {
-        case MAGE_ACT_RELU: return fmaxf(v, 0.f);
-        case MAGE_ACT_QUICKGELU: return v / (1.f + __expf(-1.702f * v));
-        case MAGE_ACT_GELU_ERF: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-        case MAGE_ACT_TANH: return tanhf(v);
-        default: return v;
+template <int ACT>
+__device__ __forceinline__ float act_apply(float v) {
+    if (ACT == MAGE_ACT_RELU) return fmaxf(v, 0.f);
+    if (ACT == MAGE_ACT_QUICKGELU) return v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
+    if (ACT == MAGE_ACT_GELU_ERF) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    return v;
+}
+
+// Epilogue of one wave's 64x64 sub-tile.  The MFMA layout leaves each lane with 4 consecutive n of 16 different rows
+// per accumulator; stores straight from it would touch 16 rows x 32..64 B per instruction.  Instead the wave transposes
+// its sub-tile through a wave-private LDS staging tile (32 rows x 64 fp32, +4 pad: conflict-free b128 writes), in two
+// halves, and reads it back row-major with VEC consecutive columns per lane: a store instruction then covers whole
+// 128/256-byte lines, and the per-column vectors (bias, BN scale/shift) are loaded once per lane.
+template <int ACT, int VEC, typename OT>
+__device__ __forceinline__ void epilogue_rows(const mage_gemm_desc& d, f32x4 (&acc)[4][4], char* smem, int m0, int n0,
+                                              int wave, int lane, int plane) {
+    constexpr int LPR = 64 / VEC;          // lanes per row (16 | 8)
+    constexpr int RPP = 64 / LPR;          // rows per pass (4 | 8)
+    constexpr int NQ = 64 / RPP;           // row slots per lane (16 | 8)
+    constexpr int NV = VEC / 4;            // f32x4 vectors per slot (1 | 2)
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int rsub = lane / LPR;           // row inside a pass
+    const int c0 = (lane % LPR) * VEC;     // first column inside the wave's 64
+    const int n = n0 + wn * 64 + c0;
+    const bool nv = n < d.N;               // N % VEC == 0 is checked on the host for bf16 output
+    const bool simple_rows = d.out_h == 1 && d.out_w >= d.M;       // no regrouping: yrow = m*y_mul_x + y_off
+    // Rows/columns outside the problem are CLAMPED to valid ones for the loads (hipcc turns a predicated load into a
+    // branch + s_waitcnt vmcnt(0) per element, serialising the round trips); only the stores are predicated.
+    const int n_ld = nv ? n : 0;
+    int yrow[NQ];
+    unsigned valid = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int mq = m0 + wm * 64 + q * RPP + rsub;
+        const int m = min(mq, d.M - 1);
+        if (simple_rows) {
+            yrow[q] = m * d.y_mul_x + d.y_off;
+        } else {
+            const int img = m / plane;
+            const int rem = m - img * plane;
+            const int oy = rem / d.out_w;
+            const int ox = rem - oy * d.out_w;
+            yrow[q] = img * d.y_img_stride + oy * d.y_mul_y + ox * d.y_mul_x + d.y_off;
+        }
+        valid |= (mq < d.M && nv) ? (1u << q) : 0u;
+    }
+    // Everything the epilogue reads from global memory is requested HERE, before the first store: vmcnt retires in
+    // order, so a load issued after a store would make its wait drain that store's full round trip.
+    f32x4 extra[NQ][NV];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int h = 0; h < NV; ++h) extra[q][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (d.residual) {
+        if (d.res_dtype == MAGE_F32) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int h = 0; h < NV; ++h) extra[q][h] = load4((const float*)d.residual + (long)yrow[q] * d.ldr + n_ld + 4 * h);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int h = 0; h < NV; ++h)
+                    extra[q][h] = load4((const unsigned short*)d.residual + (long)yrow[q] * d.ldr + n_ld + 4 * h);
+        }
+    }
+    if (d.rowadd) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float* rp = d.rowadd + (long)((yrow[q] / d.rowadd_div) % d.rowadd_mod) * d.N + n_ld;
+#pragma unroll
+            for (int h = 0; h < NV; ++h) extra[q][h] += *(const f32x4*)(rp + 4 * h);
+        }
+    }
+    f32x4 bias4[NV], scale4[NV], shift4[NV];
+#pragma unroll
+    for (int h = 0; h < NV; ++h) {
+        bias4[h] = d.bias ? *(const f32x4*)(d.bias + n_ld + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+        scale4[h] = d.scale ? *(const f32x4*)(d.scale + n_ld + 4 * h) : f32x4{1.f, 1.f, 1.f, 1.f};
+        shift4[h] = d.scale ? *(const f32x4*)(d.shift + n_ld + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float lo = d.post_relu ? 0.f : -INFINITY;     // post-ReLU as one max (scale/shift default to 1/0: one fma)
+    DBG_T(4);
+    __syncthreads();                                   // all waves are done reading the last K slab
+    DBG_T(5);
+    float* stg = (float*)smem + wave * (32 * 68);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) *(f32x4*)(stg + (mh * 16 + l15) * 68 + nt * 16 + grp * 4) = acc[half * 2 + mh][nt];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < NQ / 2; ++p) {
+            const int q = half * (NQ / 2) + p;
+            f32x4 v[NV];
+#pragma unroll
+            for (int h = 0; h < NV; ++h) {
+                v[h] = *(const f32x4*)(stg + (p * RPP + rsub) * 68 + c0 + 4 * h);
+                v[h] = (v[h] + bias4[h]) * scale4[h] + shift4[h];
+                if (ACT != MAGE_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[h][e] = act_apply<ACT>(v[h][e]);
+                }
+                v[h] += extra[q][h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[h][e] = fmaxf(v[h][e], lo);
+            }
+            if (valid & (1u << q)) {
+                int yr = yrow[q];
+#if MAGE_ABL == 3
+                yr &= 127;                             // ablation: all tiles write the same small (L2-resident) region
+#endif
+                OT* yp = (OT*)d.Y + (long)yr * d.ldy + n;
+                if (NV == 1) store4(yp, v[0]);
+                else store8(yp, v[0], v[NV - 1]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
-template <int DT, bool GATHER>
+template <int DT, bool GATHER, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     typedef typename TT<DT>::elem E;
     constexpr int CH = TT<DT>::CH;
@@ -143,6 +275,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (d.K + BK - 1) / BK;
+#ifndef MAGE_NO_STAGGER
+    // De-phase the two workgroups that share a CU.  All first-generation workgroups start together and every tile takes
+    // the same time, so without this the whole chip alternates between "everyone in the MFMA loop" and "everyone
+    // storing" (measured: epilogue ~= main loop).  Delaying every other first-generation workgroup by about half a main
+    // loop makes one workgroup's stores overlap its neighbour's MFMAs; later generations inherit the offset.
+    if (bid < 2 * 256 && ((bid >> 3) & 32)) __builtin_amdgcn_s_sleep(MAGE_STAGGER);
+#endif
+    DBG_T(0);
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                               // slab kt has landed; slab kt-1's readers are done
@@ -157,7 +297,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 xf[i] = *(const u32x4*)(st + xoff + i * 2048 + pc);
                 wf[i] = *(const u32x4*)(st + woff + i * 2048 + pc);
             }
+#if MAGE_ABL == 2
+            {   // ablation: loads + LDS reads only, no MFMA
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc[i][0][0] += __uint_as_float(xf[i][0] ^ wf[i][1]); }
+            }
+            if (false) {
+#else
             if (DT == MAGE_BF16) {
+#endif
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -177,48 +325,41 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
     }
 
-    // ---- epilogue: lane holds, per (mt, nt), output row m = ..+l15 and 4 consecutive columns n = ..+grp*4
+#if MAGE_ABL == 1
+    {   // ablation: main loop only (keep the accumulators alive, store nothing)
+        float sacc = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + l15;
-        if (m >= d.M) continue;
-        const int img = m / plane;
-        const int rem = m - img * plane;
-        const int oy = rem / d.out_w;
-        const int ox = rem - oy * d.out_w;
-        const long yrow = (long)img * d.y_img_stride + (long)oy * d.y_mul_y + (long)ox * d.y_mul_x + d.y_off;
-        const float* radd = d.rowadd ? d.rowadd + ((yrow / d.rowadd_div) % d.rowadd_mod) * (long)d.N : nullptr;
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wn * 64 + nt * 16 + grp * 4;
-            if (n >= d.N) continue;
-            f32x4 v = acc[mt][nt];
-            if (d.bias) v += *(const f32x4*)(d.bias + n);
-            if (d.scale) v = v * *(const f32x4*)(d.scale + n) + *(const f32x4*)(d.shift + n);
-            if (d.act != MAGE_ACT_NONE) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], d.act);
-            }
-            if (radd) v += *(const f32x4*)(radd + n);
-            if (d.residual) {
-                if (d.res_dtype == MAGE_F32) v += load4((const float*)d.residual + yrow * d.ldr + n);
-                else v += load4((const unsigned short*)d.residual + yrow * d.ldr + n);
-            }
-            if (d.post_relu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            if (d.y_dtype == MAGE_F32) store4((float*)d.Y + yrow * d.ldy + n, v);
-            else store4((unsigned short*)d.Y + yrow * d.ldy + n, v);
-        }
+            for (int b = 0; b < 4; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+        if (sacc == 123456.789f) ((float*)d.Y)[0] = sacc;
+        return;
     }
+#endif
+    // ---- epilogue (see epilogue_rows): fp32 output -> 4 columns per lane, bf16 output -> 8 columns per lane, so that
+    // every store instruction is a 16-byte-per-lane dwordx4 (a CU retires roughly one wave-store per ~70 cycles
+    // whatever its width: fewer, wider stores).
+    DBG_T(1);
+    if (d.y_dtype == MAGE_F32) epilogue_rows<ACT, 4, float>(d, acc, smem, m0, n0, wave, lane, plane);
+    else epilogue_rows<ACT, 8, unsigned short>(d, acc, smem, m0, n0, wave, lane, plane);
+#if MAGE_ABL == 4
+    DBG_T(6);
+    __builtin_amdgcn_s_waitcnt(0);
+    DBG_T(2);
+    if (lane == 0 && wave == 0 && bid < 65536) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        mage_dbg[bid * 8 + 3] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
 }
 
-template <int DT, bool GATHER>
-int launch(const mage_gemm_desc* d, hipStream_t s) {
+template <int DT, bool GATHER, int ACT>
+int launch_act(const mage_gemm_desc* d, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
     GemmArgs a;
@@ -226,9 +367,20 @@ int launch(const mage_gemm_desc* d, hipStream_t s) {
     a.zero = (const char*)mage_zero_page();
     const int tiles_m = (d->M + BM - 1) / BM;
     a.ntiles_n = (d->N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_kernel<DT, GATHER>), dim3(tiles_m * a.ntiles_n), dim3(256), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT>), dim3(tiles_m * a.ntiles_n), dim3(256), LDS_BYTES, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
     return MAGE_OK;
+}
+
+template <int DT, bool GATHER>
+int launch(const mage_gemm_desc* d, hipStream_t s) {
+    switch (d->act) {
+        case MAGE_ACT_NONE: return launch_act<DT, GATHER, MAGE_ACT_NONE>(d, s);
+        case MAGE_ACT_RELU: return launch_act<DT, GATHER, MAGE_ACT_RELU>(d, s);
+        case MAGE_ACT_QUICKGELU: return launch_act<DT, GATHER, MAGE_ACT_QUICKGELU>(d, s);
+        case MAGE_ACT_GELU_ERF: return launch_act<DT, GATHER, MAGE_ACT_GELU_ERF>(d, s);
+        default: mage_set_error("mage_gemm: activation %d is not available in the GEMM epilogue", d->act); return MAGE_EINVAL;
+    }
 }
 
 }  // namespace
@@ -245,6 +397,8 @@ extern "C" int mage_gemm(const mage_gemm_desc* d, void* stream) {
     MAGE_CHECK_ARG(d->K % ch == 0 && d->lda % ch == 0 && d->cin % ch == 0,
                    "mage_gemm: K=%d, lda=%d, cin=%d must be multiples of %d", d->K, d->lda, d->cin, ch);
     MAGE_CHECK_ARG(d->ldy % 4 == 0 && (!d->residual || d->ldr % 4 == 0), "mage_gemm: ldy/ldr must be multiples of 4");
+    MAGE_CHECK_ARG(d->y_dtype != MAGE_BF16 || (d->N % 8 == 0 && d->ldy % 8 == 0 && (!d->residual || d->ldr % 8 == 0)),
+                   "mage_gemm: bf16 output needs N, ldy (and ldr) multiples of 8 (16-byte stores)");
     MAGE_CHECK_ARG(d->taps_h >= 1 && d->taps_w >= 1 && d->K == d->taps_h * d->taps_w * d->cin,
                    "mage_gemm: K=%d != taps_h*taps_w*cin = %d*%d*%d", d->K, d->taps_h, d->taps_w, d->cin);
     MAGE_CHECK_ARG(d->out_h >= 1 && d->out_w >= 1 && d->in_h >= 1 && d->in_w >= 1, "mage_gemm: bad geometry");
