@@ -1,50 +1,48 @@
 // Fused GEMM / implicit-GEMM convolution on CDNA4 matrix cores (see include/mage_hip.h, mage_gemm).
 //
-// Tile: 128 (rows of A, "m") x 128 (rows of W, "n") per 256-thread workgroup, K consumed in slabs of
-// 128 bytes per row (64 bf16 / 32 fp32).  4 waves as 2(m) x 2(n); each wave owns a 64x64 sub-tile as 4x4
-// MFMA 16x16 accumulators (64 fp32 accumulator registers per lane).
+// Persistent kernel: one 512-thread workgroup per CU walks a list of 256 (rows of A, "m") x 256 (rows of W, "n") output
+// tiles.  8 waves as 2(m) x 4(n); each wave owns a 128x64 sub-tile as 8x4 MFMA 16x16 accumulators (128 fp32 registers).
 //
-// HBM -> LDS: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip), double buffered, one barrier per
-// K slab.  An LDS-DMA writes wave-base + lane*16, so the LDS image is lane-linear: [row][8 chunks of 16 B].
-// Bank conflicts on the fragment reads are removed by an XOR swizzle applied on the *source* address of
-// the DMA (physical chunk p of row r holds logical chunk p ^ ((r>>1)&7)) and again on the ds_read_b128.
+// Why 256x256: measured with ablation builds on the decoder shapes (M=262144, K=512), the L2 -> LDS path alone tops out
+// near 17.6 TB/s chip-wide; a 256x128 tile (85 FLOP per staged byte) needs 1.55 k cycles of it per K slab while the
+// MFMAs need 1.0 k, and the two overlapped poorly (855 TF).  256x256 is 128 FLOP per staged byte and 24 fragment reads
+// per 64 MFMAs instead of 16 per 32.
 //
-// MFMA operand roles are swapped (A-operand = W rows, B-operand = activation rows) so that each lane ends
-// up with 4 consecutive output columns n of ONE output row m: the epilogue then reads bias / BN / residual
-// and writes Y with 16-byte (fp32) or 8-byte (bf16) vectors, no LDS transpose.
+// HBM/L2 -> LDS: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip) into a 2-stage ring of K slabs (128 bytes per
+// row = 64 bf16 / 32 fp32; one stage = 256+256 rows = 64 KiB).  The ring is ONE continuous stream across tiles: while
+// the last slab of a tile is multiplied and its epilogue runs, the first slab of the next tile is already in flight.
+// The barrier is a raw `s_barrier` (a `__syncthreads()` would drain vmcnt where it stands); the DMA issue is split in
+// two halves placed in front of the two MFMA batches of an iteration so that the memory queue is fed evenly.
 //
-// fp32 mode uses v_mfma_f32_16x16x4_f32 (exact fp32 fma chain, 1/16 of the bf16 rate); it shares the
-// byte-identical LDS image, loader and epilogue with the bf16 path: only the inner MFMA differs.
+// An LDS-DMA writes wave-base + lane*16, so the LDS image is lane-linear: [row][8 chunks of 16 B].  Bank conflicts on
+// the fragment reads are removed by an XOR swizzle applied on the *source* address of the DMA (physical chunk p of row r
+// holds logical chunk p ^ ((r>>1)&7)) and again on the ds_read_b128.
+//
+// MFMA operand roles are swapped (A-operand = W rows, B-operand = activation rows) so that each lane ends up with 4
+// consecutive output columns n of ONE output row m per accumulator.
+//
+// fp32 mode uses v_mfma_f32_16x16x4_f32 (exact fp32 fma chain, 1/16 of the bf16 rate); it shares the byte-identical
+// LDS image, loader and epilogue with the bf16 path: only the inner MFMA differs.
 #include "common.h"
 
 #ifndef MAGE_ABL
-#define MAGE_ABL 0
-#endif
-#ifndef MAGE_STAGGER
-#define MAGE_STAGGER 100          // x64 clocks
-#endif
-
-#if MAGE_ABL == 4
-__device__ unsigned long long mage_dbg[8 * 65536];
-extern "C" int mage_debug_read(void* host, size_t bytes) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mage_dbg), bytes);
-}
-#define DBG_T(slot) do { if (lane == 0 && wave == 0 && blockIdx.x < 65536) mage_dbg[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define DBG_T(slot)
+#define MAGE_ABL 0               // 1 = tuning build: skip the epilogue (main loop only)
 #endif
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
-constexpr int TILE_BYTES = 128 * 128;          // one operand tile: 128 rows x 128 bytes
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A tile + W tile
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;     // double buffered: 64 KiB -> 2 workgroups per CU
+constexpr int BM = 256, BN = 256;
+constexpr int A_BYTES = BM * 128;                  // A part of a stage: 256 rows x 128 bytes
+constexpr int W_BYTES = BN * 128;
+constexpr int STAGE_BYTES = A_BYTES + W_BYTES;     // 64 KiB
+constexpr int NSTAGE = 2;
+constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;    // 128 KiB: one workgroup (8 waves, 2 per SIMD) per CU
+constexpr int STG_ROWS = 16, STG_LD = 68;          // epilogue staging: 16 rows x 64 fp32 (+4 pad) per wave = 4352 B
 
 struct GemmArgs {
     mage_gemm_desc d;
     const char* zero;
-    int ntiles_n;
+    int ntiles_n, ntiles;
 };
 
 template <int DT> struct TT;
@@ -64,115 +62,131 @@ __device__ __forceinline__ float act_apply(float v) {
     return v;
 }
 
-// Epilogue of one wave's 64x64 sub-tile.  The MFMA layout leaves each lane with 4 consecutive n of 16 different rows
-// per accumulator; stores straight from it would touch 16 rows x 32..64 B per instruction.  Instead the wave transposes
-// its sub-tile through a wave-private LDS staging tile (32 rows x 64 fp32, +4 pad: conflict-free b128 writes), in two
-// halves, and reads it back row-major with VEC consecutive columns per lane: a store instruction then covers whole
-// 128/256-byte lines, and the per-column vectors (bias, BN scale/shift) are loaded once per lane.
-template <int ACT, int VEC, typename OT>
-__device__ __forceinline__ void epilogue_rows(const mage_gemm_desc& d, f32x4 (&acc)[4][4], char* smem, int m0, int n0,
-                                              int wave, int lane, int plane) {
-    constexpr int LPR = 64 / VEC;          // lanes per row (16 | 8)
-    constexpr int RPP = 64 / LPR;          // rows per pass (4 | 8)
-    constexpr int NQ = 64 / RPP;           // row slots per lane (16 | 8)
-    constexpr int NV = VEC / 4;            // f32x4 vectors per slot (1 | 2)
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l15 = lane & 15, grp = lane >> 4;
-    const int rsub = lane / LPR;           // row inside a pass
-    const int c0 = (lane % LPR) * VEC;     // first column inside the wave's 64
-    const int n = n0 + wn * 64 + c0;
+// Epilogue of one 32x64 block of a wave's sub-tile.  The MFMA layout leaves each lane with 4 consecutive n of 16 different rows
+// per accumulator; stores straight from it would be 8-byte pieces of 16 rows.  Instead the wave transposes its sub-tile
+// through a wave-private LDS staging tile (16 rows x 64 fp32, +4 pad: conflict-free b128 writes), one 16-row quarter at
+// a time, and reads it back row-major with VEC consecutive columns per lane (fp32 out: 4, bf16 out: 8): every store is
+// a 16-byte-per-lane dwordx4 of whole lines (a CU retires roughly one wave-store per ~70 cycles whatever its width),
+// and the per-column vectors (bias, BN scale/shift) are loaded once per lane.
+// per-column epilogue vectors of one lane (bias, BN scale/shift): fetched once per tile, at the START of its K loop
+struct ColVecs {
+    f32x4 bias[2], scale[2], shift[2];
+};
+__device__ __forceinline__ void load_colvecs(ColVecs& cv, const mage_gemm_desc& d, int n0, int lane) {
+    const int vec = d.y_dtype == MAGE_F32 ? 4 : 8;
+    const int n = n0 + (lane % (64 / vec)) * vec;
+    const int n_ld = n < d.N ? n : 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int o = n_ld + (vec == 8 ? 4 * h : 0);
+        cv.bias[h] = d.bias ? *(const f32x4*)(d.bias + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+        cv.scale[h] = d.scale ? *(const f32x4*)(d.scale + o) : f32x4{1.f, 1.f, 1.f, 1.f};
+        cv.shift[h] = d.scale ? *(const f32x4*)(d.shift + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// Prefetched state of one 32x64 block: output rows, store predicate, and everything added after the activation
+// (residual + row table), requested one block AHEAD of its use so that no round trip is exposed.
+template <int VEC>
+struct EpiBlock {
+    static constexpr int LPR = 64 / VEC, RPP = 64 / LPR, NQ = 32 / RPP, NV = VEC / 4;
+    int yrow[NQ];
+    unsigned valid;
+    f32x4 extra[NQ][NV];
+};
+
+template <int VEC>
+__device__ __forceinline__ void epi_prefetch(EpiBlock<VEC>& b, const mage_gemm_desc& d, int m0, int n0, int lane, int plane) {
+    constexpr int LPR = EpiBlock<VEC>::LPR, RPP = EpiBlock<VEC>::RPP, NQ = EpiBlock<VEC>::NQ, NV = EpiBlock<VEC>::NV;
+    const int rsub = lane / LPR;
+    const int n = n0 + (lane % LPR) * VEC;
     const bool nv = n < d.N;               // N % VEC == 0 is checked on the host for bf16 output
     const bool simple_rows = d.out_h == 1 && d.out_w >= d.M;       // no regrouping: yrow = m*y_mul_x + y_off
     // Rows/columns outside the problem are CLAMPED to valid ones for the loads (hipcc turns a predicated load into a
     // branch + s_waitcnt vmcnt(0) per element, serialising the round trips); only the stores are predicated.
     const int n_ld = nv ? n : 0;
-    int yrow[NQ];
-    unsigned valid = 0;
+    b.valid = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int mq = m0 + wm * 64 + q * RPP + rsub;
+        const int mq = m0 + q * RPP + rsub;
         const int m = min(mq, d.M - 1);
         if (simple_rows) {
-            yrow[q] = m * d.y_mul_x + d.y_off;
+            b.yrow[q] = m * d.y_mul_x + d.y_off;
         } else {
             const int img = m / plane;
             const int rem = m - img * plane;
             const int oy = rem / d.out_w;
             const int ox = rem - oy * d.out_w;
-            yrow[q] = img * d.y_img_stride + oy * d.y_mul_y + ox * d.y_mul_x + d.y_off;
+            b.yrow[q] = img * d.y_img_stride + oy * d.y_mul_y + ox * d.y_mul_x + d.y_off;
         }
-        valid |= (mq < d.M && nv) ? (1u << q) : 0u;
+        b.valid |= (mq < d.M && nv) ? (1u << q) : 0u;
     }
-    // Everything the epilogue reads from global memory is requested HERE, before the first store: vmcnt retires in
-    // order, so a load issued after a store would make its wait drain that store's full round trip.
-    f32x4 extra[NQ][NV];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int h = 0; h < NV; ++h) extra[q][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < NV; ++h) b.extra[q][h] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (d.residual) {
         if (d.res_dtype == MAGE_F32) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int h = 0; h < NV; ++h) extra[q][h] = load4((const float*)d.residual + (long)yrow[q] * d.ldr + n_ld + 4 * h);
+                for (int h = 0; h < NV; ++h) b.extra[q][h] = load4((const float*)d.residual + (long)b.yrow[q] * d.ldr + n_ld + 4 * h);
         } else {
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int h = 0; h < NV; ++h)
-                    extra[q][h] = load4((const unsigned short*)d.residual + (long)yrow[q] * d.ldr + n_ld + 4 * h);
+                    b.extra[q][h] = load4((const unsigned short*)d.residual + (long)b.yrow[q] * d.ldr + n_ld + 4 * h);
         }
     }
     if (d.rowadd) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const float* rp = d.rowadd + (long)((yrow[q] / d.rowadd_div) % d.rowadd_mod) * d.N + n_ld;
+            const float* rp = d.rowadd + (long)((b.yrow[q] / d.rowadd_div) % d.rowadd_mod) * d.N + n_ld;
 #pragma unroll
-            for (int h = 0; h < NV; ++h) extra[q][h] += *(const f32x4*)(rp + 4 * h);
+            for (int h = 0; h < NV; ++h) b.extra[q][h] += *(const f32x4*)(rp + 4 * h);
         }
     }
-    f32x4 bias4[NV], scale4[NV], shift4[NV];
-#pragma unroll
-    for (int h = 0; h < NV; ++h) {
-        bias4[h] = d.bias ? *(const f32x4*)(d.bias + n_ld + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
-        scale4[h] = d.scale ? *(const f32x4*)(d.scale + n_ld + 4 * h) : f32x4{1.f, 1.f, 1.f, 1.f};
-        shift4[h] = d.scale ? *(const f32x4*)(d.shift + n_ld + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+}
+
+// Epilogue of one 32x64 block of a wave's sub-tile.  The MFMA layout leaves each lane with 4 consecutive n of 16 different
+// rows per accumulator; stores straight from it would be 8-byte pieces of 16 rows.  Instead the wave transposes the block
+// through a wave-private LDS staging tile (16 rows x 64 fp32, +4 pad: conflict-free b128 writes), 16 rows at a time, and
+// reads it back row-major with VEC consecutive columns per lane (fp32 out: 4, bf16 out: 8): every store is a
+// 16-byte-per-lane dwordx4 of whole lines (a CU retires roughly one wave-store per ~70-90 cycles whatever its width).
+template <int ACT, int VEC, typename OT>
+__device__ __forceinline__ void epi_store(const mage_gemm_desc& d, const ColVecs& cv, const EpiBlock<VEC>& b, f32x4 (&acc)[2][4],
+                                          float* stg, int n0, int lane) {
+    constexpr int LPR = EpiBlock<VEC>::LPR, RPP = EpiBlock<VEC>::RPP, NV = EpiBlock<VEC>::NV;
+    constexpr int PPQ = STG_ROWS / RPP;    // passes per staged 16 rows (4 | 2)
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int rsub = lane / LPR;           // row inside a pass
+    const int c0 = (lane % LPR) * VEC;     // first column inside the block's 64
+    const int n = n0 + c0;
     const float lo = d.post_relu ? 0.f : -INFINITY;     // post-ReLU as one max (scale/shift default to 1/0: one fma)
-    DBG_T(4);
-    __syncthreads();                                   // all waves are done reading the last K slab
-    DBG_T(5);
-    float* stg = (float*)smem + wave * (32 * 68);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) *(f32x4*)(stg + (mh * 16 + l15) * 68 + nt * 16 + grp * 4) = acc[half * 2 + mh][nt];
+        for (int nt = 0; nt < 4; ++nt) *(f32x4*)(stg + l15 * STG_LD + nt * 16 + grp * 4) = acc[mt][nt];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int p = 0; p < NQ / 2; ++p) {
-            const int q = half * (NQ / 2) + p;
+        for (int p = 0; p < PPQ; ++p) {
+            const int q = mt * PPQ + p;
             f32x4 v[NV];
 #pragma unroll
             for (int h = 0; h < NV; ++h) {
-                v[h] = *(const f32x4*)(stg + (p * RPP + rsub) * 68 + c0 + 4 * h);
-                v[h] = (v[h] + bias4[h]) * scale4[h] + shift4[h];
+                v[h] = *(const f32x4*)(stg + (p * RPP + rsub) * STG_LD + c0 + 4 * h);
+                v[h] = (v[h] + cv.bias[h]) * cv.scale[h] + cv.shift[h];
                 if (ACT != MAGE_ACT_NONE) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[h][e] = act_apply<ACT>(v[h][e]);
                 }
-                v[h] += extra[q][h];
+                v[h] += b.extra[q][h];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[h][e] = fmaxf(v[h][e], lo);
             }
-            if (valid & (1u << q)) {
-                int yr = yrow[q];
-#if MAGE_ABL == 3
-                yr &= 127;                             // ablation: all tiles write the same small (L2-resident) region
-#endif
-                OT* yp = (OT*)d.Y + (long)yr * d.ldy + n;
+            if (b.valid & (1u << q)) {
+                OT* yp = (OT*)d.Y + (long)b.yrow[q] * d.ldy + n;
                 if (NV == 1) store4(yp, v[0]);
                 else store8(yp, v[0], v[NV - 1]);
             }
@@ -181,8 +195,32 @@ __device__ __forceinline__ void epilogue_rows(const mage_gemm_desc& d, f32x4 (&a
     }
 }
 
+// The wave's 128x64 sub-tile as four 32-row blocks, the residual / row-table reads of block b+1 in flight while block b
+// is converted and stored.
+template <int ACT, int VEC, typename OT>
+__device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const ColVecs& cv, f32x4 (&acc)[8][4], float* stg, int m0,
+                                              int n0, int lane, int plane) {
+    EpiBlock<VEC> b0, b1;
+    epi_prefetch<VEC>(b0, d, m0, n0, lane, plane);
+    epi_prefetch<VEC>(b1, d, m0 + 32, n0, lane, plane);
+    epi_store<ACT, VEC, OT>(d, cv, b0, *reinterpret_cast<f32x4 (*)[2][4]>(&acc[0]), stg, n0, lane);
+    epi_prefetch<VEC>(b0, d, m0 + 64, n0, lane, plane);
+    epi_store<ACT, VEC, OT>(d, cv, b1, *reinterpret_cast<f32x4 (*)[2][4]>(&acc[2]), stg, n0, lane);
+    epi_prefetch<VEC>(b1, d, m0 + 96, n0, lane, plane);
+    epi_store<ACT, VEC, OT>(d, cv, b0, *reinterpret_cast<f32x4 (*)[2][4]>(&acc[4]), stg, n0, lane);
+    epi_store<ACT, VEC, OT>(d, cv, b1, *reinterpret_cast<f32x4 (*)[2][4]>(&acc[6]), stg, n0, lane);
+}
+
+// raw barrier that LDS-DMA may stay in flight across (a __syncthreads() would drain vmcnt to 0); the empty asm
+// statements keep the compiler from moving LDS accesses over it
+__device__ __forceinline__ void ring_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int DT, bool GATHER, int ACT>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     typedef typename TT<DT>::elem E;
     constexpr int CH = TT<DT>::CH;
     constexpr int BK = 8 * CH;
@@ -194,56 +232,62 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // XCD-aware tile order: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles so that the
-    // n-tiles sharing one activation panel hit the same L2 (bijective for any grid size).
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, loc = bid >> 3;
-    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-    const int tm = lid / g.ntiles_n, tn = lid - tm * g.ntiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    // ---- persistent tile schedule.  Workgroup b runs on XCD b%8 (observed dispatch order; only speed depends on it):
+    // each XCD owns a contiguous chunk of the tile list and its 32 workgroups walk it side by side, so the n-tiles that
+    // share an activation panel, and the whole W matrix, stay in that XCD's L2.
+    const int nwg8 = gridDim.x >> 3;                   // workgroups per XCD (grid is a multiple of 8)
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int q8 = g.ntiles >> 3, r8 = g.ntiles & 7;
+    const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int chunk1 = chunk0 + q8 + (xcd < r8 ? 1 : 0);
+    const int nk = (d.K + BK - 1) / BK;
+    const int plane = d.out_h * d.out_w;
 
-    // ---- loader state: each wave moves 4 x (8 rows x 128 B) units of each operand tile per K slab
+    // ---- loader: each wave moves 4 A units + 4 W units (a unit = 8 rows x 128 B = one wave-wide DMA) per slab
     const int lr = lane >> 3;            // row inside a unit
     const int lp = lane & 7;             // physical 16-byte chunk
     const char* a_row[4];                // plain mode: row base pointer (or null)
     int a_img[4], a_iy[4], a_ix[4];      // gather mode
     const char* w_row[4];
-    int csw[4];                          // logical chunk this lane fetches for unit i
-    const int plane = d.out_h * d.out_w;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int u = wave * 4 + i;
-        const int r = u * 8 + lr;
-        csw[i] = lp ^ ((r >> 1) & 7);
-        const int m = m0 + r;
-        const bool mv = m < d.M;
-        const int img = m / plane;
-        const int rem = m - img * plane;
-        const int oy = rem / d.out_w;
-        const int ox = rem - oy * d.out_w;
-        if (GATHER) {
-            a_img[i] = mv ? img * d.a_img_stride + d.a_off : -1;
-            a_iy[i] = oy * d.stride + d.dy0;
-            a_ix[i] = ox * d.stride + d.dx0;
-        } else {
-            const long arow = (long)img * d.a_img_stride + (long)oy * d.in_w + ox + d.a_off;
-            a_row[i] = mv ? (const char*)d.A + arow * d.lda * ES : nullptr;
-        }
-        const int n = n0 + r;
-        w_row[i] = (n < d.N) ? (const char*)d.W + (long)n * d.K * ES : nullptr;
-    }
+    int cs[4];                           // logical chunk this lane fetches for unit i (same for the A and W unit)
+    int ld_tile = chunk0 + li, ld_kt = 0, ld_stage = 0;
 
-    auto issue = [&](int kt, int stage) {
-        char* sa = smem + stage * STAGE_BYTES;
-        char* sw = sa + TILE_BYTES;
+    auto loader_set_tile = [&](int tile) {
+        const int tm = tile / g.ntiles_n, tn = tile - tm * g.ntiles_n;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int u = wave * 4 + i;
-            const int kc = kt * BK + csw[i] * CH;
-            const bool kv = kc < d.K;
+            const int r = (wave * 4 + i) * 8 + lr;
+            cs[i] = lp ^ ((r >> 1) & 7);
+            const int m = tm * BM + r;
+            const bool mv = m < d.M;
+            const int img = m / plane;
+            const int rem = m - img * plane;
+            const int oy = rem / d.out_w;
+            const int ox = rem - oy * d.out_w;
+            if (GATHER) {
+                a_img[i] = mv ? img * d.a_img_stride + d.a_off : -1;
+                a_iy[i] = oy * d.stride + d.dy0;
+                a_ix[i] = ox * d.stride + d.dx0;
+            } else {
+                const long arow = (long)img * d.a_img_stride + (long)oy * d.in_w + ox + d.a_off;
+                a_row[i] = mv ? (const char*)d.A + arow * d.lda * ES : nullptr;
+            }
+            const int n = tn * BN + r;
+            w_row[i] = (n < d.N) ? (const char*)d.W + (long)n * d.K * ES : nullptr;
+        }
+    };
+
+    // DMA of units [i0, i0+2) of slab (ld_tile, ld_kt) into stage ld_stage
+    auto issue_half = [&](int i0) {
+        char* sa = smem + ld_stage * STAGE_BYTES;
+        char* sw = sa + A_BYTES;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = i0 + ii;
+            const int kc = ld_kt * BK + cs[i] * CH;
             const char* src = g.zero;
             if (GATHER) {
-                if (kv && a_img[i] >= 0) {
+                if (kc < d.K && a_img[i] >= 0) {
                     const int tap = kc / d.cin;
                     const int ci = kc - tap * d.cin;
                     const int ky = tap / d.taps_w;
@@ -254,112 +298,121 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                         src = (const char*)d.A + ((long)(a_img[i] + iy * d.in_w + ix) * d.lda + ci) * ES;
                 }
             } else {
-                if (kv && a_row[i]) src = a_row[i] + (long)kc * ES;
+                if (kc < d.K && a_row[i]) src = a_row[i] + (long)kc * ES;
             }
-            glds16(src, sa + u * 1024);
-            const char* wsrc = (kv && w_row[i]) ? w_row[i] + (long)kc * ES : g.zero;
-            glds16(wsrc, sw + u * 1024);
+            glds16(src, sa + (wave * 4 + i) * 1024);
+            const char* wsrc = (kc < d.K && w_row[i]) ? w_row[i] + (long)kc * ES : g.zero;
+            glds16(wsrc, sw + (wave * 4 + i) * 1024);
+        }
+    };
+    auto loader_advance = [&]() {
+        ld_stage ^= 1;
+        if (++ld_kt == nk) {
+            ld_kt = 0;
+            ld_tile += nwg8;
+            if (ld_tile < chunk1) loader_set_tile(ld_tile);
         }
     };
 
-    // ---- compute state
-    const int wm = wave >> 1, wn = wave & 1;
+    // ---- compute state: wave (wm, wn) owns rows [wm*128, +128) x columns [wn*64, +64) of the tile
+    const int wm = wave >> 2, wn = wave & 3;
     const int l15 = lane & 15, grp = lane >> 4;
     const int rsw = (l15 >> 1) & 7;                    // ((row>>1)&7) for every fragment row of this lane
-    const int xoff = (wm * 64 + l15) * 128;            // + mt*16*128
-    const int woff = TILE_BYTES + (wn * 64 + l15) * 128;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int xoff = (wm * 128 + l15) * 128;           // + mt*16*128
+    const int woff = A_BYTES + (wn * 64 + l15) * 128;  // + nt*16*128
+    f32x4 acc[8][4];
 
-    const int nk = (d.K + BK - 1) / BK;
-#ifndef MAGE_NO_STAGGER
-    // De-phase the two workgroups that share a CU.  All first-generation workgroups start together and every tile takes
-    // the same time, so without this the whole chip alternates between "everyone in the MFMA loop" and "everyone
-    // storing" (measured: epilogue ~= main loop).  Delaying every other first-generation workgroup by about half a main
-    // loop makes one workgroup's stores overlap its neighbour's MFMAs; later generations inherit the offset.
-    if (bid < 2 * 256 && ((bid >> 3) & 32)) __builtin_amdgcn_s_sleep(MAGE_STAGGER);
+    int c_tile = chunk0 + li;
+    if (c_tile >= chunk1) return;                      // more workgroups than tiles in this XCD's chunk
+    loader_set_tile(ld_tile);
+    issue_half(0);
+    issue_half(2);
+    loader_advance();
+    int c_stage = 0;
+
+    for (; c_tile < chunk1; c_tile += nwg8) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int tm = c_tile / g.ntiles_n, tn = c_tile - tm * g.ntiles_n;
+        const int m0 = tm * BM + wm * 128, n0 = tn * BN + wn * 64;
+        ColVecs cv;
+        load_colvecs(cv, d, n0, lane);                 // lands under the K loop
+        for (int kt = 0; kt < nk; ++kt) {
+            // The slab to multiply was issued one whole iteration (or one epilogue) ago; nothing younger is in flight.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ring_barrier();                            // everyone's share of the slab is in LDS, and every wave is done
+                                                       // reading the other stage, which the DMAs below refill
+            const bool more = ld_tile < chunk1;
+            const char* st = smem + c_stage * STAGE_BYTES;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#if MAGE_ABL != 5
+                if (more) issue_half(2 * t);
 #endif
-    DBG_T(0);
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                               // slab kt has landed; slab kt-1's readers are done
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const char* st = smem + (kt & 1) * STAGE_BYTES;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int pc = ((grp + 4 * t) ^ rsw) * 16;
-            u32x4 xf[4], wf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xf[i] = *(const u32x4*)(st + xoff + i * 2048 + pc);
-                wf[i] = *(const u32x4*)(st + woff + i * 2048 + pc);
-            }
-#if MAGE_ABL == 2
-            {   // ablation: loads + LDS reads only, no MFMA
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { acc[i][0][0] += __uint_as_float(xf[i][0] ^ wf[i][1]); }
-            }
-            if (false) {
-#else
-            if (DT == MAGE_BF16) {
+#if MAGE_ABL == 6
+                if (false)
 #endif
+                {
+                    const int pc = ((grp + 4 * t) ^ rsw) * 16;
+                    u32x4 xf[8], wf[4];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                    for (int i = 0; i < 8; ++i) xf[i] = *(const u32x4*)(st + xoff + i * 2048 + pc);
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, wf[nt]), __builtin_bit_cast(bf16x8, xf[mt]), acc[mt][nt], 0, 0, 0);
-            } else {
+                    for (int i = 0; i < 4; ++i) wf[i] = *(const u32x4*)(st + woff + i * 2048 + pc);
+                    if (DT == MAGE_BF16) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
+                            for (int mt = 0; mt < 8; ++mt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(bf16x8, wf[nt]), __builtin_bit_cast(bf16x8, xf[mt]), acc[mt][nt], 0, 0, 0);
+                    } else {
 #pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                __uint_as_float(wf[nt][j]), __uint_as_float(xf[mt][j]), acc[mt][nt], 0, 0, 0);
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                                for (int mt = 0; mt < 8; ++mt)
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                        __uint_as_float(wf[nt][j]), __uint_as_float(xf[mt][j]), acc[mt][nt], 0, 0, 0);
+                    }
+                }
             }
+            if (more) loader_advance();
+            c_stage ^= 1;
         }
-    }
-
-#if MAGE_ABL == 1
-    {   // ablation: main loop only (keep the accumulators alive, store nothing)
-        float sacc = 0.f;
+#if MAGE_ABL == 1 || MAGE_ABL == 5 || MAGE_ABL == 6
+        {   // tuning build: main loop only (keep the accumulators alive, store nothing)
+            float sacc = 0.f;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 8; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
-        if (sacc == 123456.789f) ((float*)d.Y)[0] = sacc;
-        return;
-    }
+                for (int b = 0; b < 4; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+            if (sacc == 123456.789f) ((float*)d.Y)[0] = sacc;
+            continue;
+        }
 #endif
-    // ---- epilogue (see epilogue_rows): fp32 output -> 4 columns per lane, bf16 output -> 8 columns per lane, so that
-    // every store instruction is a 16-byte-per-lane dwordx4 (a CU retires roughly one wave-store per ~70 cycles
-    // whatever its width: fewer, wider stores).
-    DBG_T(1);
-    if (d.y_dtype == MAGE_F32) epilogue_rows<ACT, 4, float>(d, acc, smem, m0, n0, wave, lane, plane);
-    else epilogue_rows<ACT, 8, unsigned short>(d, acc, smem, m0, n0, wave, lane, plane);
-#if MAGE_ABL == 4
-    DBG_T(6);
-    __builtin_amdgcn_s_waitcnt(0);
-    DBG_T(2);
-    if (lane == 0 && wave == 0 && bid < 65536) {
-        unsigned xcc, hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        mage_dbg[bid * 8 + 3] = ((unsigned long long)xcc << 32) | hwid;
+        // ---- epilogue.  The stage that held the last slab is free once every wave is past the barrier below; the other
+        // stage is already receiving the next tile's first slab.
+        ring_barrier();
+        float* stg = (float*)(smem + (c_stage ^ 1) * STAGE_BYTES) + wave * (STG_ROWS * STG_LD);
+        if (d.y_dtype == MAGE_F32) epilogue_wave<ACT, 4, float>(d, cv, acc, stg, m0, n0, lane, plane);
+        else epilogue_wave<ACT, 8, unsigned short>(d, cv, acc, stg, m0, n0, lane, plane);
     }
-#endif
 }
 
 template <int DT, bool GATHER, int ACT>
 int launch_act(const mage_gemm_desc* d, hipStream_t s) {
     static bool attr_set = false;
+    static int n_cu = 256;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= 8)
+            n_cu = p.multiProcessorCount & ~7;
         attr_set = true;
     }
     GemmArgs a;
@@ -367,7 +420,9 @@ int launch_act(const mage_gemm_desc* d, hipStream_t s) {
     a.zero = (const char*)mage_zero_page();
     const int tiles_m = (d->M + BM - 1) / BM;
     a.ntiles_n = (d->N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT>), dim3(tiles_m * a.ntiles_n), dim3(256), LDS_BYTES, s, a);
+    a.ntiles = tiles_m * a.ntiles_n;
+    const int grid = a.ntiles >= n_cu ? n_cu : ((a.ntiles + 7) & ~7);     // one resident workgroup per CU, multiple of 8
+    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT>), dim3(grid), dim3(512), LDS_BYTES, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
     return MAGE_OK;
 }

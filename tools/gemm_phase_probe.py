@@ -29,3 +29,14 @@ for nm, a, b in (("prefetch(yrow,loads issue)", 1, 4), ("barrier wait", 4, 5), (
     dd = t[:, b] - t[:, a]
     print(f"  {nm:28s} mean {dd.mean():.0f} p10 {np.percentile(dd, 10):.0f} p90 {np.percentile(dd, 90):.0f}")
 print("distinct CU ids", len(np.unique(cu)))
+# timeline of the workgroups that ran on one CU (same XCC + SE/CU bits of HW_ID), to see how co-resident WGs phase
+hwid = hw & 0xffffffff
+xcc = hw >> 32
+cu_id = (xcc << 12) | ((hwid >> 8) & 0xf) << 4 | ((hwid >> 13) & 0x7) << 8 | ((hwid >> 12) & 1)   # cu_id[11:8], se_id[15:13], sh_id[12]
+for target in np.unique(cu_id)[:2]:
+    sel = np.flatnonzero(cu_id == target)
+    order = sel[np.argsort(t[sel, 0])][:10]
+    base = t[order[0], 0]
+    print(f"CU {target:#x}: {len(sel)} workgroups; (bid, start, ml_end, ep_end) relative ticks")
+    for b in order:
+        print(f"   bid {b:6d}  {t[b,0]-base:8d} {t[b,1]-base:8d} {t[b,2]-base:8d}   simd/wave bits {hwid[b] & 0xff:#x}")
