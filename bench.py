@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--ar-mode", default="full", choices=["full", "incremental"],
+                    help="full = the reference's per-iteration full recompute (headline); incremental = temporal KV cache")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=2)
     args = ap.parse_args()
@@ -54,6 +56,7 @@ def main():
     synth.fill_state_dict(model, 0)
     cpu_sd = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 and not args.no_cpu_baseline else None
     model = model.to(dev).set_precision(args.precision)
+    model.ar_mode = args.ar_mode
     batch = {k: v.to(dev) for k, v in synth.synth_batch_mnist(B, L, seed=100 + rank).items()}
 
     def sync_all():
@@ -72,6 +75,20 @@ def main():
     ops.PROFILE.enabled = False
     dt = D.max_over_ranks(dt, dev)
     assert tuple(out.shape) == (B, L, 1, 64, 64)
+
+    # the other AR mode, same batch, reported next to the headline (identical tokens: tests/test_gpu_parity.py)
+    other_mode = "incremental" if args.ar_mode == "full" else "full"
+    model.ar_mode = other_mode
+    tok_main = model.last_tokens.clone()
+    model.autoregressive_generate(batch)
+    same_tokens = bool(torch.equal(model.last_tokens, tok_main))
+    sync_all()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        model.autoregressive_generate(batch)
+    sync_all()
+    dt_other = D.max_over_ranks(time.perf_counter() - t1, dev)
+    model.ar_mode = args.ar_mode
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -92,11 +109,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"cfg2: Single Moving MNIST 64x64, {L} frames, batch={B}/GPU, MNIST f4 VQ-VAE + MAGE "
-                                   f"(d=512, 6 axial blocks), reference AR loop with full recompute, random-init weights",
+                                   f"(d=512, 6 axial blocks), AR loop: {'reference full recompute per iteration' if args.ar_mode == 'full' else 'incremental (temporal KV cache)'}, random-init weights",
                        "global_batch": world * B, "frames": L, "parallelism": f"clip-sharded x{world} (no collective)",
                        "ar_mode": model.ar_mode},
             "roofline": roofline,
             "kernel_time_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items())},
+            "other_ar_mode": {"ar_mode": other_mode, "value": round(world * B * L * args.steps / dt_other, 2), "unit": "frames/s",
+                              "ms_per_step": round(dt_other / args.steps * 1e3, 3), "tokens_identical_to_headline_mode": same_tokens},
         }
         if cpu_sd is not None:
             res["cpu_baseline"] = cpu_baseline(cpu_sd, L, args.cpu_clips)

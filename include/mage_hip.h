@@ -108,7 +108,8 @@ int mage_layernorm(const float* x, const float* gamma, const float* beta, void* 
  * Sequence s in [0, n_seq): outer = s / inner, in = s % inner.
  *   query i  -> row  outer*q_outer_stride  + in + i*q_axis_stride     of q  (and of out)
  *   key   j  -> row  outer*kv_outer_stride + in + j*kv_axis_stride    of k, v
- * Head h uses columns [h*32, h*32+32).  causal: key j visible to query i iff j <= i.
+ * Head h uses columns [h*32, h*32+32).  causal: key j visible to query i iff j <= i + (nk - nq) (the mask is aligned to
+ * the LAST key, so nq == nk is the usual lower triangle and nq < nk is a query block appended to a key cache).
  * kv_len (optional, int32 [ceil(n_seq / kv_len_div)]): only keys j < kv_len[s / kv_len_div] are visible.
  * ------------------------------------------------------------------------------------------- */
 typedef struct mage_attn_desc {

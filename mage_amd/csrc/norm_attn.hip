@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, 
             q[c] = load4(qp + row * d.ldq + (h0 + hl) * 32 + c * 4);
             q[c] *= d.scale;
         }
-        const int jmax = d.causal ? min(klen, i + 1) : klen;
+        const int jmax = d.causal ? min(klen, i + 1 + (d.nk - d.nq)) : klen;   // bottom-right aligned causal mask
         float sc[NK_MAX];
         float mx = -INFINITY;
 #pragma unroll

@@ -410,6 +410,71 @@ class FlatAxialDecoder(nn.Module):
                 a_img_stride=L * hw, a_off=hw)                                      # head on x[:, 1:]  (:385)
         return logits
 
+    # ------------------------------------------------------------------ incremental (temporal KV cache) decoding
+    # the decoder is causal along L (temporal blocks masked, spatial blocks per frame), so the logits of
+    # frame k do not depend on later slots.  Instead of recomputing all L positions in each of the L-1 iterations
+    # (mage_model.py:673-684) only the NEW position(s) run through the stack; the temporal blocks keep their K,V of
+    # earlier positions in a cache.  Same kernels, same per-row arithmetic: the tokens are bit-identical to the full loop.
+    @torch.no_grad()
+    def _inc_begin(self, B: int, hh: int, ww: int, device) -> dict:
+        dt, Cc, L = self.compute_dtype, self.model_channels, self.frames_length
+        caches = {i: torch.empty(B * L * hh * ww, 2 * Cc, device=device, dtype=dt) for i in range(self.layers) if i % 3 == 0}
+        return {"B": B, "hh": hh, "ww": ww, "kv": caches, "p": 0}
+
+    @torch.no_grad()
+    def _inc_step(self, st: dict, motion: Optional[torch.Tensor], imgs: torch.Tensor) -> torch.Tensor:
+        """Append position(s): the first call takes the motion anchor (slot 0) and frame 0's features (slot 1); later calls
+        take the features of the newest frame only.  Returns the logits of the last appended slot, [B*hw, K] fp32."""
+        d = self._derived.get(self._build)
+        dt, Cc, L, dev = self.compute_dtype, self.model_channels, self.frames_length, imgs.device
+        B, hh, ww = st["B"], st["hh"], st["ww"]
+        hw, H = hh * ww, Cc // 32
+        p0 = st["p"]
+        P = 2 if motion is not None else 1                                  # new positions p0 .. p0+P-1
+        assert (p0 == 0) == (motion is not None) and p0 + P <= L
+        M = B * P * hw
+        x = torch.empty(M, Cc, device=dev, dtype=F32)
+        tp = d["tpos"][p0:]
+        if motion is not None:
+            _linear(motion, d, "context_linear", x, dt, M=B * hw, N=Cc, K=self.context_channels, out_w=hw, y_img_stride=P * hw,
+                    rowadd=tp, rowadd_div=hw, rowadd_mod=P)
+        _linear(imgs, d, "in_linear", x, dt, M=B * hw, N=Cc, K=self.in_channels, out_w=hw, y_img_stride=P * hw,
+                y_off=(P - 1) * hw, rowadd=tp, rowadd_div=hw, rowadd_mod=P)
+        xn = torch.empty(M, Cc, device=dev, dtype=dt)
+        qkv = torch.empty(M, 3 * Cc, device=dev, dtype=dt)
+        ao = torch.empty(M, Cc, device=dev, dtype=dt)
+        hdn = torch.empty(M, 4 * Cc, device=dev, dtype=dt)
+        for i in range(self.layers):
+            p = f"b{i}"
+            axis = i % 3
+            ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], xn, 1e-5)
+            w, b = d[p + ".in_proj" + _sfx(dt)], d[p + ".in_proj.b"]
+            if axis == 0:
+                kv = st["kv"][i]                                             # [B, L, hw, K|V]
+                ops.gemm(xn, w[:Cc], qkv, M=M, N=Cc, K=Cc, lda=Cc, ldy=Cc, bias=b[:Cc])          # q, packed [M, C]
+                ops.gemm(xn, w[Cc:], kv, M=M, N=2 * Cc, K=Cc, lda=Cc, ldy=2 * Cc, bias=b[Cc:], out_w=P * hw,
+                         y_img_stride=L * hw, y_off=p0 * hw)                                       # k, v -> cache slots
+                ops.attention(qkv, kv, kv[:, Cc:], ao, ldq=Cc, ldk=2 * Cc, ldv=2 * Cc, ldo=Cc, n_seq=B * hw, inner=hw, nq=P,
+                              nk=p0 + P, n_head=H, q_outer_stride=P * hw, q_axis_stride=hw, kv_outer_stride=L * hw,
+                              kv_axis_stride=hw, causal=True)
+            else:
+                ops.gemm(xn, w, qkv, M=M, N=3 * Cc, K=Cc, lda=Cc, ldy=3 * Cc, bias=b)
+                if axis == 1:
+                    geo = dict(n_seq=B * P * ww, inner=ww, nq=hh, nk=hh, q_outer_stride=hw, q_axis_stride=ww)
+                else:
+                    geo = dict(n_seq=B * P * hh, inner=1, nq=ww, nk=ww, q_outer_stride=ww, q_axis_stride=1)
+                ops.attention(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], ao, ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=Cc, n_head=H,
+                              kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], **geo)
+            _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc)
+            ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5)
+            _linear(xn, d, p + ".c_fc", hdn, dt, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU)
+            _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
+        xa = x if dt == F32 else ops.cast(x, xn)
+        logits = torch.empty(B * hw, self.out_channels, device=dev, dtype=F32)
+        _linear(xa, d, "out", logits, dt, M=B * hw, N=self.out_channels, K=Cc, out_w=hw, a_img_stride=P * hw, a_off=(P - 1) * hw)
+        st["p"] = p0 + P
+        return logits
+
     def forward(self, motion: torch.Tensor, imgs: torch.Tensor) -> torch.Tensor:
         """motion [B,H,W,Cc], imgs [B,L-1,H,W,Ci] -> logits [B,L-1,H,W,out] fp32."""
         _need_gpu(motion, "FlatAxialDecoder")
@@ -484,7 +549,8 @@ class MAGE(nn.Module):
                 self.alpha, self.beta = alpha, beta
         self.initialize_parameters()
         self.precision = "fp32"
-        self.ar_mode = "full"          # 'full' = the reference's per-iteration full recompute (mage_model.py:673-684)
+        self.ar_mode = "full"          # 'full' = the reference's per-iteration full recompute (mage_model.py:673-684);
+                                       # 'incremental' = temporal KV cache, each position once
         self._derived = _Derived(self)
         self.last_tokens: Optional[torch.Tensor] = None
 
@@ -588,6 +654,20 @@ class MAGE(nn.Module):
         tok0 = self.first_stage_encode(images[:, 0:1])[:, 0].reshape(B, hw)                   # :642
         ma = self._motion_anchor(tok0, batch, batch.get("video_noise"))
         ma_dt = ma if dt == F32 else ma.to(dt)                                                # dtype plumbing of a [B*hw, C] tensor
+        gen = torch.empty(B, Lm1, R, R, device=images.device, dtype=torch.int64)
+        if self.ar_mode == "incremental":
+            # each position once, temporal K,V cached; bit-identical tokens to the reference loop below
+            st = self.generate_model._inc_begin(B, R, R, images.device)
+            prev = tok0.contiguous()
+            for i in range(Lm1):
+                feats = self._frame_features(prev, dt)                                        # newest frame only
+                step_logits = self.generate_model._inc_step(st, ma_dt if i == 0 else None, feats)
+                prev = torch.empty(B, hw, device=images.device, dtype=torch.int64)
+                ops.argmax(step_logits, prev, rows=B * hw, K=K)
+                gen[:, i] = prev.view(B, R, R)                                                # index plumbing
+            self.last_tokens, self.last_logits = gen, None
+            video = self.first_stage_decode(gen)
+            return torch.cat([images[:, 0:1].to(video.dtype), video], 1)
         cur = tok0[:, None, :].repeat(1, Lm1, 1).contiguous()                                 # :670 future slots hold frame 0
         logits = None
         for i in range(Lm1):                                                                  # :673-684
@@ -596,7 +676,6 @@ class MAGE(nn.Module):
             if i != Lm1 - 1:                                                                  # argmax of frame i -> slot i+1
                 ops.argmax(logits, cur, rows=B * hw, K=K, group=hw, in_group_stride=Lm1 * hw, in_off=i * hw,
                            out_group_stride=Lm1 * hw, out_off=(i + 1) * hw)
-        gen = torch.empty(B, Lm1, R, R, device=images.device, dtype=torch.int64)
         ops.argmax(logits, gen, rows=B * Lm1 * hw, K=K)                                       # :687
         self.last_tokens, self.last_logits = gen, logits.view(B, Lm1, R, R, K)
         video = self.first_stage_decode(gen)                                                  # :690

@@ -162,3 +162,31 @@ def test_full_size_properties_cfg2_shape():
     assert torch.equal(m.last_tokens, tok1[32:]) and torch.equal(vh, v1[32:])       # shard == slice of the whole
     assert torch.equal(v1[:, 0], batch["images"][:, 0])                              # first frame is passed through
     assert v1.abs().max().item() <= 1.0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_incremental_decoding_is_bit_identical_to_reference_loop(precision):
+    """temporal-KV-cache decoding processes each position once; same kernels, same per-row arithmetic, so
+    the token sequence and the frames are bitwise those of the reference's full-recompute loop -- and the golden ones."""
+    g = golden("mage_mnist_L6_ragged")
+    B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
+    m = build_mage(synth.mnist_model_config(frames_length=L), seed, DEV).set_precision(precision)
+    batch = dev_batch(synth.synth_batch_mnist(B, L, seed=seed, digits=int(g["digits"]), text_len=int(g["text_len"]), ragged_text=True))
+    v_full = m.autoregressive_generate(batch)
+    t_full = m.last_tokens.clone()
+    m.ar_mode = "incremental"
+    v_inc = m.autoregressive_generate(batch)
+    assert torch.equal(m.last_tokens, t_full) and torch.equal(v_inc, v_full)
+    if precision == "fp32":
+        assert assert_tokens(m.last_tokens.cpu(), g["gen_tokens"], g["margin"], TOK_TOL, "incremental AR tokens") == 0
+        torch.testing.assert_close(v_inc.cpu(), t(g["video"]), atol=LOGIT_TOL, rtol=0)
+
+
+def test_incremental_decoding_full_size_cfg2():
+    m = build_mage(synth.mnist_model_config(frames_length=16), 0, DEV).set_precision("bf16")
+    batch = dev_batch(synth.synth_batch_mnist(64, 16, seed=3))
+    v_full = m.autoregressive_generate(batch)
+    t_full = m.last_tokens.clone()
+    m.ar_mode = "incremental"
+    v_inc = m.autoregressive_generate(batch)
+    assert torch.equal(m.last_tokens, t_full) and torch.equal(v_inc, v_full)
