@@ -31,12 +31,18 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256;
-constexpr int A_BYTES = BM * 128;                  // A part of a stage: 256 rows x 128 bytes
+// MT = 16-row MFMA tiles per wave along m: 8 -> 256x256 workgroup tile (bf16 on large problems), 4 -> 128x256 (fp32, whose
+// 8x4 accumulator variant spills, and problems with too few 256-row tiles to fill the chip).
+constexpr int BN = 256;
 constexpr int W_BYTES = BN * 128;
-constexpr int STAGE_BYTES = A_BYTES + W_BYTES;     // 64 KiB
 constexpr int NSTAGE = 2;
-constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;    // 128 KiB: one workgroup (8 waves, 2 per SIMD) per CU
+template <int MT> struct Tile {
+    static constexpr int BM = MT * 32;
+    static constexpr int A_BYTES = BM * 128;                   // A part of a stage: BM rows x 128 bytes
+    static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;      // 64 KiB (MT=8) | 48 KiB (MT=4)
+    static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;     // one workgroup (8 waves, 2 per SIMD) per CU
+    static constexpr int AU = MT / 2;                          // A units (8 rows x 128 B) per wave per slab
+};
 constexpr int STG_ROWS = 16, STG_LD = 68;          // epilogue staging: 16 rows x 64 fp32 (+4 pad) per wave = 4352 B
 
 struct GemmArgs {
@@ -195,20 +201,18 @@ __device__ __forceinline__ void epi_store(const mage_gemm_desc& d, const ColVecs
     }
 }
 
-// The wave's 128x64 sub-tile as four 32-row blocks, the residual / row-table reads of block b+1 in flight while block b
-// is converted and stored.
-template <int ACT, int VEC, typename OT>
-__device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const ColVecs& cv, f32x4 (&acc)[8][4], float* stg, int m0,
+// The wave's (MT*16)x64 sub-tile as MT/2 32-row blocks, one after the other.  (Keeping block b+1's residual / row-table reads
+// in flight while block b is stored -- two EpiBlocks live -- spills >100 VGPRs next to the 128 accumulators and halves
+// the kernel's speed; measured, reverted.)
+template <int ACT, int VEC, typename OT, int MT>
+__device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const ColVecs& cv, f32x4 (&acc)[MT][4], float* stg, int m0,
                                               int n0, int lane, int plane) {
-    EpiBlock<VEC> b0, b1;
-    epi_prefetch<VEC>(b0, d, m0, n0, lane, plane);
-    epi_prefetch<VEC>(b1, d, m0 + 32, n0, lane, plane);
-    epi_store<ACT, VEC, OT>(d, cv, b0, *reinterpret_cast<f32x4 (*)[2][4]>(&acc[0]), stg, n0, lane);
-    epi_prefetch<VEC>(b0, d, m0 + 64, n0, lane, plane);
-    epi_store<ACT, VEC, OT>(d, cv, b1, *reinterpret_cast<f32x4 (*)[2][4]>(&acc[2]), stg, n0, lane);
-    epi_prefetch<VEC>(b1, d, m0 + 96, n0, lane, plane);
-    epi_store<ACT, VEC, OT>(d, cv, b0, *reinterpret_cast<f32x4 (*)[2][4]>(&acc[4]), stg, n0, lane);
-    epi_store<ACT, VEC, OT>(d, cv, b1, *reinterpret_cast<f32x4 (*)[2][4]>(&acc[6]), stg, n0, lane);
+#pragma unroll
+    for (int hb = 0; hb < MT / 2; ++hb) {
+        EpiBlock<VEC> b;
+        epi_prefetch<VEC>(b, d, m0 + hb * 32, n0, lane, plane);
+        epi_store<ACT, VEC, OT>(d, cv, b, *reinterpret_cast<f32x4 (*)[2][4]>(&acc[hb * 2]), stg, n0, lane);
+    }
 }
 
 // raw barrier that LDS-DMA may stay in flight across (a __syncthreads() would drain vmcnt to 0); the empty asm
@@ -219,9 +223,10 @@ __device__ __forceinline__ void ring_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int DT, bool GATHER, int ACT>
+template <int DT, bool GATHER, int ACT, int MT>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     typedef typename TT<DT>::elem E;
+    constexpr int BM = Tile<MT>::BM, A_BYTES = Tile<MT>::A_BYTES, STAGE_BYTES = Tile<MT>::STAGE_BYTES, AU = Tile<MT>::AU;
     constexpr int CH = TT<DT>::CH;
     constexpr int BK = 8 * CH;
     constexpr int ES = sizeof(E);
@@ -243,21 +248,21 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     const int nk = (d.K + BK - 1) / BK;
     const int plane = d.out_h * d.out_w;
 
-    // ---- loader: each wave moves 4 A units + 4 W units (a unit = 8 rows x 128 B = one wave-wide DMA) per slab
+    // ---- loader: each wave moves AU A units + 4 W units (a unit = 8 rows x 128 B = one wave-wide DMA) per slab
     const int lr = lane >> 3;            // row inside a unit
     const int lp = lane & 7;             // physical 16-byte chunk
-    const char* a_row[4];                // plain mode: row base pointer (or null)
-    int a_img[4], a_iy[4], a_ix[4];      // gather mode
+    const char* a_row[AU];               // plain mode: row base pointer (or null)
+    int a_img[AU], a_iy[AU], a_ix[AU];   // gather mode
     const char* w_row[4];
-    int cs[4];                           // logical chunk this lane fetches for unit i (same for the A and W unit)
+    int acs[AU], wcs[4];                 // logical chunk this lane fetches for each unit
     int ld_tile = chunk0 + li, ld_kt = 0, ld_stage = 0;
 
     auto loader_set_tile = [&](int tile) {
         const int tm = tile / g.ntiles_n, tn = tile - tm * g.ntiles_n;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (wave * 4 + i) * 8 + lr;
-            cs[i] = lp ^ ((r >> 1) & 7);
+        for (int i = 0; i < AU; ++i) {
+            const int r = (wave * AU + i) * 8 + lr;
+            acs[i] = lp ^ ((r >> 1) & 7);
             const int m = tm * BM + r;
             const bool mv = m < d.M;
             const int img = m / plane;
@@ -272,19 +277,24 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                 const long arow = (long)img * d.a_img_stride + (long)oy * d.in_w + ox + d.a_off;
                 a_row[i] = mv ? (const char*)d.A + arow * d.lda * ES : nullptr;
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (wave * 4 + i) * 8 + lr;
+            wcs[i] = lp ^ ((r >> 1) & 7);
             const int n = tn * BN + r;
             w_row[i] = (n < d.N) ? (const char*)d.W + (long)n * d.K * ES : nullptr;
         }
     };
 
-    // DMA of units [i0, i0+2) of slab (ld_tile, ld_kt) into stage ld_stage
-    auto issue_half = [&](int i0) {
+    // DMA of half t (0|1) of this wave's units of slab (ld_tile, ld_kt) into stage ld_stage
+    auto issue_half = [&](int t) {
         char* sa = smem + ld_stage * STAGE_BYTES;
         char* sw = sa + A_BYTES;
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const int i = i0 + ii;
-            const int kc = ld_kt * BK + cs[i] * CH;
+        for (int ii = 0; ii < AU / 2; ++ii) {
+            const int i = t * (AU / 2) + ii;
+            const int kc = ld_kt * BK + acs[i] * CH;
             const char* src = g.zero;
             if (GATHER) {
                 if (kc < d.K && a_img[i] >= 0) {
@@ -300,7 +310,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
             } else {
                 if (kc < d.K && a_row[i]) src = a_row[i] + (long)kc * ES;
             }
-            glds16(src, sa + (wave * 4 + i) * 1024);
+            glds16(src, sa + (wave * AU + i) * 1024);
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = t * 2 + ii;
+            const int kc = ld_kt * BK + wcs[i] * CH;
             const char* wsrc = (kc < d.K && w_row[i]) ? w_row[i] + (long)kc * ES : g.zero;
             glds16(wsrc, sw + (wave * 4 + i) * 1024);
         }
@@ -314,29 +329,29 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
         }
     };
 
-    // ---- compute state: wave (wm, wn) owns rows [wm*128, +128) x columns [wn*64, +64) of the tile
+    // ---- compute state: wave (wm, wn) owns rows [wm*MT*16, +MT*16) x columns [wn*64, +64) of the tile
     const int wm = wave >> 2, wn = wave & 3;
     const int l15 = lane & 15, grp = lane >> 4;
     const int rsw = (l15 >> 1) & 7;                    // ((row>>1)&7) for every fragment row of this lane
-    const int xoff = (wm * 128 + l15) * 128;           // + mt*16*128
+    const int xoff = (wm * MT * 16 + l15) * 128;       // + mt*16*128
     const int woff = A_BYTES + (wn * 64 + l15) * 128;  // + nt*16*128
-    f32x4 acc[8][4];
+    f32x4 acc[MT][4];
 
     int c_tile = chunk0 + li;
     if (c_tile >= chunk1) return;                      // more workgroups than tiles in this XCD's chunk
     loader_set_tile(ld_tile);
     issue_half(0);
-    issue_half(2);
+    issue_half(1);
     loader_advance();
     int c_stage = 0;
 
     for (; c_tile < chunk1; c_tile += nwg8) {
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < MT; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int tm = c_tile / g.ntiles_n, tn = c_tile - tm * g.ntiles_n;
-        const int m0 = tm * BM + wm * 128, n0 = tn * BN + wn * 64;
+        const int m0 = tm * BM + wm * MT * 16, n0 = tn * BN + wn * 64;
         ColVecs cv;
         load_colvecs(cv, d, n0, lane);                 // lands under the K loop
         for (int kt = 0; kt < nk; ++kt) {
@@ -349,23 +364,23 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
 #if MAGE_ABL != 5
-                if (more) issue_half(2 * t);
+                if (more) issue_half(t);
 #endif
 #if MAGE_ABL == 6
                 if (false)
 #endif
                 {
                     const int pc = ((grp + 4 * t) ^ rsw) * 16;
-                    u32x4 xf[8], wf[4];
+                    u32x4 xf[MT], wf[4];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) xf[i] = *(const u32x4*)(st + xoff + i * 2048 + pc);
+                    for (int i = 0; i < MT; ++i) xf[i] = *(const u32x4*)(st + xoff + i * 2048 + pc);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) wf[i] = *(const u32x4*)(st + woff + i * 2048 + pc);
                     if (DT == MAGE_BF16) {
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                            for (int mt = 0; mt < 8; ++mt)
+                            for (int mt = 0; mt < MT; ++mt)
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                     __builtin_bit_cast(bf16x8, wf[nt]), __builtin_bit_cast(bf16x8, xf[mt]), acc[mt][nt], 0, 0, 0);
                     } else {
@@ -374,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
                             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                                for (int mt = 0; mt < 8; ++mt)
+                                for (int mt = 0; mt < MT; ++mt)
                                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                                         __uint_as_float(wf[nt][j]), __uint_as_float(xf[mt][j]), acc[mt][nt], 0, 0, 0);
                     }
@@ -387,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
         {   // tuning build: main loop only (keep the accumulators alive, store nothing)
             float sacc = 0.f;
 #pragma unroll
-            for (int a = 0; a < 8; ++a)
+            for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
             if (sacc == 123456.789f) ((float*)d.Y)[0] = sacc;
@@ -398,33 +413,48 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
         // stage is already receiving the next tile's first slab.
         ring_barrier();
         float* stg = (float*)(smem + (c_stage ^ 1) * STAGE_BYTES) + wave * (STG_ROWS * STG_LD);
-        if (d.y_dtype == MAGE_F32) epilogue_wave<ACT, 4, float>(d, cv, acc, stg, m0, n0, lane, plane);
-        else epilogue_wave<ACT, 8, unsigned short>(d, cv, acc, stg, m0, n0, lane, plane);
+        if (d.y_dtype == MAGE_F32) epilogue_wave<ACT, 4, float, MT>(d, cv, acc, stg, m0, n0, lane, plane);
+        else epilogue_wave<ACT, 8, unsigned short, MT>(d, cv, acc, stg, m0, n0, lane, plane);
     }
 }
 
-template <int DT, bool GATHER, int ACT>
-int launch_act(const mage_gemm_desc* d, hipStream_t s) {
+template <int DT, bool GATHER, int ACT, int MT>
+int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     static bool attr_set = false;
-    static int n_cu = 256;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= 8)
-            n_cu = p.multiProcessorCount & ~7;
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  Tile<MT>::LDS_BYTES);
         attr_set = true;
     }
     GemmArgs a;
     a.d = *d;
     a.zero = (const char*)mage_zero_page();
-    const int tiles_m = (d->M + BM - 1) / BM;
+    const int tiles_m = (d->M + Tile<MT>::BM - 1) / Tile<MT>::BM;
     a.ntiles_n = (d->N + BN - 1) / BN;
     a.ntiles = tiles_m * a.ntiles_n;
     const int grid = a.ntiles >= n_cu ? n_cu : ((a.ntiles + 7) & ~7);     // one resident workgroup per CU, multiple of 8
-    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT>), dim3(grid), dim3(512), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT, MT>), dim3(grid), dim3(512), Tile<MT>::LDS_BYTES, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
     return MAGE_OK;
+}
+
+template <int DT, bool GATHER, int ACT>
+int launch_act(const mage_gemm_desc* d, hipStream_t s) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        n_cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= 8)
+            n_cu = p.multiProcessorCount & ~7;
+    }
+    // 256-row tiles only where there are enough of them to give every CU at least two (bf16; the fp32 8x4-accumulator
+    // variant does not fit the register file)
+    const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + BN - 1) / BN);
+    if constexpr (DT == MAGE_BF16) {
+        if (tiles256 >= 2L * n_cu) return launch_tile<DT, GATHER, ACT, 8>(d, s, n_cu);
+    }
+    return launch_tile<DT, GATHER, ACT, 4>(d, s, n_cu);
 }
 
 template <int DT, bool GATHER>
