@@ -109,10 +109,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     d.residual, d.ldr, d.res_dtype = _p(residual), ldr, (code(residual) if residual is not None else 0)
     d.post_relu = int(post_relu)
     if PROFILE.enabled:
-        gather = taps_h * taps_w > 1 or stride != 1 or d.in_h != d.out_h or d.in_w != d.out_w
+        # key = the kernel instantiation mage_gemm dispatches to (mirrors launch_act in csrc/gemm.hip), so that the
+        # per-kernel averages line up with rocprofv3's per-symbol statistics
+        gather = taps_h * taps_w > 1 or stride != 1 or dy0 != 0 or dx0 != 0 or d.in_h != d.out_h or d.in_w != d.out_w
+        n_cu = torch.cuda.get_device_properties(a.device).multi_processor_count & ~7
+        mt = 8 if (d.dtype == BF16 and ((M + 255) // 256) * ((N + 255) // 256) >= 2 * n_cu) else 4
+        key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act}, {mt}>"
         ev = PROFILE.begin()
         _lib.check(l.mage_gemm(C.byref(d), s), l)
-        PROFILE.end("gemm/conv" if gather else "gemm/plain", ev, 2.0 * M * N * K)
+        PROFILE.end(key, ev, 2.0 * M * N * K)
         return y
     _lib.check(l.mage_gemm(C.byref(d), s), l)
     return y
