@@ -287,13 +287,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
         }
     };
 
-    // DMA of half t (0|1) of this wave's units of slab (ld_tile, ld_kt) into stage ld_stage
-    auto issue_half = [&](int t) {
+    // DMA of this wave's unit u (A units 0..AU-1, then W units) of slab (ld_tile, ld_kt) into stage ld_stage
+    auto issue_one = [&](int u) {
         char* sa = smem + ld_stage * STAGE_BYTES;
-        char* sw = sa + A_BYTES;
-#pragma unroll
-        for (int ii = 0; ii < AU / 2; ++ii) {
-            const int i = t * (AU / 2) + ii;
+        if (u < AU) {
+            const int i = u;
             const int kc = ld_kt * BK + acs[i] * CH;
             const char* src = g.zero;
             if (GATHER) {
@@ -311,14 +309,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                 if (kc < d.K && a_row[i]) src = a_row[i] + (long)kc * ES;
             }
             glds16(src, sa + (wave * AU + i) * 1024);
-        }
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const int i = t * 2 + ii;
+        } else {
+            const int i = u - AU;
             const int kc = ld_kt * BK + wcs[i] * CH;
             const char* wsrc = (kc < d.K && w_row[i]) ? w_row[i] + (long)kc * ES : g.zero;
-            glds16(wsrc, sw + (wave * 4 + i) * 1024);
+            glds16(wsrc, sa + A_BYTES + (wave * 4 + i) * 1024);
         }
+    };
+    auto issue_all = [&]() {
+#pragma unroll
+        for (int u = 0; u < AU + 4; ++u) issue_one(u);
     };
     auto loader_advance = [&]() {
         ld_stage ^= 1;
@@ -340,8 +340,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     int c_tile = chunk0 + li;
     if (c_tile >= chunk1) return;                      // more workgroups than tiles in this XCD's chunk
     loader_set_tile(ld_tile);
-    issue_half(0);
-    issue_half(1);
+    issue_all();
     loader_advance();
     int c_stage = 0;
 
@@ -361,38 +360,59 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                                                        // reading the other stage, which the DMAs below refill
             const bool more = ld_tile < chunk1;
             const char* st = smem + c_stage * STAGE_BYTES;
+            // Software-pipelined phases: MT phases per slab (2 k-halves x MT/2 pairs of 16-row tiles).  Each phase requests
+            // the NEXT phase's fragments (2 ds_read_b128, or the 6 that open the second k-half), issues its share of the
+            // next slab's DMAs, then runs 8 MFMAs on fragments requested one phase earlier: LDS latency and DMA issue sit
+            // under the matrix pipe instead of in front of it (the compiler's own order was read-all / wait / MFMA-all).
+            constexpr int NG = MT / 2, NU = AU + 4;
+            const char* xs = st + xoff;
+            const char* ws = st + woff;
+            const int pcs[2] = {((grp + 0) ^ rsw) * 16, ((grp + 4) ^ rsw) * 16};
+            u32x4 wf[2][4], xf[2][MT];
+#if MAGE_ABL != 6
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[0][i] = *(const u32x4*)(ws + i * 2048 + pcs[0]);
+            xf[0][0] = *(const u32x4*)(xs + pcs[0]);
+            xf[0][1] = *(const u32x4*)(xs + 2048 + pcs[0]);
+#endif
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int gq = 0; gq < NG; ++gq) {
+                    const int ph = t * NG + gq;
 #if MAGE_ABL != 5
-                if (more) issue_half(t);
-#endif
-#if MAGE_ABL == 6
-                if (false)
-#endif
-                {
-                    const int pc = ((grp + 4 * t) ^ rsw) * 16;
-                    u32x4 xf[MT], wf[4];
+                    if (more) {
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) xf[i] = *(const u32x4*)(st + xoff + i * 2048 + pc);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) wf[i] = *(const u32x4*)(st + woff + i * 2048 + pc);
-                    if (DT == MAGE_BF16) {
-#pragma unroll
-                        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                    __builtin_bit_cast(bf16x8, wf[nt]), __builtin_bit_cast(bf16x8, xf[mt]), acc[mt][nt], 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-#pragma unroll
-                            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                                for (int mt = 0; mt < MT; ++mt)
-                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                        __uint_as_float(wf[nt][j]), __uint_as_float(xf[mt][j]), acc[mt][nt], 0, 0, 0);
+                        for (int u = ph * NU / MT; u < (ph + 1) * NU / MT; ++u) issue_one(u);
                     }
+#endif
+#if MAGE_ABL != 6
+                    if (gq + 1 < NG) {
+                        xf[t][2 * gq + 2] = *(const u32x4*)(xs + (2 * gq + 2) * 2048 + pcs[t]);
+                        xf[t][2 * gq + 3] = *(const u32x4*)(xs + (2 * gq + 3) * 2048 + pcs[t]);
+                    } else if (t == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) wf[1][i] = *(const u32x4*)(ws + i * 2048 + pcs[1]);
+                        xf[1][0] = *(const u32x4*)(xs + pcs[1]);
+                        xf[1][1] = *(const u32x4*)(xs + 2048 + pcs[1]);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mm = 0; mm < 2; ++mm) {
+                            const int mt = 2 * gq + mm;
+                            if (DT == MAGE_BF16) {
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(bf16x8, wf[t][nt]), __builtin_bit_cast(bf16x8, xf[t][mt]), acc[mt][nt], 0, 0, 0);
+                            } else {
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj)
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                        __uint_as_float(wf[t][nt][jj]), __uint_as_float(xf[t][mt][jj]), acc[mt][nt], 0, 0, 0);
+                            }
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
             }
             if (more) loader_advance();
