@@ -51,16 +51,32 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------ attention
-// Workgroup = (sequence, head group).  K and V of the head group are staged once in LDS as fp32;
-// each thread then owns (query i, head h) pairs: q in registers, scores in registers (NK_MAX <= 64),
-// softmax in registers, output accumulated in registers.  Lanes of a wave that share h read the same
-// LDS address (broadcast), the (up to 4) distinct heads of a wave sit 128 B apart: conflict-free b128 reads.
+// Workgroup = (sequence, head group).  K and V of the head group are staged once in LDS in their storage type
+// (bf16 stays bf16: half the LDS bytes and half the ds_read_b128 per key, twice the resident workgroups);
+// each thread then owns (query i, head h) pairs: q in registers, scores in registers (NK_MAX <= 64), softmax in
+// registers, output accumulated in registers, all fp32.  Lanes of a wave that share h read the same LDS address
+// (broadcast); the (up to 4) distinct heads of a wave sit 64/128 B apart: conflict-free b128 reads.
+__device__ __forceinline__ void load8f(const float* p, f32x4& a, f32x4& b) {
+    a = *(const f32x4*)p;
+    b = *(const f32x4*)(p + 4);
+}
+__device__ __forceinline__ void load8f(const unsigned short* p, f32x4& a, f32x4& b) {
+    const uint4 r = *(const uint4*)p;
+    a = f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+    b = f32x4{__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u), __uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u)};
+}
+__device__ __forceinline__ void copy8(const float* src, float* dst) {
+    *(f32x4*)dst = *(const f32x4*)src;
+    *(f32x4*)(dst + 4) = *(const f32x4*)(src + 4);
+}
+__device__ __forceinline__ void copy8(const unsigned short* src, unsigned short* dst) { *(uint4*)dst = *(const uint4*)src; }
+
 template <typename T, int NK_MAX>
 __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, int hg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* ks = (float*)smem_raw;                    // [nk][hg*32]
+    T* ks = (T*)smem_raw;                            // [nk][hg*32]
     const int rowf = hg * 32;
-    float* vs = ks + (long)d.nk * rowf;
+    T* vs = ks + (long)d.nk * rowf;
     const int s = blockIdx.x;
     const int h0 = blockIdx.y * hg;
     const int outer = s / d.inner, in = s - outer * d.inner;
@@ -68,13 +84,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, 
     const long kv_base = (long)outer * d.kv_outer_stride + in;
     const T* kp = (const T*)d.k;
     const T* vp = (const T*)d.v;
-    // stage K, V: nk rows x (hg*32) columns, 4 elements per thread-step
-    const int vec_per_row = rowf / 4;
+    // stage K, V: nk rows x (hg*32) columns, 8 elements per thread-step
+    const int vec_per_row = rowf / 8;
     for (int e = threadIdx.x; e < d.nk * vec_per_row; e += 256) {
-        const int j = e / vec_per_row, c = (e - j * vec_per_row) * 4;
+        const int j = e / vec_per_row, c = (e - j * vec_per_row) * 8;
         const long row = kv_base + (long)j * d.kv_axis_stride;
-        *(f32x4*)(ks + j * rowf + c) = load4(kp + row * d.ldk + h0 * 32 + c);
-        *(f32x4*)(vs + j * rowf + c) = load4(vp + row * d.ldv + h0 * 32 + c);
+        copy8(kp + row * d.ldk + h0 * 32 + c, ks + j * rowf + c);
+        copy8(vp + row * d.ldv + h0 * 32 + c, vs + j * rowf + c);
     }
     __syncthreads();
     int klen = d.nk;
@@ -86,9 +102,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, 
         const long row = q_base + (long)i * d.q_axis_stride;
         f32x4 q[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            q[c] = load4(qp + row * d.ldq + (h0 + hl) * 32 + c * 4);
-            q[c] *= d.scale;
+        for (int c = 0; c < 4; ++c) {
+            load8f(qp + row * d.ldq + (h0 + hl) * 32 + c * 8, q[2 * c], q[2 * c + 1]);
+            q[2 * c] *= d.scale;
+            q[2 * c + 1] *= d.scale;
         }
         const int jmax = d.causal ? min(klen, i + 1 + (d.nk - d.nq)) : klen;   // bottom-right aligned causal mask
         float sc[NK_MAX];
@@ -97,13 +114,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, 
         for (int j = 0; j < NK_MAX; ++j) {
             float a = -INFINITY;
             if (j < jmax) {
-                const float* kr = ks + j * rowf + hl * 32;
+                const T* kr = ks + j * rowf + hl * 32;
                 float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-                for (int c = 0; c < 8; c += 2) {
-                    const f32x4 k0 = *(const f32x4*)(kr + c * 4), k1 = *(const f32x4*)(kr + c * 4 + 4);
-                    a0 += q[c][0] * k0[0] + q[c][1] * k0[1] + q[c][2] * k0[2] + q[c][3] * k0[3];
-                    a1 += q[c + 1][0] * k1[0] + q[c + 1][1] * k1[1] + q[c + 1][2] * k1[2] + q[c + 1][3] * k1[3];
+                for (int c = 0; c < 4; ++c) {
+                    f32x4 k0, k1;
+                    load8f(kr + c * 8, k0, k1);
+                    a0 += q[2 * c][0] * k0[0] + q[2 * c][1] * k0[1] + q[2 * c][2] * k0[2] + q[2 * c][3] * k0[3];
+                    a1 += q[2 * c + 1][0] * k1[0] + q[2 * c + 1][1] * k1[1] + q[2 * c + 1][2] * k1[2] + q[2 * c + 1][3] * k1[3];
                 }
                 a = a0 + a1;
             }
@@ -119,14 +137,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, 
             if (j < jmax) {
                 const float pj = expf(sc[j] - mx);
                 den += pj;
-                const float* vr = vs + j * rowf + hl * 32;
+                const T* vr = vs + j * rowf + hl * 32;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) o[c] += pj * *(const f32x4*)(vr + c * 4);
+                for (int c = 0; c < 4; ++c) {
+                    f32x4 v0, v1;
+                    load8f(vr + c * 8, v0, v1);
+                    o[2 * c] += pj * v0;
+                    o[2 * c + 1] += pj * v1;
+                }
             }
         }
         const float inv = 1.0f / den;
+        T* orow = op + row * d.ldo + (h0 + hl) * 32;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) store4(op + row * d.ldo + (h0 + hl) * 32 + c * 4, o[c] * inv);
+        for (int c = 0; c < 4; ++c) store8(orow + c * 8, o[2 * c] * inv, o[2 * c + 1] * inv);
     }
 }
 
@@ -198,8 +222,8 @@ template <typename T>
 int attn_launch(const mage_attn_desc* d, hipStream_t s) {
     // heads per workgroup: all of them if K,V fit 64 KiB of LDS, else the largest power of two that does
     int hg = d->n_head;
-    while ((long)d->nk * hg * 32 * 8 > 64 * 1024 && hg > 1 && hg % 2 == 0) hg /= 2;
-    const size_t lds = (size_t)d->nk * hg * 32 * 8;
+    while ((long)d->nk * hg * 32 * 2 * sizeof(T) > 64 * 1024 && hg > 1 && hg % 2 == 0) hg /= 2;
+    const size_t lds = (size_t)d->nk * hg * 32 * 2 * sizeof(T);
     MAGE_CHECK_ARG(lds <= 64 * 1024 && d->n_head % hg == 0, "mage_attention: nk=%d too large for LDS staging", d->nk);
     const dim3 grid(d->n_seq, d->n_head / hg), blk(256);
     if (d->nk <= 16) hipLaunchKernelGGL((attention_kernel<T, 16>), grid, blk, lds, s, *d, hg);
@@ -225,7 +249,7 @@ extern "C" int mage_attention(const mage_attn_desc* d, void* stream) {
     MAGE_CHECK_ARG(d && d->q && d->k && d->v && d->out, "mage_attention: null pointer");
     MAGE_CHECK_ARG(d->nk >= 1 && d->nk <= 64, "mage_attention: nk=%d outside [1, 64]", d->nk);
     MAGE_CHECK_ARG(d->nq >= 1 && d->n_seq >= 1 && d->n_head >= 1 && d->inner >= 1, "mage_attention: bad sizes");
-    MAGE_CHECK_ARG((d->ldq | d->ldk | d->ldv | d->ldo) % 4 == 0, "mage_attention: leading dims must be multiples of 4");
+    MAGE_CHECK_ARG((d->ldq | d->ldk | d->ldv | d->ldo) % 8 == 0, "mage_attention: leading dims must be multiples of 8");
     MAGE_CHECK_ARG(!d->kv_len || d->kv_len_div >= 1, "mage_attention: kv_len_div must be >= 1");
     if (d->dtype == MAGE_F32) return attn_launch<float>(d, (hipStream_t)stream);
     if (d->dtype == MAGE_BF16) return attn_launch<unsigned short>(d, (hipStream_t)stream);
