@@ -103,6 +103,13 @@ def main():
         dom_key = max(gemms, key=lambda k: gemms[k]["ms"]) if gemms else None
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
         roofline = None
+        # HBM bytes per launch of the dominant kernel come from PMC counters (FETCH_SIZE x2-corrected + WRITE_SIZE), which
+        # only rocprofv3 can read: tools/pmc_bench.sh collects them on this same command in two separate --pmc passes
+        # and the summary is committed under profiles/; bench.py reports it only for the matching workload.
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if dom_key and os.path.exists(pmc_path) and (B, L, args.precision, args.ar_mode) == (64, 16, "bf16", "full"):
+            traffic = json.load(open(pmc_path)).get(dom_key, {}).get("hbm_bytes_per_launch")
         if dom_key:
             dom = gemms[dom_key]
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
@@ -110,7 +117,7 @@ def main():
             roofline = {"bound": "mfma", "kernel": dom_key + "  [dtype, gather, act, m-tiles/wave: QKV / out_proj / c_proj / head / "
                                                              "in_linear GEMMs of the decoder stack]",
                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": None, "launches_per_step": dom["calls"] // args.steps,
+                        "traffic": traffic, "launches_per_step": dom["calls"] // args.steps,
                         "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
                         "flops_per_launch": dom["flops"] / dom["calls"],
                         "all_gemm_kernels": {"achieved": round(allf / (allms * 1e-3) / 1e12, 2), "frac": round(allf / (allms * 1e-3) / 1e12 / peak, 4),

@@ -193,8 +193,15 @@ __device__ __forceinline__ void epi_store(const mage_gemm_desc& d, const ColVecs
             }
             if (b.valid & (1u << q)) {
                 OT* yp = (OT*)d.Y + (long)b.yrow[q] * d.ldy + n;
-                if (NV == 1) store4(yp, v[0]);
-                else store8(yp, v[0], v[NV - 1]);
+                // streaming (non-temporal) stores: the output is not re-read by this kernel, keep the XCD's L2 for the
+                // activation panels and W that the neighbouring workgroups re-read
+                if (NV == 1) {
+                    __builtin_nontemporal_store(v[0], (f32x4*)yp);
+                } else {
+                    u32x4 pk = {pack_bf16x2(v[0][0], v[0][1]), pack_bf16x2(v[0][2], v[0][3]),
+                                pack_bf16x2(v[NV - 1][0], v[NV - 1][1]), pack_bf16x2(v[NV - 1][2], v[NV - 1][3])};
+                    __builtin_nontemporal_store(pk, (u32x4*)yp);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
