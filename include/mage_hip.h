@@ -63,8 +63,8 @@ int mage_init(int device);
  * v = act(v);  v += rowadd[((yrow / rowadd_div) % rowadd_mod), n];  v += residual[yrow, n];
  * v = relu(v) if post_relu;  store as y_dtype.  Null pointers skip a stage.  Y may alias residual.
  *
- * Requirements: lda/ldy/ldr and cin multiples of 8 (bf16) / 4 (f32); N multiple of 4; A, W, Y 16-byte
- * aligned; W is [N][K] row-major in `dtype`.
+ * Requirements: lda and cin multiples of 8 (bf16) / 4 (f32); N multiple of 8; ldy/ldr multiples of 4 (fp32) / 8 (bf16);
+ * A, W, Y 16-byte aligned; W is [N][K] row-major in `dtype`.
  * ------------------------------------------------------------------------------------------- */
 typedef struct mage_gemm_desc {
     int32_t dtype;                     /* MAGE_F32 | MAGE_BF16: type of A and W and of the MFMA */

@@ -43,7 +43,6 @@ template <int MT> struct Tile {
     static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;     // one workgroup (8 waves, 2 per SIMD) per CU
     static constexpr int AU = MT / 2;                          // A units (8 rows x 128 B) per wave per slab
 };
-constexpr int STG_ROWS = 16, STG_LD = 68;          // epilogue staging: 16 rows x 64 fp32 (+4 pad) per wave = 4352 B
 
 struct GemmArgs {
     mage_gemm_desc d;
@@ -69,160 +68,134 @@ __device__ __forceinline__ float act_apply(float v) {
 }
 
 // Epilogue of one 32x64 block of a wave's sub-tile.  The MFMA layout leaves each lane with 4 consecutive n of 16 different rows
-// per accumulator; stores straight from it would be 8-byte pieces of 16 rows.  Instead the wave transposes its sub-tile
-// through a wave-private LDS staging tile (16 rows x 64 fp32, +4 pad: conflict-free b128 writes), one 16-row quarter at
-// a time, and reads it back row-major with VEC consecutive columns per lane (fp32 out: 4, bf16 out: 8): every store is
-// a 16-byte-per-lane dwordx4 of whole lines (a CU retires roughly one wave-store per ~70 cycles whatever its width),
-// and the per-column vectors (bias, BN scale/shift) are loaded once per lane.
-// per-column epilogue vectors of one lane (bias, BN scale/shift): fetched once per tile, at the START of its K loop
+// ---- epilogue --------------------------------------------------------------------------------------------------------
+// The MFMA (operands swapped) leaves lane (l15 = lane&15, grp = lane>>4) of accumulator [mt][nt] with output row
+// mt*16 + l15 and the 4 consecutive columns nt*16 + grp*4 + {0..3}.  One v_permlane16_swap per register between the
+// accumulators nt = 2k and 2k+1 gives every lane 8 CONSECUTIVE columns of its row
+//     columns 16*(2k + (grp&1)) + 8*(grp>>1) + {0..7}      (k = 0, 1)
+// so the epilogue runs and stores straight from registers: no LDS transpose, no barrier, no wait chains (the earlier
+// LDS-staged version spent ~10 k cycles per 256x256 tile in exposed ds_write -> ds_read latency), 16-byte bf16 stores.
+// Per-column bias is fetched once per tile at the START of its K loop (lands under the MFMAs); BatchNorm scale/shift
+// (VQ-VAE convolutions only) are fetched in the epilogue.
 struct ColVecs {
-    f32x4 bias[2], scale[2], shift[2];
+    f32x4 bias[2][2];                  // [k][half]: 8 columns per k
 };
+__device__ __forceinline__ int epi_col(int n0, int k, int lane) { return n0 + 16 * (2 * k + ((lane >> 4) & 1)) + 8 * (lane >> 5); }
 __device__ __forceinline__ void load_colvecs(ColVecs& cv, const mage_gemm_desc& d, int n0, int lane) {
-    const int vec = d.y_dtype == MAGE_F32 ? 4 : 8;
-    const int n = n0 + (lane % (64 / vec)) * vec;
-    const int n_ld = n < d.N ? n : 0;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int o = n_ld + (vec == 8 ? 4 * h : 0);
-        cv.bias[h] = d.bias ? *(const f32x4*)(d.bias + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-        cv.scale[h] = d.scale ? *(const f32x4*)(d.scale + o) : f32x4{1.f, 1.f, 1.f, 1.f};
-        cv.shift[h] = d.scale ? *(const f32x4*)(d.shift + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 2; ++k) {
+        const int n = epi_col(n0, k, lane);
+        const int n_ld = n < d.N ? n : 0;               // clamped, never predicated (see epilogue_wave); N % 8 == 0
+#pragma unroll
+        for (int h = 0; h < 2; ++h) cv.bias[k][h] = d.bias ? *(const f32x4*)(d.bias + n_ld + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
-// Prefetched state of one 32x64 block: output rows, store predicate, and everything added after the activation
-// (residual + row table), requested one block AHEAD of its use so that no round trip is exposed.
-template <int VEC>
-struct EpiBlock {
-    static constexpr int LPR = 64 / VEC, RPP = 64 / LPR, NQ = 32 / RPP, NV = VEC / 4;
-    int yrow[NQ];
-    unsigned valid;
-    f32x4 extra[NQ][NV];
-};
-
-template <int VEC>
-__device__ __forceinline__ void epi_prefetch(EpiBlock<VEC>& b, const mage_gemm_desc& d, int m0, int n0, int lane, int plane) {
-    constexpr int LPR = EpiBlock<VEC>::LPR, RPP = EpiBlock<VEC>::RPP, NQ = EpiBlock<VEC>::NQ, NV = EpiBlock<VEC>::NV;
-    const int rsub = lane / LPR;
-    const int n = n0 + (lane % LPR) * VEC;
-    const bool nv = n < d.N;               // N % VEC == 0 is checked on the host for bf16 output
+template <int ACT, typename OT, int MT>
+__device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const ColVecs& cv, f32x4 (&acc)[MT][4], int m0, int n0,
+                                              int lane, int plane) {
+    const int l15 = lane & 15;
     const bool simple_rows = d.out_h == 1 && d.out_w >= d.M;       // no regrouping: yrow = m*y_mul_x + y_off
-    // Rows/columns outside the problem are CLAMPED to valid ones for the loads (hipcc turns a predicated load into a
-    // branch + s_waitcnt vmcnt(0) per element, serialising the round trips); only the stores are predicated.
-    const int n_ld = nv ? n : 0;
-    b.valid = 0;
+    const float lo = d.post_relu ? 0.f : -INFINITY;                 // post-ReLU as one max
+    int ncol[2], nld[2];
+    bool nv[2];
+    f32x4 scale4[2][2], shift4[2][2];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int mq = m0 + q * RPP + rsub;
+    for (int k = 0; k < 2; ++k) {
+        ncol[k] = epi_col(n0, k, lane);
+        nv[k] = ncol[k] < d.N;                                      // N % 8 == 0 (host check): a chunk is all in or all out
+        // Columns/rows outside the problem are CLAMPED to valid ones for the loads (hipcc turns a predicated load into a
+        // branch + s_waitcnt vmcnt(0) per element, serialising the round trips); only the stores are predicated.
+        nld[k] = nv[k] ? ncol[k] : 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            scale4[k][h] = d.scale ? *(const f32x4*)(d.scale + nld[k] + 4 * h) : f32x4{1.f, 1.f, 1.f, 1.f};
+            shift4[k][h] = d.scale ? *(const f32x4*)(d.shift + nld[k] + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // One output row of the lane per round.  Keeping a second row's reads in flight (tried: 1-ahead prefetch, rows in
+    // pairs) costs 16 more live registers next to the 128 accumulators and hipcc answers with 65-175 spilled VGPRs
+    // (603 TF instead of 693): measured, reverted.
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int mq = m0 + mt * 16 + l15;
         const int m = min(mq, d.M - 1);
+        int yrow;
         if (simple_rows) {
-            b.yrow[q] = m * d.y_mul_x + d.y_off;
+            yrow = m * d.y_mul_x + d.y_off;
         } else {
             const int img = m / plane;
             const int rem = m - img * plane;
             const int oy = rem / d.out_w;
             const int ox = rem - oy * d.out_w;
-            b.yrow[q] = img * d.y_img_stride + oy * d.y_mul_y + ox * d.y_mul_x + d.y_off;
+            yrow = img * d.y_img_stride + oy * d.y_mul_y + ox * d.y_mul_x + d.y_off;
         }
-        b.valid |= (mq < d.M && nv) ? (1u << q) : 0u;
-    }
+        // everything added after the activation (residual + row table), requested before this row's first store
+        f32x4 extra[2][2];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int h = 0; h < NV; ++h) b.extra[q][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (d.residual) {
-        if (d.res_dtype == MAGE_F32) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                for (int h = 0; h < NV; ++h) b.extra[q][h] = load4((const float*)d.residual + (long)b.yrow[q] * d.ldr + n_ld + 4 * h);
-        } else {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                for (int h = 0; h < NV; ++h)
-                    b.extra[q][h] = load4((const unsigned short*)d.residual + (long)b.yrow[q] * d.ldr + n_ld + 4 * h);
+        for (int k = 0; k < 2; ++k) {
+            extra[k][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            extra[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    }
-    if (d.rowadd) {
+        if (d.residual) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const float* rp = d.rowadd + (long)((b.yrow[q] / d.rowadd_div) % d.rowadd_mod) * d.N + n_ld;
-#pragma unroll
-            for (int h = 0; h < NV; ++h) b.extra[q][h] += *(const f32x4*)(rp + 4 * h);
+            for (int k = 0; k < 2; ++k) {
+                if (d.res_dtype == MAGE_F32) {
+                    const float* rp = (const float*)d.residual + (long)yrow * d.ldr + nld[k];
+                    extra[k][0] = *(const f32x4*)rp;
+                    extra[k][1] = *(const f32x4*)(rp + 4);
+                } else {
+                    const uint4 r = *(const uint4*)((const unsigned short*)d.residual + (long)yrow * d.ldr + nld[k]);
+                    extra[k][0] = f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                                        __uint_as_float(r.y & 0xffff0000u)};
+                    extra[k][1] = f32x4{__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u), __uint_as_float(r.w << 16),
+                                        __uint_as_float(r.w & 0xffff0000u)};
+                }
+            }
         }
-    }
-}
-
-// Epilogue of one 32x64 block of a wave's sub-tile.  The MFMA layout leaves each lane with 4 consecutive n of 16 different
-// rows per accumulator; stores straight from it would be 8-byte pieces of 16 rows.  Instead the wave transposes the block
-// through a wave-private LDS staging tile (16 rows x 64 fp32, +4 pad: conflict-free b128 writes), 16 rows at a time, and
-// reads it back row-major with VEC consecutive columns per lane (fp32 out: 4, bf16 out: 8): every store is a
-// 16-byte-per-lane dwordx4 of whole lines (a CU retires roughly one wave-store per ~70-90 cycles whatever its width).
-template <int ACT, int VEC, typename OT>
-__device__ __forceinline__ void epi_store(const mage_gemm_desc& d, const ColVecs& cv, const EpiBlock<VEC>& b, f32x4 (&acc)[2][4],
-                                          float* stg, int n0, int lane) {
-    constexpr int LPR = EpiBlock<VEC>::LPR, RPP = EpiBlock<VEC>::RPP, NV = EpiBlock<VEC>::NV;
-    constexpr int PPQ = STG_ROWS / RPP;    // passes per staged 16 rows (4 | 2)
-    const int l15 = lane & 15, grp = lane >> 4;
-    const int rsub = lane / LPR;           // row inside a pass
-    const int c0 = (lane % LPR) * VEC;     // first column inside the block's 64
-    const int n = n0 + c0;
-    const float lo = d.post_relu ? 0.f : -INFINITY;     // post-ReLU as one max (scale/shift default to 1/0: one fma)
+        if (d.rowadd) {
+            const float* tp = d.rowadd + (long)((yrow / d.rowadd_div) % d.rowadd_mod) * d.N;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+            for (int k = 0; k < 2; ++k) {
+                extra[k][0] += *(const f32x4*)(tp + nld[k]);
+                extra[k][1] += *(const f32x4*)(tp + nld[k] + 4);
+            }
+        }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) *(f32x4*)(stg + l15 * STG_LD + nt * 16 + grp * 4) = acc[mt][nt];
-        __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < 2; ++k) {
+            f32x4 v[2];
 #pragma unroll
-        for (int p = 0; p < PPQ; ++p) {
-            const int q = mt * PPQ + p;
-            f32x4 v[NV];
+            for (int e = 0; e < 4; ++e) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mt][2 * k][e]), __float_as_uint(acc[mt][2 * k + 1][e]),
+                                                                false, false);
+                v[0][e] = __uint_as_float(r[0]);
+                v[1][e] = __uint_as_float(r[1]);
+            }
 #pragma unroll
-            for (int h = 0; h < NV; ++h) {
-                v[h] = *(const f32x4*)(stg + (p * RPP + rsub) * STG_LD + c0 + 4 * h);
-                v[h] = (v[h] + cv.bias[h]) * cv.scale[h] + cv.shift[h];
+            for (int h = 0; h < 2; ++h) {
+                v[h] = (v[h] + cv.bias[k][h]) * scale4[k][h] + shift4[k][h];
                 if (ACT != MAGE_ACT_NONE) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[h][e] = act_apply<ACT>(v[h][e]);
                 }
-                v[h] += b.extra[q][h];
+                v[h] += extra[k][h];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[h][e] = fmaxf(v[h][e], lo);
             }
-#if MAGE_ABL == 7     // tuning: full epilogue arithmetic, (almost) no global stores
-            if ((b.valid & (1u << q)) && v[0][0] == 123456.789f) {
-#else
-            if (b.valid & (1u << q)) {
-#endif
-                OT* yp = (OT*)d.Y + (long)b.yrow[q] * d.ldy + n;
-                // streaming (non-temporal) stores: the output is not re-read by this kernel, keep the XCD's L2 for the
-                // activation panels and W that the neighbouring workgroups re-read
-                if (NV == 1) {
+            // streaming (non-temporal) stores: the output is not re-read by this kernel, keep the XCD's L2 for the
+            // activation panels and W that the neighbouring workgroups re-read
+            if (mq < d.M && nv[k]) {
+                OT* yp = (OT*)d.Y + (long)yrow * d.ldy + ncol[k];
+                if (sizeof(OT) == 4) {
                     __builtin_nontemporal_store(v[0], (f32x4*)yp);
+                    __builtin_nontemporal_store(v[1], (f32x4*)yp + 1);
                 } else {
-                    u32x4 pk = {pack_bf16x2(v[0][0], v[0][1]), pack_bf16x2(v[0][2], v[0][3]),
-                                pack_bf16x2(v[NV - 1][0], v[NV - 1][1]), pack_bf16x2(v[NV - 1][2], v[NV - 1][3])};
+                    u32x4 pk = {pack_bf16x2(v[0][0], v[0][1]), pack_bf16x2(v[0][2], v[0][3]), pack_bf16x2(v[1][0], v[1][1]),
+                                pack_bf16x2(v[1][2], v[1][3])};
                     __builtin_nontemporal_store(pk, (u32x4*)yp);
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// The wave's (MT*16)x64 sub-tile as MT/2 32-row blocks, one after the other.  (Keeping block b+1's residual / row-table reads
-// in flight while block b is stored -- two EpiBlocks live -- spills >100 VGPRs next to the 128 accumulators and halves
-// the kernel's speed; measured, reverted.)
-template <int ACT, int VEC, typename OT, int MT>
-__device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const ColVecs& cv, f32x4 (&acc)[MT][4], float* stg, int m0,
-                                              int n0, int lane, int plane) {
-#pragma unroll
-    for (int hb = 0; hb < MT / 2; ++hb) {
-        EpiBlock<VEC> b;
-        epi_prefetch<VEC>(b, d, m0 + hb * 32, n0, lane, plane);
-        epi_store<ACT, VEC, OT>(d, cv, b, *reinterpret_cast<f32x4 (*)[2][4]>(&acc[hb * 2]), stg, n0, lane);
     }
 }
 
@@ -443,12 +416,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
             continue;
         }
 #endif
-        // ---- epilogue.  The stage that held the last slab is free once every wave is past the barrier below; the other
-        // stage is already receiving the next tile's first slab.
-        ring_barrier();
-        float* stg = (float*)(smem + (c_stage ^ 1) * STAGE_BYTES) + wave * (STG_ROWS * STG_LD);
-        if (d.y_dtype == MAGE_F32) epilogue_wave<ACT, 4, float, MT>(d, cv, acc, stg, m0, n0, lane, plane);
-        else epilogue_wave<ACT, 8, unsigned short, MT>(d, cv, acc, stg, m0, n0, lane, plane);
+        // ---- epilogue: straight from the accumulators (no LDS), while the next tile's first slab lands in the other stage
+        if (d.y_dtype == MAGE_F32) epilogue_wave<ACT, float, MT>(d, cv, acc, m0, n0, lane, plane);
+        else epilogue_wave<ACT, unsigned short, MT>(d, cv, acc, m0, n0, lane, plane);
     }
 }
 
@@ -512,12 +482,12 @@ extern "C" int mage_gemm(const mage_gemm_desc* d, void* stream) {
     MAGE_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "mage_gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
     MAGE_CHECK_ARG(d->A && d->W && d->Y, "mage_gemm: null operand");
     const int ch = d->dtype == MAGE_BF16 ? 8 : 4;
-    MAGE_CHECK_ARG(d->N % 4 == 0, "mage_gemm: N=%d must be a multiple of 4", d->N);
+    MAGE_CHECK_ARG(d->N % 8 == 0, "mage_gemm: N=%d must be a multiple of 8", d->N);
     MAGE_CHECK_ARG(d->K % ch == 0 && d->lda % ch == 0 && d->cin % ch == 0,
                    "mage_gemm: K=%d, lda=%d, cin=%d must be multiples of %d", d->K, d->lda, d->cin, ch);
     MAGE_CHECK_ARG(d->ldy % 4 == 0 && (!d->residual || d->ldr % 4 == 0), "mage_gemm: ldy/ldr must be multiples of 4");
-    MAGE_CHECK_ARG(d->y_dtype != MAGE_BF16 || (d->N % 8 == 0 && d->ldy % 8 == 0 && (!d->residual || d->ldr % 8 == 0)),
-                   "mage_gemm: bf16 output needs N, ldy (and ldr) multiples of 8 (16-byte stores)");
+    MAGE_CHECK_ARG(d->y_dtype != MAGE_BF16 || (d->ldy % 8 == 0 && (!d->residual || d->res_dtype != MAGE_BF16 || d->ldr % 8 == 0)),
+                   "mage_gemm: bf16 output / residual need ldy / ldr multiples of 8 (16-byte accesses)");
     MAGE_CHECK_ARG(d->taps_h >= 1 && d->taps_w >= 1 && d->K == d->taps_h * d->taps_w * d->cin,
                    "mage_gemm: K=%d != taps_h*taps_w*cin = %d*%d*%d", d->K, d->taps_h, d->taps_w, d->cin);
     MAGE_CHECK_ARG(d->out_h >= 1 && d->out_w >= 1 && d->in_h >= 1 && d->in_w >= 1, "mage_gemm: bad geometry");

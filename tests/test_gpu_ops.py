@@ -31,7 +31,7 @@ TOL = {torch.float32: dict(atol=2e-5, rtol=2e-5), torch.bfloat16: dict(atol=6e-2
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (300, 132, 200), (33, 64, 2048), (1000, 1536, 512), (7, 4, 8)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (300, 136, 200), (33, 64, 2048), (1000, 1536, 512), (7, 8, 8)])
 def test_gemm_plain(dt, M, N, K):
     o = ops()
     a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
@@ -284,6 +284,6 @@ def test_errors_are_loud():
     o = ops()
     a = torch.zeros(8, 8, device=DEV)
     with pytest.raises(ValueError):
-        o.gemm(a, a, a, M=8, N=6, K=8, lda=8, ldy=6)           # N not a multiple of 4
+        o.gemm(a, a, a, M=8, N=4, K=8, lda=8, ldy=4)           # N not a multiple of 8
     with pytest.raises(RuntimeError):
         o.layernorm(torch.zeros(4, 8), torch.zeros(8), torch.zeros(8), torch.zeros(4, 8), 1e-5)   # CPU tensors: no fallback
