@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--ar-mode", default="full", choices=["full", "incremental"],
                     help="full = the reference's per-iteration full recompute (headline); incremental = temporal KV cache")
+    ap.add_argument("--streams", type=int, default=2, help="clip groups on concurrent HIP streams inside one generate call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the second AR mode (clean rocprofv3 runs)")
     ap.add_argument("--cpu-clips", type=int, default=2)
@@ -58,6 +59,7 @@ def main():
     cpu_sd = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 and not args.no_cpu_baseline else None
     model = model.to(dev).set_precision(args.precision)
     model.ar_mode = args.ar_mode
+    model.streams = args.streams
     batch = {k: v.to(dev) for k, v in synth.synth_batch_mnist(B, L, seed=100 + rank).items()}
 
     def sync_all():
@@ -82,6 +84,7 @@ def main():
     other = None
     if not args.no_other_mode:
         model.ar_mode = other_mode
+        model.streams = 1 if other_mode == "incremental" else args.streams     # small launches: concurrency only adds gaps
         tok_main = model.last_tokens.clone()
         model.autoregressive_generate(batch)
         same_tokens = bool(torch.equal(model.last_tokens, tok_main))
@@ -92,6 +95,7 @@ def main():
         sync_all()
         dt_other = D.max_over_ranks(time.perf_counter() - t1, dev)
         model.ar_mode = args.ar_mode
+        model.streams = args.streams
         other = {"ar_mode": other_mode, "value": round(world * B * L * args.steps / dt_other, 2), "unit": "frames/s",
                  "ms_per_step": round(dt_other / args.steps * 1e3, 3), "tokens_identical_to_headline_mode": same_tokens}
 
@@ -129,7 +133,7 @@ def main():
             "config": {"workload": f"cfg2: Single Moving MNIST 64x64, {L} frames, batch={B}/GPU, MNIST f4 VQ-VAE + MAGE "
                                    f"(d=512, 6 axial blocks), AR loop: {'reference full recompute per iteration' if args.ar_mode == 'full' else 'incremental (temporal KV cache)'}, random-init weights",
                        "global_batch": world * B, "frames": L, "parallelism": f"clip-sharded x{world} (no collective)",
-                       "ar_mode": model.ar_mode},
+                       "ar_mode": model.ar_mode, "streams_per_gpu": args.streams},
             "roofline": roofline,
             "kernel_time_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items())},
             "other_ar_mode": other,

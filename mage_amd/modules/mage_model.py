@@ -549,6 +549,7 @@ class MAGE(nn.Module):
                 self.alpha, self.beta = alpha, beta
         self.initialize_parameters()
         self.precision = "fp32"
+        self.streams = 1               # >1: clip groups on concurrent HIP streams (see autoregressive_generate)
         self.ar_mode = "full"          # 'full' = the reference's per-iteration full recompute (mage_model.py:673-684);
                                        # 'incremental' = temporal KV cache, each position once
         self._derived = _Derived(self)
@@ -642,11 +643,43 @@ class MAGE(nn.Module):
     @torch.no_grad()
     def autoregressive_generate(self, batch):
         """batch {'images' [B,L,C,H,W] (only frame 0 is read), 'text' int64 [B,S], 'speed' [B] optional,
-        'video_noise' [B,64,h,w] optional (injects the randomness-branch noise instead of torch.randn)} -> [B,L,C,H,W]."""
+        'video_noise' [B,64,h,w] optional (injects the randomness-branch noise instead of torch.randn)} -> [B,L,C,H,W].
+
+        With ``self.streams = n > 1`` the clips are processed as n independent groups on n HIP streams: clips never
+        interact, so the results are bit-identical, and the HBM-bound kernels of one group (LayerNorm, attention, casts)
+        run under the MFMA-bound GEMMs of the other instead of in front of them."""
         images = batch["images"]
         _need_gpu(images, "MAGE.autoregressive_generate")
         if not self.use_cids:
             raise NotImplementedError("use_cids=False (MAGE+ over an ldm AutoencoderKL) is a 'next' row (SURVEY.md 8f-3)")
+        n = int(getattr(self, "streams", 1))
+        if n > 1 and images.shape[0] >= 2 * n and images.shape[0] % n == 0:
+            return self._generate_multistream(batch, n)
+        return self._generate_one(batch)
+
+    def _generate_multistream(self, batch, n):
+        B = batch["images"].shape[0]
+        per = B // n
+        main = torch.cuda.current_stream(batch["images"].device)
+        if getattr(self, "_side_streams", None) is None or len(self._side_streams) != n:
+            self._side_streams = [torch.cuda.Stream(device=batch["images"].device) for _ in range(n)]
+        outs, toks = [None] * n, [None] * n
+        for g, st in enumerate(self._side_streams):
+            st.wait_stream(main)                                      # inputs were produced on the caller's stream
+            with torch.cuda.stream(st):
+                sub = {k: v[g * per:(g + 1) * per] for k, v in batch.items()}
+                outs[g] = self._generate_one(sub)
+                toks[g] = self.last_tokens
+        for st in self._side_streams:
+            main.wait_stream(st)
+        for t_ in outs + toks:
+            t_.record_stream(main)                                    # allocator plumbing: consumed on the caller's stream
+        self.last_tokens, self.last_logits = torch.cat(toks, 0), None
+        return torch.cat(outs, 0)
+
+    @torch.no_grad()
+    def _generate_one(self, batch):
+        images = batch["images"]
         B = images.shape[0]
         R, L, K = self.image_resolution, self.frames_length, self.codebook_size
         hw, Lm1 = R * R, self.frames_length - 1

@@ -190,3 +190,16 @@ def test_incremental_decoding_full_size_cfg2():
     m.ar_mode = "incremental"
     v_inc = m.autoregressive_generate(batch)
     assert torch.equal(m.last_tokens, t_full) and torch.equal(v_inc, v_full)
+
+
+def test_multistream_clip_groups_are_bit_identical():
+    m = build_mage(synth.mnist_model_config(frames_length=6), 5, DEV).set_precision("bf16")
+    batch = dev_batch(synth.synth_batch_mnist(8, 6, seed=5))
+    v1 = m.autoregressive_generate(batch)
+    t1 = m.last_tokens.clone()
+    m.streams = 2
+    v2 = m.autoregressive_generate(batch)
+    assert torch.equal(m.last_tokens, t1) and torch.equal(v1, v2)
+    m.streams, m.ar_mode = 4, "incremental"
+    v3 = m.autoregressive_generate(batch)
+    assert torch.equal(m.last_tokens, t1) and torch.equal(v1, v3)
