@@ -208,6 +208,14 @@ def main():
     save("mage_cater_small", seed=41, B=2, L=4, width=64, layers=3, vq_dim=32, K=64, text_len=12, noise=noise,
          motion=trace[0][0], gen_tokens=trace[-1][1].max(-1)[1].to(torch.int16), margin=top2_margin(step_logits),
          step_logits=step_logits, video_sub=video[..., ::4, ::4].contiguous(), video_chk=chk(video))
+    # ---- 8. state_dict layout (keys, shapes, dtypes) of the reference modules: the drop-in boundary ----------------
+    import json
+    layout = {}
+    for tag, cfg in (("mnist_L16", synth.mnist_model_config(frames_length=16)), ("caterv1_L10", synth.cater_model_config(frames_length=10))):
+        rm = ref_mage.MAGE(**to_cfg(cfg["params"]))
+        layout[tag] = [[k, list(v.shape), str(v.dtype)] for k, v in rm.state_dict().items()]
+    json.dump(layout, open(os.path.join(OUT, "state_dict_layout.json"), "w"))
+    print("  wrote state_dict_layout.json")
     print("done")
 
 
