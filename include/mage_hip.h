@@ -201,6 +201,14 @@ int mage_add_scaled_rowvec(float* x, const float* s, const float* vec, int32_t B
 int mage_row_affine(float* x, const float* rs, const float* table, int64_t rows, int32_t C, int32_t div, int32_t mod,
                     void* stream);
 
+/* MAGE+ head (mage_model.py:350-354,387-388): y = SiLU(GroupNorm(groups, C)(x)) with the statistics of each sample taken
+ * over rows_per_sample rows x (C/groups) channels.  x fp32 rows; sample b uses rows [b*sample_stride_rows + row_off, +rows_per_sample)
+ * (this is how x[:, 1:] of the [B, L, hw, C] decoder stream is addressed without a copy); y is packed [n_samples*rows_per_sample, C]
+ * in y_dtype; stats is a [n_samples, groups, 2] fp32 workspace (mean, rstd).  Two-pass, fixed-order reductions. */
+int mage_groupnorm_silu(const float* x, int64_t sample_stride_rows, int64_t row_off, int32_t n_samples, int32_t rows_per_sample,
+                        int32_t C, int32_t groups, const float* gamma, const float* beta, float eps, float* stats, void* y,
+                        int32_t y_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

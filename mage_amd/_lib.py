@@ -69,6 +69,7 @@ SIGNATURES = {
     "mage_adain": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "mage_add_scaled_rowvec": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "mage_row_affine": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, vp]),
+    "mage_groupnorm_silu": (C.c_int, [vp, i64, i64, i32, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

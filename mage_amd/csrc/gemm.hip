@@ -324,9 +324,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     int c_tile = chunk0 + li;
     if (c_tile >= chunk1) return;                      // more workgroups than tiles in this XCD's chunk
     loader_set_tile(ld_tile);
-    // (Tried and measured null: starting the workgroups of an XCD a quarter tile apart so that store bursts overlap other
-    // workgroups' K loops.  The store cost is per-CU -- loads and stores share the CU's vector-memory pipe -- not a chip-
-    // level HBM burst.)
+#ifdef MAGE_DEPHASE
+    // tuning experiment: start the workgroups of an XCD in 4 groups a quarter tile apart
+    if ((chunk1 - chunk0) >= 4 * nwg8) {
+        const int quarter = (nk * MAGE_DEPHASE + 12000) / (4 * 1024);        // s_sleep(16) = 1024 clocks
+        for (int w = (li & 3) * quarter; w > 0; --w) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     issue_all();
     loader_advance();
     int c_stage = 0;

@@ -287,3 +287,91 @@ extern "C" int mage_row_affine(float* x, const float* rs, const float* table, in
     MAGE_CHECK_LAUNCH("mage_row_affine");
     return MAGE_OK;
 }
+
+// ------------------------------------------------------------------------------------ GroupNorm + SiLU (MAGE+ head)
+namespace {
+
+// stats[b][g] = {mean, rstd} over rows_per_sample rows x (C/groups) channels; one workgroup per (b, g), two passes,
+// fixed-order reductions (deterministic).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, long sample_stride_rows, long row_off,
+                                                       int rows_per_sample, int C, int groups, float eps,
+                                                       float* __restrict__ stats) {
+    __shared__ double red[4];
+    const int b = blockIdx.x, g = blockIdx.y, cpg = C / groups;
+    const float* base = x + ((long)b * sample_stride_rows + row_off) * C + g * cpg;
+    const long n = (long)rows_per_sample * cpg;
+    auto block_sum = [&](double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    double s = 0.0;
+    for (int r = threadIdx.x; r < rows_per_sample; r += 256)
+        for (int c = 0; c < cpg; ++c) s += (double)base[(long)r * C + c];
+    const double mean = block_sum(s) / (double)n;
+    double q = 0.0;
+    for (int r = threadIdx.x; r < rows_per_sample; r += 256)
+        for (int c = 0; c < cpg; ++c) {
+            const double dlt = (double)base[(long)r * C + c] - mean;
+            q += dlt * dlt;
+        }
+    const double var = block_sum(q) / (double)n;
+    if (threadIdx.x == 0) {
+        stats[((long)b * groups + g) * 2] = (float)mean;
+        stats[((long)b * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+template <typename OT>
+__global__ __launch_bounds__(256) void gn_apply_silu_kernel(const float* __restrict__ x, long sample_stride_rows, long row_off,
+                                                            int rows_per_sample, int C, int groups,
+                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, OT* __restrict__ y, long total) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    const long orow = i / C;
+    const int c = (int)(i - orow * C);
+    const long b = orow / rows_per_sample, r = orow - b * rows_per_sample;
+    const int cpg = C / groups;
+    const f32x4 v = *(const f32x4*)(x + ((b * sample_stride_rows + row_off + r) * C + c));
+    const f32x4 gm = *(const f32x4*)(gamma + c), bt = *(const f32x4*)(beta + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int g = (c + e) / cpg;                                  // a vector may straddle groups when C/groups < 4
+        const float mean = stats[(b * groups + g) * 2], rstd = stats[(b * groups + g) * 2 + 1];
+        const float t = (v[e] - mean) * rstd * gm[e] + bt[e];
+        o[e] = t / (1.0f + expf(-t));
+    }
+    store4(y + i, o);
+}
+
+}  // namespace
+
+extern "C" int mage_groupnorm_silu(const float* x, int64_t sample_stride_rows, int64_t row_off, int32_t n_samples,
+                                   int32_t rows_per_sample, int32_t C, int32_t groups, const float* gamma, const float* beta,
+                                   float eps, float* stats, void* y, int32_t y_dtype, void* stream) {
+    MAGE_CHECK_ARG(x && gamma && beta && stats && y, "mage_groupnorm_silu: null pointer");
+    MAGE_CHECK_ARG(n_samples > 0 && rows_per_sample > 0 && groups > 0 && C % groups == 0 && C % 4 == 0,
+                   "mage_groupnorm_silu: C=%d groups=%d unsupported", C, groups);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(n_samples, groups), dim3(256), 0, s, x, (long)sample_stride_rows, (long)row_off,
+                       rows_per_sample, C, groups, eps, stats);
+    const long total = (long)n_samples * rows_per_sample * C;
+    const dim3 grid((unsigned)((total / 4 + 255) / 256));
+    if (y_dtype == MAGE_F32)
+        hipLaunchKernelGGL((gn_apply_silu_kernel<float>), grid, dim3(256), 0, s, x, (long)sample_stride_rows, (long)row_off,
+                           rows_per_sample, C, groups, stats, gamma, beta, (float*)y, total);
+    else if (y_dtype == MAGE_BF16)
+        hipLaunchKernelGGL((gn_apply_silu_kernel<unsigned short>), grid, dim3(256), 0, s, x, (long)sample_stride_rows, (long)row_off,
+                           rows_per_sample, C, groups, stats, gamma, beta, (unsigned short*)y, total);
+    else {
+        mage_set_error("mage_groupnorm_silu: bad y_dtype %d", y_dtype);
+        return MAGE_EINVAL;
+    }
+    MAGE_CHECK_LAUNCH("mage_groupnorm_silu");
+    return MAGE_OK;
+}

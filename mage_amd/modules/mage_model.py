@@ -362,6 +362,15 @@ class FlatAxialDecoder(nn.Module):
         _pack_linear(d, "context_linear", self.context_linear.weight, self.context_linear.bias)
         if self.use_cids:
             _pack_linear(d, "out", self.out.weight, self.out.bias)
+        else:                                  # MAGE+ head: GroupNorm(32) + SiLU + Conv3d 1x1x1 (mage_model.py:350-354)
+            d["gn.w"], d["gn.b"] = self.out[0].weight.float().contiguous(), self.out[0].bias.float().contiguous()
+            w = self.out[2].weight.float().reshape(self.out_channels, self.model_channels)
+            n8 = (self.out_channels + 7) // 8 * 8                        # GEMM wants N % 8 == 0: zero rows pad the 4 outputs
+            wp = torch.zeros(n8, self.model_channels, device=w.device)
+            wp[:self.out_channels] = w
+            bp = torch.zeros(n8, device=w.device)
+            bp[:self.out_channels] = self.out[2].bias.float()
+            _pack_linear(d, "out", wp, bp)
         d["tpos"] = self.T_positional_embedding.float().reshape(self.frames_length, self.model_channels).contiguous()
         for i, blk in enumerate(self.blocks):
             _pack_block(d, f"b{i}", blk)
@@ -369,9 +378,8 @@ class FlatAxialDecoder(nn.Module):
 
     @torch.no_grad()
     def _run(self, motion: torch.Tensor, imgs: torch.Tensor, *, B: int, hh: int, ww: int) -> torch.Tensor:
-        """motion [B*hw, Cc], imgs [B*(L-1)*hw, Ci] in the compute dtype -> logits [B*(L-1)*hw, K] fp32."""
-        if not self.use_cids:
-            raise NotImplementedError("use_cids=False (MAGE+ GroupNorm/SiLU/Conv3d head) is a 'next' row (SURVEY.md 8f-3)")
+        """motion [B*hw, Cc], imgs [B*(L-1)*hw, Ci] in the compute dtype -> logits [B*(L-1)*hw, K] fp32
+        (use_cids=False: predicted latents [B*(L-1)*hw, 8] fp32 whose first out_channels columns are valid)."""
         d = self._derived.get(self._build)
         dt, Cc, L, dev = self.compute_dtype, self.model_channels, self.frames_length, motion.device
         hw = hh * ww
@@ -404,6 +412,14 @@ class FlatAxialDecoder(nn.Module):
             ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5)
             _linear(xn, d, p + ".c_fc", hdn, dt, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU)
             _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
+        if not self.use_cids:
+            # GroupNorm statistics span all L-1 frames of a clip (:387-388): this head is NOT causal along L
+            y = ops.groupnorm_silu(x, d["gn.w"], d["gn.b"], torch.empty(B * (L - 1) * hw, Cc, device=dev, dtype=dt), n_samples=B,
+                                   rows_per_sample=(L - 1) * hw, sample_stride_rows=L * hw, row_off=hw, groups=32,
+                                   eps=self.out[0].eps)
+            n8 = d["out.f32"].shape[0]
+            pred = torch.empty(B * (L - 1) * hw, n8, device=dev, dtype=F32)
+            return _linear(y, d, "out", pred, dt, M=B * (L - 1) * hw, N=n8, K=Cc)
         xa = x if dt == F32 else ops.cast(x, xn)
         logits = torch.empty(B * (L - 1) * hw, self.out_channels, device=dev, dtype=F32)
         _linear(xa, d, "out", logits, dt, M=B * (L - 1) * hw, N=self.out_channels, K=Cc, out_w=(L - 1) * hw,
@@ -482,7 +498,8 @@ class FlatAxialDecoder(nn.Module):
         dt = self.compute_dtype
         m = motion.reshape(B * hh * ww, -1).to(dt).contiguous()
         im = imgs.reshape(-1, imgs.shape[-1]).to(dt).contiguous()
-        return self._run(m, im, B=B, hh=hh, ww=ww).view(B, self.frames_length - 1, hh, ww, self.out_channels)
+        out = self._run(m, im, B=B, hh=hh, ww=ww)
+        return out.view(B, self.frames_length - 1, hh, ww, -1)[..., :self.out_channels]
 
 
 class PIDControl:
@@ -572,7 +589,8 @@ class MAGE(nn.Module):
             raise ValueError("precision must be 'fp32' or 'bf16'")
         self.precision = precision
         self.generate_model.compute_dtype = F32 if precision == "fp32" else BF16
-        self.first_stage_model.set_precision(precision)
+        if hasattr(self.first_stage_model, "set_precision"):     # an external latent first stage (MAGE+) has no such switch
+            self.first_stage_model.set_precision(precision)
         return self
 
     def _dt(self) -> torch.dtype:
@@ -582,6 +600,9 @@ class MAGE(nn.Module):
         d: Dict[str, torch.Tensor] = {}
         if self.use_cids:
             d["emb"] = self.visual_token_embedding.weight.float().contiguous()
+        else:
+            d["emb_lin.w"] = self.visual_token_embedding.weight.float().contiguous()       # [C, embed_dim]
+            d["emb_lin.b"] = self.visual_token_embedding.bias.float().contiguous()
         cw = _conv_w(self.conv[0])
         d["conv.f32"], d["conv.bf16"] = cw, cw.to(BF16)
         R, Cc = self.image_resolution, self.vision_width
@@ -595,12 +616,14 @@ class MAGE(nn.Module):
     @torch.no_grad()
     def first_stage_encode(self, x):
         """[B, T, C, H, W] -> token ids int64 [B, T, h, w]."""
-        out = self.first_stage_model.encode(x.reshape(-1, *x.shape[-3:]))
-        return self.get_first_stage_encoding(out).view(*x.shape[:-3], *out.shape[1:]).contiguous()
+        out = self.get_first_stage_encoding(self.first_stage_model.encode(x.reshape(-1, *x.shape[-3:])))
+        return out.view(*x.shape[:-3], *out.shape[1:]).contiguous()
 
     def get_first_stage_encoding(self, encoder_posterior):
         if isinstance(encoder_posterior, torch.Tensor):
             return encoder_posterior
+        if hasattr(encoder_posterior, "sample"):          # ldm DiagonalGaussianDistribution (mage_model.py:543-544)
+            return encoder_posterior.sample()
         raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
 
     @torch.no_grad()
@@ -619,12 +642,25 @@ class MAGE(nn.Module):
         return VectorQuantizedVAE._conv(emb, d["conv" + _sfx(dt)], torch.empty_like(emb), n_img=n, H=R, W=R, cin=Cc, cout=Cc,
                                         k=3, rowadd=d["hwpos"], rowadd_div=1, rowadd_mod=R * R)
 
-    def _motion_anchor(self, tok0: torch.Tensor, batch, noise: Optional[torch.Tensor]) -> torch.Tensor:
+    def _frame_features_latent(self, lat: torch.Tensor, ld: int, dt: torch.dtype) -> torch.Tensor:
+        """use_cids=False: latents as fp32 rows [n*hw, ld] (first embed_dim columns valid) -> Linear(embed_dim -> C)
+        (mage_model.py:483,583,646) -> conv3x3 + (H_pos + W_pos), rows [n*hw, C]."""
+        d = self._derived.get(self._build)
+        R, Cc = self.image_resolution, self.vision_width
+        rows = lat.numel() // ld
+        E = d["emb_lin.w"].shape[1]
+        emb = ops.gemm(lat, d["emb_lin.w"], torch.empty(rows, Cc, device=lat.device, dtype=dt), M=rows, N=Cc, K=E, lda=ld, ldy=Cc,
+                       bias=d["emb_lin.b"])                                                   # K = 4: fp32 MFMA path
+        return VectorQuantizedVAE._conv(emb, d["conv" + _sfx(dt)], torch.empty_like(emb), n_img=rows // (R * R), H=R, W=R, cin=Cc,
+                                        cout=Cc, k=3, rowadd=d["hwpos"], rowadd_div=1, rowadd_mod=R * R)
+
+    def _motion_anchor(self, tok0: torch.Tensor, batch, noise: Optional[torch.Tensor], first: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Once-per-clip prologue, fp32 (mage_model.py:648-668): rows [B*hw, C]."""
         d = self._derived.get(self._build)
-        B = tok0.shape[0]
+        B = batch["text"].shape[0]
         R, Cc = self.image_resolution, self.vision_width
-        first = self._frame_features(tok0, F32)                                               # [B*hw, C]
+        if first is None:
+            first = self._frame_features(tok0, F32)                                           # [B*hw, C]
         txt = self.text_encoder(batch["text"])                                                # [B, S, C]
         S = txt.shape[1]
         ma = self.ma_encoder._run(first, txt.reshape(B * S, -1), B=B, nq=R * R, nk=S, seq_first=False)
@@ -651,7 +687,7 @@ class MAGE(nn.Module):
         images = batch["images"]
         _need_gpu(images, "MAGE.autoregressive_generate")
         if not self.use_cids:
-            raise NotImplementedError("use_cids=False (MAGE+ over an ldm AutoencoderKL) is a 'next' row (SURVEY.md 8f-3)")
+            return self._generate_latent(batch)
         n = int(getattr(self, "streams", 1))
         if n > 1 and images.shape[0] >= 2 * n and images.shape[0] % n == 0:
             return self._generate_multistream(batch, n)
@@ -676,6 +712,36 @@ class MAGE(nn.Module):
             t_.record_stream(main)                                    # allocator plumbing: consumed on the caller's stream
         self.last_tokens, self.last_logits = torch.cat(toks, 0), None
         return torch.cat(outs, 0)
+
+    @torch.no_grad()
+    def _generate_latent(self, batch):
+        """use_cids=False (MAGE+, mage_model.py:645-646,683-684,689): the first stage is an external latent autoencoder
+        (ldm AutoencoderKL in config/mage+_*.yaml); its encode/decode are the boundary, everything between runs here.
+        The GroupNorm head mixes all frames of a clip, so only the reference's full-recompute loop is valid."""
+        images = batch["images"]
+        B = images.shape[0]
+        R, L = self.image_resolution, self.frames_length
+        hw, Lm1 = R * R, L - 1
+        dt = self._dt()
+        E = self.first_stage_model.embed_dim
+        lat0 = self.first_stage_encode(images[:, 0:1])[:, 0]                                   # [B, E, h, w]
+        LD = 8                                                                                # row stride of the latent buffer
+        cur = torch.zeros(B, Lm1, hw, LD, device=images.device, dtype=F32)
+        cur[..., :E] = lat0.permute(0, 2, 3, 1).reshape(B, 1, hw, E).float()                  # :670 every slot holds frame 0
+        first = self._frame_features_latent(cur[:, 0].contiguous(), LD, F32)
+        ma = self._motion_anchor(None, batch, batch.get("video_noise"), first=first)
+        ma_dt = ma if dt == F32 else ma.to(dt)
+        pred = None
+        for i in range(Lm1):                                                                  # :673-684
+            feats = self._frame_features_latent(cur.view(-1, LD), LD, dt)
+            pred = self.generate_model._run(ma_dt, feats, B=B, hh=R, ww=R).view(B, Lm1, hw, -1)
+            if i != Lm1 - 1:
+                cur[:, i + 1, :, :E] = pred[:, i, :, :E]                                      # :684 (index plumbing)
+        self.last_tokens, self.last_logits = None, pred[..., :E].reshape(B, Lm1, R, R, E)
+        gen = pred[..., :E].reshape(B * Lm1, R, R, E).permute(0, 3, 1, 2).contiguous()          # :689
+        video = self.first_stage_model.decode(gen)
+        video = video.view(B, Lm1, *video.shape[1:])
+        return torch.cat([images[:, 0:1].to(video.dtype), video], 1)
 
     @torch.no_grad()
     def _generate_one(self, batch):

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc
 
 __all__ = ["gemm", "layernorm", "attention", "embedding", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
-           "conv_in", "conv_out", "row_affine", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
+           "conv_in", "conv_out", "row_affine", "groupnorm_silu", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
            "PROFILE", "F32", "BF16", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
 
 
@@ -270,3 +270,13 @@ def row_affine(x, rs=None, table=None, *, div: int = 1, mod: int = 1):
     Cc = x.shape[-1]
     _lib.check(l.mage_row_affine(x.data_ptr(), _p(rs), _p(table), x.numel() // Cc, Cc, div, mod, s), l)
     return x
+
+
+def groupnorm_silu(x, gamma, beta, y, *, n_samples, rows_per_sample, sample_stride_rows, row_off, groups, eps=1e-5):
+    l, s = _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    Cc = x.shape[-1]
+    stats = torch.empty(n_samples, groups, 2, device=x.device, dtype=torch.float32)
+    _lib.check(l.mage_groupnorm_silu(x.data_ptr(), sample_stride_rows, row_off, n_samples, rows_per_sample, Cc, groups,
+                                     gamma.data_ptr(), beta.data_ptr(), float(eps), stats.data_ptr(), y.data_ptr(), code(y), s), l)
+    return y

@@ -24,7 +24,7 @@ import torch
 
 __all__ = [
     "rng_for", "synth_tensor", "fill_state_dict", "synth_batch_mnist",
-    "synth_batch_cater", "mnist_model_config", "cater_model_config",
+    "synth_batch_cater", "mnist_model_config", "cater_model_config", "magep_model_config",
 ]
 
 
@@ -220,4 +220,16 @@ def cater_model_config(frames_length: int = 32, width: int = 512, layers: int = 
     cfg["params"]["alpha"] = 0.001
     cfg["params"]["beta"] = 0.00025
     cfg["params"]["first_stage_config"]["params"].update({"input_dim": 3, "down_ratio": 8})
+    return cfg
+
+
+def magep_model_config(frames_length: int = 32, width: int = 512, layers: int = 6, vocab: int = 50, context_length: int = 38,
+                       first_stage_target: str = "tests.standin_first_stage.StandInLatentFirstStage") -> dict:
+    """BASELINE cfg5 MAGE side: config/mage+_caterv2.yaml (use_cids False, out_channels 4, randomness + auto_beta) with the
+    `ldm` AutoencoderKL (absent from the reference mount) replaced by a latent first stage exposing embed_dim/encode/decode."""
+    cfg = mnist_model_config(frames_length, width, layers, vocab=vocab, context_length=context_length)
+    p = cfg["params"]
+    p.update({"use_cids": False, "randomness": True, "auto_beta": True, "v_kl": 100, "dropout": 0.2})
+    p["first_stage_config"] = {"target": first_stage_target, "params": {"embed_dim": 4, "down": 8, "in_ch": 3}}
+    p["generate_decoder_config"]["params"]["out_channels"] = 4
     return cfg

@@ -310,3 +310,50 @@ def mage_forward_loss(sd: SD, batch: Dict[str, torch.Tensor], frames_length: int
     logits = flat_axial_decoder(sd, "generate_model.", ma, _frame_features(sd, tok[:, :frames_length - 1]))
     loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), tok[:, 1:frames_length].reshape(-1))
     return loss, logits
+
+
+# ----------------------------------------------------------------------------- MAGE+ (use_cids=False), sampling side
+def _frame_features_latent(sd: SD, lat: torch.Tensor) -> torch.Tensor:
+    """latents [B,T,E,h,w] -> Linear(E->C) -> conv3x3 + positional tables, [B,T,h,w,C] (mage_model.py:583,646,674-676)."""
+    B, T, E, h, w = lat.shape
+    emb = F.linear(lat.permute(0, 1, 3, 4, 2), sd["visual_token_embedding.weight"], sd["visual_token_embedding.bias"])
+    emb = emb.permute(0, 1, 4, 2, 3).reshape(B * T, -1, h, w)
+    f = F.conv2d(emb, sd["conv.0.weight"], None, padding=1).view(B, T, -1, h, w).permute(0, 1, 3, 4, 2)
+    return f + sd["H_positional_embedding"] + sd["W_positional_embedding"]
+
+
+def flat_axial_decoder_latent(sd: SD, p: str, motion: torch.Tensor, imgs: torch.Tensor) -> torch.Tensor:
+    """FlatAxialDecoder.forward with the MAGE+ head (mage_model.py:350-354,387-388): GroupNorm(32) over
+    [C, L-1, h, w] per clip -> SiLU -> Conv3d 1x1x1.  -> [B, L-1, h, w, out]."""
+    x = torch.cat([F.linear(motion, sd[p + "context_linear.weight"], sd[p + "context_linear.bias"]).unsqueeze(1),
+                   F.linear(imgs, sd[p + "in_linear.weight"], sd[p + "in_linear.bias"])], 1)
+    x = x + sd[p + "T_positional_embedding"]
+    i = 0
+    while (p + f"blocks.{i}.ln_1.weight") in sd:
+        x = axial_block(sd, p + f"blocks.{i}", x, axis=i % 3 + 1, causal=(i % 3 == 0))
+        i += 1
+    y = x[:, 1:].permute(0, 4, 1, 2, 3)
+    y = F.silu(F.group_norm(y, 32, sd[p + "out.0.weight"], sd[p + "out.0.bias"], 1e-5))
+    return F.conv3d(y, sd[p + "out.2.weight"], sd[p + "out.2.bias"]).permute(0, 2, 3, 4, 1)
+
+
+def mage_generate_latent(sd: SD, batch: Dict[str, torch.Tensor], frames_length: int, lat0: torch.Tensor,
+                         noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """MAGE.autoregressive_generate for use_cids=False between the first stage's encode and decode:
+    lat0 [B, E, h, w] (latents of frame 0) -> predicted latents [B, L-1, h, w, E]."""
+    B, E, h, w = lat0.shape
+    Lm1 = frames_length - 1
+    first = _frame_features_latent(sd, lat0[:, None])[:, 0].reshape(B, h * w, -1)
+    txt = text_encoder(sd, "text_encoder.", batch["text"])
+    ma = ma_encoder(sd, "ma_encoder.", first, txt).view(B, h, w, -1)
+    if noise is not None:
+        ma = adain(sd, ma, noise)
+    if batch.get("speed") is not None:
+        ma = ma + (batch["speed"].view(B, 1) @ sd["speed_embedding"])[:, None, None, :]
+    cur = lat0[:, None].repeat(1, Lm1, 1, 1, 1)
+    pred = None
+    for i in range(Lm1):
+        pred = flat_axial_decoder_latent(sd, "generate_model.", ma, _frame_features_latent(sd, cur))
+        if i != Lm1 - 1:
+            cur[:, i + 1] = pred[:, i].permute(0, 3, 1, 2)
+    return pred

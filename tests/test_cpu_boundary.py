@@ -22,6 +22,8 @@ def test_state_dict_layout_identical_to_reference():
     assert _layout(mn) == want["mnist_L16"] and len(want["mnist_L16"]) == 205
     ct = instantiate_from_config(synth.cater_model_config(frames_length=10))
     assert _layout(ct) == want["caterv1_L10"] and len(want["caterv1_L10"]) == 256
+    mp = instantiate_from_config(synth.magep_model_config(frames_length=10))          # MAGE+ (use_cids=False) layout
+    assert _layout(mp) == want["magep_caterv2_L10"]
 
 
 def test_reference_yaml_targets_resolve_and_shims_import():

@@ -203,3 +203,17 @@ def test_multistream_clip_groups_are_bit_identical():
     m.streams, m.ar_mode = 4, "incremental"
     v3 = m.autoregressive_generate(batch)
     assert torch.equal(m.last_tokens, t1) and torch.equal(v1, v3)
+
+
+def test_mage_plus_latent_path_golden():
+    """BASELINE cfg5, MAGE side only (use_cids=False over a latent first stage): golden from the reference's MAGE driven
+    with the same stand-in first stage (tests/standin_first_stage.py; the real `ldm` AutoencoderKL is outside the mount)."""
+    g = golden("mage_plus_small")
+    B, L = int(g["B"]), int(g["L"])
+    m = build_mage(synth.magep_model_config(frames_length=L, width=64, layers=3), int(g["seed"]), DEV)
+    batch = dev_batch(synth.synth_batch_cater(B, L, seed=int(g["seed"]), text_len=int(g["text_len"]), vocab=50))
+    batch["video_noise"] = t(g["noise"]).to(DEV)
+    video = m.autoregressive_generate(batch)
+    assert tuple(video.shape) == (B, L, 3, 128, 128)
+    torch.testing.assert_close(m.last_logits.cpu(), t(g["pred_latents"]), atol=2e-4, rtol=1e-4)
+    torch.testing.assert_close(video[..., ::4, ::4].cpu(), t(g["video_sub"]), atol=2e-4, rtol=0)

@@ -101,3 +101,18 @@ def test_mage_L16_tokens():
     assert torch.equal(gen, t(g["gen_tokens"]).long())
     assert torch.allclose(trace[:, :, ::8, ::8, ::4], t(g["step_logits_sub"]), atol=1e-4, rtol=1e-4)
     np.testing.assert_allclose(chk(video), g["video_chk"], rtol=1e-5)
+
+
+def test_mage_plus_latent_path():
+    """MAGE+ side (use_cids=False): Linear(4->C) in, GroupNorm/SiLU/Conv3d head out, over the stand-in latent first stage."""
+    from tests.standin_first_stage import StandInLatentFirstStage
+    g = golden("mage_plus_small")
+    cfg = synth.magep_model_config(frames_length=int(g["L"]), width=64, layers=3)
+    sd = cpu_sd(build_mage(cfg, int(g["seed"])))
+    batch = synth.synth_batch_cater(int(g["B"]), int(g["L"]), seed=int(g["seed"]), text_len=int(g["text_len"]), vocab=50)
+    fs = StandInLatentFirstStage()
+    lat0 = fs.encode(batch["images"][:, 0])
+    pred = O.mage_generate_latent(sd, batch, int(g["L"]), lat0, noise=t(g["noise"]))
+    assert torch.allclose(pred, t(g["pred_latents"]), atol=1e-4, rtol=1e-4)
+    video = fs.decode(pred.reshape(-1, 16, 16, 4).permute(0, 3, 1, 2)).view(int(g["B"]), -1, 3, 128, 128)
+    assert torch.allclose(video[..., ::4, ::4], t(g["video_sub"])[:, 1:], atol=1e-4)

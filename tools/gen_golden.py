@@ -208,10 +208,38 @@ def main():
     save("mage_cater_small", seed=41, B=2, L=4, width=64, layers=3, vq_dim=32, K=64, text_len=12, noise=noise,
          motion=trace[0][0], gen_tokens=trace[-1][1].max(-1)[1].to(torch.int16), margin=top2_margin(step_logits),
          step_logits=step_logits, video_sub=video[..., ::4, ::4].contiguous(), video_chk=chk(video))
+    # ---- 7b. MAGE+ side (use_cids=False, GroupNorm/SiLU/Conv3d head) over a stand-in latent first stage -------------
+    print("mage_plus_small")
+    cfg = synth.magep_model_config(frames_length=4, width=64, layers=3)
+    m = build_ref_mage(ref_mage, cfg, 51)
+    batch = synth.synth_batch_cater(2, 4, seed=51, text_len=12, vocab=50)
+    noise = torch.from_numpy(synth.rng_for(51, "video_noise").standard_normal((2, 64, 16, 16)).astype(np.float32))
+
+    def fake_randn2(*a, **k):
+        shape = a[0] if len(a) == 1 and isinstance(a[0], (list, tuple)) else a
+        return noise.clone() if tuple(shape) == tuple(noise.shape) else real_randn(*a, **k)
+    trace = []
+    orig_gen = m.generate_model.forward
+
+    def spyp(motion, imgs):
+        out = orig_gen(motion, imgs)
+        trace.append((motion.clone(), out.clone()))
+        return out
+    m.generate_model.forward = spyp
+    torch.randn = fake_randn2
+    try:
+        with torch.no_grad():
+            video = m.autoregressive_generate({k: v.clone() for k, v in batch.items()})
+    finally:
+        torch.randn = real_randn
+    save("mage_plus_small", seed=51, B=2, L=4, width=64, layers=3, text_len=12, noise=noise, motion=trace[0][0],
+         pred_latents=trace[-1][1], pred_step0=trace[0][1], video_sub=video[..., ::4, ::4].contiguous(), video_chk=chk(video))
+
     # ---- 8. state_dict layout (keys, shapes, dtypes) of the reference modules: the drop-in boundary ----------------
     import json
     layout = {}
-    for tag, cfg in (("mnist_L16", synth.mnist_model_config(frames_length=16)), ("caterv1_L10", synth.cater_model_config(frames_length=10))):
+    for tag, cfg in (("mnist_L16", synth.mnist_model_config(frames_length=16)), ("caterv1_L10", synth.cater_model_config(frames_length=10)),
+                     ("magep_caterv2_L10", synth.magep_model_config(frames_length=10))):
         rm = ref_mage.MAGE(**to_cfg(cfg["params"]))
         layout[tag] = [[k, list(v.shape), str(v.dtype)] for k, v in rm.state_dict().items()]
     json.dump(layout, open(os.path.join(OUT, "state_dict_layout.json"), "w"))
