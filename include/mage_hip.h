@@ -93,6 +93,12 @@ typedef struct mage_gemm_desc {
 
 int mage_gemm(const mage_gemm_desc* desc, void* stream);
 
+/* Fused MLP half of an AxialAttentionBlock (mage_model.py:22-26,51):  x += c_proj(QuickGELU(c_fc(xn))), bf16 MFMA with
+ * fp32 accumulation, the hidden activation [M, 4C] never leaves the CU.  xn [M, C] bf16 (ln_2 output), w_fc [4C, C] bf16,
+ * b_fc [4C] fp32, w_proj [C, 4C] bf16, b_proj [C] fp32, x [M, C] fp32 residual stream updated in place.  C = 256 or 512. */
+int mage_mlp_fused(const void* xn, const void* w_fc, const float* b_fc, const void* w_proj, const float* b_proj, float* x,
+                   int64_t M, int32_t C, void* stream);
+
 /* LayerNorm over the last dim of fp32 rows; y may be fp32 (may alias x) or bf16.
  * Replaces nn.LayerNorm at mage_model.py:21,27,84,204,206 and inside nn.TransformerEncoderLayer. */
 int mage_layernorm(const float* x, const float* gamma, const float* beta, void* y, int32_t y_dtype,

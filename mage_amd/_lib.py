@@ -53,6 +53,7 @@ SIGNATURES = {
     "mage_last_error": (C.c_char_p, []),
     "mage_init": (C.c_int, [C.c_int]),
     "mage_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "mage_mlp_fused": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i32, vp]),
     "mage_layernorm": (C.c_int, [vp, vp, vp, vp, i32, i64, i32, f32, vp]),
     "mage_attention": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "mage_embedding": (C.c_int, [vp, vp, vp, i32, i64, i32, i32, i32, i64, i64, i64, vp]),

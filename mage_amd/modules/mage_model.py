@@ -336,6 +336,9 @@ class FlatAxialDecoder(nn.Module):
                                      zero_module(nn.Conv3d(model_channels, out_channels, 1)))
         self.initialize_parameters()
         self.compute_dtype = F32
+        self.fused_mlp = False         # mage_mlp_fused (hidden activation kept on chip).  Measured SLOWER than the two GEMMs
+                                       # on MI355X (1.81 vs 1.44-1.58 ms per block at cfg2: 4 MiB of weights per 64-row panel
+                                       # through a 64 KiB LDS window is L2-latency bound), so it is off; kept as a tested op.
         self._derived = _Derived(self)
 
     def initialize_parameters(self):
@@ -410,8 +413,11 @@ class FlatAxialDecoder(nn.Module):
                           kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], **geo)
             _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc)
             ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5)
-            _linear(xn, d, p + ".c_fc", hdn, dt, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU)
-            _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
+            if self.fused_mlp and dt == BF16 and Cc in (256, 512):
+                ops.mlp_fused(xn, d[p + ".c_fc.bf16"], d[p + ".c_fc.b"], d[p + ".c_proj.bf16"], d[p + ".c_proj.b"], x)
+            else:
+                _linear(xn, d, p + ".c_fc", hdn, dt, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU)
+                _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
         if not self.use_cids:
             # GroupNorm statistics span all L-1 frames of a clip (:387-388): this head is NOT causal along L
             y = ops.groupnorm_silu(x, d["gn.w"], d["gn.b"], torch.empty(B * (L - 1) * hw, Cc, device=dev, dtype=dt), n_samples=B,

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc
 
 __all__ = ["gemm", "layernorm", "attention", "embedding", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
-           "conv_in", "conv_out", "row_affine", "groupnorm_silu", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
+           "conv_in", "conv_out", "row_affine", "groupnorm_silu", "mlp_fused", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
            "PROFILE", "F32", "BF16", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
 
 
@@ -280,3 +280,17 @@ def groupnorm_silu(x, gamma, beta, y, *, n_samples, rows_per_sample, sample_stri
     _lib.check(l.mage_groupnorm_silu(x.data_ptr(), sample_stride_rows, row_off, n_samples, rows_per_sample, Cc, groups,
                                      gamma.data_ptr(), beta.data_ptr(), float(eps), stats.data_ptr(), y.data_ptr(), code(y), s), l)
     return y
+
+
+def mlp_fused(xn, w_fc, b_fc, w_proj, b_proj, x):
+    """x += c_proj(QuickGELU(c_fc(xn))): bf16 operands, fp32 residual stream updated in place."""
+    l, s = _dev(x)
+    assert xn.dtype == torch.bfloat16 and w_fc.dtype == torch.bfloat16 and w_proj.dtype == torch.bfloat16 and x.dtype == torch.float32
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    ev = PROFILE.begin() if PROFILE.enabled else None
+    _lib.check(l.mage_mlp_fused(xn.data_ptr(), w_fc.data_ptr(), b_fc.data_ptr(), w_proj.data_ptr(), b_proj.data_ptr(), x.data_ptr(),
+                                M, Cc, s), l)
+    if ev is not None:
+        PROFILE.end(f"mlp_kernel<{Cc // 128}>", ev, 16.0 * M * Cc * Cc)
+    return x

@@ -287,3 +287,19 @@ def test_errors_are_loud():
         o.gemm(a, a, a, M=8, N=4, K=8, lda=8, ldy=4)           # N not a multiple of 8
     with pytest.raises(RuntimeError):
         o.layernorm(torch.zeros(4, 8), torch.zeros(8), torch.zeros(8), torch.zeros(4, 8), 1e-5)   # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("Cc,M", [(512, 1000), (256, 64 * 5), (512, 64 * 300 + 17)])
+def test_mlp_fused_vs_torch(Cc, M):
+    """x += c_proj(QuickGELU(c_fc(xn))) with the hidden activation kept on chip (bf16 operands, fp32 accumulate)."""
+    o = ops()
+    xn = rnd(M, Cc, seed=80).bfloat16()
+    w1 = rnd(4 * Cc, Cc, seed=81, scale=(2 * Cc) ** -0.5).bfloat16()
+    w2 = rnd(Cc, 4 * Cc, seed=82, scale=(4 * Cc) ** -0.5).bfloat16()
+    b1, b2, x0 = rnd(4 * Cc, seed=83, scale=0.1), rnd(Cc, seed=84, scale=0.1), rnd(M, Cc, seed=85)
+    h = xn.float() @ w1.float().t() + b1
+    h = (h * torch.sigmoid(1.702 * h)).bfloat16().float()            # the kernel rounds the hidden activation to bf16
+    want = x0 + h @ w2.float().t() + b2
+    x = x0.to(DEV).clone()
+    o.mlp_fused(xn.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), x)
+    torch.testing.assert_close(x.cpu(), want, atol=3e-3, rtol=1e-3)
