@@ -34,7 +34,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--ar-mode", default="full", choices=["full", "incremental"],
                     help="full = the reference's per-iteration full recompute (headline); incremental = temporal KV cache")
-    ap.add_argument("--streams", type=int, default=2, help="clip groups on concurrent HIP streams inside one generate call")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="clip groups on concurrent HIP streams inside one generate call (2: +4 %% frames/s, but per-kernel "
+                         "event times then overlap: the roofline object needs 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the second AR mode (clean rocprofv3 runs)")
     ap.add_argument("--cpu-clips", type=int, default=2)
