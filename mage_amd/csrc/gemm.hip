@@ -23,6 +23,8 @@
 //
 // fp32 mode uses v_mfma_f32_16x16x4_f32 (exact fp32 fma chain, 1/16 of the bf16 rate); it shares the byte-identical
 // LDS image, loader and epilogue with the bf16 path: only the inner MFMA differs.
+#include <type_traits>
+
 #include "common.h"
 
 #ifndef MAGE_ABL
@@ -40,7 +42,8 @@ template <int MT> struct Tile {
     static constexpr int BM = MT * 32;
     static constexpr int A_BYTES = BM * 128;                   // A part of a stage: BM rows x 128 bytes
     static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;      // 64 KiB (MT=8) | 48 KiB (MT=4)
-    static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;     // one workgroup (8 waves, 2 per SIMD) per CU
+    static constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;    // one workgroup (8 waves, 2 per SIMD) per CU
+    static constexpr int LDS_BYTES = RING_BYTES + 8 * 4096;    // + 4 KiB per wave of epilogue staging (epilogue_lean)
     static constexpr int AU = MT / 2;                          // A units (8 rows x 128 B) per wave per slab
 };
 
@@ -91,7 +94,14 @@ __device__ __forceinline__ void load_colvecs(ColVecs& cv, const mage_gemm_desc& 
     }
 }
 
-template <int ACT, typename OT, int MT>
+// EK (epilogue kind, compile time: every runtime "is this pointer set" test inside the row loop made hipcc fence the
+// block with s_waitcnt vmcnt(0), i.e. wait for the previous row's store ack — 16 chained HBM round trips per tile):
+//   EK_BIAS     y = act(acc + bias)                                   no loads in the epilogue at all
+//   EK_RES_INIT same; the fp32 residual was loaded INTO the accumulators before the K loop (gemm_kernel)
+//   EK_GENERAL  y = act((acc + bias)*scale + shift) + residual + rowadd   (VQ-VAE convolutions, positional tables)
+enum { EK_BIAS = 0, EK_RES_INIT = 1, EK_GENERAL = 2 };
+
+template <int ACT, typename OT, int MT, int EK>
 __device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const ColVecs& cv, f32x4 (&acc)[MT][4], int m0, int n0,
                                               int lane, int plane) {
     const int l15 = lane & 15;
@@ -100,6 +110,7 @@ __device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const Col
     int ncol[2], nld[2];
     bool nv[2];
     f32x4 scale4[2][2], shift4[2][2];
+    constexpr bool GEN = EK == EK_GENERAL;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         ncol[k] = epi_col(n0, k, lane);
@@ -109,8 +120,8 @@ __device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const Col
         nld[k] = nv[k] ? ncol[k] : 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            scale4[k][h] = d.scale ? *(const f32x4*)(d.scale + nld[k] + 4 * h) : f32x4{1.f, 1.f, 1.f, 1.f};
-            shift4[k][h] = d.scale ? *(const f32x4*)(d.shift + nld[k] + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+            scale4[k][h] = GEN && d.scale ? *(const f32x4*)(d.scale + nld[k] + 4 * h) : f32x4{1.f, 1.f, 1.f, 1.f};
+            shift4[k][h] = GEN && d.scale ? *(const f32x4*)(d.shift + nld[k] + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     // One output row of the lane per round.  Keeping a second row's reads in flight (tried: 1-ahead prefetch, rows in
@@ -137,7 +148,7 @@ __device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const Col
             extra[k][0] = f32x4{0.f, 0.f, 0.f, 0.f};
             extra[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (d.residual) {
+        if (GEN && d.residual) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 if (d.res_dtype == MAGE_F32) {
@@ -153,7 +164,7 @@ __device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const Col
                 }
             }
         }
-        if (d.rowadd) {
+        if (GEN && d.rowadd) {
             const float* tp = d.rowadd + (long)((yrow / d.rowadd_div) % d.rowadd_mod) * d.N;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -173,12 +184,13 @@ __device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const Col
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                v[h] = (v[h] + cv.bias[k][h]) * scale4[k][h] + shift4[k][h];
+                v[h] = v[h] + cv.bias[k][h];
+                if (GEN) v[h] = v[h] * scale4[k][h] + shift4[k][h];
                 if (ACT != MAGE_ACT_NONE) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[h][e] = act_apply<ACT>(v[h][e]);
                 }
-                v[h] += extra[k][h];
+                if (GEN) v[h] += extra[k][h];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[h][e] = fmaxf(v[h][e], lo);
             }
@@ -199,6 +211,125 @@ __device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const Col
     }
 }
 
+#ifdef MAGE_PROBE
+// tuning build: s_memtime stamps of wave 0 per (workgroup, tile): [0] K loop done, [1] epilogue issued, [2] first-slab wait
+// done, [3] first-slab barrier passed (tools/gemm_phase_probe.py)
+__device__ unsigned long long mage_probe_buf[256 * 64 * 8];   // [0..3] shader clock (per CU), [4..7] 100 MHz wall clock (chip-wide)
+__device__ unsigned long long mage_probe_wave[256 * 16 * 8 * 2];  // per (workgroup, tile < 16, wave): epilogue begin / end, shader clock
+#define MAGE_WSTAMP(it, p)                                                                                 \
+    do {                                                                                                   \
+        if (lane == 0 && (it) < 16 && blockIdx.x < 256)                                                    \
+            mage_probe_wave[((blockIdx.x * 16 + (it)) * 8 + wave) * 2 + (p)] = __builtin_readcyclecounter(); \
+    } while (0)
+#define MAGE_STAMP(it, p)                                                                                  \
+    do {                                                                                                   \
+        if (tid == 0 && (it) < 64 && blockIdx.x < 256) {                                                   \
+            mage_probe_buf[(blockIdx.x * 64 + (it)) * 8 + (p)] = __builtin_readcyclecounter();             \
+            mage_probe_buf[(blockIdx.x * 64 + (it)) * 8 + 4 + (p)] = __builtin_amdgcn_s_memrealtime();     \
+        }                                                                                                  \
+    } while (0)
+#else
+#define MAGE_STAMP(it, p)
+#define MAGE_WSTAMP(it, p)
+#endif
+
+// Lean epilogue of the two kinds without loads: per (16-row tile mt, 32-column half k) 4 lane swaps, 4 packed bias adds, the
+// activation, 4 packed converts and ONE 16-byte store (two for fp32 output) off a pointer that steps by 16 rows.  The
+// per-wave cost of the general epilogue below was ~760 issued instructions (~4.5 k cycles, and the two waves of a SIMD run
+// their epilogues back to back, not overlapped): 64-bit address arithmetic, the post-ReLU max and the row regrouping on
+// every row.  Workgroup-edge tiles and regrouped rows take the predicated branch.
+// ---- lean epilogue (EK_BIAS, EK_RES_INIT): y = act(acc + bias), no loads ------------------------------------------------
+// What the stores look like to memory decides its cost.  The MFMA layout (and its permlane16_swap variant above) gives a
+// wave-wide 16-byte store 16 rows x 64 bytes (bf16) or 64 scattered 16-byte pieces (fp32): 16-64 separate line accesses
+// per instruction and half/eighth-filled 128-byte lines.  Measured in isolation (tools/probes/epi_probe.hip): ~275 cycles
+// per store instruction, the two waves of a SIMD one after the other, 10.5 k cycles per 256x256 tile, 3.0 TB/s (bf16) and
+// 2.4 TB/s (fp32) chip-wide; the same bytes as 8 rows x 128 contiguous bytes per instruction go at 22 cycles each, 5.2 TB/s.
+// So each wave transposes its 16x64 block through a private 4 KiB LDS window (XOR-swizzled, conflict-free both ways; DS
+// operations of one wave execute in order, so no barrier and no wait between its writes and reads) and stores whole rows:
+//   bf16: one instruction = 8 rows x 128 B;   fp32: one instruction = 4 rows x 256 B.
+template <int ACT, typename OT, int MT>
+__device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32x4 (&bias)[4], f32x4 (&acc)[MT][4], int m0, int n0,
+                                              int lane, int plane, char* stg) {
+    constexpr bool F32 = sizeof(OT) == 4;
+    constexpr int RB = F32 ? 256 : 128;            // bytes of one staged row (64 columns)
+    constexpr int NCH = RB / 16;                   // 16-byte chunks per row: 16 | 8
+    constexpr int RPI = 64 / NCH;                  // rows per store instruction: 4 | 8
+    constexpr int NST = 16 / RPI;                  // store instructions per 16-row tile: 4 | 2
+    constexpr int CPC = 16 / (int)sizeof(OT);      // columns per chunk: 4 | 8
+    const int l15 = lane & 15, grp = lane >> 4;
+    // write side: lane (l15, grp) owns row l15, columns nt*16 + grp*4 + {0..3} of each 16-column block nt
+    int woff[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+        woff[nt] = F32 ? l15 * RB + (((nt * 4 + grp) ^ l15) << 4) : l15 * RB + (((nt * 2 + (grp >> 1)) ^ ((l15 >> 1) & 7)) << 4) + (grp & 1) * 8;
+    // read side: lane -> (row rr + RPI*i, chunk cc)
+    const int rr = lane / NCH, cc = lane % NCH;
+    int roff[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int r = rr + RPI * i;
+        roff[i] = F32 ? r * RB + ((cc ^ r) << 4) : r * RB + ((cc ^ ((r >> 1) & 7)) << 4);
+    }
+    const int col = n0 + cc * CPC;
+    const bool simple_rows = d.out_h == 1 && d.out_w >= d.M;
+    const bool interior = simple_rows && m0 + MT * 16 <= d.M && n0 + 64 <= d.N;     // wave-uniform
+    const bool cv_ok = col < d.N;                                                    // N % 8 == 0: a chunk is all in or all out
+    OT* yp = (OT*)d.Y + (long)((m0 + rr) * d.y_mul_x + d.y_off) * d.ldy + col;      // simple rows: row m0 + rr, then steps
+    const long step = (long)RPI * d.y_mul_x * d.ldy;
+
+    auto stage = [&](int mt, u32x4 (&o)[NST]) {     // math + transpose of 16-row tile mt: results land in o[] (row-contiguous)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 v = acc[mt][nt] + bias[nt];
+            if (ACT != MAGE_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_apply<ACT>(v[e]);
+            }
+            if constexpr (F32) {
+                *(f32x4*)(stg + woff[nt]) = v;
+            } else {
+                *(uint2*)(stg + woff[nt]) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NST; ++i) o[i] = *(const u32x4*)(stg + roff[i]);
+    };
+    auto store = [&](int mt, const u32x4 (&o)[NST]) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            // streaming (non-temporal) stores: the output is not re-read by this kernel, keep the XCD's L2 for the
+            // activation panels and W that the neighbouring workgroups re-read
+            if (interior) {
+                __builtin_nontemporal_store(o[i], (u32x4*)yp);
+                yp += step;
+            } else {
+                const int m = m0 + mt * 16 + rr + RPI * i;
+                if (m < d.M && cv_ok) {
+                    int yrow;
+                    if (simple_rows) {
+                        yrow = m * d.y_mul_x + d.y_off;
+                    } else {
+                        const int img = m / plane;
+                        const int rem = m - img * plane;
+                        const int oy = rem / d.out_w;
+                        const int ox = rem - oy * d.out_w;
+                        yrow = img * d.y_img_stride + oy * d.y_mul_y + ox * d.y_mul_x + d.y_off;
+                    }
+                    __builtin_nontemporal_store(o[i], (u32x4*)((OT*)d.Y + (long)yrow * d.ldy + col));
+                }
+            }
+        }
+    };
+    // skewed by one tile: the LDS round trip of tile mt+1 is in flight while tile mt's rows are stored
+    u32x4 o[2][NST];
+    stage(0, o[0]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (mt + 1 < MT) stage(mt + 1, o[(mt + 1) & 1]);
+        store(mt, o[mt & 1]);
+    }
+}
+
 // raw barrier that LDS-DMA may stay in flight across (a __syncthreads() would drain vmcnt to 0); the empty asm
 // statements keep the compiler from moving LDS accesses over it
 __device__ __forceinline__ void ring_barrier() {
@@ -207,7 +338,7 @@ __device__ __forceinline__ void ring_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int DT, bool GATHER, int ACT, int MT>
+template <int DT, bool GATHER, int ACT, int MT, int EK>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     typedef typename TT<DT>::elem E;
     constexpr int BM = Tile<MT>::BM, A_BYTES = Tile<MT>::A_BYTES, STAGE_BYTES = Tile<MT>::STAGE_BYTES, AU = Tile<MT>::AU;
@@ -230,6 +361,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int chunk1 = chunk0 + q8 + (xcd < r8 ? 1 : 0);
     const int nk = (d.K + BK - 1) / BK;
+    __builtin_assume(nk > 0);                          // K > 0 (host check): lets hipcc see that the K loop's vmcnt(0) always runs
     const int plane = d.out_h * d.out_w;
 
     // ---- loader: each wave moves AU A units + 4 W units (a unit = 8 rows x 128 B = one wave-wide DMA) per slab
@@ -272,14 +404,14 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     };
 
     // DMA of this wave's unit u (A units 0..AU-1, then W units) of slab (ld_tile, ld_kt) into stage ld_stage
-    auto issue_one = [&](int u) {
+    auto issue_one = [&](int u, bool live = true) {
         char* sa = smem + ld_stage * STAGE_BYTES;
         if (u < AU) {
             const int i = u;
             const int kc = ld_kt * BK + acs[i] * CH;
             const char* src = g.zero;
             if (GATHER) {
-                if (kc < d.K && a_img[i] >= 0) {
+                if (live && kc < d.K && a_img[i] >= 0) {
                     const int tap = kc / d.cin;
                     const int ci = kc - tap * d.cin;
                     const int ky = tap / d.taps_w;
@@ -290,13 +422,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                         src = (const char*)d.A + ((long)(a_img[i] + iy * d.in_w + ix) * d.lda + ci) * ES;
                 }
             } else {
-                if (kc < d.K && a_row[i]) src = a_row[i] + (long)kc * ES;
+                src = (live && kc < d.K && a_row[i]) ? a_row[i] + (long)kc * ES : g.zero;
             }
             glds16(src, sa + (wave * AU + i) * 1024);
         } else {
             const int i = u - AU;
             const int kc = ld_kt * BK + wcs[i] * CH;
-            const char* wsrc = (kc < d.K && w_row[i]) ? w_row[i] + (long)kc * ES : g.zero;
+            const char* wsrc = (live && kc < d.K && w_row[i]) ? w_row[i] + (long)kc * ES : g.zero;
             glds16(wsrc, sa + A_BYTES + (wave * 4 + i) * 1024);
         }
     };
@@ -335,19 +467,50 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     loader_advance();
     int c_stage = 0;
 
-    for (; c_tile < chunk1; c_tile += nwg8) {
-#pragma unroll
-        for (int a = 0; a < MT; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; c_tile < chunk1; c_tile += nwg8, ++it) {
         const int tm = c_tile / g.ntiles_n, tn = c_tile - tm * g.ntiles_n;
         const int m0 = tm * BM + wm * MT * 16, n0 = tn * BN + wn * 64;
-        ColVecs cv;
-        load_colvecs(cv, d, n0, lane);                 // lands under the K loop
+        if constexpr (EK == EK_RES_INIT) {
+            // y = x + (A W^T + b): start the accumulators from the fp32 residual.  32 independent 16-byte loads per lane,
+            // straight into the MFMA layout (row mt*16 + l15, columns nt*16 + grp*4 + {0..3}), no register cost, one
+            // round trip per tile that the first slab's vmcnt(0) below absorbs together with the previous tile's store acks.
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int m = min(m0 + a * 16 + l15, d.M - 1);
+                const float* rp = (const float*)d.residual + (long)(m * d.y_mul_x + d.y_off) * d.ldr;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int n = n0 + b * 16 + grp * 4;
+                    acc[a][b] = *(const f32x4*)(rp + (n < d.N ? n : 0));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        ColVecs cv;                                    // EK_GENERAL: bias in the permuted epilogue layout
+        f32x4 biasm[4];                                // lean kinds: bias in the MFMA layout (columns nt*16 + grp*4 + {0..3})
+        if constexpr (EK == EK_GENERAL) {
+            load_colvecs(cv, d, n0, lane);             // lands under the K loop
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int n = n0 + b * 16 + grp * 4;
+                biasm[b] = d.bias ? *(const f32x4*)(d.bias + (n < d.N ? n : 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
         for (int kt = 0; kt < nk; ++kt) {
             // The slab to multiply was issued one whole iteration (or one epilogue) ago; nothing younger is in flight.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (the builtin, not inline asm: hipcc's own wait-count pass must SEE this wait, or it guards every later use of
+            // the bias vectors fetched above with its own vmcnt(0) — in the epilogue that meant "wait for the previous row's
+            // store ack" 16 times per tile)
+            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt/lgkmcnt untouched
+            asm volatile("" ::: "memory");
+            if (kt == 0) MAGE_STAMP(it, 2);
             ring_barrier();                            // everyone's share of the slab is in LDS, and every wave is done
+            if (kt == 0) MAGE_STAMP(it, 3);
                                                        // reading the other stage, which the DMAs below refill
             const bool more = ld_tile < chunk1;
             const char* st = smem + c_stage * STAGE_BYTES;
@@ -372,9 +535,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                 for (int gq = 0; gq < NG; ++gq) {
                     const int ph = t * NG + gq;
 #if MAGE_ABL != 5
-                    if (more) {
+                    // Plain GEMM: ALWAYS issue (the zero page, into the stage nobody reads, once the tile list is exhausted) so
+                    // the slab body is one basic block and hipcc counts lgkmcnt exactly instead of draining it at every join.
+                    if (GATHER) {
+                        if (more) {
 #pragma unroll
-                        for (int u = ph * NU / MT; u < (ph + 1) * NU / MT; ++u) issue_one(u);
+                            for (int u = ph * NU / MT; u < (ph + 1) * NU / MT; ++u) issue_one(u);
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = ph * NU / MT; u < (ph + 1) * NU / MT; ++u) issue_one(u, more);
                     }
 #endif
 #if MAGE_ABL != 6
@@ -421,16 +591,26 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
         }
 #endif
         // ---- epilogue: straight from the accumulators (no LDS), while the next tile's first slab lands in the other stage
-        if (d.y_dtype == MAGE_F32) epilogue_wave<ACT, float, MT>(d, cv, acc, m0, n0, lane, plane);
-        else epilogue_wave<ACT, unsigned short, MT>(d, cv, acc, m0, n0, lane, plane);
+        MAGE_STAMP(it, 0);
+        MAGE_WSTAMP(it, 0);
+        if constexpr (EK == EK_GENERAL) {
+            if (d.y_dtype == MAGE_F32) epilogue_wave<ACT, float, MT, EK>(d, cv, acc, m0, n0, lane, plane);
+            else epilogue_wave<ACT, unsigned short, MT, EK>(d, cv, acc, m0, n0, lane, plane);
+        } else {
+            char* stg = smem + Tile<MT>::RING_BYTES + wave * 4096;
+            if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane, plane, stg);
+            else epilogue_lean<ACT, unsigned short, MT>(d, biasm, acc, m0, n0, lane, plane, stg);
+        }
+        MAGE_STAMP(it, 1);
+        MAGE_WSTAMP(it, 1);
     }
 }
 
-template <int DT, bool GATHER, int ACT, int MT>
+template <int DT, bool GATHER, int ACT, int MT, int EK>
 int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT, MT, EK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   Tile<MT>::LDS_BYTES);
         attr_set = true;
     }
@@ -441,13 +621,13 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     a.ntiles_n = (d->N + BN - 1) / BN;
     a.ntiles = tiles_m * a.ntiles_n;
     const int grid = a.ntiles >= n_cu ? n_cu : ((a.ntiles + 7) & ~7);     // one resident workgroup per CU, multiple of 8
-    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT, MT>), dim3(grid), dim3(512), Tile<MT>::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT, MT, EK>), dim3(grid), dim3(512), Tile<MT>::LDS_BYTES, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
     return MAGE_OK;
 }
 
-template <int DT, bool GATHER, int ACT>
-int launch_act(const mage_gemm_desc* d, hipStream_t s) {
+template <int DT, bool GATHER, int ACT, int EK>
+int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -460,9 +640,22 @@ int launch_act(const mage_gemm_desc* d, hipStream_t s) {
     // variant does not fit the register file)
     const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + BN - 1) / BN);
     if constexpr (DT == MAGE_BF16) {
-        if (tiles256 >= 2L * n_cu) return launch_tile<DT, GATHER, ACT, 8>(d, s, n_cu);
+        if (tiles256 >= 2L * n_cu) return launch_tile<DT, GATHER, ACT, 8, EK>(d, s, n_cu);
     }
-    return launch_tile<DT, GATHER, ACT, 4>(d, s, n_cu);
+    return launch_tile<DT, GATHER, ACT, 4, EK>(d, s, n_cu);
+}
+
+template <int DT, bool GATHER, int ACT>
+int launch_act(const mage_gemm_desc* d, hipStream_t s) {
+    const bool extras = d->scale || d->rowadd || d->residual || d->post_relu;
+    if (!extras) return launch_ek<DT, GATHER, ACT, EK_BIAS>(d, s);
+    if constexpr (!GATHER && ACT == MAGE_ACT_NONE) {
+        // the transformer's "x + Linear(.)": fp32 residual, nothing else after the bias, rows not regrouped
+        if (d->residual && d->res_dtype == MAGE_F32 && !d->scale && !d->rowadd && !d->post_relu && d->out_h == 1 &&
+            d->out_w >= d->M && (((uintptr_t)d->residual) & 15) == 0)
+            return launch_ek<DT, GATHER, ACT, EK_RES_INIT>(d, s);
+    }
+    return launch_ek<DT, GATHER, ACT, EK_GENERAL>(d, s);
 }
 
 template <int DT, bool GATHER>
@@ -477,6 +670,22 @@ int launch(const mage_gemm_desc* d, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef MAGE_PROBE
+extern "C" int mage_debug_read_waves(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mage_probe_wave), bytes < sizeof(mage_probe_wave) ? bytes : sizeof(mage_probe_wave)) ==
+                   hipSuccess
+               ? 0
+               : -1;
+}
+extern "C" int mage_debug_read(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mage_probe_buf), bytes < sizeof(mage_probe_buf) ? bytes : sizeof(mage_probe_buf)) ==
+                   hipSuccess
+               ? 0
+               : -1;
+}
+#endif
+
 
 extern "C" int mage_gemm(const mage_gemm_desc* d, void* stream) {
     MAGE_CHECK_ARG(d != nullptr, "mage_gemm: null descriptor");

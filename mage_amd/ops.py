@@ -114,7 +114,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
         gather = taps_h * taps_w > 1 or stride != 1 or dy0 != 0 or dx0 != 0 or d.in_h != d.out_h or d.in_w != d.out_w
         n_cu = torch.cuda.get_device_properties(a.device).multi_processor_count & ~7
         mt = 8 if (d.dtype == BF16 and ((M + 255) // 256) * ((N + 255) // 256) >= 2 * n_cu) else 4
-        key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act}, {mt}>"
+        if scale is None and rowadd is None and residual is None and not post_relu:
+            ek = 0
+        elif (not gather and act == ACT_NONE and residual is not None and residual.dtype == torch.float32 and scale is None
+              and rowadd is None and not post_relu and out_h == 1 and out_w >= M and residual.data_ptr() % 16 == 0):
+            ek = 1
+        else:
+            ek = 2
+        key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act}, {mt}, {ek}>"
         ev = PROFILE.begin()
         _lib.check(l.mage_gemm(C.byref(d), s), l)
         PROFILE.end(key, ev, 2.0 * M * N * K)
