@@ -23,10 +23,17 @@
 //
 // fp32 mode uses v_mfma_f32_16x16x4_f32 (exact fp32 fma chain, 1/16 of the bf16 rate); it shares the byte-identical
 // LDS image, loader and epilogue with the bf16 path: only the inner MFMA differs.
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
 
+#ifndef MAGE_DMA_PHASES
+#define MAGE_DMA_PHASES (MT / 2) // the next slab's DMA pieces go out in the first half of a slab's MT phases (2 per phase): issued
+                                // later they are still in flight at the slab's closing vmcnt(0) (+2 % on the 4-GEMM block)
+#endif
+#define MAGE_U0(ph) ((ph) >= MAGE_DMA_PHASES ? NU : (ph) * NU / MAGE_DMA_PHASES)
 #ifndef MAGE_ABL
 #define MAGE_ABL 0               // 1 = tuning build: skip the epilogue (main loop only)
 #endif
@@ -51,6 +58,7 @@ struct GemmArgs {
     mage_gemm_desc d;
     const char* zero;
     int ntiles_n, ntiles;
+    int stagger_groups, stagger_sleeps;    // start group (li % groups) of an XCD's workgroups after group * sleeps s_sleep(16)
 };
 
 template <int DT> struct TT;
@@ -65,7 +73,7 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 template <int ACT>
 __device__ __forceinline__ float act_apply(float v) {
     if (ACT == MAGE_ACT_RELU) return fmaxf(v, 0.f);
-    if (ACT == MAGE_ACT_QUICKGELU) return v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
+    if (ACT == MAGE_ACT_QUICKGELU) return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669596f * v));
     if (ACT == MAGE_ACT_GELU_ERF) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
     return v;
 }
@@ -281,7 +289,19 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             f32x4 v = acc[mt][nt] + bias[nt];
-            if (ACT != MAGE_ACT_NONE) {
+            if constexpr (ACT == MAGE_ACT_QUICKGELU) {
+                // x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)): the two transcendentals (quarter rate) are the cost;
+                // everything around them as 4-wide vector arithmetic, which hipcc packs into v_pk_* (one multiply fewer per
+                // element than the scalar form, which scales by -1.702 and by log2(e) separately)
+                const f32x4 t = v * -2.4554669596f;
+                f32x4 e4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) e4[e] = __builtin_amdgcn_exp2f(t[e]);
+                e4 = e4 + 1.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) e4[e] = __builtin_amdgcn_rcpf(e4[e]);
+                v = v * e4;
+            } else if (ACT != MAGE_ACT_NONE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_apply<ACT>(v[e]);
             }
@@ -456,13 +476,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     int c_tile = chunk0 + li;
     if (c_tile >= chunk1) return;                      // more workgroups than tiles in this XCD's chunk
     loader_set_tile(ld_tile);
-#ifdef MAGE_DEPHASE
-    // tuning experiment: start the workgroups of an XCD in 4 groups a quarter tile apart
-    if ((chunk1 - chunk0) >= 4 * nwg8) {
-        const int quarter = (nk * MAGE_DEPHASE + 12000) / (4 * 1024);        // s_sleep(16) = 1024 clocks
-        for (int w = (li & 3) * quarter; w > 0; --w) __builtin_amdgcn_s_sleep(16);
+    // Staggered start.  Every workgroup runs the same K loop, so left alone all 256 reach their epilogues together: the
+    // chip alternates between "nobody touches HBM" and one burst of 256 x (residual tile in + output tile out) that runs at
+    // the HBM write/read limit (5.2 TB/s measured) while every matrix core idles.  Starting the workgroups of an XCD in
+    // groups a fraction of a tile period apart spreads the bursts under the other groups' K loops (host: launch_tile).
+    if (g.stagger_groups > 1) {
+        for (int w = (li % g.stagger_groups) * g.stagger_sleeps; w > 0; --w) __builtin_amdgcn_s_sleep(16);   // 1024 clocks each
     }
-#endif
     issue_all();
     loader_advance();
     int c_stage = 0;
@@ -540,11 +560,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                     if (GATHER) {
                         if (more) {
 #pragma unroll
-                            for (int u = ph * NU / MT; u < (ph + 1) * NU / MT; ++u) issue_one(u);
+                            for (int u = MAGE_U0(ph); u < MAGE_U0(ph + 1); ++u) issue_one(u);
                         }
                     } else {
 #pragma unroll
-                        for (int u = ph * NU / MT; u < (ph + 1) * NU / MT; ++u) issue_one(u, more);
+                        for (int u = MAGE_U0(ph); u < MAGE_U0(ph + 1); ++u) issue_one(u, more);
                     }
 #endif
 #if MAGE_ABL != 6
@@ -621,6 +641,30 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     a.ntiles_n = (d->N + BN - 1) / BN;
     a.ntiles = tiles_m * a.ntiles_n;
     const int grid = a.ntiles >= n_cu ? n_cu : ((a.ntiles + 7) & ~7);     // one resident workgroup per CU, multiple of 8
+    // staggered start (see gemm_kernel): G groups spread over a fraction of one estimated tile period = K loop (~3.4 k clocks
+    // per 64-wide slab of a 256x256 tile, measured) + the tile's HBM burst at the all-at-once rate (~10.6 B per clock per CU,
+    // measured).  Only when every workgroup has enough tiles for the idle start to pay.  MAGE_GEMM_STAGGER="G,percent"
+    // overrides (tuning), "0" disables.  Measured on the decoder's 4-GEMM block: 775 -> 800 TFLOP/s with 8 groups over 60 %.
+    static int st_groups = -1, st_percent = 60;
+    if (st_groups < 0) {
+        st_groups = 8;
+        if (const char* e = getenv("MAGE_GEMM_STAGGER")) {
+            if (sscanf(e, "%d,%d", &st_groups, &st_percent) < 2) st_percent = 60;
+            if (st_groups < 0) st_groups = 0;
+        }
+    }
+    a.stagger_groups = 0;
+    a.stagger_sleeps = 0;
+    const int tiles_per_wg = a.ntiles / grid;
+    if (st_groups > 1 && a.ntiles >= n_cu && tiles_per_wg >= 6) {
+        const int es = d->dtype == MAGE_BF16 ? 2 : 4;
+        const long nk = ((long)d->K * es + 127) / 128;
+        const long out_b = (long)Tile<MT>::BM * BN * (d->y_dtype == MAGE_BF16 ? 2 : 4);
+        const long res_b = d->residual ? (long)Tile<MT>::BM * BN * (d->res_dtype == MAGE_BF16 ? 2 : 4) : 0;
+        const long period = nk * 3400 * MT / 8 + (long)((out_b + res_b) / 10.6);
+        a.stagger_groups = st_groups;
+        a.stagger_sleeps = (int)(period * st_percent / 100 / st_groups / 1024);
+    }
     hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT, MT, EK>), dim3(grid), dim3(512), Tile<MT>::LDS_BYTES, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
     return MAGE_OK;
