@@ -184,6 +184,13 @@ int mage_conv_in(const float* x, const float* weight_t, const float* bias, const
                  int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t act, void* stream);
 int mage_conv_out(const void* x, int32_t x_dtype, const float* weight_t, const float* bias, float* y,
                   int32_t N, int32_t IH, int32_t IW, int32_t cin, int32_t cout, int32_t transposed, void* stream);
+/* The same ConvTranspose2d(dim, cout, 4, 2, 1) + Tanh head (vqvae_model.py:187-189) as GEMM + fold, which reads the
+ * wide activation exactly once: taps = mage_gemm(x [N*IH*IW, cin], weight_t viewed as [16*cout, cin]) holds, per INPUT
+ * pixel, its product with each of the 16 kernel taps (column (ky*4 + kx)*cout + co, fp32); this call sums the (up to) 4
+ * taps that land on every OUTPUT pixel (oy = 2*iy - 1 + ky), adds the bias, applies tanh and writes NCHW fp32
+ * [N, cout<=4, 2*IH, 2*IW]. */
+int mage_convt_fold_tanh(const float* taps, const float* bias, float* y, int32_t N, int32_t IH, int32_t IW,
+                         int32_t cout, void* stream);
 
 /* Channels-last elementwise helpers of the f8 stack (vqvae_model.py:194-210): 2x2 max-pool,
  * nearest 2x upsample, and a ReLU'd copy (the non-in-place ReLU that opens every Encoder/DecoderBlock). */

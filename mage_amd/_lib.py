@@ -63,6 +63,7 @@ SIGNATURES = {
     "mage_cross_entropy": (C.c_int, [vp, vp, i64, i32, vp, vp, vp]),
     "mage_conv_in": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "mage_conv_out": (C.c_int, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mage_convt_fold_tanh": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "mage_maxpool2": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mage_upsample2": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "mage_relu": (C.c_int, [vp, vp, i32, i64, vp]),

@@ -99,6 +99,33 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const IT* __restrict__ x,
     }
 }
 
+// Fold of a 4x4 / stride 2 / pad 1 transposed convolution (see mage_convt_fold_tanh): thread = output pixel (NCHW, x fastest).
+__global__ __launch_bounds__(256) void convt_fold_tanh_kernel(const float* __restrict__ taps, const float* __restrict__ bias,
+                                                              float* __restrict__ y, int N, int IH, int IW, int cout) {
+    const int OH = IH * 2, OW = IW * 2;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)N * cout * OH * OW) return;
+    const int ox = (int)(gid % OW), oy = (int)((gid / OW) % OH), co = (int)((gid / ((long)OW * OH)) % cout);
+    const int n = (int)(gid / ((long)OW * OH * cout));
+    // oy = 2*iy - 1 + ky: the two contributing input rows are iy0 = (oy+1)>>1 with ky0 = oy+1-2*iy0, and iy0-1 with ky0+2
+    const int iy0 = (oy + 1) >> 1, ky0 = oy + 1 - 2 * iy0;
+    const int ix0 = (ox + 1) >> 1, kx0 = ox + 1 - 2 * ix0;
+    const int ld = 16 * cout;
+    float s = bias ? bias[co] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int iy = iy0 - a, ky = ky0 + 2 * a;
+        if ((unsigned)iy >= (unsigned)IH) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ix = ix0 - b, kx = kx0 + 2 * b;
+            if ((unsigned)ix >= (unsigned)IW) continue;
+            s += taps[(((long)n * IH + iy) * IW + ix) * ld + (ky * 4 + kx) * cout + co];
+        }
+    }
+    y[gid] = tanhf(s);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
                                                        int C, int relu) {
@@ -182,6 +209,17 @@ extern "C" int mage_conv_out(const void* x, int32_t x_dtype, const float* weight
     else { mage_set_error("mage_conv_out: bad x_dtype %d", x_dtype); return MAGE_EINVAL; }
 #undef CO_LAUNCH
     MAGE_CHECK_LAUNCH("mage_conv_out");
+    return MAGE_OK;
+}
+
+extern "C" int mage_convt_fold_tanh(const float* taps, const float* bias, float* y, int32_t N, int32_t IH, int32_t IW,
+                                    int32_t cout, void* stream) {
+    MAGE_CHECK_ARG(taps && y, "mage_convt_fold_tanh: null pointer");
+    MAGE_CHECK_ARG(N > 0 && IH > 0 && IW > 0 && cout >= 1 && cout <= 4, "mage_convt_fold_tanh: bad shape N=%d IH=%d IW=%d cout=%d", N,
+                   IH, IW, cout);
+    const long items = (long)N * cout * IH * 2 * IW * 2;
+    hipLaunchKernelGGL(convt_fold_tanh_kernel, grid1(items), dim3(256), 0, (hipStream_t)stream, taps, bias, y, N, IH, IW, cout);
+    MAGE_CHECK_LAUNCH("mage_convt_fold_tanh");
     return MAGE_OK;
 }
 

@@ -147,7 +147,7 @@ class VectorQuantizedVAE(nn.Module):
             raise ValueError(f"down_ratio must be 4 or 8, got {down_ratio}")
         self.apply(weights_init)
         self.decode_dtype = torch.float32          # torch.bfloat16 = MFMA-bf16 performance mode for decode
-        self.decode_chunk = 256                    # frames per decode launch group (bounds workspace)
+        self.decode_chunk = 1024                   # frames per decode launch group (bounds workspace: 0.8 GB at dim 256)
         self._derived = _Derived(self)
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
@@ -215,6 +215,9 @@ class VectorQuantizedVAE(nn.Module):
             d["d3.b"] = dec[3].bias.float().contiguous()
             d["d3.s"], d["d3.t"] = _bn_vectors(dec[4])
             d["d6.wt"] = dec[6].weight.float().permute(2, 3, 1, 0).contiguous()         # [4,4,cout,cin]
+            # the same taps as GEMM rows [(ky*4+kx)*cout + co, cin], padded to a multiple of 8 rows (mage_gemm: N % 8 == 0)
+            taps = d["d6.wt"].reshape(16 * self.input_dim, -1)
+            both("d6.w16", taps)
             d["d6.b"] = dec[6].bias.float().contiguous()
         else:
             d["e0.wt"] = enc[0].weight.float().permute(1, 2, 3, 0).contiguous()
@@ -356,7 +359,11 @@ class VectorQuantizedVAE(nn.Module):
                              in_h=16, in_w=16, taps_h=2, taps_w=2, cin=dim, stride=1, dy0=py, dx0=px, dys=-1, dxs=-1,
                              y_img_stride=1024, y_mul_y=64, y_mul_x=2, y_off=py * 32 + px, bias=w["d3.b"], scale=w["d3.s"],
                              shift=w["d3.t"], act=ops.ACT_RELU)
-            ops.conv_out(up, w["d6.wt"], w["d6.b"], out, N=N, IH=32, IW=32, cin=dim, cout=self.input_dim, transposed=True)
+            # ConvTranspose2d(dim, C, 4, 2, 1) + Tanh as GEMM + fold: `up` (the widest activation of the stack) is read once
+            nt = 16 * self.input_dim
+            taps = torch.empty(N * 1024, nt, device=dev, dtype=torch.float32)
+            ops.gemm(up, w["d6.w16" + s], taps, M=N * 1024, N=nt, K=dim, lda=dim, ldy=nt)
+            ops.convt_fold_tanh(taps, w["d6.b"], out, N=N, IH=32, IW=32, cout=self.input_dim)
             return
         H, W = h, wd
         x = ops.embedding(ids, w["cb"], torch.empty(N * H * W, 4 * dim, device=dev, dtype=dt))

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc
 
 __all__ = ["gemm", "layernorm", "attention", "embedding", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
-           "conv_in", "conv_out", "row_affine", "groupnorm_silu", "mlp_fused", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
+           "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "mlp_fused", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
            "PROFILE", "F32", "BF16", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
 
 
@@ -234,6 +234,14 @@ def conv_out(x, weight_t, bias, y, *, N, IH, IW, cin, cout, transposed: bool):
                                int(transposed), s), l)
     return y
 
+
+
+def convt_fold_tanh(taps, bias, y, *, N, IH, IW, cout):
+    """ConvTranspose2d(., cout, 4, 2, 1) + tanh from per-input-pixel tap products [N*IH*IW, 16*cout] (see mage_hip.h)."""
+    l, s = _dev(taps)
+    assert taps.dtype == torch.float32 and taps.is_contiguous() and taps.numel() == N * IH * IW * 16 * cout
+    _lib.check(l.mage_convt_fold_tanh(taps.data_ptr(), _p(bias), y.data_ptr(), N, IH, IW, cout, s), l)
+    return y
 
 def maxpool2(x, y, *, N, H, W, Cc, relu=False):
     l, s = _dev(x)

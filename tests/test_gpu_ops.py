@@ -251,6 +251,17 @@ def test_direct_convs_pool_upsample_adain():
     o.conv_out(xi.permute(0, 2, 3, 1).contiguous().to(DEV), wt.permute(2, 3, 1, 0).contiguous().to(DEV), bt.to(DEV), out, N=2, IH=8,
                IW=8, cin=64, cout=1, transposed=True)
     torch.testing.assert_close(out.cpu(), torch.tanh(F.conv_transpose2d(xi, wt, bt, stride=2, padding=1)), atol=2e-5, rtol=1e-5)
+    # the same transposed head as GEMM (per-input-pixel tap products) + fold, 1 and 3 output channels
+    for cout, seed in ((1, 69), (3, 169)):
+        wt = rnd(64, cout, 4, 4, seed=seed, scale=0.1)
+        bt = rnd(cout, seed=seed + 1)
+        a = xi.permute(0, 2, 3, 1).contiguous().view(2 * 64, 64).to(DEV)
+        w16 = wt.permute(2, 3, 1, 0).contiguous().view(16 * cout, 64).to(DEV)            # row (ky*4+kx)*cout + co
+        taps = torch.empty(2 * 64, 16 * cout, device=DEV)
+        o.gemm(a, w16, taps, M=128, N=16 * cout, K=64, lda=64, ldy=16 * cout)
+        out = torch.empty(2, cout, 16, 16, device=DEV)
+        o.convt_fold_tanh(taps, bt.to(DEV), out, N=2, IH=8, IW=8, cout=cout)
+        torch.testing.assert_close(out.cpu(), torch.tanh(F.conv_transpose2d(xi, wt, bt, stride=2, padding=1)), atol=2e-5, rtol=1e-5)
     w1, b1 = rnd(3, 64, 1, 1, seed=71, scale=0.2), rnd(3, seed=72)
     out = torch.empty(2, 3, 8, 8, device=DEV)
     o.conv_out(xi.permute(0, 2, 3, 1).contiguous().to(DEV), w1.reshape(3, 64).contiguous().to(DEV), b1.to(DEV), out, N=2, IH=8, IW=8,
