@@ -120,8 +120,8 @@ def main():
             dom = gemms[dom_key]
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             allf, allms = sum(v["flops"] for v in gemms.values()), sum(v["ms"] for v in gemms.values())
-            roofline = {"bound": "mfma", "kernel": dom_key + "  [dtype, gather, act, m-tiles/wave: QKV / out_proj / c_proj / head / "
-                                                             "in_linear GEMMs of the decoder stack]",
+            roofline = {"bound": "mfma", "kernel": dom_key + "  [dtype, gather, act, m-tiles/wave, epilogue kind; kind 1 = x + Linear(.) with the "
+                                                             "fp32 residual: attention out_proj and MLP c_proj of the decoder stack]",
                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": traffic, "launches_per_step": dom["calls"] // args.steps,
                         "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
