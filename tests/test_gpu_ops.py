@@ -44,6 +44,36 @@ def test_gemm_plain(dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1000, 520, 320), (140000, 520, 320), (4100, 264, 72)])
+def test_gemm_lean_epilogue_kinds(dt, M, N, K):
+    """The two epilogue kinds without loads (bias [+ act]; x + Linear(.) with the fp32 residual folded into the
+    accumulators), bf16 and fp32 output, ragged tiles; (140000, 520, 320) gives every workgroup >= 6 tiles of 256x256 so
+    the staggered start of the persistent kernel runs too."""
+    o = ops()
+    a, w, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=K ** -0.5), rnd(N, seed=13)
+    if dt == torch.bfloat16:
+        a, w = a.bfloat16().float(), w.bfloat16().float()
+    lin = a @ w.t() + b
+    tol = dict(atol=3e-5, rtol=2e-5) if dt == torch.float32 else dict(atol=3e-3, rtol=1e-4)
+    ad, wd, bd = to_dev(a, dt), to_dev(w, dt), b.to(DEV)
+    # bias only -> fp32 and bf16
+    y = torch.empty(M, N, device=DEV)
+    o.gemm(ad, wd, y, M=M, N=N, K=K, lda=K, ldy=N, bias=bd)
+    torch.testing.assert_close(y.cpu(), lin, **tol)
+    yb = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    o.gemm(ad, wd, yb, M=M, N=N, K=K, lda=K, ldy=N, bias=bd)
+    torch.testing.assert_close(yb.float().cpu(), lin, atol=3e-2, rtol=1e-2)
+    # QuickGELU -> bf16 (the decoder's c_fc)
+    o.gemm(ad, wd, yb, M=M, N=N, K=K, lda=K, ldy=N, bias=bd, act=o.ACT_QUICKGELU)
+    torch.testing.assert_close(yb.float().cpu(), lin * torch.sigmoid(1.702 * lin), atol=3e-2, rtol=1e-2)
+    # x + Linear(.), fp32 residual updated in place (the decoder's out_proj / c_proj)
+    res = rnd(M, N, seed=14)
+    y = res.to(DEV).clone()
+    o.gemm(ad, wd, y, M=M, N=N, K=K, lda=K, ldy=N, bias=bd, residual=y, ldr=N)
+    torch.testing.assert_close(y.cpu(), lin + res, **tol)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_gemm_epilogue_full(dt):
     """bias -> BN scale/shift -> QuickGELU -> row table -> residual (in place, fp32) -> relu, bf16/fp32 output."""
     o = ops()
