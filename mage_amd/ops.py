@@ -49,9 +49,13 @@ class _Profile:
     def __init__(self):
         self.enabled = False
         self.records = []
+        self.only = None             # None: every instrumented launch; else the set of keys to time (others run un-bracketed)
 
-    def reset(self, enabled: bool = False):
-        self.enabled, self.records = enabled, []
+    def reset(self, enabled: bool = False, only=None):
+        self.enabled, self.records, self.only = enabled, [], (set(only) if only is not None else None)
+
+    def wants(self, key: str) -> bool:
+        return self.enabled and (self.only is None or key in self.only)
 
     def begin(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -122,10 +126,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
         else:
             ek = 2
         key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act}, {mt}, {ek}>"
-        ev = PROFILE.begin()
-        _lib.check(l.mage_gemm(C.byref(d), s), l)
-        PROFILE.end(key, ev, 2.0 * M * N * K)
-        return y
+        if PROFILE.wants(key):
+            ev = PROFILE.begin()
+            _lib.check(l.mage_gemm(C.byref(d), s), l)
+            PROFILE.end(key, ev, 2.0 * M * N * K)
+            return y
     _lib.check(l.mage_gemm(C.byref(d), s), l)
     return y
 
@@ -134,7 +139,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch
     l, s = _dev(x)
     assert x.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous()
     Cc = x.shape[-1]
-    ev = PROFILE.begin() if PROFILE.enabled else None
+    ev = PROFILE.begin() if PROFILE.wants("layernorm") else None
     _lib.check(l.mage_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), code(y),
                                 x.numel() // Cc, Cc, float(eps), s), l)
     if ev is not None:
@@ -155,7 +160,7 @@ def attention(q, k, v, out, *, ldq, ldk, ldv, ldo, n_seq, inner, nq, nk, n_head,
     d.causal = int(causal)
     d.kv_len, d.kv_len_div = _p(kv_len), kv_len_div
     d.scale = float(32 ** -0.5 if scale is None else scale)
-    ev = PROFILE.begin() if PROFILE.enabled else None
+    ev = PROFILE.begin() if PROFILE.wants("attention") else None
     _lib.check(l.mage_attention(C.byref(d), s), l)
     if ev is not None:
         es = q.element_size()
