@@ -80,7 +80,7 @@ def main():
     ops.PROFILE.reset(enabled=True)
     model.autoregressive_generate(batch)
     warm_prof = ops.PROFILE.summary()
-    warm_gemms = {k: v for k, v in warm_prof.items() if k.startswith("gemm_kernel")}
+    warm_gemms = {k: v for k, v in warm_prof.items() if k.startswith(("gemm_kernel", "gemm8_kernel"))}
     dom_warm = max(warm_gemms, key=lambda k: warm_gemms[k]["ms"]) if warm_gemms else None
     sync_all()
     # timed region: HIP events on the launch stream around the dominant symbol's launches (--events all: around all)
@@ -118,7 +118,7 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = world * B * L * args.steps / dt
         prof = ops.PROFILE.summary()
-        gemms = {k: v for k, v in prof.items() if k.startswith("gemm_kernel")}
+        gemms = {k: v for k, v in prof.items() if k.startswith(("gemm_kernel", "gemm8_kernel"))}
         dom_key = max(gemms, key=lambda k: gemms[k]["ms"]) if gemms else None
         all_src, all_div = (gemms, args.steps) if args.events == "all" else (warm_gemms, 1)
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
@@ -134,8 +134,10 @@ def main():
             dom = gemms[dom_key]
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             allf, allms = sum(v["flops"] for v in all_src.values()), sum(v["ms"] for v in all_src.values())
-            roofline = {"bound": "mfma", "kernel": dom_key + "  [dtype, gather, act, m-tiles/wave, epilogue kind; kind 1 = x + Linear(.) with the "
-                                                             "fp32 residual: attention out_proj and MLP c_proj of the decoder stack]",
+            roofline = {"bound": "mfma", "kernel": dom_key + "  [gemm8_kernel<act, epilogue kind>: the 8-phase ping-pong bf16 256x256 GEMM; "
+                                                             "gemm_kernel<dtype, gather, act, m-tiles/wave, epilogue kind>: the lockstep one.  "
+                                                             "Epilogue kind 1 = x + Linear(.) with the fp32 residual: attention out_proj and "
+                                                             "MLP c_proj of the decoder stack]",
                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": traffic, "launches_per_step": dom["calls"] // args.steps,
                         "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),

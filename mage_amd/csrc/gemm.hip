@@ -229,6 +229,11 @@ __device__ unsigned long long mage_probe_wave[256 * 16 * 8 * 2];  // per (workgr
         if (lane == 0 && (it) < 16 && blockIdx.x < 256)                                                    \
             mage_probe_wave[((blockIdx.x * 16 + (it)) * 8 + wave) * 2 + (p)] = __builtin_readcyclecounter(); \
     } while (0)
+__device__ unsigned long long mage_probe_seg[8 * 160];   // gemm8: workgroup 8, one tile: per wave, 4 stamps per phase
+#define MAGE_SEG(i)                                                                                        \
+    do {                                                                                                   \
+        if (lane == 0 && blockIdx.x == 8 && seg_on && (i) < 160) mage_probe_seg[wave * 160 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
 #define MAGE_STAMP(it, p)                                                                                  \
     do {                                                                                                   \
         if (tid == 0 && (it) < 64 && blockIdx.x < 256) {                                                   \
@@ -239,6 +244,7 @@ __device__ unsigned long long mage_probe_wave[256 * 16 * 8 * 2];  // per (workgr
 #else
 #define MAGE_STAMP(it, p)
 #define MAGE_WSTAMP(it, p)
+#define MAGE_SEG(i)
 #endif
 
 // Lean epilogue of the two kinds without loads: per (16-row tile mt, 32-column half k) 4 lane swaps, 4 packed bias adds, the
@@ -626,6 +632,240 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     }
 }
 
+// ======================================================================================================================
+// gemm8_kernel: the 8-phase ping-pong variant of the bf16 256x256 plain GEMM with a lean epilogue (the decoder's Linear
+// layers).  Structure after cdna_hip_programming.md "The 256^2 8-phase template": the wave's 128x64 output is four 64x32
+// quadrants; a PHASE = [12/4/8/4 ds_read_b128 of one quadrant's operand fragments + one 16 KiB "piece" of DMA (2 per wave)]
+// s_barrier [16 MFMA] s_barrier; the two wave halves (wr = 0: rows 0-127, wr = 1: rows 128-255; SIMD partners) run ONE
+// barrier apart, so on every SIMD one wave is in its 16-MFMA section while its partner reads LDS and issues DMA.  vmcnt is
+// never drained in the loop: one counted wait per K slab.
+//
+// LDS: 2 slab buffers x 4 pieces x 16 KiB (+ 32 KiB epilogue staging).  A piece is 128 rows x 128 B, cut by QUADRANT INDEX,
+// not by tile half, so that every piece has a long window between its last read and the first read of its replacement:
+//     A_a (a = 0,1): tile rows {wr*128 + a*64 + [0,64)} of both wave halves        read in phase 1 (a=0) / phase 3 (a=1)
+//     W_b (b = 0,1): W rows   {wc*64 + b*32 + [0,32)} of the four wave columns     read in phases 1 and 4 (b=0) / 2 (b=1)
+// Quadrant order (0,0) (0,1) (1,1) (1,0).  With slab j computed from buffer j&1, phase p of slab j issues
+//     p=1: A_1 of slab j+1   p=2: W_0 of slab j+1   p=3: A_0 of slab j+2   p=4: W_1 of slab j+2, then s_waitcnt vmcnt(4)
+// WAR (a buffer is restaged >= 2 phases after its last ds_read, which covers the half that runs a barrier behind):
+//     A_1 last read j-1.p3 -> restaged j.p1;  W_0: j-1.p4 -> j.p2;  A_0: j.p1 -> j.p3;  W_1: j.p2 -> j.p4.
+// RAW (loads return in order, so "at most the 2 newest pieces outstanding" = everything issued up to j.p2 has landed; the
+// wait sits before phase 4's first barrier and the data is first read one phase later, after the trailing half has also
+// waited): slab j+1's A_0 (issued j-1.p3), W_1 (j-1.p4), A_1 (j.p1), W_0 (j.p2) are all complete at j.p4's wait.
+// The loader cursors run across tile boundaries (the next tile's slabs 0 and 1 stream in under this tile's last phases and
+// its epilogue).  At a tile's end the leading half gives the trailing half one barrier (both then run the epilogue in
+// step), and the trailing half drops back by one barrier before the next tile's first phase.
+template <int ACT, int EK>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
+    constexpr int MT = 8, BM = 256;
+    constexpr int PIECE = 16384, KBUF = 4 * PIECE;
+    constexpr int P_A0 = 0, P_A1 = 1, P_W0 = 2, P_W1 = 3;
+    const mage_gemm_desc& d = g.d;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg8 = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int q8 = g.ntiles >> 3, r8 = g.ntiles & 7;
+    const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int chunk1 = chunk0 + q8 + (xcd < r8 ? 1 : 0);
+    const int nk = (d.K + 63) / 64;
+    __builtin_assume(nk > 0);
+    const int plane = d.out_h * d.out_w;
+    int c_tile = chunk0 + li;
+    if (c_tile >= chunk1) return;
+
+    // ---- loader: per piece type a cursor (tile, slab) and this lane's two row pointers (units 2*wave, 2*wave+1 of the piece)
+    const int lr = lane >> 3, lp = lane & 7;
+    const int lc[2] = {lp ^ ((lr >> 1) & 7), lp ^ ((4 + (lr >> 1)) & 7)};       // logical 16-byte chunk fetched for unit i (swizzle)
+    // A piece-unit's source = uniform base (operand + slab offset, SGPRs) + a per-lane 32-bit byte offset (row and swizzled
+    // chunk): no vector arithmetic per DMA piece (the partner wave holds priority during its MFMA section: every VALU
+    // instruction of a load section waits for a slot).  Rows beyond M / N are clamped to the last valid row (their products
+    // only reach outputs that are never stored); the host sends K % 64 != 0 or operands >= 4 GiB to gemm_kernel.
+    int cur_tile[4], cur_kt[4], cur_buf[4];
+    unsigned voff[4][2];
+    auto set_rows = [&](int P) {
+        const int tile = cur_tile[P];
+        const int tm = tile / g.ntiles_n, tn = tile - tm * g.ntiles_n;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (2 * wave + i) * 8 + lr;                               // row of the piece
+            if (P == P_A0 || P == P_A1) {
+                const int m = min(tm * BM + (r >> 6) * 128 + (P == P_A1 ? 64 : 0) + (r & 63), d.M - 1);
+                const int img = m / plane;
+                const int rem = m - img * plane;
+                const int oy = rem / d.out_w;
+                const int ox = rem - oy * d.out_w;
+                const long arow = (long)img * d.a_img_stride + (long)oy * d.in_w + ox + d.a_off;
+                voff[P][i] = (unsigned)(arow * d.lda * 2 + lc[i] * 16);
+            } else {
+                const int n = min(tn * BN + (r >> 5) * 64 + (P == P_W1 ? 32 : 0) + (r & 31), d.N - 1);
+                voff[P][i] = (unsigned)((long)n * d.K * 2 + lc[i] * 16);
+            }
+        }
+    };
+    auto issue = [&](int P) {
+        char* dst = smem + cur_buf[P] * KBUF + P * PIECE + (2 * wave) * 1024;
+        const char* sbase = (const char*)((P == P_A0 || P == P_A1) ? d.A : d.W) + cur_kt[P] * 128;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(sbase + voff[P][i], dst + i * 1024);
+        cur_buf[P] ^= 1;
+        if (++cur_kt[P] == nk) {
+            cur_kt[P] = 0;
+            cur_tile[P] += nwg8;
+            set_rows(P);
+        }
+    };
+#pragma unroll
+    for (int P = 0; P < 4; ++P) {
+        cur_tile[P] = c_tile;
+        cur_kt[P] = 0;
+        cur_buf[P] = 0;
+        set_rows(P);
+    }
+    if (g.stagger_groups > 1) {
+        for (int w = (li % g.stagger_groups) * g.stagger_sleeps; w > 0; --w) __builtin_amdgcn_s_sleep(16);
+    }
+    // prologue: slab 0 complete, slab 1's A_0 and W_1 (the two pieces the steady state issues two slabs ahead)
+    issue(P_A0); issue(P_W1); issue(P_A1); issue(P_W0); issue(P_A0); issue(P_W1);
+    __builtin_amdgcn_s_waitcnt(0x0F74);                // vmcnt(4)
+    asm volatile("" ::: "memory");
+    ring_barrier();
+
+    // ---- compute state
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int rsw = (l15 >> 1) & 7;
+    const int pc0 = ((grp + 0) ^ rsw) * 16, pc1 = ((grp + 4) ^ rsw) * 16;        // k-half 0 / 1 chunk of this lane's fragment row
+    const int a_off = (wr * 64 + l15) * 128;                                     // + m*2048 inside an A piece
+    const int w_off = (wc * 32 + l15) * 128;                                     // + n*2048 inside a W piece
+    f32x4 acc[MT][4];
+    int c_buf = 0;
+
+    for (; c_tile < chunk1; c_tile += nwg8) {
+        const int tm = c_tile / g.ntiles_n, tn = c_tile - tm * g.ntiles_n;
+        const int m0 = tm * BM + wr * 128, n0 = tn * BN + wc * 64;
+        if constexpr (EK == EK_RES_INIT) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int m = min(m0 + a * 16 + l15, d.M - 1);
+                const float* rp = (const float*)d.residual + (long)(m * d.y_mul_x + d.y_off) * d.ldr;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int n = n0 + b * 16 + grp * 4;
+                    acc[a][b] = *(const f32x4*)(rp + (n < d.N ? n : 0));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 biasm[4];
+        [[maybe_unused]] const bool seg_on = c_tile == chunk0 + li + 2 * nwg8;     // probe build: stamp the third tile
+        if (wr) ring_barrier();                        // the trailing half drops one barrier behind
+        for (int kt = 0; kt < nk; ++kt) {
+            [[maybe_unused]] int seg_ph = kt * 4;
+            const char* base = smem + c_buf * KBUF;
+            u32x4 af[4][2], wf[2][2];                  // [16-row tile of the quadrant][k-half]
+            auto read_a = [&](int a) {
+                const char* pa = base + (a ? P_A1 : P_A0) * PIECE + a_off;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    af[m][0] = *(const u32x4*)(pa + m * 2048 + pc0);
+                    af[m][1] = *(const u32x4*)(pa + m * 2048 + pc1);
+                }
+            };
+            auto read_w = [&](int b) {
+                const char* pw = base + (b ? P_W1 : P_W0) * PIECE + w_off;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    wf[n][0] = *(const u32x4*)(pw + n * 2048 + pc0);
+                    wf[n][1] = *(const u32x4*)(pw + n * 2048 + pc1);
+                }
+            };
+            auto mfma_quadrant = [&](int a, int b) {
+                __builtin_amdgcn_sched_barrier(0);
+                MAGE_SEG(seg_ph * 4 + 1);
+                ring_barrier();
+                __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0)
+                MAGE_SEG(seg_ph * 4 + 2);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[a * 4 + m][b * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, wf[n][t]), __builtin_bit_cast(bf16x8, af[m][t]), acc[a * 4 + m][b * 2 + n], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                MAGE_SEG(seg_ph * 4 + 3);
+                ring_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                ++seg_ph;
+                MAGE_SEG(seg_ph * 4 + 0);
+            };
+            // phase 1: quadrant (0,0)
+            read_w(0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(0);
+            issue(P_A1);
+            if (EK == EK_RES_INIT && kt == 0) {
+                // the residual tile (requested before this slab's two DMA instructions) is in the accumulators: loads return in
+                // order, so "at most 2 outstanding" proves it whatever the previous epilogue's stores are doing
+                __builtin_amdgcn_s_waitcnt(0x0F72);
+                asm volatile("" ::: "memory");
+            }
+            mfma_quadrant(0, 0);
+            // phase 2: quadrant (0,1)
+            read_w(1);
+            issue(P_W0);
+            mfma_quadrant(0, 1);
+            // phase 3: quadrant (1,1)
+            read_a(1);
+            issue(P_A0);
+            if (kt == nk - 1) {                        // the epilogue's bias vector, late: its registers are free during the K loop
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int n = n0 + b * 16 + grp * 4;
+                    biasm[b] = d.bias ? *(const f32x4*)(d.bias + (n < d.N ? n : 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            mfma_quadrant(1, 1);
+            // phase 4: quadrant (1,0)
+            read_w(0);
+            issue(P_W1);
+            // vmcnt(4): all but the two newest pieces have landed.  Tile's last slab: vmcnt(2) -- the bias vector was requested
+            // between those two pieces
+            if (kt == nk - 1) __builtin_amdgcn_s_waitcnt(0x0F72);
+            else __builtin_amdgcn_s_waitcnt(0x0F74);
+            asm volatile("" ::: "memory");
+            mfma_quadrant(1, 0);
+            c_buf ^= 1;
+        }
+        if (!wr) ring_barrier();                       // the leading half waits for the trailing half's last MFMA section
+#if MAGE_ABL == 1
+        {   // tuning build: main loop only (keep the accumulators alive, store nothing)
+            float sacc = 0.f;
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+            if (sacc == 123456.789f) ((float*)d.Y)[0] = sacc + biasm[0][0];
+            continue;
+        }
+#endif
+        char* stg = smem + 2 * KBUF + wave * 4096;
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));               // keep the epilogue's lane-derived constants out of the K loop's registers
+        if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane_e, plane, stg);
+        else epilogue_lean<ACT, unsigned short, MT>(d, biasm, acc, m0, n0, lane_e, plane, stg);
+    }
+}
+
 template <int DT, bool GATHER, int ACT, int MT, int EK>
 int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     static bool attr_set = false;
@@ -664,6 +904,21 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
         const long period = nk * 3400 * MT / 8 + (long)((out_b + res_b) / 10.6);
         a.stagger_groups = st_groups;
         a.stagger_sleeps = (int)(period * st_percent / 100 / st_groups / 1024);
+    }
+    if constexpr (DT == MAGE_BF16 && !GATHER && MT == 8 && EK != EK_GENERAL) {
+        static int use8 = -1;
+        if (use8 < 0) use8 = getenv("MAGE_GEMM_NO_8PHASE") ? 0 : 1;
+        const long a_rows = (long)((d->M + d->out_h * d->out_w - 1) / (d->out_h * d->out_w)) * d->a_img_stride + d->a_off + 1;
+        if (use8 && d->K % 64 == 0 && a_rows * d->lda * 2 < (1L << 32) && (long)d->N * d->K * 2 < (1L << 32)) {
+            static bool attr8 = false;
+            if (!attr8) {
+                (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr8 = true;
+            }
+            hipLaunchKernelGGL((gemm8_kernel<ACT, EK>), dim3(grid), dim3(512), 160 * 1024, s, a);
+            MAGE_CHECK_LAUNCH("mage_gemm");
+            return MAGE_OK;
+        }
     }
     hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT, MT, EK>), dim3(grid), dim3(512), Tile<MT>::LDS_BYTES, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
@@ -718,6 +973,12 @@ int launch(const mage_gemm_desc* d, hipStream_t s) {
 #ifdef MAGE_PROBE
 extern "C" int mage_debug_read_waves(void* dst, size_t bytes) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mage_probe_wave), bytes < sizeof(mage_probe_wave) ? bytes : sizeof(mage_probe_wave)) ==
+                   hipSuccess
+               ? 0
+               : -1;
+}
+extern "C" int mage_debug_read_seg(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mage_probe_seg), bytes < sizeof(mage_probe_seg) ? bytes : sizeof(mage_probe_seg)) ==
                    hipSuccess
                ? 0
                : -1;

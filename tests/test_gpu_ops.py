@@ -44,11 +44,12 @@ def test_gemm_plain(dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(1000, 520, 320), (140000, 520, 320), (4100, 264, 72)])
+@pytest.mark.parametrize("M,N,K", [(1000, 520, 320), (140000, 520, 320), (140000, 520, 328), (131072 + 8, 512, 64), (4100, 264, 72)])
 def test_gemm_lean_epilogue_kinds(dt, M, N, K):
     """The two epilogue kinds without loads (bias [+ act]; x + Linear(.) with the fp32 residual folded into the
     accumulators), bf16 and fp32 output, ragged tiles; (140000, 520, 320) gives every workgroup >= 6 tiles of 256x256 so
-    the staggered start of the persistent kernel runs too."""
+    the staggered start of the persistent kernel runs too.  bf16 with K % 64 == 0 and >= 512 tiles runs the 8-phase ping-pong
+    kernel (K = 320: 5 slabs; K = 64: a single slab per tile, the DMA cursors two tiles ahead); K = 328 the lockstep one."""
     o = ops()
     a, w, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=K ** -0.5), rnd(N, seed=13)
     if dt == torch.bfloat16:

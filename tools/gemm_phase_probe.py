@@ -51,3 +51,16 @@ w = wb.reshape(256, 16, 8, 2).astype(np.int64)[:, 2:min(ntile, 16)]
 rel = w - w[:, :, :, 0].min(axis=2)[:, :, None, None]
 print("per-wave epilogue begin (mean ticks after the first wave's begin):", [int(rel[:, :, i, 0].mean()) for i in range(8)])
 print("per-wave epilogue end                                            :", [int(rel[:, :, i, 1].mean()) for i in range(8)])
+# 8-phase kernel, workgroup 8, third tile (shader clock), per wave and slab: per phase  load / wait-A / mfma / wait-B  clocks
+sb = np.zeros(8 * 160, np.uint64)
+l.mage_debug_read_seg.argtypes = [C.c_void_p, C.c_size_t]
+if l.mage_debug_read_seg(sb.ctypes.data, sb.nbytes) == 0 and sb.any():
+    sg = sb.reshape(8, 160).astype(np.int64)
+    ns = min((K + 63) // 64, 9)
+    for wv in (0, 4):
+        for k in range(1, min(ns - 1, 5)):
+            parts = []
+            for ph in range(4):
+                st = sg[wv, (k * 4 + ph) * 4: (k * 4 + ph) * 4 + 5]
+                parts.append(f"p{ph + 1} {st[1] - st[0]}/{st[2] - st[1]}/{st[3] - st[2]}/{st[4] - st[3]}")
+            print(f"wave {wv} slab {k}: " + "   ".join(parts))
