@@ -14,7 +14,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f"/tmp/pmc_{c}/p_counter_collection.csv")):
         if r["Counter_Name"] == c:
-            name = re.sub(r"^void \(anonymous namespace\)::|\(.*$", "", r["Kernel_Name"])
+            name = re.sub(r"\(.*$", "", r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", ""))
             agg[name].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         out[k][c + "_KB_avg"] = sum(v) / len(v)
