@@ -43,7 +43,7 @@ def main():
                          "every GEMM / attention / LayerNorm launch (937 launches x 2 event packets: ~1 %% slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the second AR mode (clean rocprofv3 runs)")
-    ap.add_argument("--cpu-clips", type=int, default=2)
+    ap.add_argument("--cpu-clips", type=int, default=4, help="clips of the CPU baseline sample (4 = SURVEY cfg1, the reference's CPU-runnable batch)")
     args = ap.parse_args()
 
     from mage_amd.utils import dist as D
