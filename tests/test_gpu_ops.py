@@ -236,6 +236,40 @@ def test_attention_key_padding_and_cross():
     torch.testing.assert_close(out.cpu(), want, atol=2e-5, rtol=1e-4)
 
 
+def test_attention_mfma_short_sequences_masks():
+    """The matrix-core attention kernel (bf16, nq, nk <= 16) off the square axial case: a query block appended to a longer key
+    cache with the causal mask aligned to the last key (nq = 1 and 3 of nk = 7 and 16: the incremental AR loop), per-sequence
+    key lengths, 16 heads, and the same inputs through the vector-ALU kernel (MAGE_ATTN_NO_MFMA is read per call)."""
+    import os
+    o = ops()
+    for nq, nk, causal, use_len in ((1, 7, True, False), (3, 16, True, False), (5, 12, False, True), (16, 16, True, True)):
+        B, Cc, H = 6, 512, 16
+        q = rnd(B * nq, Cc, seed=50 + nq).bfloat16()
+        kv = rnd(B * nk, 2 * Cc, seed=60 + nk).bfloat16()
+        lens = torch.tensor([nk, 1, max(1, nk - 3), nk, 2, nk], dtype=torch.int32)
+        args = dict(ldq=Cc, ldk=2 * Cc, ldv=2 * Cc, ldo=Cc, n_seq=B, inner=1, nq=nq, nk=nk, n_head=H, q_outer_stride=nq,
+                    q_axis_stride=1, kv_outer_stride=nk, kv_axis_stride=1, causal=causal, kv_len=lens.to(DEV) if use_len else None)
+        dq, dkv = q.to(DEV), kv.to(DEV)
+        out = torch.empty(B * nq, Cc, device=DEV, dtype=torch.bfloat16)
+        o.attention(dq, dkv, dkv[:, Cc:], out, **args)
+        mask = torch.zeros(B, 1, nq, nk)
+        for b in range(B):
+            kl = int(lens[b]) if use_len else nk
+            for i in range(nq):
+                jmax = min(kl, i + 1 + (nk - nq)) if causal else kl
+                mask[b, 0, i, jmax:] = float("-inf")
+        want = _ref_attn(q.float().view(B, nq, Cc), kv.float().view(B, nk, 2 * Cc)[..., :Cc], kv.float().view(B, nk, 2 * Cc)[..., Cc:], H,
+                         mask).reshape(B * nq, Cc)
+        torch.testing.assert_close(out.float().cpu(), want, atol=2e-2, rtol=2e-2)
+        os.environ["MAGE_ATTN_NO_MFMA"] = "1"
+        try:
+            out2 = torch.empty_like(out)
+            o.attention(dq, dkv, dkv[:, Cc:], out2, **args)
+        finally:
+            del os.environ["MAGE_ATTN_NO_MFMA"]
+        torch.testing.assert_close(out2.float().cpu(), out.float().cpu(), atol=1e-2, rtol=1e-2)
+
+
 def test_vq_nearest_golden_ties_and_margin():
     o = ops()
     g = golden("vq_unit")
