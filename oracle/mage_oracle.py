@@ -311,6 +311,67 @@ def mage_forward_loss(sd: SD, batch: Dict[str, torch.Tensor], frames_length: int
     loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), tok[:, 1:frames_length].reshape(-1))
     return loss, logits
 
+# ----------------------------------------------------------------------------- MAGE.forward with randomness=True
+def basic_block(sd: SD, p: str, x: torch.Tensor, stride_t: int = 2) -> torch.Tensor:
+    """BasicBlock.forward (mage_model.py:280-297): Conv3d 3x3x3 (temporal stride) -> GroupNorm(16) -> ReLU -> Conv3d ->
+    GroupNorm, plus the Conv3d + GroupNorm downsample of the input, ReLU of the sum.  x [B,C,T,H,W]."""
+    out = F.conv3d(x, sd[p + "conv1.weight"], None, stride=(stride_t, 1, 1), padding=1)
+    out = F.relu(F.group_norm(out, 16, sd[p + "bn1.weight"], sd[p + "bn1.bias"]))
+    out = F.conv3d(out, sd[p + "conv2.weight"], None, padding=1)
+    out = F.group_norm(out, 16, sd[p + "bn2.weight"], sd[p + "bn2.bias"])
+    res = F.conv3d(x, sd[p + "downsample.0.weight"], None, stride=(stride_t, 1, 1), padding=1)
+    res = F.group_norm(res, 16, sd[p + "downsample.1.weight"], sd[p + "downsample.1.bias"])
+    return F.relu(out + res)
+
+
+def video_prior(sd: SD, x_emb: torch.Tensor) -> torch.Tensor:
+    """self.conv3d (mage_model.py:496-501,602-603): four temporal-stride-2 BasicBlocks over the token embeddings of ALL frames,
+    [B,L,C,h,w] -> [B,C,h,w] (L in 9..16 collapses to one frame; squeeze(2))."""
+    v = x_emb.permute(0, 2, 1, 3, 4)
+    for i in range(4):
+        v = basic_block(sd, f"conv3d.{i}.", v, 2)
+    return v.squeeze(2)
+
+
+def mage_forward_loss_random(sd: SD, batch: Dict[str, torch.Tensor], frames_length: int, eps: torch.Tensor, alpha: float,
+                             beta: float, auto_beta: bool = False, v_kl: float = 0.0, pid=None):
+    """MAGE.forward (mage_model.py:575-639), use_cids=True, randomness=True.  eps [B,64,h,w] is the reparameterisation noise
+    the reference draws with torch.randn_like (:571), injected.  Returns (final_loss, dict of the reference's loss_dict
+    values without the train/val prefix, logits, video_emb_prior)."""
+    images = batch["images"]
+    B, L = images.shape[:2]
+    tok = vqvae_encode(sd, "first_stage_model.", images.reshape(B * L, *images.shape[2:]))
+    tok = tok.view(B, L, *tok.shape[1:])
+    h, w = tok.shape[2:]
+    x_emb = sd["visual_token_embedding.weight"][tok].permute(0, 1, 4, 2, 3)                       # :581
+    prior = video_prior(sd, x_emb)                                                               # :602-603
+    mu = F.conv2d(prior, sd["conv_mu2.weight"], sd["conv_mu2.bias"], padding=1)                  # :570
+    logvar = F.conv2d(prior, sd["conv_var2.weight"], sd["conv_var2.bias"], padding=1)
+    video_emb = eps * (0.5 * logvar).exp() + mu                                                  # :571-573
+    speed = batch.get("speed")
+    first = _frame_features(sd, tok[:, :1])[:, 0].reshape(B, h * w, -1)
+    txt = text_encoder(sd, "text_encoder.", batch["text"])
+    ma = ma_encoder(sd, "ma_encoder.", first, txt).view(B, h, w, -1)
+    ma = adain(sd, ma, video_emb)                                                                # :606-609 (conv_d2 inside)
+    speed_emb = None
+    if speed is not None:
+        speed_emb = speed.view(B, 1) @ sd["speed_embedding"]
+        ma = ma + speed_emb[:, None, None, :]
+    logits = flat_axial_decoder(sd, "generate_model.", ma, _frame_features(sd, tok[:, :frames_length - 1]))
+    recon = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), tok[:, 1:frames_length].reshape(-1))
+    mu2, lv2 = mu.reshape(B, -1), logvar.reshape(B, -1)
+    kl = -0.5 * torch.mean(torch.sum(1 + lv2 - mu2.pow(2) - lv2.exp(), dim=1))                   # :623
+    parts = {"prediction": recon.item(), "kl_loss": kl.item()}
+    if auto_beta:
+        beta, _ = pid.pid(v_kl, kl.item())                                                       # :627
+        parts["beta"] = beta
+        final = recon + beta * kl
+    else:
+        l2 = torch.mean(torch.pow(torch.norm(speed_emb, dim=-1), 2))                             # :631
+        final = recon + beta * kl + alpha * l2
+    parts["final_loss"] = final.item()
+    return final, parts, logits, prior
+
 
 # ----------------------------------------------------------------------------- MAGE+ (use_cids=False), sampling side
 def _frame_features_latent(sd: SD, lat: torch.Tensor) -> torch.Tensor:

@@ -93,6 +93,24 @@ def test_mage_cater_small_randomness_branch():
     assert torch.allclose(video[..., ::4, ::4], t(g["video_sub"]), atol=1e-5)
 
 
+def test_mage_cater_forward_randomness_losses():
+    """MAGE.forward with randomness=True (Conv3d video prior, reparameterisation with the reference's noise injected, KL and
+    speed-l2 terms) against the reference's own (loss, loss_dict), its conv3d output and its teacher-forced logits."""
+    g = golden("mage_cater_forward_small")
+    B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
+    cfg = synth.cater_model_config(frames_length=L, width=int(g["width"]), layers=int(g["layers"]), vq_dim=int(g["vq_dim"]), K=int(g["K"]))
+    sd = cpu_sd(build_mage(cfg, seed))
+    batch = synth.synth_batch_cater(B, L, seed=seed, text_len=int(g["text_len"]))
+    final, parts, logits, prior = O.mage_forward_loss_random(sd, batch, L, t(g["eps"]), alpha=cfg["params"]["alpha"],
+                                                             beta=cfg["params"]["beta"])
+    assert torch.allclose(prior[:, ::4, ::2, ::2], t(g["prior_sub"]), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(chk(prior), g["prior_chk"], rtol=1e-5)
+    assert torch.allclose(logits[:, ::3, ::4, ::4, ::8], t(g["logits_sub"]), atol=1e-4, rtol=1e-4)
+    assert abs(parts["prediction"] - float(g["prediction"])) < 1e-5
+    assert abs(parts["kl_loss"] - float(g["kl_loss"])) < 1e-4 * max(1.0, abs(float(g["kl_loss"])))
+    assert abs(final.item() - float(g["final_loss"])) < 1e-5 * max(1.0, abs(float(g["final_loss"])))
+
+
 def test_mage_L16_tokens():
     g = golden("mage_mnist_L16")
     sd = cpu_sd(build_mage(synth.mnist_model_config(frames_length=16), int(g["seed"])))

@@ -50,9 +50,40 @@ def build_ref_mage(ref_mage, cfg, seed):
     return m
 
 
+def gen_forward_random(ref_mage):
+    # ---- 7c. MAGE.forward with randomness=True: Conv3d video prior, reparameterisation (noise injected), KL + l2 terms ----
+    print("mage_cater_forward_small")
+    cfg = synth.cater_model_config(frames_length=10, width=64, layers=3, vq_dim=32, K=64)
+    m = build_ref_mage(ref_mage, cfg, 61)
+    batch = synth.synth_batch_cater(2, 10, seed=61, text_len=12)
+    eps = torch.from_numpy(synth.rng_for(61, "reparam_noise").standard_normal((2, 64, 16, 16)).astype(np.float32))
+    real_randn_like = torch.randn_like
+
+    def fake_randn_like(t, *a, **k):
+        return eps.clone() if tuple(t.shape) == tuple(eps.shape) else real_randn_like(t, *a, **k)
+    cap = {}
+    h1 = m.conv3d.register_forward_hook(lambda mod, i, o: cap.__setitem__("prior", o.detach().clone()))
+    h2 = m.generate_model.register_forward_hook(lambda mod, i, o: cap.__setitem__("logits", o.detach().clone()))
+    torch.randn_like = fake_randn_like
+    try:
+        with torch.no_grad():
+            loss, ld = m({k: v.clone() for k, v in batch.items()})
+    finally:
+        torch.randn_like = real_randn_like
+        h1.remove(); h2.remove()
+    prior = cap["prior"].squeeze(2)
+    save("mage_cater_forward_small", seed=61, B=2, L=10, width=64, layers=3, vq_dim=32, K=64, text_len=12, eps=eps,
+         final_loss=np.float64(loss.item()), prediction=np.float64(ld["val/prediction"]), kl_loss=np.float64(ld["val/kl_loss"]),
+         prior_sub=prior[:, ::4, ::2, ::2].contiguous(), prior_chk=chk(prior), logits_sub=cap["logits"][:, ::3, ::4, ::4, ::8].contiguous(),
+         logits_chk=chk(cap["logits"]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_mage, ref_vq = import_reference()
+    if "--only-forward-random" in sys.argv:      # regenerate just fixture 7c
+        gen_forward_random(ref_mage)
+        return
 
     # ---- 1. VQ unit: exact ties, near ties, reference-init regime --------------------------
     print("vq unit")
@@ -235,6 +266,7 @@ def main():
     save("mage_plus_small", seed=51, B=2, L=4, width=64, layers=3, text_len=12, noise=noise, motion=trace[0][0],
          pred_latents=trace[-1][1], pred_step0=trace[0][1], video_sub=video[..., ::4, ::4].contiguous(), video_chk=chk(video))
 
+    gen_forward_random(ref_mage)
     # ---- 8. state_dict layout (keys, shapes, dtypes) of the reference modules: the drop-in boundary ----------------
     import json
     layout = {}
