@@ -222,6 +222,22 @@ int mage_groupnorm_silu(const float* x, int64_t sample_stride_rows, int64_t row_
                         int32_t C, int32_t groups, const float* gamma, const float* beta, float eps, float* stats, void* y,
                         int32_t y_dtype, void* stream);
 
+/* GroupNorm of the Conv3d video prior (BasicBlock, mage_model.py:264-297: GroupNorm(16, C) after each Conv3d, then ReLU, or the
+ * sum with the downsample branch then ReLU): same statistics and addressing of x as mage_groupnorm_silu, plus
+ *   y[b*y_sample_stride_rows + y_row_off + r, :] = act(GroupNorm(x)[b, r, :] + residual[b*rows_per_sample + r, :])
+ * residual optional (fp32, packed); act 0 none / 1 ReLU / 2 SiLU.  The output addressing lets a block write straight into the
+ * zero-padded frame buffer the next temporal convolution gathers from. */
+int mage_groupnorm_act(const float* x, int64_t sample_stride_rows, int64_t row_off, int32_t n_samples, int32_t rows_per_sample,
+                       int32_t C, int32_t groups, const float* gamma, const float* beta, float eps, float* stats,
+                       const float* residual, int32_t act, void* y, int32_t y_dtype, int64_t y_sample_stride_rows,
+                       int64_t y_row_off, void* stream);
+
+/* Reparameterisation of MAGE.reparameterize (mage_model.py:569-573) and the summand of the KL term (:623), fp32:
+ *   out = eps * exp(0.5 * logvar) + mu;   kl_sum[b] = sum over the n elements of sample b of (1 + logvar - mu^2 - exp(logvar))
+ * mu, logvar, eps, out: [B, n] (any common layout); kl_sum [B]. */
+int mage_reparam_kl(const float* mu, const float* logvar, const float* eps, float* out, float* kl_sum, int32_t B, int64_t n,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,8 @@ SIGNATURES = {
     "mage_add_scaled_rowvec": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "mage_row_affine": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, vp]),
     "mage_groupnorm_silu": (C.c_int, [vp, i64, i64, i32, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp]),
+    "mage_groupnorm_act": (C.c_int, [vp, i64, i64, i32, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, i32, i64, i64, vp]),
+    "mage_reparam_kl": (C.c_int, [vp, vp, vp, vp, vp, i32, i64, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -447,11 +447,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     }
 }
 
+// act: 0 none, 1 ReLU, 2 SiLU.  residual (optional, fp32, packed like the logical output) is added after the affine, before act.
+// Output row of (sample b, row r): b*y_sample_stride_rows + y_row_off + r.
 template <typename OT>
-__global__ __launch_bounds__(256) void gn_apply_silu_kernel(const float* __restrict__ x, long sample_stride_rows, long row_off,
-                                                            int rows_per_sample, int C, int groups,
-                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, OT* __restrict__ y, long total) {
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, long sample_stride_rows, long row_off,
+                                                       int rows_per_sample, int C, int groups, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ residual, int act, OT* __restrict__ y,
+                                                       long y_sample_stride_rows, long y_row_off, long total) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= total) return;
     const long orow = i / C;
@@ -460,15 +463,39 @@ __global__ __launch_bounds__(256) void gn_apply_silu_kernel(const float* __restr
     const int cpg = C / groups;
     const f32x4 v = *(const f32x4*)(x + ((b * sample_stride_rows + row_off + r) * C + c));
     const f32x4 gm = *(const f32x4*)(gamma + c), bt = *(const f32x4*)(beta + c);
+    f32x4 res = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (residual) res = *(const f32x4*)(residual + i);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int g = (c + e) / cpg;                                  // a vector may straddle groups when C/groups < 4
         const float mean = stats[(b * groups + g) * 2], rstd = stats[(b * groups + g) * 2 + 1];
-        const float t = (v[e] - mean) * rstd * gm[e] + bt[e];
-        o[e] = t / (1.0f + expf(-t));
+        const float t = (v[e] - mean) * rstd * gm[e] + bt[e] + res[e];
+        o[e] = act == 2 ? t / (1.0f + expf(-t)) : act == 1 ? fmaxf(t, 0.f) : t;
     }
-    store4(y + i, o);
+    store4(y + ((b * y_sample_stride_rows + y_row_off + r) * C + c), o);
+}
+
+int gn_launch(const char* who, const float* x, int64_t sample_stride_rows, int64_t row_off, int32_t n_samples, int32_t rows_per_sample,
+              int32_t C, int32_t groups, const float* gamma, const float* beta, float eps, float* stats, const float* residual,
+              int32_t act, void* y, int32_t y_dtype, int64_t y_sample_stride_rows, int64_t y_row_off, hipStream_t s) {
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(n_samples, groups), dim3(256), 0, s, x, (long)sample_stride_rows, (long)row_off,
+                       rows_per_sample, C, groups, eps, stats);
+    const long total = (long)n_samples * rows_per_sample * C;
+    const dim3 grid((unsigned)((total / 4 + 255) / 256));
+    if (y_dtype == MAGE_F32)
+        hipLaunchKernelGGL((gn_apply_kernel<float>), grid, dim3(256), 0, s, x, (long)sample_stride_rows, (long)row_off, rows_per_sample,
+                           C, groups, stats, gamma, beta, residual, act, (float*)y, (long)y_sample_stride_rows, (long)y_row_off, total);
+    else if (y_dtype == MAGE_BF16)
+        hipLaunchKernelGGL((gn_apply_kernel<unsigned short>), grid, dim3(256), 0, s, x, (long)sample_stride_rows, (long)row_off,
+                           rows_per_sample, C, groups, stats, gamma, beta, residual, act, (unsigned short*)y,
+                           (long)y_sample_stride_rows, (long)y_row_off, total);
+    else {
+        mage_set_error("%s: bad y_dtype %d", who, y_dtype);
+        return MAGE_EINVAL;
+    }
+    MAGE_CHECK_LAUNCH(who);
+    return MAGE_OK;
 }
 
 }  // namespace
@@ -479,21 +506,47 @@ extern "C" int mage_groupnorm_silu(const float* x, int64_t sample_stride_rows, i
     MAGE_CHECK_ARG(x && gamma && beta && stats && y, "mage_groupnorm_silu: null pointer");
     MAGE_CHECK_ARG(n_samples > 0 && rows_per_sample > 0 && groups > 0 && C % groups == 0 && C % 4 == 0,
                    "mage_groupnorm_silu: C=%d groups=%d unsupported", C, groups);
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(n_samples, groups), dim3(256), 0, s, x, (long)sample_stride_rows, (long)row_off,
-                       rows_per_sample, C, groups, eps, stats);
-    const long total = (long)n_samples * rows_per_sample * C;
-    const dim3 grid((unsigned)((total / 4 + 255) / 256));
-    if (y_dtype == MAGE_F32)
-        hipLaunchKernelGGL((gn_apply_silu_kernel<float>), grid, dim3(256), 0, s, x, (long)sample_stride_rows, (long)row_off,
-                           rows_per_sample, C, groups, stats, gamma, beta, (float*)y, total);
-    else if (y_dtype == MAGE_BF16)
-        hipLaunchKernelGGL((gn_apply_silu_kernel<unsigned short>), grid, dim3(256), 0, s, x, (long)sample_stride_rows, (long)row_off,
-                           rows_per_sample, C, groups, stats, gamma, beta, (unsigned short*)y, total);
-    else {
-        mage_set_error("mage_groupnorm_silu: bad y_dtype %d", y_dtype);
-        return MAGE_EINVAL;
+    return gn_launch("mage_groupnorm_silu", x, sample_stride_rows, row_off, n_samples, rows_per_sample, C, groups, gamma, beta, eps,
+                     stats, nullptr, 2, y, y_dtype, rows_per_sample, 0, (hipStream_t)stream);
+}
+
+extern "C" int mage_groupnorm_act(const float* x, int64_t sample_stride_rows, int64_t row_off, int32_t n_samples,
+                                  int32_t rows_per_sample, int32_t C, int32_t groups, const float* gamma, const float* beta,
+                                  float eps, float* stats, const float* residual, int32_t act, void* y, int32_t y_dtype,
+                                  int64_t y_sample_stride_rows, int64_t y_row_off, void* stream) {
+    MAGE_CHECK_ARG(x && gamma && beta && stats && y, "mage_groupnorm_act: null pointer");
+    MAGE_CHECK_ARG(n_samples > 0 && rows_per_sample > 0 && groups > 0 && C % groups == 0 && C % 4 == 0,
+                   "mage_groupnorm_act: C=%d groups=%d unsupported", C, groups);
+    MAGE_CHECK_ARG(act >= 0 && act <= 2, "mage_groupnorm_act: act=%d (0 none, 1 relu, 2 silu)", act);
+    return gn_launch("mage_groupnorm_act", x, sample_stride_rows, row_off, n_samples, rows_per_sample, C, groups, gamma, beta, eps,
+                     stats, residual, act, y, y_dtype, y_sample_stride_rows, y_row_off, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------ reparameterisation + KL summand
+namespace {
+__global__ __launch_bounds__(256) void reparam_kl_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                                         const float* __restrict__ eps, float* __restrict__ out,
+                                                         float* __restrict__ kl_sum, long n) {
+    __shared__ double red[4];
+    const long base = (long)blockIdx.x * n;
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const float m = mu[base + i], lv = logvar[base + i];
+        out[base + i] = eps[base + i] * expf(0.5f * lv) + m;
+        acc += (double)(1.0f + lv - m * m - expf(lv));
     }
-    MAGE_CHECK_LAUNCH("mage_groupnorm_silu");
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) kl_sum[blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+}  // namespace
+
+extern "C" int mage_reparam_kl(const float* mu, const float* logvar, const float* eps, float* out, float* kl_sum, int32_t B,
+                               int64_t n, void* stream) {
+    MAGE_CHECK_ARG(mu && logvar && eps && out && kl_sum && B > 0 && n > 0, "mage_reparam_kl: bad arguments");
+    hipLaunchKernelGGL(reparam_kl_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mu, logvar, eps, out, kl_sum, (long)n);
+    MAGE_CHECK_LAUNCH("mage_reparam_kl");
     return MAGE_OK;
 }

@@ -247,8 +247,9 @@ class TransformerTextEncoder(nn.Module):
 
 
 class BasicBlock(nn.Module):
-    """Conv3d + GroupNorm video-prior block (mage_model.py:264-297): TRAINING-ONLY (MAGE.forward with
-    randomness=True); kept as a parameter container so checkpoints load.  'next' row, SURVEY.md 8f-3."""
+    """Conv3d + GroupNorm video-prior block (mage_model.py:264-297), used by MAGE.forward with randomness=True only.
+    Parameter container with the reference's keys; MAGE._video_prior runs the four blocks on the GPU (three temporal-tap
+    implicit GEMMs per Conv3d + mage_groupnorm_act)."""
 
     def __init__(self, in_planes, out_planes, stride=1, stride_t=1, downsample=False, spectral=False):
         super().__init__()
@@ -616,6 +617,16 @@ class MAGE(nn.Module):
         d["speed"] = self.speed_embedding.float().reshape(-1).contiguous()
         if self.randomness:
             d["conv_d2"] = _conv_w(self.conv_d2)
+            # MAGE.forward only: the Conv3d video prior, one [Cout, 3, 3, Cin] slice per temporal tap, and the two 3x3 heads
+            for i, blk in enumerate(self.conv3d):
+                for nm, conv in (("c1", blk.conv1), ("c2", blk.conv2), ("ds", blk.downsample[0])):
+                    w = conv.weight.float()                                                # [Cout, Cin, kd, kh, kw]
+                    for kd in range(3):
+                        d[f"p{i}.{nm}.{kd}"] = w[:, :, kd].permute(0, 2, 3, 1).contiguous()
+                for nm, gn in (("g1", blk.bn1), ("g2", blk.bn2), ("gd", blk.downsample[1])):
+                    d[f"p{i}.{nm}.w"], d[f"p{i}.{nm}.b"] = gn.weight.float().contiguous(), gn.bias.float().contiguous()
+            for nm, conv in (("mu2", self.conv_mu2), ("var2", self.conv_var2)):
+                d[nm + ".w"], d[nm + ".b"] = _conv_w(conv), conv.bias.float().contiguous()
         return d
 
     # ------------------------------------------------------------------ first stage wrappers (mage_model.py:530-567)
@@ -660,8 +671,10 @@ class MAGE(nn.Module):
         return VectorQuantizedVAE._conv(emb, d["conv" + _sfx(dt)], torch.empty_like(emb), n_img=rows // (R * R), H=R, W=R, cin=Cc,
                                         cout=Cc, k=3, rowadd=d["hwpos"], rowadd_div=1, rowadd_mod=R * R)
 
-    def _motion_anchor(self, tok0: torch.Tensor, batch, noise: Optional[torch.Tensor], first: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Once-per-clip prologue, fp32 (mage_model.py:648-668): rows [B*hw, C]."""
+    def _motion_anchor(self, tok0: torch.Tensor, batch, noise: Optional[torch.Tensor], first: Optional[torch.Tensor] = None,
+                       video_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Once-per-clip prologue, fp32 (mage_model.py:648-668 / 586-613): rows [B*hw, C].  video_rows [B*hw, 64] (forward with
+        randomness: the reparameterised video prior, before conv_d2) replaces the sampled noise."""
         d = self._derived.get(self._build)
         B = batch["text"].shape[0]
         R, Cc = self.image_resolution, self.vision_width
@@ -671,9 +684,12 @@ class MAGE(nn.Module):
         S = txt.shape[1]
         ma = self.ma_encoder._run(first, txt.reshape(B * S, -1), B=B, nq=R * R, nk=S, seq_first=False)
         if self.randomness:
-            if noise is None:
-                noise = torch.randn([B, 64, R, R], device=ma.device)                          # mage_model.py:661
-            nz = noise.float().permute(0, 2, 3, 1).reshape(B * R * R, 64).contiguous()
+            if video_rows is not None:                                                        # forward(): reparameterised prior
+                nz = video_rows
+            else:
+                if noise is None:
+                    noise = torch.randn([B, 64, R, R], device=ma.device)                      # mage_model.py:661
+                nz = noise.float().permute(0, 2, 3, 1).reshape(B * R * R, 64).contiguous()
             y = VectorQuantizedVAE._conv(nz, d["conv_d2"], torch.empty(B * R * R, Cc, device=ma.device, dtype=F32), n_img=B,
                                          H=R, W=R, cin=64, cout=Cc, k=3)
             ma = self.adain._run(ma, y, B, R, R)
@@ -788,30 +804,120 @@ class MAGE(nn.Module):
 
     # ------------------------------------------------------------------ teacher-forced pass (mage_model.py:575-639)
     @torch.no_grad()
-    def teacher_forced_logits(self, batch):
-        """tokens [B, L, h, w] and logits [B, L-1, h, w, K] of one teacher-forced decoder pass."""
+    @torch.no_grad()
+    def _video_prior(self, tok: torch.Tensor) -> torch.Tensor:
+        """self.conv3d over the token embeddings of ALL frames (mage_model.py:496-501,602-603): tok int64 [B, L, hw] -> rows
+        [B*hw, d_model] fp32.  Each Conv3d(3x3x3, temporal stride s, pad 1) is three implicit-GEMM launches, one per temporal tap,
+        accumulating in place: the block input lives in a zero-padded frame buffer in which clip b owns frames
+        [b*Lp, (b+1)*Lp) (frame 0 = the leading zero pad) with Lp = s * (virtual output frames per clip), so that output image
+        i' = b*Lv + t' gathers from frame s*i' + kd: one affine image stride for the whole batch, the clip boundaries and the
+        temporal padding are zero frames.  The Lv - Lout virtual frames per clip are never normalised or read."""
+        d = self._derived.get(self._build)
+        R, Cc = self.image_resolution, self.vision_width
+        hw = R * R
+        B, L = tok.shape[0], tok.shape[1]
+        dev = tok.device
+
+        def conv3(xpad, key, Lv, s_t, cin, cout):
+            out = torch.empty(B * Lv * hw, cout, device=dev, dtype=F32)
+            for kd in range(3):
+                ops.gemm(xpad, d[f"{key}.{kd}"], out, M=B * Lv * hw, N=cout, K=9 * cin, lda=cin, ldy=cout, out_h=R, out_w=R,
+                         in_h=R, in_w=R, taps_h=3, taps_w=3, cin=cin, stride=1, dy0=-1, dx0=-1, a_img_stride=s_t * hw,
+                         a_off=kd * hw, residual=out if kd else None, ldr=cout)
+            return out
+
+        Lin = L
+        Lout = (Lin + 1) // 2
+        Lp = 2 * (Lout + 1)
+        xa = torch.zeros((B * Lp + 1) * hw, Cc, device=dev, dtype=F32)                        # block 0 input: the embeddings
+        ops.embedding(tok.reshape(-1).contiguous(), d["emb"], xa, group=L * hw, group_stride=Lp * hw, off=hw)
+        cin = Cc
+        for i, blk in enumerate(self.conv3d):
+            cout = blk.conv1.out_channels
+            Lout = (Lin + 1) // 2
+            Lv = Lout + 1
+            gn = dict(n_samples=B, rows_per_sample=Lout * hw, groups=16)
+            c1 = conv3(xa, f"p{i}.c1", Lv, 2, cin, cout)
+            cd = conv3(xa, f"p{i}.ds", Lv, 2, cin, cout)
+            xb = torch.zeros((B * (Lout + 2) + 2) * hw, cout, device=dev, dtype=F32)           # conv2 input: stride-1 layout
+            ops.groupnorm_act(c1, d[f"p{i}.g1.w"], d[f"p{i}.g1.b"], xb, sample_stride_rows=Lv * hw, row_off=0, eps=blk.bn1.eps,
+                              act=1, y_sample_stride_rows=(Lout + 2) * hw, y_row_off=hw, **gn)
+            res = ops.groupnorm_act(cd, d[f"p{i}.gd.w"], d[f"p{i}.gd.b"], torch.empty(B * Lout * hw, cout, device=dev, dtype=F32),
+                                    sample_stride_rows=Lv * hw, row_off=0, eps=blk.downsample[1].eps, act=0, **gn)
+            c2 = conv3(xb, f"p{i}.c2", Lout + 2, 1, cout, cout)
+            if i + 1 < len(self.conv3d):                                                       # next block's stride-2 input
+                Lp2 = 2 * ((Lout + 1) // 2 + 1)
+                nxt = torch.zeros((B * Lp2 + 1) * hw, cout, device=dev, dtype=F32)
+                ops.groupnorm_act(c2, d[f"p{i}.g2.w"], d[f"p{i}.g2.b"], nxt, sample_stride_rows=(Lout + 2) * hw, row_off=0,
+                                  eps=blk.bn2.eps, act=1, residual=res, y_sample_stride_rows=Lp2 * hw, y_row_off=hw, **gn)
+            else:
+                if Lout != 1:
+                    raise ValueError(f"the Conv3d video prior needs 9 <= frames <= 16 to collapse to one frame (got {L})")
+                nxt = ops.groupnorm_act(c2, d[f"p{i}.g2.w"], d[f"p{i}.g2.b"], torch.empty(B * hw, cout, device=dev, dtype=F32),
+                                        sample_stride_rows=(Lout + 2) * hw, row_off=0, eps=blk.bn2.eps, act=1, residual=res, **gn)
+            xa, cin, Lin = nxt, cout, Lout
+        return xa
+
+    def teacher_forced_logits(self, batch, extras: Optional[dict] = None):
+        """tokens [B, L, h, w] and logits [B, L-1, h, w, K] of one teacher-forced decoder pass.  With randomness=True the motion
+        anchor is modulated by the reparameterised Conv3d video prior (mage_model.py:601-609); `extras` (a dict) then receives
+        'kl_sum' [B] (sum of 1 + logvar - mu^2 - exp(logvar) per sample) and 'prior' rows [B*hw, C]."""
         images = batch["images"]
         _need_gpu(images, "MAGE.forward")
         if not self.use_cids:
-            raise NotImplementedError("use_cids=False is a 'next' row (SURVEY.md 8f-3)")
-        if self.randomness:
-            raise NotImplementedError("MAGE.forward with randomness=True needs the Conv3d video prior (training-only, "
-                                      "SURVEY.md 8f-3); sampling with randomness=True is supported")
+            raise NotImplementedError("MAGE.forward with use_cids=False is a 'next' row (SURVEY.md 8f-3)")
         B = images.shape[0]
         R, L = self.image_resolution, self.frames_length
         dt = self._dt()
         tok = self.first_stage_encode(images).reshape(B, -1, R * R)                          # :579
-        ma = self._motion_anchor(tok[:, 0].contiguous(), batch, None)
+        video_rows = None
+        if self.randomness:
+            d = self._derived.get(self._build)
+            prior = self._video_prior(tok)                                                    # :602-603
+            Cp, dev = prior.shape[1], prior.device
+            mu = VectorQuantizedVAE._conv(prior, d["mu2.w"], torch.empty(B * R * R, 64, device=dev, dtype=F32), n_img=B, H=R, W=R,
+                                          cin=Cp, cout=64, k=3, bias=d["mu2.b"])              # :570
+            logvar = VectorQuantizedVAE._conv(prior, d["var2.w"], torch.empty_like(mu), n_img=B, H=R, W=R, cin=Cp, cout=64, k=3,
+                                              bias=d["var2.b"])
+            eps = batch.get("reparam_noise")                                                  # [B,64,h,w]; else torch.randn (:571)
+            if eps is None:
+                eps = torch.randn(B, 64, R, R, device=dev)
+            eps = eps.to(dev).float().permute(0, 2, 3, 1).reshape(B * R * R, 64).contiguous()
+            kl_sum = torch.empty(B, device=dev, dtype=F32)
+            video_rows = ops.reparam_kl(mu.view(B, -1), logvar.view(B, -1), eps.view(B, -1), torch.empty_like(mu).view(B, -1), kl_sum)
+            video_rows = video_rows.view(B * R * R, 64)
+            if extras is not None:
+                extras.update(kl_sum=kl_sum, prior=prior)
+        ma = self._motion_anchor(tok[:, 0].contiguous(), batch, None, video_rows=video_rows)
         feats = self._frame_features(tok[:, :L - 1].contiguous(), dt)
         logits = self.generate_model._run(ma if dt == F32 else ma.to(dt), feats, B=B, hh=R, ww=R)
         return tok.view(B, -1, R, R), logits.view(B, L - 1, R, R, self.codebook_size)
 
     def forward(self, batch, test_flag=False):
-        """(loss, loss_dict) of the teacher-forced pass.  Values only: the HIP path builds no autograd graph yet
+        """(loss, loss_dict) of the teacher-forced pass (mage_model.py:575-639), incl. the randomness=True terms (KL of the
+        reparameterised video prior, the PID-controlled or fixed beta, the speed-embedding l2).  batch['reparam_noise']
+        [B,64,h,w] optionally injects the reparameterisation noise.  Values only: the HIP path builds no autograd graph yet
         (backward kernels are a 'next' row), so ``loss.backward()`` raises."""
-        tok, logits = self.teacher_forced_logits(batch)
+        if test_flag and self.randomness:
+            raise NotImplementedError("forward(test_flag=True) replaces the video embedding by noise AFTER computing it; use "
+                                      "autoregressive_generate for sampling")
+        extras: dict = {}
+        tok, logits = self.teacher_forced_logits(batch, extras)
         L = self.frames_length
-        loss = ops.cross_entropy(logits.reshape(-1, self.codebook_size), tok[:, 1:L].reshape(-1).contiguous())   # :618
+        recon = ops.cross_entropy(logits.reshape(-1, self.codebook_size), tok[:, 1:L].reshape(-1).contiguous())   # :618
         prefix = "train" if self.training else "val"
-        val = loss.item()
-        return loss, {f"{prefix}/prediction": val, f"{prefix}/final_loss": val}
+        ld = {f"{prefix}/prediction": recon.item()}
+        final = recon
+        if self.randomness:
+            kl = -0.5 * extras["kl_sum"].mean()                                               # :623 (a [B]-element reduction)
+            ld[f"{prefix}/kl_loss"] = kl.item()
+            if self.auto_beta:
+                self.beta, _ = self.PID.pid(self.KL_loss, kl.item())                          # :627
+                ld[f"{prefix}/beta"] = self.beta
+                final = recon + self.beta * kl
+            else:
+                # mean_b || speed_b * speed_embedding ||^2 (:631); like the reference this branch needs batch['speed']
+                l2 = (batch["speed"].float().to(recon.device) ** 2).mean() * (self.speed_embedding.float() ** 2).sum()
+                final = recon + self.beta * kl + self.alpha * l2
+        ld[f"{prefix}/final_loss"] = final.item()
+        return final, ld

@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc
 
 __all__ = ["gemm", "layernorm", "attention", "embedding", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
-           "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "mlp_fused", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
+           "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mlp_fused", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
            "PROFILE", "F32", "BF16", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
 
 
@@ -305,6 +305,32 @@ def groupnorm_silu(x, gamma, beta, y, *, n_samples, rows_per_sample, sample_stri
     _lib.check(l.mage_groupnorm_silu(x.data_ptr(), sample_stride_rows, row_off, n_samples, rows_per_sample, Cc, groups,
                                      gamma.data_ptr(), beta.data_ptr(), float(eps), stats.data_ptr(), y.data_ptr(), code(y), s), l)
     return y
+
+
+def groupnorm_act(x, gamma, beta, y, *, n_samples, rows_per_sample, sample_stride_rows, row_off, groups, eps=1e-5, act=0,
+                  residual=None, y_sample_stride_rows=None, y_row_off=0):
+    """y rows (b*y_sample_stride_rows + y_row_off + r) = act(GroupNorm(x rows (b*sample_stride_rows + row_off + r)) + residual);
+    act 0 none / 1 ReLU / 2 SiLU (see mage_hip.h)."""
+    l, s = _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous()
+    assert residual is None or (residual.dtype == torch.float32 and residual.is_contiguous())
+    Cc = x.shape[-1]
+    stats = torch.empty(n_samples, groups, 2, device=x.device, dtype=torch.float32)
+    _lib.check(l.mage_groupnorm_act(x.data_ptr(), sample_stride_rows, row_off, n_samples, rows_per_sample, Cc, groups,
+                                    gamma.data_ptr(), beta.data_ptr(), float(eps), stats.data_ptr(), _p(residual), act, y.data_ptr(),
+                                    code(y), rows_per_sample if y_sample_stride_rows is None else y_sample_stride_rows, y_row_off, s), l)
+    return y
+
+
+def reparam_kl(mu, logvar, eps, out, kl_sum):
+    """out = eps * exp(0.5 logvar) + mu; kl_sum[b] = sum(1 + logvar - mu^2 - exp(logvar)) over sample b.  All [B, n] fp32."""
+    l, s = _dev(mu)
+    B = mu.shape[0]
+    n = mu.numel() // B
+    for t_ in (mu, logvar, eps, out):
+        assert t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == B * n
+    _lib.check(l.mage_reparam_kl(mu.data_ptr(), logvar.data_ptr(), eps.data_ptr(), out.data_ptr(), kl_sum.data_ptr(), B, n, s), l)
+    return out
 
 
 def mlp_fused(xn, w_fc, b_fc, w_proj, b_proj, x):

@@ -119,6 +119,36 @@ def test_mage_cater_randomness_branch_golden():
     np.testing.assert_allclose(chk(video.cpu()), g["video_chk"], rtol=1e-4)
 
 
+def test_mage_cater_forward_randomness_golden():
+    """MAGE.forward with randomness=True through the HIP path (Conv3d video prior as temporal-tap GEMMs + GroupNorm kernels,
+    reparameterisation with the reference's noise injected, KL + speed-l2 terms) against the reference's own loss values, its
+    conv3d output and its teacher-forced logits (fp32 mode), and against the CPU oracle."""
+    from oracle import mage_oracle as O
+    from tests.helpers import cpu_sd
+    g = golden("mage_cater_forward_small")
+    B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
+    cfg = synth.cater_model_config(frames_length=L, width=int(g["width"]), layers=int(g["layers"]), vq_dim=int(g["vq_dim"]), K=int(g["K"]))
+    m = build_mage(cfg, seed, DEV)
+    batch = synth.synth_batch_cater(B, L, seed=seed, text_len=int(g["text_len"]))
+    db = dev_batch(batch)
+    db["reparam_noise"] = t(g["eps"]).to(DEV)
+    extras = {}
+    tok, logits = m.teacher_forced_logits(db, extras)
+    R = 16
+    prior = extras["prior"].view(B, R, R, -1).permute(0, 3, 1, 2).cpu()                     # rows -> NCHW
+    torch.testing.assert_close(prior[:, ::4, ::2, ::2], t(g["prior_sub"]), atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(chk(prior), g["prior_chk"], rtol=1e-4)
+    torch.testing.assert_close(logits[:, ::3, ::4, ::4, ::8].cpu(), t(g["logits_sub"]), atol=LOGIT_TOL, rtol=1e-4)
+    loss, ld = m(db)
+    assert abs(ld["val/prediction"] - float(g["prediction"])) < 1e-4
+    assert abs(ld["val/kl_loss"] - float(g["kl_loss"])) < 1e-4 * max(1.0, abs(float(g["kl_loss"])))
+    assert abs(loss.item() - float(g["final_loss"])) < 1e-4 * max(1.0, abs(float(g["final_loss"])))
+    # and the oracle on the same inputs (what smoke()/bench compare against on a box without the reference)
+    sd = cpu_sd(m)
+    final, parts, _, _ = O.mage_forward_loss_random(sd, batch, L, t(g["eps"]), alpha=cfg["params"]["alpha"], beta=cfg["params"]["beta"])
+    assert abs(loss.item() - final.item()) < 1e-4 * max(1.0, abs(final.item()))
+
+
 def test_mage_L16_golden_tokens():
     """BASELINE cfg1 model (MNIST f4, L=16) at B=2: the reference's own token sequence."""
     g = golden("mage_mnist_L16")
