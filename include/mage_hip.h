@@ -238,6 +238,11 @@ int mage_groupnorm_act(const float* x, int64_t sample_stride_rows, int64_t row_o
 int mage_reparam_kl(const float* mu, const float* logvar, const float* eps, float* out, float* kl_sum, int32_t B, int64_t n,
                     void* stream);
 
+/* out[0] = mean over rows x cols of (a[r*lda + c] - b[r*ldb + c])^2, fp32 inputs, fp64 fixed-order accumulation
+ * (F.mse_loss of the MAGE+ latent prediction, mage_model.py:620).  workspace: 256 doubles. */
+int mage_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t cols, double* workspace, float* out,
+             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,7 @@ SIGNATURES = {
     "mage_groupnorm_silu": (C.c_int, [vp, i64, i64, i32, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp]),
     "mage_groupnorm_act": (C.c_int, [vp, i64, i64, i32, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, i32, i64, i64, vp]),
     "mage_reparam_kl": (C.c_int, [vp, vp, vp, vp, vp, i32, i64, vp]),
+    "mage_mse": (C.c_int, [vp, i64, vp, i64, i64, i32, vp, vp, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -550,3 +550,40 @@ extern "C" int mage_reparam_kl(const float* mu, const float* logvar, const float
     MAGE_CHECK_LAUNCH("mage_reparam_kl");
     return MAGE_OK;
 }
+
+// ------------------------------------------------------------------------------------ mean squared error (MAGE+ latent loss)
+namespace {
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                                          long rows, int cols, double* __restrict__ partial) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    const long total = rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float dlt = a[r * lda + c] - b[r * ldb + c];
+        acc += (double)(dlt * dlt);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void mse_final_kernel(const double* __restrict__ partial, int n, double inv_count, float* __restrict__ out) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += partial[i];          // fixed order: deterministic
+    out[0] = (float)(s * inv_count);
+}
+}  // namespace
+
+extern "C" int mage_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t cols, double* workspace,
+                        float* out, void* stream) {
+    MAGE_CHECK_ARG(a && b && workspace && out && rows > 0 && cols > 0, "mage_mse: bad arguments");
+    const int nblk = (int)((rows * cols + 255) / 256 < 256 ? (rows * cols + 255) / 256 : 256);
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a, (long)lda, b, (long)ldb, (long)rows, cols,
+                       workspace);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, workspace, nblk, 1.0 / ((double)rows * cols), out);
+    MAGE_CHECK_LAUNCH("mage_mse");
+    return MAGE_OK;
+}

@@ -805,9 +805,9 @@ class MAGE(nn.Module):
     # ------------------------------------------------------------------ teacher-forced pass (mage_model.py:575-639)
     @torch.no_grad()
     @torch.no_grad()
-    def _video_prior(self, tok: torch.Tensor) -> torch.Tensor:
-        """self.conv3d over the token embeddings of ALL frames (mage_model.py:496-501,602-603): tok int64 [B, L, hw] -> rows
-        [B*hw, d_model] fp32.  Each Conv3d(3x3x3, temporal stride s, pad 1) is three implicit-GEMM launches, one per temporal tap,
+    def _video_prior(self, tok: Optional[torch.Tensor], lat_rows: Optional[torch.Tensor] = None, B: int = 0, L: int = 0) -> torch.Tensor:
+        """self.conv3d over the token embeddings of ALL frames (mage_model.py:496-501,602-603): tok int64 [B, L, hw] (or, for
+        use_cids=False, lat_rows [B*L*hw, 8] fp32 latents whose Linear(E -> C) embedding is taken) -> rows [B*hw, d_model] fp32.  Each Conv3d(3x3x3, temporal stride s, pad 1) is three implicit-GEMM launches, one per temporal tap,
         accumulating in place: the block input lives in a zero-padded frame buffer in which clip b owns frames
         [b*Lp, (b+1)*Lp) (frame 0 = the leading zero pad) with Lp = s * (virtual output frames per clip), so that output image
         i' = b*Lv + t' gathers from frame s*i' + kd: one affine image stride for the whole batch, the clip boundaries and the
@@ -815,8 +815,9 @@ class MAGE(nn.Module):
         d = self._derived.get(self._build)
         R, Cc = self.image_resolution, self.vision_width
         hw = R * R
-        B, L = tok.shape[0], tok.shape[1]
-        dev = tok.device
+        if tok is not None:
+            B, L = tok.shape[0], tok.shape[1]
+        dev = tok.device if tok is not None else lat_rows.device
 
         def conv3(xpad, key, Lv, s_t, cin, cout):
             out = torch.empty(B * Lv * hw, cout, device=dev, dtype=F32)
@@ -830,7 +831,12 @@ class MAGE(nn.Module):
         Lout = (Lin + 1) // 2
         Lp = 2 * (Lout + 1)
         xa = torch.zeros((B * Lp + 1) * hw, Cc, device=dev, dtype=F32)                        # block 0 input: the embeddings
-        ops.embedding(tok.reshape(-1).contiguous(), d["emb"], xa, group=L * hw, group_stride=Lp * hw, off=hw)
+        if tok is not None:
+            ops.embedding(tok.reshape(-1).contiguous(), d["emb"], xa, group=L * hw, group_stride=Lp * hw, off=hw)
+        else:                                                      # Linear(E -> C) straight into the padded frame buffer (:583)
+            E = d["emb_lin.w"].shape[1]
+            ops.gemm(lat_rows, d["emb_lin.w"], xa, M=B * L * hw, N=Cc, K=E, lda=lat_rows.shape[1], ldy=Cc, out_w=L * hw,
+                     y_img_stride=Lp * hw, y_off=hw, bias=d["emb_lin.b"])
         cin = Cc
         for i, blk in enumerate(self.conv3d):
             cout = blk.conv1.out_channels
@@ -865,33 +871,61 @@ class MAGE(nn.Module):
         images = batch["images"]
         _need_gpu(images, "MAGE.forward")
         if not self.use_cids:
-            raise NotImplementedError("MAGE.forward with use_cids=False is a 'next' row (SURVEY.md 8f-3)")
+            raise NotImplementedError("teacher_forced_logits is the use_cids=True path; MAGE.forward handles use_cids=False")
         B = images.shape[0]
         R, L = self.image_resolution, self.frames_length
         dt = self._dt()
         tok = self.first_stage_encode(images).reshape(B, -1, R * R)                          # :579
-        video_rows = None
-        if self.randomness:
-            d = self._derived.get(self._build)
-            prior = self._video_prior(tok)                                                    # :602-603
-            Cp, dev = prior.shape[1], prior.device
-            mu = VectorQuantizedVAE._conv(prior, d["mu2.w"], torch.empty(B * R * R, 64, device=dev, dtype=F32), n_img=B, H=R, W=R,
-                                          cin=Cp, cout=64, k=3, bias=d["mu2.b"])              # :570
-            logvar = VectorQuantizedVAE._conv(prior, d["var2.w"], torch.empty_like(mu), n_img=B, H=R, W=R, cin=Cp, cout=64, k=3,
-                                              bias=d["var2.b"])
-            eps = batch.get("reparam_noise")                                                  # [B,64,h,w]; else torch.randn (:571)
-            if eps is None:
-                eps = torch.randn(B, 64, R, R, device=dev)
-            eps = eps.to(dev).float().permute(0, 2, 3, 1).reshape(B * R * R, 64).contiguous()
-            kl_sum = torch.empty(B, device=dev, dtype=F32)
-            video_rows = ops.reparam_kl(mu.view(B, -1), logvar.view(B, -1), eps.view(B, -1), torch.empty_like(mu).view(B, -1), kl_sum)
-            video_rows = video_rows.view(B * R * R, 64)
-            if extras is not None:
-                extras.update(kl_sum=kl_sum, prior=prior)
+        video_rows = self._reparam_video_rows(batch, B, extras, tok=tok) if self.randomness else None
         ma = self._motion_anchor(tok[:, 0].contiguous(), batch, None, video_rows=video_rows)
         feats = self._frame_features(tok[:, :L - 1].contiguous(), dt)
         logits = self.generate_model._run(ma if dt == F32 else ma.to(dt), feats, B=B, hh=R, ww=R)
         return tok.view(B, -1, R, R), logits.view(B, L - 1, R, R, self.codebook_size)
+
+    def _reparam_video_rows(self, batch, B: int, extras: Optional[dict], tok=None, lat_rows=None, L: int = 0) -> torch.Tensor:
+        """Conv3d video prior -> conv_mu2 / conv_var2 -> reparameterisation (mage_model.py:601-604,569-573): rows [B*hw, 64]
+        (before conv_d2); extras receives 'kl_sum' [B] and 'prior' rows."""
+        R = self.image_resolution
+        d = self._derived.get(self._build)
+        prior = self._video_prior(tok, lat_rows, B, L)                                    # :602-603
+        Cp, dev = prior.shape[1], prior.device
+        mu = VectorQuantizedVAE._conv(prior, d["mu2.w"], torch.empty(B * R * R, 64, device=dev, dtype=F32), n_img=B, H=R, W=R,
+                                      cin=Cp, cout=64, k=3, bias=d["mu2.b"])              # :570
+        logvar = VectorQuantizedVAE._conv(prior, d["var2.w"], torch.empty_like(mu), n_img=B, H=R, W=R, cin=Cp, cout=64, k=3,
+                                          bias=d["var2.b"])
+        eps = batch.get("reparam_noise")                                                  # [B,64,h,w]; else torch.randn (:571)
+        if eps is None:
+            eps = torch.randn(B, 64, R, R, device=dev)
+        eps = eps.to(dev).float().permute(0, 2, 3, 1).reshape(B * R * R, 64).contiguous()
+        kl_sum = torch.empty(B, device=dev, dtype=F32)
+        video_rows = ops.reparam_kl(mu.view(B, -1), logvar.view(B, -1), eps.view(B, -1), torch.empty_like(mu).view(B, -1), kl_sum)
+        video_rows = video_rows.view(B * R * R, 64)
+        if extras is not None:
+            extras.update(kl_sum=kl_sum, prior=prior)
+        return video_rows
+
+    @torch.no_grad()
+    def _forward_latent(self, batch, extras: dict):
+        """use_cids=False (MAGE+, mage_model.py:579,583,620): latents of ALL frames from the external first stage, teacher-forced
+        latent prediction, MSE.  Returns (mse 0-dim tensor, pred rows [B*(L-1)*hw, 8])."""
+        images = batch["images"]
+        B = images.shape[0]
+        R, L = self.image_resolution, self.frames_length
+        hw, dt = R * R, self._dt()
+        E, LD = self.first_stage_model.embed_dim, 8
+        lat = self.first_stage_encode(images)                                                 # [B, L, E, h, w]
+        Lb = lat.shape[1]
+        rows = torch.zeros(B, Lb, hw, LD, device=images.device, dtype=F32)
+        rows[..., :E] = lat.permute(0, 1, 3, 4, 2).reshape(B, Lb, hw, E).float()              # layout plumbing (channels last)
+        video_rows = None
+        if self.randomness:
+            video_rows = self._reparam_video_rows(batch, B, extras, lat_rows=rows.view(-1, LD), L=Lb)
+        first = self._frame_features_latent(rows[:, 0].contiguous().view(-1, LD), LD, F32)
+        ma = self._motion_anchor(None, batch, None, first=first, video_rows=video_rows)
+        feats = self._frame_features_latent(rows[:, :L - 1].contiguous().view(-1, LD), LD, dt)
+        pred = self.generate_model._run(ma if dt == F32 else ma.to(dt), feats, B=B, hh=R, ww=R)      # [B*(L-1)*hw, 8]
+        tgt = rows[:, 1:L].contiguous().view(-1, LD)
+        return ops.mse(pred, tgt, rows=B * (L - 1) * hw, cols=E, lda=pred.shape[1], ldb=LD), pred
 
     def forward(self, batch, test_flag=False):
         """(loss, loss_dict) of the teacher-forced pass (mage_model.py:575-639), incl. the randomness=True terms (KL of the
@@ -902,9 +936,13 @@ class MAGE(nn.Module):
             raise NotImplementedError("forward(test_flag=True) replaces the video embedding by noise AFTER computing it; use "
                                       "autoregressive_generate for sampling")
         extras: dict = {}
-        tok, logits = self.teacher_forced_logits(batch, extras)
         L = self.frames_length
-        recon = ops.cross_entropy(logits.reshape(-1, self.codebook_size), tok[:, 1:L].reshape(-1).contiguous())   # :618
+        if self.use_cids:
+            tok, logits = self.teacher_forced_logits(batch, extras)
+            recon = ops.cross_entropy(logits.reshape(-1, self.codebook_size), tok[:, 1:L].reshape(-1).contiguous())   # :618
+        else:
+            _need_gpu(batch["images"], "MAGE.forward")
+            recon, self.last_logits = self._forward_latent(batch, extras)                                            # :620
         prefix = "train" if self.training else "val"
         ld = {f"{prefix}/prediction": recon.item()}
         final = recon

@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc
 
 __all__ = ["gemm", "layernorm", "attention", "embedding", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
-           "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mlp_fused", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
+           "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mse", "mlp_fused", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
            "PROFILE", "F32", "BF16", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
 
 
@@ -331,6 +331,16 @@ def reparam_kl(mu, logvar, eps, out, kl_sum):
         assert t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == B * n
     _lib.check(l.mage_reparam_kl(mu.data_ptr(), logvar.data_ptr(), eps.data_ptr(), out.data_ptr(), kl_sum.data_ptr(), B, n, s), l)
     return out
+
+
+def mse(a, b, *, rows, cols, lda, ldb):
+    """mean((a[:, :cols] - b[:, :cols])^2) over `rows` rows with row strides lda / ldb (fp32) -> 0-dim fp32 tensor."""
+    l, s = _dev(a)
+    assert a.dtype == torch.float32 and b.dtype == torch.float32
+    out = torch.empty(1, device=a.device, dtype=torch.float32)
+    ws = torch.empty(256, device=a.device, dtype=torch.float64)
+    _lib.check(l.mage_mse(a.data_ptr(), lda, b.data_ptr(), ldb, rows, cols, ws.data_ptr(), out.data_ptr(), s), l)
+    return out[0]
 
 
 def mlp_fused(xn, w_fc, b_fc, w_proj, b_proj, x):

@@ -418,3 +418,30 @@ def mage_generate_latent(sd: SD, batch: Dict[str, torch.Tensor], frames_length: 
         if i != Lm1 - 1:
             cur[:, i + 1] = pred[:, i].permute(0, 3, 1, 2)
     return pred
+
+
+def mage_forward_loss_latent(sd: SD, batch: Dict[str, torch.Tensor], frames_length: int, lat: torch.Tensor, eps: torch.Tensor,
+                             v_kl: float, pid):
+    """MAGE.forward (mage_model.py:575-639) for use_cids=False with randomness=True and auto_beta=True (config/mage+_*.yaml),
+    between the external first stage's encode and the loss: lat [B,L,E,h,w] = first_stage_encode(images), eps the injected
+    reparameterisation noise.  Returns (final_loss, parts, predicted latents [B,L-1,h,w,E])."""
+    B, L, E, h, w = lat.shape
+    x_emb = F.linear(lat.permute(0, 1, 3, 4, 2), sd["visual_token_embedding.weight"], sd["visual_token_embedding.bias"])
+    x_emb = x_emb.permute(0, 1, 4, 2, 3)                                                          # :583
+    prior = video_prior(sd, x_emb)
+    mu = F.conv2d(prior, sd["conv_mu2.weight"], sd["conv_mu2.bias"], padding=1)
+    logvar = F.conv2d(prior, sd["conv_var2.weight"], sd["conv_var2.bias"], padding=1)
+    video_emb = eps * (0.5 * logvar).exp() + mu
+    first = _frame_features_latent(sd, lat[:, :1])[:, 0].reshape(B, h * w, -1)
+    txt = text_encoder(sd, "text_encoder.", batch["text"])
+    ma = adain(sd, ma_encoder(sd, "ma_encoder.", first, txt).view(B, h, w, -1), video_emb)
+    if batch.get("speed") is not None:
+        ma = ma + (batch["speed"].view(B, 1) @ sd["speed_embedding"])[:, None, None, :]
+    pred = flat_axial_decoder_latent(sd, "generate_model.", ma, _frame_features_latent(sd, lat[:, :frames_length - 1]))
+    recon = F.mse_loss(pred.permute(0, 1, 4, 2, 3), lat[:, 1:frames_length])                       # :620
+    mu2, lv2 = mu.reshape(B, -1), logvar.reshape(B, -1)
+    kl = -0.5 * torch.mean(torch.sum(1 + lv2 - mu2.pow(2) - lv2.exp(), dim=1))
+    beta, _ = pid.pid(v_kl, kl.item())
+    final = recon + beta * kl
+    return final, {"prediction": recon.item(), "kl_loss": kl.item(), "beta": beta, "final_loss": final.item()}, pred
+

@@ -149,6 +149,24 @@ def test_mage_cater_forward_randomness_golden():
     assert abs(loss.item() - final.item()) < 1e-4 * max(1.0, abs(final.item()))
 
 
+def test_mage_plus_forward_latent_golden():
+    """MAGE.forward for use_cids=False on the HIP path (Linear embedding written straight into the padded frame buffer of the
+    video prior, MSE kernel, PID-controlled beta) against the reference's own loss values and predicted latents."""
+    g = golden("mage_plus_forward_small")
+    B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
+    cfg = synth.magep_model_config(frames_length=L, width=int(g["width"]), layers=int(g["layers"]))
+    m = build_mage(cfg, seed, DEV)
+    db = dev_batch(synth.synth_batch_cater(B, L, seed=seed, text_len=int(g["text_len"]), vocab=50))
+    db["reparam_noise"] = t(g["eps"]).to(DEV)
+    loss, ld = m(db)
+    pred = m.last_logits.view(B, L - 1, 16, 16, -1)[..., :4].cpu()
+    torch.testing.assert_close(pred, t(g["pred"]), atol=2e-4, rtol=1e-4)
+    assert abs(ld["val/prediction"] - float(g["prediction"])) < 1e-4 * max(1.0, abs(float(g["prediction"])))
+    assert abs(ld["val/kl_loss"] - float(g["kl_loss"])) < 1e-4 * max(1.0, abs(float(g["kl_loss"])))
+    assert abs(ld["val/beta"] - float(g["beta"])) < 1e-6
+    assert abs(loss.item() - float(g["final_loss"])) < 1e-4 * max(1.0, abs(float(g["final_loss"])))
+
+
 def test_mage_L16_golden_tokens():
     """BASELINE cfg1 model (MNIST f4, L=16) at B=2: the reference's own token sequence."""
     g = golden("mage_mnist_L16")

@@ -111,6 +111,26 @@ def test_mage_cater_forward_randomness_losses():
     assert abs(final.item() - float(g["final_loss"])) < 1e-5 * max(1.0, abs(float(g["final_loss"])))
 
 
+def test_mage_plus_forward_latent_losses():
+    """MAGE.forward for use_cids=False (MSE on latents, randomness + PID-controlled beta: config/mage+_*.yaml) over the stand-in
+    latent first stage, against the reference's own (loss, loss_dict) and predicted latents."""
+    from modules.mage_model import PIDControl
+    from tests.standin_first_stage import StandInLatentFirstStage
+    g = golden("mage_plus_forward_small")
+    B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
+    cfg = synth.magep_model_config(frames_length=L, width=int(g["width"]), layers=int(g["layers"]))
+    sd = cpu_sd(build_mage(cfg, seed))
+    batch = synth.synth_batch_cater(B, L, seed=seed, text_len=int(g["text_len"]), vocab=50)
+    fs = StandInLatentFirstStage()
+    lat = fs.encode(batch["images"].reshape(B * L, *batch["images"].shape[2:])).view(B, L, 4, 16, 16)
+    final, parts, pred = O.mage_forward_loss_latent(sd, batch, L, lat, t(g["eps"]), v_kl=cfg["params"]["v_kl"], pid=PIDControl())
+    assert torch.allclose(pred, t(g["pred"]), atol=1e-4, rtol=1e-4)
+    assert abs(parts["prediction"] - float(g["prediction"])) < 1e-5 * max(1.0, abs(float(g["prediction"])))
+    assert abs(parts["kl_loss"] - float(g["kl_loss"])) < 1e-4 * max(1.0, abs(float(g["kl_loss"])))
+    assert abs(parts["beta"] - float(g["beta"])) < 1e-9
+    assert abs(final.item() - float(g["final_loss"])) < 1e-5 * max(1.0, abs(float(g["final_loss"])))
+
+
 def test_mage_L16_tokens():
     g = golden("mage_mnist_L16")
     sd = cpu_sd(build_mage(synth.mnist_model_config(frames_length=16), int(g["seed"])))

@@ -76,6 +76,27 @@ def gen_forward_random(ref_mage):
          final_loss=np.float64(loss.item()), prediction=np.float64(ld["val/prediction"]), kl_loss=np.float64(ld["val/kl_loss"]),
          prior_sub=prior[:, ::4, ::2, ::2].contiguous(), prior_chk=chk(prior), logits_sub=cap["logits"][:, ::3, ::4, ::4, ::8].contiguous(),
          logits_chk=chk(cap["logits"]))
+    # MAGE+ (use_cids=False, auto_beta): MSE on the latents of a stand-in first stage, PID-controlled beta
+    print("mage_plus_forward_small")
+    cfg = synth.magep_model_config(frames_length=10, width=64, layers=3)
+    m = build_ref_mage(ref_mage, cfg, 71)
+    batch = synth.synth_batch_cater(2, 10, seed=71, text_len=12, vocab=50)
+    eps2 = torch.from_numpy(synth.rng_for(71, "reparam_noise").standard_normal((2, 64, 16, 16)).astype(np.float32))
+
+    def fake_randn_like2(t, *a, **k):
+        return eps2.clone() if tuple(t.shape) == tuple(eps2.shape) else real_randn_like(t, *a, **k)
+    cap = {}
+    h2 = m.generate_model.register_forward_hook(lambda mod, i, o: cap.__setitem__("pred", o.detach().clone()))
+    torch.randn_like = fake_randn_like2
+    try:
+        with torch.no_grad():
+            loss, ld = m({k: v.clone() for k, v in batch.items()})
+    finally:
+        torch.randn_like = real_randn_like
+        h2.remove()
+    save("mage_plus_forward_small", seed=71, B=2, L=10, width=64, layers=3, text_len=12, eps=eps2,
+         final_loss=np.float64(loss.item()), prediction=np.float64(ld["val/prediction"]), kl_loss=np.float64(ld["val/kl_loss"]),
+         beta=np.float64(ld["val/beta"]), pred=cap["pred"])
 
 
 def main():
