@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, 
 }
 
 // ------------------------------------------------------------------------------------ attention on the matrix cores
-// bf16, nq <= 16 and nk <= 16 (every axial attention of the decoder): one wave per (sequence, head), three MFMA steps.
+// bf16, nq <= 32 and nk <= 32 (every axial attention of the decoder, frames_length up to 32): one wave per (sequence, head),
+// three MFMA steps per block of 16 queries (and per block of 16 keys).
 //   S^T = K Q^T   (v_mfma_f32_16x16x32_bf16, operands straight from global: lane (r = lane&15, g = lane>>4) loads the 16
 //                  bytes [g*8, g*8+8) of row r of K resp. Q): the result lane (i = lane&15, g) holds S^T[j = 4g+e][i], e=0..3,
 //                  i.e. four consecutive keys of ITS query -- exactly the B-operand layout of the next MFMA (swapped-QK idiom).
@@ -170,9 +171,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, 
 typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
 typedef __attribute__((ext_vector_type(4))) short ashort4;
 
-__global__ __launch_bounds__(256) void attention_mfma16_kernel(const mage_attn_desc d) {
+// NKB = key blocks of 16 (nk <= 16*NKB); queries are walked in blocks of 16 (nq <= 32 at the call sites: frames_length 32).
+template <int NKB>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const mage_attn_desc d) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    unsigned short* vs = (unsigned short*)smem_raw;     // [16][n_head*32 + 16]: rows >= nk are zero
+    unsigned short* vs = (unsigned short*)smem_raw;     // [16*NKB][n_head*32 + 16]: rows >= nk are zero
     const int rowf = d.n_head * 32, vpitch = rowf + 16;
     const int s = blockIdx.x;
     const int outer = s / d.inner, in = s - outer * d.inner;
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256) void attention_mfma16_kernel(const mage_attn_d
     const unsigned short* vp = (const unsigned short*)d.v;
     unsigned short* op = (unsigned short*)d.out;
     const int vec_per_row = rowf / 8;
-    for (int e = threadIdx.x; e < 16 * vec_per_row; e += 256) {
+    for (int e = threadIdx.x; e < 16 * NKB * vec_per_row; e += 256) {
         const int j = e / vec_per_row, c = (e - j * vec_per_row) * 8;
         uint4 val = uint4{0u, 0u, 0u, 0u};
         if (j < d.nk) val = *(const uint4*)(vp + (kv_base + (long)j * d.kv_axis_stride) * d.ldv + c);
@@ -193,75 +196,91 @@ __global__ __launch_bounds__(256) void attention_mfma16_kernel(const mage_attn_d
     if (d.kv_len) klen = min(klen, d.kv_len[s / d.kv_len_div]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    // rows this lane loads its Q / K fragments from (clamped: out-of-range queries are never stored, keys are masked)
-    const long qrow = q_base + (long)min(r, d.nq - 1) * d.q_axis_stride;
-    const long krow = kv_base + (long)min(r, d.nk - 1) * d.kv_axis_stride;
-    const int jmax = d.causal ? min(klen, r + 1 + (d.nk - d.nq)) : klen;      // query i = r sees keys j < jmax
-    // all of this wave's Q/K fragments up front (independent 16-byte loads)
+    // all of this wave's K fragments up front (independent 16-byte loads; out-of-range keys clamped, masked below)
     constexpr int MAXH = 8;                                                   // heads per wave (n_head <= 32)
-    uint4 qf[MAXH], kf[MAXH];
+    uint4 kf[MAXH][NKB];
 #pragma unroll
     for (int t = 0; t < MAXH; ++t) {
         const int h = wave + 4 * t;
         if (h < d.n_head) {
-            qf[t] = *(const uint4*)(qp + qrow * d.ldq + h * 32 + g * 8);
-            kf[t] = *(const uint4*)(kp + krow * d.ldk + h * 32 + g * 8);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const long krow = kv_base + (long)min(kb * 16 + r, d.nk - 1) * d.kv_axis_stride;
+                kf[t][kb] = *(const uint4*)(kp + krow * d.ldk + h * 32 + g * 8);
+            }
         }
     }
     __syncthreads();
+    const int nqb = (d.nq + 15) >> 4;
+    for (int qb = 0; qb < nqb; ++qb) {
+        const int qi = qb * 16 + r;                                           // this lane's query
+        const long qrow = q_base + (long)min(qi, d.nq - 1) * d.q_axis_stride;
+        const int jmax = d.causal ? min(klen, qi + 1 + (d.nk - d.nq)) : klen;  // query qi sees keys j < jmax
+        uint4 qf[MAXH];
 #pragma unroll
-    for (int t = 0; t < MAXH; ++t) {
-        const int h = wave + 4 * t;
-        if (h >= d.n_head) break;
-        f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(abf16x8, kf[t]), __builtin_bit_cast(abf16x8, qf[t]),
-                                                           f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        float mx = -INFINITY;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            st[e] = (4 * g + e < jmax) ? st[e] * d.scale : -INFINITY;
-            mx = fmaxf(mx, st[e]);
+        for (int t = 0; t < MAXH; ++t) {
+            const int h = wave + 4 * t;
+            if (h < d.n_head) qf[t] = *(const uint4*)(qp + qrow * d.ldq + h * 32 + g * 8);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float den = 0.f;
-        f32x4 p;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            p[e] = (4 * g + e < jmax) ? expf(st[e] - mx) : 0.f;
-            den += p[e];
-        }
-        den += __shfl_xor(den, 16);
-        den += __shfl_xor(den, 32);
-        // P = hi + lo in bf16 (lo = the rounding residue of hi): two B operands
-        ashort4 phi, plo;
+        for (int t = 0; t < MAXH; ++t) {
+            const int h = wave + 4 * t;
+            if (h >= d.n_head) break;
+            f32x4 st[NKB];
+            float mx = -INFINITY;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned hb = __float_as_uint(p[e]) & 0xffff0000u;          // truncation: the residue is exactly representable
-            phi[e] = (short)(hb >> 16);
-            plo[e] = (short)(__float_as_uint(p[e] - __uint_as_float(hb)) >> 16);
-        }
-        f32x4 o[2];
+            for (int kb = 0; kb < NKB; ++kb) {
+                st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(abf16x8, kf[t][kb]), __builtin_bit_cast(abf16x8, qf[t]),
+                                                                 f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const unsigned short* vr = vs + (4 * g) * vpitch + h * 32 + b * 16 + r;
-            ashort4 vt;
+                for (int e = 0; e < 4; ++e) {
+                    st[kb][e] = (kb * 16 + 4 * g + e < jmax) ? st[kb][e] * d.scale : -INFINITY;
+                    mx = fmaxf(mx, st[kb][e]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float den = 0.f;
+            ashort4 phi[NKB], plo[NKB];                                       // P = hi + lo in bf16 (lo = the truncation residue)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vt[e] = (short)vr[e * vpitch];
-            o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, phi, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, plo, o[b], 0, 0, 0);
-        }
-        // lane (i = r, g) holds O[i][b*16 + 4g + e]; swap halves between neighbouring lane groups: 8 consecutive dims per lane
-        const float inv = 1.0f / den;
-        f32x4 v0, v1;
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[0][e]), __float_as_uint(o[1][e]), false, false);
-            v0[e] = __uint_as_float(sw[0]) * inv;
-            v1[e] = __uint_as_float(sw[1]) * inv;
-        }
-        if (r < d.nq) {
-            const int col = h * 32 + 16 * (g & 1) + 8 * (g >> 1);
-            store8(op + (q_base + (long)r * d.q_axis_stride) * d.ldo + col, v0, v1);
+                for (int e = 0; e < 4; ++e) {
+                    const float p = (kb * 16 + 4 * g + e < jmax) ? expf(st[kb][e] - mx) : 0.f;
+                    den += p;
+                    const unsigned hb = __float_as_uint(p) & 0xffff0000u;
+                    phi[kb][e] = (short)(hb >> 16);
+                    plo[kb][e] = (short)(__float_as_uint(p - __uint_as_float(hb)) >> 16);
+                }
+            den += __shfl_xor(den, 16);
+            den += __shfl_xor(den, 32);
+            f32x4 o[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                o[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    const unsigned short* vr = vs + (kb * 16 + 4 * g) * vpitch + h * 32 + b * 16 + r;
+                    ashort4 vt;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vt[e] = (short)vr[e * vpitch];
+                    o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, phi[kb], o[b], 0, 0, 0);
+                    o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, plo[kb], o[b], 0, 0, 0);
+                }
+            }
+            // lane (i = r, g) holds O[i][b*16 + 4g + e]; swap halves between neighbouring lane groups: 8 consecutive dims per lane
+            const float inv = 1.0f / den;
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[0][e]), __float_as_uint(o[1][e]), false, false);
+                v0[e] = __uint_as_float(sw[0]) * inv;
+                v1[e] = __uint_as_float(sw[1]) * inv;
+            }
+            if (qi < d.nq) {
+                const int col = h * 32 + 16 * (g & 1) + 8 * (g >> 1);
+                store8(op + (q_base + (long)qi * d.q_axis_stride) * d.ldo + col, v0, v1);
+            }
         }
     }
 }
@@ -334,10 +353,12 @@ template <typename T>
 int attn_launch(const mage_attn_desc* d, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         // the axial attentions: short sequences on the matrix cores (16-byte aligned 64-byte head segments)
-        if (d->nq <= 16 && d->nk <= 16 && d->n_head <= 32 && !getenv("MAGE_ATTN_NO_MFMA") &&
+        if (d->nq <= 32 && d->nk <= 32 && d->n_head <= 32 && !getenv("MAGE_ATTN_NO_MFMA") &&
             ((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->out) & 15) == 0)) {
-            const size_t lds = (size_t)16 * (d->n_head * 32 + 16) * 2;
-            hipLaunchKernelGGL(attention_mfma16_kernel, dim3(d->n_seq), dim3(256), lds, s, *d);
+            const int nkb = d->nk <= 16 ? 1 : 2;
+            const size_t lds = (size_t)16 * nkb * (d->n_head * 32 + 16) * 2;
+            if (nkb == 1) hipLaunchKernelGGL(attention_mfma_kernel<1>, dim3(d->n_seq), dim3(256), lds, s, *d);
+            else hipLaunchKernelGGL(attention_mfma_kernel<2>, dim3(d->n_seq), dim3(256), lds, s, *d);
             MAGE_CHECK_LAUNCH("mage_attention");
             return MAGE_OK;
         }

@@ -237,12 +237,13 @@ def test_attention_key_padding_and_cross():
 
 
 def test_attention_mfma_short_sequences_masks():
-    """The matrix-core attention kernel (bf16, nq, nk <= 16) off the square axial case: a query block appended to a longer key
+    """The matrix-core attention kernel (bf16, nq, nk <= 32: one or two key blocks, query blocks of 16) off the square axial case: a query block appended to a longer key
     cache with the causal mask aligned to the last key (nq = 1 and 3 of nk = 7 and 16: the incremental AR loop), per-sequence
     key lengths, 16 heads, and the same inputs through the vector-ALU kernel (MAGE_ATTN_NO_MFMA is read per call)."""
     import os
     o = ops()
-    for nq, nk, causal, use_len in ((1, 7, True, False), (3, 16, True, False), (5, 12, False, True), (16, 16, True, True)):
+    for nq, nk, causal, use_len in ((1, 7, True, False), (3, 16, True, False), (5, 12, False, True), (16, 16, True, True),
+                                    (1, 29, True, False), (32, 32, True, True), (20, 27, False, True), (17, 32, True, False)):
         B, Cc, H = 6, 512, 16
         q = rnd(B * nq, Cc, seed=50 + nq).bfloat16()
         kv = rnd(B * nk, 2 * Cc, seed=60 + nk).bfloat16()

@@ -8,6 +8,7 @@ m = instantiate_from_config(cfg).eval()
 synth.fill_state_dict(m, 0)
 m = m.to('cuda:0').set_precision('bf16')
 batch = {k: v.to('cuda:0') for k, v in synth.synth_batch_cater(B, L, seed=1).items()}
+batch['video_noise'] = torch.randn(B, 64, 16, 16, generator=torch.Generator().manual_seed(5)).to('cuda:0')   # same ADAIN noise in both modes
 for mode in ('incremental', 'full'):
     m.ar_mode = mode
     v = m.autoregressive_generate(batch); torch.cuda.synchronize()
