@@ -1,5 +1,11 @@
 // Fused GEMM / implicit-GEMM convolution on CDNA4 matrix cores (see include/mage_hip.h, mage_gemm).
 //
+// Two kernels share the tile geometry, the LDS image, the tile schedule and the epilogues:
+//   gemm_kernel  -- the general one (fp32 and bf16, implicit-GEMM gather, every epilogue kind, any K): lockstep K loop, one
+//                   barrier per K slab, described below;
+//   gemm8_kernel -- the 8-phase ping-pong variant for the shapes the decoder spends its time in (bf16, plain A, K % 64 == 0,
+//                   lean epilogue kinds, >= 2 tiles per CU); its schedule and hazard table are at its definition.
+//
 // Persistent kernel: one 512-thread workgroup per CU walks a list of 256 (rows of A, "m") x 256 (rows of W, "n") output
 // tiles.  8 waves as 2(m) x 4(n); each wave owns a 128x64 sub-tile as 8x4 MFMA 16x16 accumulators (128 fp32 registers).
 //
@@ -11,8 +17,8 @@
 // HBM/L2 -> LDS: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip) into a 2-stage ring of K slabs (128 bytes per
 // row = 64 bf16 / 32 fp32; one stage = 256+256 rows = 64 KiB).  The ring is ONE continuous stream across tiles: while
 // the last slab of a tile is multiplied and its epilogue runs, the first slab of the next tile is already in flight.
-// The barrier is a raw `s_barrier` (a `__syncthreads()` would drain vmcnt where it stands); the DMA issue is split in
-// two halves placed in front of the two MFMA batches of an iteration so that the memory queue is fed evenly.
+// The barrier is a raw `s_barrier` (a `__syncthreads()` would drain vmcnt where it stands); the next slab's 8 DMA pieces per
+// wave go out in the first half of a slab's phases, between the MFMA batches.
 //
 // An LDS-DMA writes wave-base + lane*16, so the LDS image is lane-linear: [row][8 chunks of 16 B].  Bank conflicts on
 // the fragment reads are removed by an XOR swizzle applied on the *source* address of the DMA (physical chunk p of row r
