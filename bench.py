@@ -62,7 +62,8 @@ def main():
     cfg = synth.mnist_model_config(frames_length=L)
     model = instantiate_from_config(cfg).eval()
     synth.fill_state_dict(model, 0)
-    cpu_sd = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 and not args.no_cpu_baseline else None
+    cpu_sd = ({k: v.detach().clone() for k, v in model.state_dict().items()}
+              if rank == 0 and world == 1 and not args.no_cpu_baseline else None)      # CPU baseline: rank 0 at N=1 only
     model = model.to(dev).set_precision(args.precision)
     model.ar_mode = args.ar_mode
     model.streams = args.streams
