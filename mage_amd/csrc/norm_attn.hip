@@ -172,7 +172,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
 typedef __attribute__((ext_vector_type(4))) short ashort4;
 
 // NKB = key blocks of 16 (nk <= 16*NKB); queries are walked in blocks of 16 (nq <= 32 at the call sites: frames_length 32).
-template <int NKB>
+// MAXH = heads per wave (ceil(n_head / 4) rounded up to 2, 4 or 8): sizes the preloaded fragment registers; 16 heads -> 4, which
+// keeps the kernel at a register count that lets 4-5 workgroups share a CU (a memory-bound kernel lives off that).
+template <int NKB, int MAXH>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const mage_attn_desc d) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned short* vs = (unsigned short*)smem_raw;     // [16*NKB][n_head*32 + 16]: rows >= nk are zero
@@ -197,7 +199,6 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const mage_attn_des
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
     // all of this wave's K fragments up front (independent 16-byte loads; out-of-range keys clamped, masked below)
-    constexpr int MAXH = 8;                                                   // heads per wave (n_head <= 32)
     uint4 kf[MAXH][NKB];
 #pragma unroll
     for (int t = 0; t < MAXH; ++t) {
@@ -357,8 +358,11 @@ int attn_launch(const mage_attn_desc* d, hipStream_t s) {
             ((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->out) & 15) == 0)) {
             const int nkb = d->nk <= 16 ? 1 : 2;
             const size_t lds = (size_t)16 * nkb * (d->n_head * 32 + 16) * 2;
-            if (nkb == 1) hipLaunchKernelGGL(attention_mfma_kernel<1>, dim3(d->n_seq), dim3(256), lds, s, *d);
-            else hipLaunchKernelGGL(attention_mfma_kernel<2>, dim3(d->n_seq), dim3(256), lds, s, *d);
+            const int hpw = (d->n_head + 3) / 4;
+#define ATTN_MFMA(NKB, MH) hipLaunchKernelGGL((attention_mfma_kernel<NKB, MH>), dim3(d->n_seq), dim3(256), lds, s, *d)
+            if (nkb == 1) { if (hpw <= 2) ATTN_MFMA(1, 2); else if (hpw <= 4) ATTN_MFMA(1, 4); else ATTN_MFMA(1, 8); }
+            else { if (hpw <= 2) ATTN_MFMA(2, 2); else if (hpw <= 4) ATTN_MFMA(2, 4); else ATTN_MFMA(2, 8); }
+#undef ATTN_MFMA
             MAGE_CHECK_LAUNCH("mage_attention");
             return MAGE_OK;
         }
