@@ -2,12 +2,20 @@
 """Headline benchmark: generated frames/sec of MAGE.autoregressive_generate on synthetic Moving-MNIST-shaped
 clips (BASELINE.json: 64x64, 16-frame clips; cfg2 = MNIST f4 VQ-VAE + MAGE, batch 64 per GPU, bf16 MFMA).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--frames 16] [--precision bf16|fp32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3] [--scaling weak|strong]
+                    [--batch 64] [--global-batch 256] [--frames 16] [--precision bf16|fp32] [--ar-mode full|incremental]
 
 One "step" = one autoregressive_generate(batch) call: VQ-VAE encode of the first frames + text encoder +
 motion-anchor encoder + the reference's L-1 full decoder recomputes + VQ-VAE decode of the L-1 generated
-frames (nothing skipped, inputs resident in HBM).  N > 1: one process per GPU (torchrun), clips sharded
-across ranks, no data-path collective (clips are independent), weak scaling.  Rank 0 prints ONE JSON line.
+frames (nothing skipped, inputs resident in HBM).
+
+N > 1: one process per GPU.  Under torchrun (RANK / WORLD_SIZE in the environment) this process is one rank; started
+plainly with --gpus N it launches the N ranks itself (mage_amd.utils.dist.launch_ranks -> python -m
+torch.distributed.run, the counterpart of the reference's mp.spawn, main_mage.py:279-295).  Clips are sharded across
+ranks, no data-path collective (clips are independent); RCCL carries the barrier, the max-over-ranks timing and the
+`ranks_seen` all-reduce.  --scaling weak (default, the driver's contract): --batch clips per GPU; --scaling strong:
+--global-batch clips split evenly (cfg3 = Double Moving MNIST, 256 clips, ragged 16/18/20-token captions).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -22,14 +30,32 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3        # fp32-input MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0          # HBM3E (MI355X_MICROARCH.md)
+DEC_FLOP_PER_FRAME = 1.216e9   # f4 VQ-VAE decode (forward hooks on the reference modules)
+DEC_BYTES_PER_FRAME = {"bf16": 2.2365e6, "fp32": 4.473e6}   # layer-materialised traffic model of SURVEY.md 8d
 
 
-def main():
+def call_flops(B, L, d=512, K=512, hw=256):
+    """FLOPs of one autoregressive_generate call as the reference computes it:
+    (L-1) * (F_step + F_conv) + VQ-VAE encode of B frames + decode of B(L-1) frames (the once-per-clip prologue, < 0.1 %,
+    is left out).  F_step = N_tok (2 d^2 + 6 * 24 d^2) + N_tok 4 d (2 L + 64) + B (L-1) hw 2 d K."""
+    n_tok = B * L * hw
+    f_step = n_tok * (2 * d * d + 6 * 24 * d * d) + n_tok * 4 * d * (2 * L + 64) + B * (L - 1) * hw * 2 * d * K
+    f_conv = B * (L - 1) * hw * 18 * d * d
+    return (L - 1) * (f_step + f_conv) + B * DEC_FLOP_PER_FRAME + B * (L - 1) * DEC_FLOP_PER_FRAME, f_step
+
+
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"],
+                    help="cfg2: Single Moving MNIST (one digit, 11-token captions); cfg3: Double Moving MNIST (two digits, "
+                         "captions of 16/18/20 tokens right-padded to 20)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=256, help="clips in total (strong scaling; split evenly over the ranks)")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--ar-mode", default="full", choices=["full", "incremental"],
@@ -37,28 +63,50 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="clip groups on concurrent HIP streams inside one generate call (2: +4 %% frames/s, but per-kernel "
                          "event times then overlap: the roofline object needs 1)")
+    ap.add_argument("--graph", type=int, default=1, help="1: replay the AR loop from a captured HIP graph where the model supports it")
     ap.add_argument("--events", default="dominant", choices=["dominant", "all"],
                     help="HIP events inside the timed region: around the dominant GEMM symbol's launches only (it is found, "
                          "and the per-kernel table filled, in the last warm-up call, which brackets every launch), or around "
-                         "every GEMM / attention / LayerNorm launch (937 launches x 2 event packets: ~1 %% slower)")
+                         "every GEMM / attention / LayerNorm launch (~1 %% slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the second AR mode (clean rocprofv3 runs)")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 (parity-gated) pass and the bf16-vs-fp32 token agreement")
+    ap.add_argument("--no-decode-roofline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=4, help="clips of the CPU baseline sample (4 = SURVEY cfg1, the reference's CPU-runnable batch)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def main():
+    args = parse()
     from mage_amd.utils import dist as D
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the N ranks ourselves (one process per GPU) and relay the exit code
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            sys.exit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible")
+        sys.exit(D.launch_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     rank, local_rank, world = D.env_rank_world()
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    D.init_from_env("nccl", dev)            # backend "nccl" is RCCL on ROCm; only barrier + max-reduce use it
+    D.init_from_env("nccl", dev)            # backend "nccl" is RCCL on ROCm; only barrier / max-reduce / ranks_seen use it
+    seen = D.ranks_seen(dev)
 
     from mage_amd import ops
     from mage_amd.utils import synth
     from mage_amd.utils.util import instantiate_from_config
 
-    B, L = args.batch, args.frames
+    L = args.frames
+    wl_kw = dict(digits=1) if args.workload == "cfg2" else dict(digits=2, caption_lengths=(16, 18, 20))
+    if args.scaling == "strong":
+        if args.global_batch % world:
+            sys.exit(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
+        B = args.global_batch // world
+        batch = D.shard_batch(synth.synth_batch_mnist(args.global_batch, L, seed=100, **wl_kw), rank, world)
+    else:
+        B = args.batch
+        batch = synth.synth_batch_mnist(B, L, seed=100 + rank, **wl_kw)
     cfg = synth.mnist_model_config(frames_length=L)
     model = instantiate_from_config(cfg).eval()
     synth.fill_state_dict(model, 0)
@@ -67,25 +115,38 @@ def main():
     model = model.to(dev).set_precision(args.precision)
     model.ar_mode = args.ar_mode
     model.streams = args.streams
-    batch = {k: v.to(dev) for k, v in synth.synth_batch_mnist(B, L, seed=100 + rank).items()}
+    if hasattr(model, "use_graph"):
+        model.use_graph = bool(args.graph)
+    batch = {k: v.to(dev) for k, v in batch.items()}
 
     def sync_all():
         D.barrier()
         torch.cuda.synchronize()
 
+    def prime():
+        """Graph replay: the first call of a (shape, mode, profiling) combination is eager, the second captures the graph;
+        both happen here, outside any timed region."""
+        if getattr(model, "use_graph", False):
+            model.autoregressive_generate(batch)
+            model.autoregressive_generate(batch)
+
     for _ in range(max(args.warmup - 1, 0)):
         model.autoregressive_generate(batch)
     sync_all()
     # last warm-up call (or an extra one): every instrumented launch bracketed by HIP events -> the per-kernel table and the
-    # dominant GEMM symbol.  Not timed.
+    # dominant GEMM symbol.  Not timed.  (Events bracket eager launches: graph replay is off for this one call.)
     ops.PROFILE.reset(enabled=True)
     model.autoregressive_generate(batch)
     warm_prof = ops.PROFILE.summary()
-    warm_gemms = {k: v for k, v in warm_prof.items() if k.startswith(("gemm_kernel", "gemm8_kernel"))}
+    warm_gemms = {k: v for k, v in warm_prof.items() if k.startswith(("gemm_kernel", "gemm8_kernel", "gemm8c_kernel"))}
     dom_warm = max(warm_gemms, key=lambda k: warm_gemms[k]["ms"]) if warm_gemms else None
     sync_all()
-    # timed region: HIP events on the launch stream around the dominant symbol's launches (--events all: around all)
+    # timed region: HIP events on the launch stream around the dominant symbol's launches (--events all: around all).  With
+    # graph replay the event pairs are event-record nodes of the captured graph (same stream, same positions).
     ops.PROFILE.reset(enabled=True, only=None if (args.events == "all" or dom_warm is None) else [dom_warm])
+    prime()
+    ops.PROFILE.clear()
+    sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = model.autoregressive_generate(batch)
@@ -94,6 +155,9 @@ def main():
     ops.PROFILE.enabled = False
     dt = D.max_over_ranks(dt, dev)
     assert tuple(out.shape) == (B, L, 1, 64, 64)
+    tok_main = model.last_tokens.clone()
+    prof = ops.PROFILE.summary()
+    replayed = getattr(model, "last_call_mode", "eager") == "graph"
 
     # the other AR mode, same batch, reported next to the headline (identical tokens: tests/test_gpu_parity.py)
     other_mode = "incremental" if args.ar_mode == "full" else "full"
@@ -101,9 +165,9 @@ def main():
     if not args.no_other_mode:
         model.ar_mode = other_mode
         model.streams = 1 if other_mode == "incremental" else args.streams     # small launches: concurrency only adds gaps
-        tok_main = model.last_tokens.clone()
         model.autoregressive_generate(batch)
         same_tokens = bool(torch.equal(model.last_tokens, tok_main))
+        prime()
         sync_all()
         t1 = time.perf_counter()
         for _ in range(args.steps):
@@ -115,22 +179,84 @@ def main():
         other = {"ar_mode": other_mode, "value": round(world * B * L * args.steps / dt_other, 2), "unit": "frames/s",
                  "ms_per_step": round(dt_other / args.steps * 1e3, 3), "tokens_identical_to_headline_mode": same_tokens}
 
+    # the parity-gated precision (fp32: every 1e-4 / bit-exact gate of tests/ is stated for it) on the same batch, and how far
+    # the free-running bf16 token sequence is from it
+    parity = None
+    if args.precision == "bf16" and not args.no_parity_mode:
+        model.set_precision("fp32")
+        model.autoregressive_generate(batch)
+        tok32 = model.last_tokens.clone()
+        prime()
+        sync_all()
+        t2 = time.perf_counter()
+        n32 = max(1, min(args.steps, 2))
+        for _ in range(n32):
+            model.autoregressive_generate(batch)
+        sync_all()
+        dt32 = D.max_over_ranks(time.perf_counter() - t2, dev)
+        model.set_precision(args.precision)
+        eq = (tok32 == tok_main)
+        per_clip = eq.flatten(1).all(1)
+        agree = torch.tensor([eq.float().mean().item(), eq[:, 0].float().mean().item(), per_clip.float().mean().item()],
+                             dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(agree)
+            agree /= world
+        parity = {"dtype": "fp32", "value": round(world * B * L * n32 / dt32, 2), "unit": "frames/s",
+                  "ms_per_step": round(dt32 / n32 * 1e3, 3), "steps": n32,
+                  "note": "fp32 mode (v_mfma_f32_16x16x4_f32) is the mode whose tokens are bit-exact / logits within 1e-4 of the "
+                          "reference's goldens (tests/test_gpu_parity.py); same batch, same AR mode",
+                  "bf16_free_running_token_agreement": {
+                      "all_positions": round(agree[0].item(), 5), "first_generated_frame": round(agree[1].item(), 5),
+                      "clips_identical": round(agree[2].item(), 5),
+                      "note": "fraction of the bf16 run's VQ tokens equal to the fp32 run's on this batch; frame 1 has identical "
+                              "inputs in both runs, later frames feed back each run's own tokens (one flip changes the rest of the clip)"}}
+
+    # VQ-VAE decode of this call's B*(L-1) generated frames on its own: HBM roofline under SURVEY 8d's traffic model + MFMA fraction
+    decode = None
+    if not args.no_decode_roofline:
+        gen = tok_main.view(B, L - 1, 16, 16)
+        model.first_stage_decode(gen)
+        torch.cuda.synchronize()
+        reps = 10
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            a.record()
+            model.first_stage_decode(gen)
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in evs)[reps // 2]
+        frames = B * (L - 1)
+        by = DEC_BYTES_PER_FRAME[args.precision] * frames
+        gbs = by / (ms * 1e-3) / 1e9
+        tf = DEC_FLOP_PER_FRAME * frames / (ms * 1e-3) / 1e12
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        decode = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                  "traffic": None, "frames": frames, "ms": round(ms, 4), "bytes_model_per_frame": DEC_BYTES_PER_FRAME[args.precision],
+                  "mfma": {"achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)},
+                  "note": "VectorQuantizedVAE.decode of the call's generated frames (median of 10, HIP events); bytes = SURVEY 8d's "
+                          "layer-materialised model (sum over the 6 conv layers of input+output activations at the storage dtype); "
+                          "the same stack is 1.216 GFLOP/frame, so the MFMA fraction is reported beside it"}
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * B * L * args.steps / dt
-        prof = ops.PROFILE.summary()
-        gemms = {k: v for k, v in prof.items() if k.startswith(("gemm_kernel", "gemm8_kernel"))}
+        gemms = {k: v for k, v in prof.items() if k.startswith(("gemm_kernel", "gemm8_kernel", "gemm8c_kernel"))}
         dom_key = max(gemms, key=lambda k: gemms[k]["ms"]) if gemms else None
         all_src, all_div = (gemms, args.steps) if args.events == "all" else (warm_gemms, 1)
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
         roofline = None
         # HBM bytes per launch of the dominant kernel come from PMC counters (FETCH_SIZE x2-corrected + WRITE_SIZE), which
         # only rocprofv3 can read: tools/pmc_bench.sh collects them on this same command in two separate --pmc passes
-        # and the summary is committed under profiles/; bench.py reports it only for the matching workload.
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if dom_key and os.path.exists(pmc_path) and (B, L, args.precision, args.ar_mode) == (64, 16, "bf16", "full"):
-            traffic = json.load(open(pmc_path)).get(dom_key, {}).get("hbm_bytes_per_launch")
+        # and the summary is committed under profiles/; bench.py reports it only for the matching workload and says where from.
+        traffic, traffic_source = None, None
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            pmc_path = os.path.join(ROOT, "profiles", name)
+            if dom_key and os.path.exists(pmc_path) and (B, L, args.precision, args.ar_mode, args.workload) == (64, 16, "bf16", "full", "cfg2"):
+                traffic = json.load(open(pmc_path)).get(dom_key, {}).get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_source = f"profiles/{name} (builder's rocprofv3 --pmc passes of this command via tools/pmc_bench.sh; not re-measured in this run)"
+                    break
         if dom_key:
             dom = gemms[dom_key]
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
@@ -140,21 +266,39 @@ def main():
                                                              "Epilogue kind 1 = x + Linear(.) with the fp32 residual: attention out_proj and "
                                                              "MLP c_proj of the decoder stack]",
                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": traffic, "launches_per_step": dom["calls"] // args.steps,
+                        "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": dom["calls"] // args.steps,
                         "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
                         "flops_per_launch": dom["flops"] / dom["calls"],
                         "all_gemm_kernels": {"achieved": round(allf / (allms * 1e-3) / 1e12, 2), "frac": round(allf / (allms * 1e-3) / 1e12 / peak, 4),
                                              "ms_per_step": round(allms / all_div, 3),
                                              "measured_in": "timed region" if args.events == "all" else "last warm-up call"}}
+        f_call, f_step = call_flops(B, L)
+        whole = {"flops_per_call": f_call, "decoder_step_flops": f_step,
+                 "achieved": round(f_call / (ms_per_step * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+                 "frac": round(f_call / (ms_per_step * 1e-3) / 1e12 / peak, 4),
+                 "note": "executed FLOPs of one autoregressive_generate call per GPU (SURVEY 8d formula; full AR mode = the reference's "
+                         "(L-1) full recomputes) over its wall time: the whole transformer step incl. LayerNorm / attention / casts"
+                 } if args.ar_mode == "full" else None
+        wl_name = ("cfg2: Single Moving MNIST" if args.workload == "cfg2" else "cfg3: Double Moving MNIST (two digits, captions 16/18/20 tokens padded to 20)")
         res = {
             "metric": "generated frames/sec (64x64, 16-frame clips)", "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"cfg2: Single Moving MNIST 64x64, {L} frames, batch={B}/GPU, MNIST f4 VQ-VAE + MAGE "
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"{wl_name} 64x64, {L} frames, batch={B}/GPU, MNIST f4 VQ-VAE + MAGE "
                                    f"(d=512, 6 axial blocks), AR loop: {'reference full recompute per iteration' if args.ar_mode == 'full' else 'incremental (temporal KV cache)'}, random-init weights",
-                       "global_batch": world * B, "frames": L, "parallelism": f"clip-sharded x{world} (no collective)",
-                       "ar_mode": model.ar_mode, "streams_per_gpu": args.streams},
+                       "global_batch": world * B, "frames": L, "parallelism": f"clip-sharded x{world} (no data-path collective)",
+                       "ranks_seen": seen, "ar_mode": model.ar_mode, "streams_per_gpu": args.streams,
+                       "graph_replay": replayed,
+                       "graph_replay_note": "the timed calls replay ONE captured HIP graph of the whole autoregressive_generate call "
+                                            "(same kernels, same order, bit-identical results; tests/test_gpu_parity.py); the HIP events "
+                                            "around the dominant kernel are event-record nodes of that graph",
+                       "frame_count_convention": "B*L frames per call: the output clip [B,L,C,H,W] incl. the passed-through first frame "
+                                                 "(SURVEY 8d, reference mage_model.py:691); generated-only = value * (L-1)/L",
+                       "generated_only_value": round(value * (L - 1) / L, 2)},
             "roofline": roofline,
+            "whole_call": whole,
+            "roofline_decode": decode,
+            "parity_mode": parity,
             "kernel_time_ms_per_step": ({k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items())} if args.events == "all"
                                         else {k: round(v["ms"], 3) for k, v in sorted(warm_prof.items())}),
             "kernel_time_measured_in": "timed region" if args.events == "all" else "last warm-up call (every launch bracketed)",
@@ -168,9 +312,20 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def _cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sd, L, clips):
     """The CPU oracle (validated against the reference's golden vectors) timed on this box's host cores on a
-    bounded sample of the same workload: `clips` clips of the cfg shape through the reference's full AR loop."""
+    bounded sample of the same workload: `clips` clips of the cfg shape through the reference's full AR loop, with the
+    thread count chosen by calibration, and one clip on ONE thread."""
     from mage_amd.utils import synth
     from oracle import mage_oracle as O
     batch = synth.synth_batch_mnist(clips, L, seed=100)
@@ -179,9 +334,10 @@ def cpu_baseline(sd, L, clips):
     ma = torch.zeros(clips, 16, 16, 512)
     imgs = torch.zeros(clips, L - 1, 16, 16, 512)
     best = (float("inf"), 1)
+    ncpu = os.cpu_count() or 1
     with torch.no_grad():
         for th in (8, 16, 32, 64, 128):
-            if th > (os.cpu_count() or 1):
+            if th > ncpu:
                 break
             torch.set_num_threads(th)
             O.flat_axial_decoder(sd, "generate_model.", ma, imgs)
@@ -192,10 +348,32 @@ def cpu_baseline(sd, L, clips):
         t0 = time.perf_counter()
         O.mage_generate(sd, batch, L)
         dt = time.perf_counter() - t0
-    return {"value": round(clips * L / dt, 3), "unit": "frames/s", "cores": best[1], "kind": "port",
+        # one thread, one clip: first a SHORT clip (6 frames); if that predicts < 40 s for the full clip length (the loop's
+        # cost grows ~L^2), the full-length clip is timed too and reported instead.  The sample is stated, never extrapolated.
+        torch.set_num_threads(1)
+
+        def one_thread(L1):
+            sd1 = dict(sd)
+            sd1["generate_model.T_positional_embedding"] = sd["generate_model.T_positional_embedding"][:L1].clone()
+            b1 = synth.synth_batch_mnist(1, L1, seed=100)
+            t0 = time.perf_counter()
+            O.mage_generate(sd1, b1, L1)
+            return time.perf_counter() - t0
+        L1 = min(L, 6)
+        dt1 = one_thread(L1)
+        if L1 < L and dt1 * (L * (L - 1)) / (L1 * (L1 - 1)) < 40.0:
+            L1 = L
+            dt1 = one_thread(L1)
+        torch.set_num_threads(best[1])
+    return {"value": round(clips * L / dt, 3), "unit": "frames/s", "cores": best[1], "kind": "port", "cpu": _cpu_model_name(),
+            "host_threads": ncpu,
             "sample": f"{clips} clips x {L} frames (same model, fp32, oracle/mage_oracle.py mage_generate = the reference's "
-                      f"full-recompute AR loop, torch {torch.__version__} CPU ops, {best[1]} of {os.cpu_count()} host threads "
-                      f"chosen by calibration), {dt:.1f} s"}
+                      f"full-recompute AR loop, torch {torch.__version__} CPU ops, {best[1]} of {ncpu} host threads "
+                      f"chosen by calibration), {dt:.1f} s",
+            "one_thread": {"value": round(L1 / dt1, 3), "unit": "frames/s", "cores": 1,
+                           "sample": f"1 clip x {L1} frames on 1 thread (same model and loop" +
+                                     ("" if L1 == L else "; shorter clip so that the sample stays bounded: the loop's cost grows ~L^2") +
+                                     f"), {dt1:.1f} s"}}
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MAGE_ABI_VERSION 1
+#define MAGE_ABI_VERSION 2
 
 enum { MAGE_F32 = 0, MAGE_BF16 = 1 };
 enum { MAGE_OK = 0, MAGE_EINVAL = -1, MAGE_EHIP = -2, MAGE_EUNSUPPORTED = -3 };
@@ -38,9 +38,17 @@ enum { MAGE_ACT_NONE = 0, MAGE_ACT_RELU = 1, MAGE_ACT_QUICKGELU = 2, MAGE_ACT_GE
 
 int mage_abi_version(void);
 const char* mage_last_error(void);
-/* One-time per-device setup (allocates the 4 KiB zero page the gather loads use for padding).
- * Must be called once per process+device before any other call, outside stream capture. */
+/* One-time per-device setup (allocates the 4 KiB zero page the gather loads use for padding and the deferred-error word).
+ * Must be called once per process+device before any other call, outside stream capture.  Leaves the caller's current
+ * device unchanged; returns MAGE_EUNSUPPORTED (every time) on a device that is not gfx950. */
 int mage_init(int device);
+/* Deferred device-side argument errors.  Kernels cannot return a code, and the host cannot see an index that lives in device
+ * memory: mage_embedding (an id outside [0, n_table): where the reference's nn.Embedding raises IndexError) and
+ * mage_cross_entropy (a target outside [0, K)) record the first such event in a per-device word and carry on with a clamped,
+ * memory-safe value.  This call synchronises `stream`, returns MAGE_EINVAL with the message (and clears the word) if one
+ * was recorded since the last check, MAGE_OK otherwise.  The host-side mirror calls it at the end of every public entry
+ * (MAGE.forward, MAGE.autoregressive_generate, VectorQuantizedVAE.decode / forward). */
+int mage_check_device_errors(void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused GEMM / implicit-GEMM convolution on MFMA:   Y[yrow(m), n] = epi( sum_k A[arow(m,k), .] * W[n, k] )
@@ -93,12 +101,6 @@ typedef struct mage_gemm_desc {
 
 int mage_gemm(const mage_gemm_desc* desc, void* stream);
 
-/* Fused MLP half of an AxialAttentionBlock (mage_model.py:22-26,51):  x += c_proj(QuickGELU(c_fc(xn))), bf16 MFMA with
- * fp32 accumulation, the hidden activation [M, 4C] never leaves the CU.  xn [M, C] bf16 (ln_2 output), w_fc [4C, C] bf16,
- * b_fc [4C] fp32, w_proj [C, 4C] bf16, b_proj [C] fp32, x [M, C] fp32 residual stream updated in place.  C = 256 or 512. */
-int mage_mlp_fused(const void* xn, const void* w_fc, const float* b_fc, const void* w_proj, const float* b_proj, float* x,
-                   int64_t M, int32_t C, void* stream);
-
 /* LayerNorm over the last dim of fp32 rows; y may be fp32 (may alias x) or bf16.
  * Replaces nn.LayerNorm at mage_model.py:21,27,84,204,206 and inside nn.TransformerEncoderLayer. */
 int mage_layernorm(const float* x, const float* gamma, const float* beta, void* y, int32_t y_dtype,
@@ -140,8 +142,8 @@ int mage_attention(const mage_attn_desc* desc, void* stream);
 /* out[orow(i), :] = act(table[ids[i], :]),  orow(i) = (i / group)*group_stride + i % group + off.
  * Replaces nn.Embedding lookups: visual_token_embedding (mage_model.py:581,644,682), the codebook
  * gather of VectorQuantizedVAE.decode (vqvae_model.py:240; relu=1 folds the in-place ReLU that
- * opens the first decoder ResBlock :113), text token embedding (:226).  Out-of-range ids -> MAGE_EINVAL
- * is NOT checked on device; ids are clamped to [0, n_table). */
+ * opens the first decoder ResBlock :113), text token embedding (:226).  An id outside [0, n_table) is read as the nearest valid
+ * row AND recorded for mage_check_device_errors (the reference raises IndexError). */
 int mage_embedding(const int64_t* ids, const float* table, void* out, int32_t out_dtype, int64_t n,
                    int32_t C, int32_t n_table, int32_t relu, int64_t group, int64_t group_stride, int64_t off,
                    void* stream);
@@ -165,7 +167,7 @@ int mage_argmax(const float* logits, int64_t rows, int32_t K, int64_t ld, int64_
 
 /* Mean cross entropy over rows (F.cross_entropy, mage_model.py:618): row_loss[i] = logsumexp(logits[i]) -
  * logits[i, target[i]] (workspace, [rows] fp32), loss_mean[0] = mean_i row_loss[i] (fixed-order fp64 sum:
- * deterministic). */
+ * deterministic).  A target outside [0, K) is recorded for mage_check_device_errors. */
 int mage_cross_entropy(const float* logits, const int64_t* target, int64_t rows, int32_t K, float* row_loss,
                        float* loss_mean, void* stream);
 

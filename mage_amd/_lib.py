@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MAGE_HIP_LIB", os.path.join(_HERE, "lib", "libmage_hi
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_QUICKGELU, ACT_GELU_ERF, ACT_TANH = 0, 1, 2, 3, 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -52,8 +52,8 @@ SIGNATURES = {
     "mage_abi_version": (C.c_int, []),
     "mage_last_error": (C.c_char_p, []),
     "mage_init": (C.c_int, [C.c_int]),
+    "mage_check_device_errors": (C.c_int, [vp]),
     "mage_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
-    "mage_mlp_fused": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i32, vp]),
     "mage_layernorm": (C.c_int, [vp, vp, vp, vp, i32, i64, i32, f32, vp]),
     "mage_attention": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "mage_embedding": (C.c_int, [vp, vp, vp, i32, i64, i32, i32, i32, i64, i64, i64, vp]),

@@ -12,8 +12,19 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+#define MAGE_MAX_DEVICES 16
 void mage_set_error(const char* fmt, ...);
+int mage_device_index();               // current HIP device, or -1 (per-device caches of launch attributes are indexed by it)
 const void* mage_zero_page();          // device pointer, >= 4096 zero bytes; null before mage_init
+int* mage_error_word();                // device pointer to the deferred-error word of the current device (mage_check_device_errors)
+enum { MAGE_DEVERR_EMBEDDING_ID = 1, MAGE_DEVERR_CE_TARGET = 2 };
+// raise a deferred error from a kernel: the first one wins, the offending value and the bound are kept for the message
+__device__ __forceinline__ void mage_raise(int* word, int code, long value, int bound) {
+    if (atomicCAS(word, 0, code) == 0) {
+        word[1] = (int)value;
+        word[2] = bound;
+    }
+}
 
 #define MAGE_CHECK_ARG(cond, ...)                                   \
     do {                                                            \

@@ -874,11 +874,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
 
 template <int DT, bool GATHER, int ACT, int MT, int EK>
 int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // launch attributes are per DEVICE (a process may drive several GPUs, e.g. nn.DataParallel, main_mage.py:106): cached per
+    // device index; setting one twice from two threads is harmless
+    static bool attr_set[MAGE_MAX_DEVICES] = {false};
+    const int dev = mage_device_index();
+    MAGE_CHECK_ARG(dev >= 0, "mage_gemm: no current device");
+    if (!attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT, MT, EK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   Tile<MT>::LDS_BYTES);
-        attr_set = true;
+        attr_set[dev] = true;
     }
     GemmArgs a;
     a.d = *d;
@@ -916,10 +920,10 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
         if (use8 < 0) use8 = getenv("MAGE_GEMM_NO_8PHASE") ? 0 : 1;
         const long a_rows = (long)((d->M + d->out_h * d->out_w - 1) / (d->out_h * d->out_w)) * d->a_img_stride + d->a_off + 1;
         if (use8 && d->K % 64 == 0 && a_rows * d->lda * 2 < (1L << 32) && (long)d->N * d->K * 2 < (1L << 32)) {
-            static bool attr8 = false;
-            if (!attr8) {
+            static bool attr8[MAGE_MAX_DEVICES] = {false};
+            if (!attr8[dev]) {
                 (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr8 = true;
+                attr8[dev] = true;
             }
             hipLaunchKernelGGL((gemm8_kernel<ACT, EK>), dim3(grid), dim3(512), 160 * 1024, s, a);
             MAGE_CHECK_LAUNCH("mage_gemm");
@@ -933,14 +937,16 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
 
 template <int DT, bool GATHER, int ACT, int EK>
 int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
+    static int n_cu_dev[MAGE_MAX_DEVICES] = {0};
+    const int dev = mage_device_index();
+    MAGE_CHECK_ARG(dev >= 0, "mage_gemm: no current device");
+    if (!n_cu_dev[dev]) {
         hipDeviceProp_t p;
-        n_cu = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= 8)
-            n_cu = p.multiProcessorCount & ~7;
+        int n = 256;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= 8) n = p.multiProcessorCount & ~7;
+        n_cu_dev[dev] = n;
     }
+    const int n_cu = n_cu_dev[dev];
     // 256-row tiles only where there are enough of them to give every CU at least two (bf16; the fp32 8x4-accumulator
     // variant does not fit the register file)
     const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + BN - 1) / BN);

@@ -110,12 +110,15 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict
 template <typename OT>
 __global__ __launch_bounds__(256) void embedding_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
                                                         OT* __restrict__ out, long n, int C, int n_table, int relu,
-                                                        long group, long group_stride, long off) {
+                                                        long group, long group_stride, long off, int* __restrict__ err) {
     const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const int lane = threadIdx.x & 63;
     long id = ids[i];
-    id = id < 0 ? 0 : (id >= n_table ? n_table - 1 : id);
+    if (id < 0 || id >= n_table) {          // the reference raises IndexError here: reported by mage_check_device_errors
+        if (lane == 0) mage_raise(err, MAGE_DEVERR_EMBEDDING_ID, id, n_table);
+        id = id < 0 ? 0 : n_table - 1;      // stay memory-safe meanwhile
+    }
     const long orow = (i / group) * group_stride + (i % group) + off;
     const float* src = table + id * C;
     OT* dst = out + orow * C;
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
 }
 
 __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
-                                                      long rows, int K, float* __restrict__ row_loss) {
+                                                      long rows, int K, float* __restrict__ row_loss, int* __restrict__ err) {
     const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -163,7 +166,14 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
     float s = 0.f;
     for (int k = lane; k < K; k += 64) s += expf(p[k] - mx);
     s = wave_sum(s);
-    if (lane == 0) row_loss[i] = (logf(s) + mx) - p[target[i]];
+    if (lane == 0) {
+        long tg = target[i];
+        if (tg < 0 || tg >= K) {
+            mage_raise(err, MAGE_DEVERR_CE_TARGET, tg, K);
+            tg = 0;
+        }
+        row_loss[i] = (logf(s) + mx) - p[tg];
+    }
 }
 
 __global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ v, long n, float* __restrict__ out, double inv) {
@@ -197,12 +207,14 @@ extern "C" int mage_vq_nearest(const float* z, const float* codebook_t, const fl
     MAGE_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && K > 0 && K <= 1024, "mage_vq_nearest: M=%ld D=%d K=%d unsupported", (long)M, D, K);
     const size_t lds = (size_t)(16 * D + 16 + 16 * K) * 4;
     MAGE_CHECK_ARG(lds <= 144 * 1024, "mage_vq_nearest: D=%d K=%d exceed the LDS budget", D, K);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[MAGE_MAX_DEVICES] = {false};      // the attribute is per device (idempotent: a racing second call is harmless)
+    const int dev = mage_device_index();
+    MAGE_CHECK_ARG(dev >= 0, "mage_vq_nearest: no current device");
+    if (!attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)vq_nearest_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         (void)hipFuncSetAttribute((const void*)vq_nearest_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         (void)hipFuncSetAttribute((const void*)vq_nearest_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const dim3 grid((unsigned)((M + 15) / 16)), blk(256);
     hipStream_t s = (hipStream_t)stream;
@@ -219,12 +231,14 @@ extern "C" int mage_embedding(const int64_t* ids, const float* table, void* out,
     MAGE_CHECK_ARG(n > 0 && C > 0 && C % 4 == 0 && n_table > 0 && group > 0, "mage_embedding: bad sizes n=%ld C=%d", (long)n, C);
     const dim3 grid((unsigned)((n + 3) / 4)), blk(256);
     hipStream_t s = (hipStream_t)stream;
+    int* err = mage_error_word();
+    MAGE_CHECK_ARG(err != nullptr, "mage_embedding: mage_init() has not been called");
     if (out_dtype == MAGE_F32)
         hipLaunchKernelGGL((embedding_kernel<float>), grid, blk, 0, s, ids, table, (float*)out, (long)n, C, n_table, relu,
-                           (long)group, (long)group_stride, (long)off);
+                           (long)group, (long)group_stride, (long)off, err);
     else if (out_dtype == MAGE_BF16)
         hipLaunchKernelGGL((embedding_kernel<unsigned short>), grid, blk, 0, s, ids, table, (unsigned short*)out, (long)n, C,
-                           n_table, relu, (long)group, (long)group_stride, (long)off);
+                           n_table, relu, (long)group, (long)group_stride, (long)off, err);
     else {
         mage_set_error("mage_embedding: bad out_dtype %d", out_dtype);
         return MAGE_EINVAL;
@@ -250,7 +264,9 @@ extern "C" int mage_cross_entropy(const float* logits, const int64_t* target, in
     MAGE_CHECK_ARG(logits && target && row_loss && loss_mean, "mage_cross_entropy: null pointer");
     MAGE_CHECK_ARG(rows > 0 && K > 0, "mage_cross_entropy: bad sizes");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, target, (long)rows, K, row_loss);
+    int* err = mage_error_word();
+    MAGE_CHECK_ARG(err != nullptr, "mage_cross_entropy: mage_init() has not been called");
+    hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, target, (long)rows, K, row_loss, err);
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, row_loss, (long)rows, loss_mean, 1.0 / (double)rows);
     MAGE_CHECK_LAUNCH("mage_cross_entropy");
     return MAGE_OK;

@@ -115,7 +115,7 @@ class MAEncoder(nn.Module):
         super().__init__()
         self.d_model, self.layers = d_model, layers
         self.blocks = nn.ModuleList([TransformerBlock(d_model, d_model // 32, dropout) for _ in range(layers)])
-        self.mage_plus = False          # True = the ln_q/ln_kv variant of mage_model.py:93 (MAGE+)
+        self.mage_plus = False          # True = the ln_q/ln_kv variant of mage_model.py:93 (MAGE+); MAGE(use_cids=False) sets it
         self._derived = _Derived(self)
 
     def _build(self):
@@ -337,9 +337,6 @@ class FlatAxialDecoder(nn.Module):
                                      zero_module(nn.Conv3d(model_channels, out_channels, 1)))
         self.initialize_parameters()
         self.compute_dtype = F32
-        self.fused_mlp = False         # mage_mlp_fused (hidden activation kept on chip).  Measured SLOWER than the two GEMMs
-                                       # on MI355X (1.81 vs 1.44-1.58 ms per block at cfg2: 4 MiB of weights per 64-row panel
-                                       # through a 64 KiB LDS window is L2-latency bound), so it is off; kept as a tested op.
         self._derived = _Derived(self)
 
     def initialize_parameters(self):
@@ -414,10 +411,13 @@ class FlatAxialDecoder(nn.Module):
                           kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], **geo)
             _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc)
             ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5)
-            if self.fused_mlp and dt == BF16 and Cc in (256, 512):
-                ops.mlp_fused(xn, d[p + ".c_fc.bf16"], d[p + ".c_fc.b"], d[p + ".c_proj.bf16"], d[p + ".c_proj.b"], x)
+            _linear(xn, d, p + ".c_fc", hdn, dt, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU)
+            if i == self.layers - 1 and self.use_cids and dt != F32:
+                # the last block's x + c_proj(.) is only read by the head GEMM: the epilogue rounds it to the compute dtype on the
+                # way out (same fp32 sum, same round-to-nearest-even as a separate cast pass: bit-identical) instead of writing
+                # the fp32 stream and converting it in another launch
+                _linear(hdn, d, p + ".c_proj", xn, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
             else:
-                _linear(xn, d, p + ".c_fc", hdn, dt, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU)
                 _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
         if not self.use_cids:
             # GroupNorm statistics span all L-1 frames of a clip (:387-388): this head is NOT causal along L
@@ -427,7 +427,7 @@ class FlatAxialDecoder(nn.Module):
             n8 = d["out.f32"].shape[0]
             pred = torch.empty(B * (L - 1) * hw, n8, device=dev, dtype=F32)
             return _linear(y, d, "out", pred, dt, M=B * (L - 1) * hw, N=n8, K=Cc)
-        xa = x if dt == F32 else ops.cast(x, xn)
+        xa = x if dt == F32 else xn
         logits = torch.empty(B * (L - 1) * hw, self.out_channels, device=dev, dtype=F32)
         _linear(xa, d, "out", logits, dt, M=B * (L - 1) * hw, N=self.out_channels, K=Cc, out_w=(L - 1) * hw,
                 a_img_stride=L * hw, a_off=hw)                                      # head on x[:, 1:]  (:385)
@@ -491,8 +491,9 @@ class FlatAxialDecoder(nn.Module):
             _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc)
             ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5)
             _linear(xn, d, p + ".c_fc", hdn, dt, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU)
-            _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
-        xa = x if dt == F32 else ops.cast(x, xn)
+            last_bf16 = i == self.layers - 1 and dt != F32          # see _run: the head's input straight from the epilogue
+            _linear(hdn, d, p + ".c_proj", xn if last_bf16 else x, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
+        xa = x if dt == F32 else xn
         logits = torch.empty(B * hw, self.out_channels, device=dev, dtype=F32)
         _linear(xa, d, "out", logits, dt, M=B * hw, N=self.out_channels, K=Cc, out_w=hw, a_img_stride=P * hw, a_off=(P - 1) * hw)
         st["p"] = p0 + P
@@ -545,6 +546,11 @@ class MAGE(nn.Module):
         self.dropout, self.use_cids, self.auto_beta = dropout, use_cids, auto_beta
         self.text_encoder = instantiate_from_config(text_encoder_config)
         self.ma_encoder = instantiate_from_config(ma_config, {"dropout": dropout})
+        # The reference ships ONE TransformerBlock.forward with two alternative first lines (mage_model.py:92-93) and tells the
+        # user to swap them by hand for MAGE+.  MAGE+ is exactly the use_cids=False family (config/mage+_*.yaml), so the variant
+        # follows that switch; `model.ma_encoder.mage_plus = False` restores the shipped line for a MAGE+ config.
+        if hasattr(self.ma_encoder, "mage_plus"):
+            self.ma_encoder.mage_plus = not use_cids
         self.generate_model = instantiate_from_config(
             generate_decoder_config, {"use_cids": use_cids, "dropout": dropout, "context_channels": ma_config["params"]["d_model"]})
         self.codebook_size = codebook_size
@@ -576,6 +582,9 @@ class MAGE(nn.Module):
         self.streams = 1               # >1: clip groups on concurrent HIP streams (see autoregressive_generate)
         self.ar_mode = "full"          # 'full' = the reference's per-iteration full recompute (mage_model.py:673-684);
                                        # 'incremental' = temporal KV cache, each position once
+        self.last_call_mode = "eager"
+        self.use_graph = False         # True: autoregressive_generate replays a captured HIP graph of the whole call (see there)
+        self._graphs: dict = {}
         self._derived = _Derived(self)
         self.last_tokens: Optional[torch.Tensor] = None
 
@@ -646,7 +655,8 @@ class MAGE(nn.Module):
     @torch.no_grad()
     def first_stage_decode(self, x):
         """[B, T, h, w] ids -> [B, T, C, H, W]."""
-        out = self.first_stage_model.decode(x.reshape(-1, *x.shape[-2:]) if self.use_cids else x.reshape(-1, *x.shape[-3:]))
+        dec = getattr(self.first_stage_model, "_decode_nocheck", self.first_stage_model.decode)   # one error check per public call
+        out = dec(x.reshape(-1, *x.shape[-2:]) if self.use_cids else x.reshape(-1, *x.shape[-3:]))
         return out.view(*x.shape[:2], *out.shape[1:]).contiguous()
 
     # ------------------------------------------------------------------ shared pieces
@@ -708,16 +718,84 @@ class MAGE(nn.Module):
         run under the MFMA-bound GEMMs of the other instead of in front of them."""
         images = batch["images"]
         _need_gpu(images, "MAGE.autoregressive_generate")
+        with torch.cuda.device(images.device):
+            if self.use_graph and int(getattr(self, "streams", 1)) == 1 and not torch.cuda.is_current_stream_capturing():
+                out = self._generate_graphed(batch)
+            else:
+                out = self._generate_eager(batch)
+            ops.check_device_errors(images.device)        # e.g. a caption id >= vocab_size: the reference raises IndexError
+        return out
+
+    def _generate_eager(self, batch):
         if not self.use_cids:
             return self._generate_latent(batch)
         n = int(getattr(self, "streams", 1))
-        if n > 1 and images.shape[0] >= 2 * n and images.shape[0] % n == 0:
+        if n > 1 and batch["images"].shape[0] >= 2 * n and batch["images"].shape[0] % n == 0:
             return self._generate_multistream(batch, n)
         return self._generate_one(batch)
+
+    def _generate_graphed(self, batch):
+        """HIP-graph replay of the whole call ("whole-loop residency").  The call is a fixed sequence of
+        kernel launches on device-resident buffers -- no host decision depends on device data (the argmax of frame i is written
+        into slot i+1 of the token buffer on the device) -- so one capture of the launch stream replays it with ONE host call
+        instead of ~50 per AR iteration: the Python / ctypes launch loop (14 of 30 ms per call in incremental mode) disappears.
+        First call with a given (shapes, precision, AR mode, weights): eager, which also builds every derived cache; second:
+        captured on static copies of the inputs (all intermediates live in the graph's private pool: an arena that is never
+        re-allocated); from then on: inputs are copied into the static buffers, the graph is replayed, the video and tokens are
+        cloned out (last_logits stays a view of the arena, valid until the next call).  Same kernels, same order, same
+        arithmetic: bit-identical to the eager call."""
+        self._warm_derived()
+        gens = tuple(getattr(m, "_derived").gen for m in (self, self.generate_model, self.ma_encoder, self.text_encoder,
+                                                          getattr(self, "adain", None), self.first_stage_model)
+                     if m is not None and hasattr(m, "_derived"))
+        prof = ops.PROFILE.mode_key()
+        self.last_call_mode = "eager"
+        if prof != "off" and not ops.graph_events_supported(batch["images"].device):
+            return self._generate_eager(batch)              # per-launch events wanted, but they cannot be captured here
+        key = (tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items())), self.precision, self.ar_mode, gens, prof,
+               str(batch["images"].device))
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._graphs = {k: v for k, v in self._graphs.items() if k[3] == gens}       # graphs of replaced weights are dead
+            self._graphs[key] = "warm"
+            return self._generate_eager(batch)
+        if ent == "warm":
+            static = {k: v.clone() for k, v in batch.items()}
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            saved = ops.PROFILE.capture_begin()
+            try:
+                with torch.cuda.graph(g):
+                    out = self._generate_eager(static)
+                    toks, logits = self.last_tokens, self.last_logits
+            finally:
+                recs = ops.PROFILE.capture_end(saved)
+            ent = self._graphs[key] = {"g": g, "in": static, "out": out, "tok": toks, "logits": logits, "recs": recs}
+        else:
+            for k, v in batch.items():
+                ent["in"][k].copy_(v)
+        ent["g"].replay()
+        self.last_call_mode = "graph"
+        if ent["recs"] and ops.PROFILE.enabled:
+            torch.cuda.current_stream().synchronize()
+            ops.PROFILE.absorb(ent["recs"])
+        self.last_tokens = None if ent["tok"] is None else ent["tok"].clone()
+        self.last_logits = ent["logits"]
+        return ent["out"].clone()
+
+    def _warm_derived(self) -> None:
+        """Build every derived weight cache (bf16 copies, transposed codebook, folded BatchNorm vectors, summed positional
+        tables) on the CALLER's stream: a cache built lazily inside one side stream would be read by the others with no event
+        in between."""
+        self._derived.get(self._build)
+        for mod in (self.generate_model, self.ma_encoder, self.text_encoder, getattr(self, "adain", None), self.first_stage_model):
+            if mod is not None and hasattr(mod, "_derived") and hasattr(mod, "_build"):
+                mod._derived.get(mod._build)
 
     def _generate_multistream(self, batch, n):
         B = batch["images"].shape[0]
         per = B // n
+        self._warm_derived()                                          # before the fork: side streams only READ the caches
         main = torch.cuda.current_stream(batch["images"].device)
         if getattr(self, "_side_streams", None) is None or len(self._side_streams) != n:
             self._side_streams = [torch.cuda.Stream(device=batch["images"].device) for _ in range(n)]
@@ -958,4 +1036,5 @@ class MAGE(nn.Module):
                 l2 = (batch["speed"].float().to(recon.device) ** 2).mean() * (self.speed_embedding.float() ** 2).sum()
                 final = recon + self.beta * kl + self.alpha * l2
         ld[f"{prefix}/final_loss"] = final.item()
+        ops.check_device_errors(batch["images"].device)
         return final, ld

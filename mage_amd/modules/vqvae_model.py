@@ -101,6 +101,7 @@ class _Derived:
         self._m = module
         self._sig = None
         self._store: Dict[str, torch.Tensor] = {}
+        self.gen = 0                   # bumped at every rebuild: captured HIP graphs that reference the old copies are stale
 
     def get(self, builder) -> Dict[str, torch.Tensor]:
         sig = tuple((t.data_ptr(), t._version, t.device) for t in chain(self._m.parameters(), self._m.buffers()))
@@ -108,6 +109,7 @@ class _Derived:
             with torch.no_grad():
                 self._store = builder()
             self._sig = sig
+            self.gen += 1
         return self._store
 
 
@@ -251,14 +253,14 @@ class VectorQuantizedVAE(nn.Module):
         return ops.gemm(a, w, y, M=n_img * OH * OW, N=cout, K=k * k * cin, lda=cin, ldy=cout, out_h=OH, out_w=OW, in_h=H,
                         in_w=W, taps_h=k, taps_w=k, cin=cin, stride=stride, dy0=-pad, dx0=-pad, **epi)
 
-    def _resblock(self, w, p, r, dt, n_img, post_relu):
+    def _resblock(self, w, p, r, dt, n_img, post_relu, H=16, W=16):
         """r = relu(x) already (in-place-ReLU quirk, vqvae_model.py:113): out = r + BN(conv1(relu(BN(conv3(r)))))."""
         dim, s = self.dim, "." + ("f32" if dt == torch.float32 else "bf16")
         t = torch.empty_like(r)
-        self._conv(r, w[p + ".w3" + s], t, n_img=n_img, H=16, W=16, cin=dim, cout=dim, k=3, bias=w[p + ".b3"],
+        self._conv(r, w[p + ".w3" + s], t, n_img=n_img, H=H, W=W, cin=dim, cout=dim, k=3, bias=w[p + ".b3"],
                    scale=w[p + ".s3"], shift=w[p + ".t3"], act=ops.ACT_RELU)
         out = torch.empty_like(r)
-        self._conv(t, w[p + ".w1" + s], out, n_img=n_img, H=16, W=16, cin=dim, cout=dim, k=1, bias=w[p + ".b1"],
+        self._conv(t, w[p + ".w1" + s], out, n_img=n_img, H=H, W=W, cin=dim, cout=dim, k=1, bias=w[p + ".b1"],
                    scale=w[p + ".s1"], shift=w[p + ".t1"], residual=r, ldr=dim, post_relu=post_relu)
         return out
 
@@ -302,9 +304,10 @@ class VectorQuantizedVAE(nn.Module):
             # relu folded: the only consumers of conv3's output are ResBlock e4's skip and body, both behind its in-place ReLU
             self._conv(h0, w["e3.w.f32"], h1, n_img=N, H=H // 2, W=W // 2, cin=dim, cout=dim, k=4, stride=2, pad=1,
                        OH=H // 4, OW=W // 4, bias=w["e3.b"], act=ops.ACT_RELU)
-            assert H // 4 == 16 and W // 4 == 16, "f4 VQ-VAE kernels are specialised for 64x64 inputs"
-            h2 = self._resblock(w, "e4", h1, f, N, post_relu=True)
-            return self._resblock(w, "e5", h2, f, N, post_relu=False)
+            if H % 4 or W % 4:
+                raise ValueError(f"f4 VQ-VAE input {H}x{W} must be a multiple of 4 in both dimensions")
+            h2 = self._resblock(w, "e4", h1, f, N, post_relu=True, H=H // 4, W=W // 4)
+            return self._resblock(w, "e5", h2, f, N, post_relu=False, H=H // 4, W=W // 4)
         H, W = x.shape[2], x.shape[3]
         h = torch.empty(N * H * W, dim, device=dev, dtype=f)
         ops.conv_in(x, w["e0.wt"], w["e0.b"], None, None, h, cin=self.input_dim, H=H, W=W, cout=dim, kh=7, kw=7, stride=1,
@@ -330,7 +333,16 @@ class VectorQuantizedVAE(nn.Module):
     # ------------------------------------------------------------------ decoder
     @torch.no_grad()
     def decode(self, latents: torch.Tensor = None) -> torch.Tensor:
-        """vqvae_model.py:239-242: int64 [N, h, w] -> fp32 [N, C, H, W] in (-1, 1)."""
+        """vqvae_model.py:239-242: int64 [N, h, w] -> fp32 [N, C, H, W] in (-1, 1).  Ids outside [0, K) raise (ValueError), as the
+        reference's nn.Embedding does (IndexError)."""
+        out = self._decode_nocheck(latents)
+        ops.check_device_errors(latents.device)
+        return out
+
+    @torch.no_grad()
+    def _decode_nocheck(self, latents: torch.Tensor) -> torch.Tensor:
+        """decode without the closing device-error check (which synchronises the stream): for callers that check once at the
+        end of their own call (MAGE.autoregressive_generate)."""
         self._check_input(latents)
         N = latents.shape[0]
         out = torch.empty(N, self.input_dim, latents.shape[1] * self.down_ratio, latents.shape[2] * self.down_ratio,
@@ -348,22 +360,22 @@ class VectorQuantizedVAE(nn.Module):
         N, dev, dim = ids.shape[0], ids.device, self.dim
         h, wd = ids.shape[1], ids.shape[2]
         if self.down_ratio == 4:
-            assert h == 16 and wd == 16, "f4 VQ-VAE kernels are specialised for 16x16 latents"
-            r = ops.embedding(ids, w["cb"], torch.empty(N * 256, dim, device=dev, dtype=dt), relu=True)
-            r = self._resblock(w, "d0", r, dt, N, post_relu=True)
-            r = self._resblock(w, "d1", r, dt, N, post_relu=True)           # decoder[2] ReLU folded
-            up = torch.empty(N * 1024, dim, device=dev, dtype=dt)
+            hw = h * wd
+            r = ops.embedding(ids, w["cb"], torch.empty(N * hw, dim, device=dev, dtype=dt), relu=True)
+            r = self._resblock(w, "d0", r, dt, N, post_relu=True, H=h, W=wd)
+            r = self._resblock(w, "d1", r, dt, N, post_relu=True, H=h, W=wd)          # decoder[2] ReLU folded
+            up = torch.empty(N * 4 * hw, dim, device=dev, dtype=dt)
             for py in range(2):
                 for px in range(2):
-                    ops.gemm(r, w[f"d3.w{py}{px}{s}"], up, M=N * 256, N=dim, K=4 * dim, lda=dim, ldy=dim, out_h=16, out_w=16,
-                             in_h=16, in_w=16, taps_h=2, taps_w=2, cin=dim, stride=1, dy0=py, dx0=px, dys=-1, dxs=-1,
-                             y_img_stride=1024, y_mul_y=64, y_mul_x=2, y_off=py * 32 + px, bias=w["d3.b"], scale=w["d3.s"],
+                    ops.gemm(r, w[f"d3.w{py}{px}{s}"], up, M=N * hw, N=dim, K=4 * dim, lda=dim, ldy=dim, out_h=h, out_w=wd,
+                             in_h=h, in_w=wd, taps_h=2, taps_w=2, cin=dim, stride=1, dy0=py, dx0=px, dys=-1, dxs=-1,
+                             y_img_stride=4 * hw, y_mul_y=4 * wd, y_mul_x=2, y_off=py * 2 * wd + px, bias=w["d3.b"], scale=w["d3.s"],
                              shift=w["d3.t"], act=ops.ACT_RELU)
             # ConvTranspose2d(dim, C, 4, 2, 1) + Tanh as GEMM + fold: `up` (the widest activation of the stack) is read once
             nt = 16 * self.input_dim
-            taps = torch.empty(N * 1024, nt, device=dev, dtype=torch.float32)
-            ops.gemm(up, w["d6.w16" + s], taps, M=N * 1024, N=nt, K=dim, lda=dim, ldy=nt)
-            ops.convt_fold_tanh(taps, w["d6.b"], out, N=N, IH=32, IW=32, cout=self.input_dim)
+            taps = torch.empty(N * 4 * hw, nt, device=dev, dtype=torch.float32)
+            ops.gemm(up, w["d6.w16" + s], taps, M=N * 4 * hw, N=nt, K=dim, lda=dim, ldy=nt)
+            ops.convt_fold_tanh(taps, w["d6.b"], out, N=N, IH=2 * h, IW=2 * wd, cout=self.input_dim)
             return
         H, W = h, wd
         x = ops.embedding(ids, w["cb"], torch.empty(N * H * W, 4 * dim, device=dev, dtype=dt))
@@ -389,5 +401,5 @@ class VectorQuantizedVAE(nn.Module):
         ids = ops.vq_nearest(z, w["cbt"], w["c2"]).view(N, hh, ww)
         D = z.shape[1]
         z_q = ops.embedding(ids, w["cb"], torch.empty(N * hh * ww, D, device=x.device, dtype=torch.float32))
-        x_tilde = self.decode(ids)
+        x_tilde = self._decode_nocheck(ids)
         return x_tilde, z.view(N, hh, ww, D).permute(0, 3, 1, 2), z_q.view(N, hh, ww, D).permute(0, 3, 1, 2)

@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc
 
 __all__ = ["gemm", "layernorm", "attention", "embedding", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
-           "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mse", "mlp_fused", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
+           "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mse", "check_device_errors", "graph_events_supported", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
            "PROFILE", "F32", "BF16", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
 
 
@@ -35,7 +35,55 @@ def tdtype(c: int) -> torch.dtype:
 def _dev(t: torch.Tensor):
     if not t.is_cuda:
         raise RuntimeError("mage_amd ops need tensors on a ROCm GPU (cuda device); there is no CPU fallback")
-    return _lib.lib(t.device.index or 0), torch.cuda.current_stream(t.device).cuda_stream
+    idx = t.device.index or 0
+    if idx != torch.cuda.current_device():
+        # the C ABI launches on the CURRENT device (zero page, launch attributes, the kernels themselves): a tensor of another
+        # device would be addressed from the wrong GPU
+        raise RuntimeError(f"mage_amd ops: tensor on cuda:{idx} but the current device is cuda:{torch.cuda.current_device()}; "
+                           f"wrap the call in torch.cuda.device({idx})")
+    return _lib.lib(idx), torch.cuda.current_stream(t.device).cuda_stream
+
+
+_GRAPH_EVENTS = {}
+
+
+def graph_events_supported(device) -> bool:
+    """Can timing events be captured into a HIP graph as event-record nodes (torch.cuda.Event(external=True)) and read back
+    after a replay?  Probed once per device with a two-node graph."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _GRAPH_EVENTS:
+        ok = False
+        try:
+            with torch.cuda.device(idx):
+                x = torch.zeros(1 << 20, device=dev)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                a = torch.cuda.Event(enable_timing=True, external=True)
+                b = torch.cuda.Event(enable_timing=True, external=True)
+                with torch.cuda.graph(g):
+                    a.record()
+                    x.add_(1.0)
+                    b.record()
+                for _ in range(2):
+                    g.replay()
+                    torch.cuda.synchronize()
+                    ms = a.elapsed_time(b)
+                ok = 0.0 < ms < 100.0
+        except Exception:
+            ok = False
+        _GRAPH_EVENTS[idx] = ok
+    return _GRAPH_EVENTS[idx]
+
+
+def check_device_errors(device) -> None:
+    """Raise (ValueError) if a kernel met an out-of-range id / target since the last check; synchronises the current stream
+    of `device` (include/mage_hip.h: mage_check_device_errors)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(idx):
+        l = _lib.lib(idx)
+        _lib.check(l.mage_check_device_errors(torch.cuda.current_stream(idx).cuda_stream), l)
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -45,38 +93,74 @@ def _p(t: Optional[torch.Tensor]):
 class _Profile:
     """Optional per-launch timing with HIP events recorded on the launch stream (torch.cuda.Event on the
     current stream IS a hipEvent on the stream the kernels are enqueued on).  Used by bench.py for the
-    roofline of the dominant kernel; off by default (zero overhead)."""
+    roofline of the dominant kernel; off by default (zero overhead).
+
+    Eager launches: begin()/end() record a pair of events per instrumented launch.  Graph replay (MAGE.use_graph): the pairs
+    are recorded ONCE, while the graph is captured, as `external` events (event-record nodes of the graph); every replay
+    re-records them, and absorb() adds their elapsed times after the replay has been synchronised."""
 
     def __init__(self):
         self.enabled = False
         self.records = []
         self.only = None             # None: every instrumented launch; else the set of keys to time (others run un-bracketed)
+        self.external = False        # True while a HIP graph is being captured
+        self.acc = {}
 
     def reset(self, enabled: bool = False, only=None):
         self.enabled, self.records, self.only = enabled, [], (set(only) if only is not None else None)
+        self.acc = {}
+
+    def clear(self):
+        """Drop what was measured so far, keep the mode (so that graphs captured for this mode stay valid)."""
+        self.records, self.acc = [], {}
+
+    def mode_key(self):
+        """What a captured graph has to match: off / every launch / a set of keys."""
+        if not self.enabled:
+            return "off"
+        return "all" if self.only is None else tuple(sorted(self.only))
 
     def wants(self, key: str) -> bool:
         return self.enabled and (self.only is None or key in self.only)
 
     def begin(self):
-        e = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True, external=True) if self.external else torch.cuda.Event(enable_timing=True)
         e.record()
         return e
 
     def end(self, key: str, start, flops: float = 0.0, nbytes: float = 0.0):
-        e = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True, external=True) if self.external else torch.cuda.Event(enable_timing=True)
         e.record()
         self.records.append((key, start, e, flops, nbytes))
 
-    def summary(self):
-        torch.cuda.synchronize()
-        out = {}
-        for key, s, e, fl, nb in self.records:
+    def capture_begin(self):
+        """Start collecting the event pairs of a graph capture; returns the state to hand back to capture_end."""
+        saved = (self.records, self.external)
+        self.records, self.external = [], True
+        return saved
+
+    def capture_end(self, saved):
+        recs = self.records
+        self.records, self.external = saved
+        return recs
+
+    def _add(self, out, recs):
+        for key, s, e, fl, nb in recs:
             d = out.setdefault(key, {"ms": 0.0, "calls": 0, "flops": 0.0, "bytes": 0.0})
             d["ms"] += s.elapsed_time(e)
             d["calls"] += 1
             d["flops"] += fl
             d["bytes"] += nb
+
+    def absorb(self, recs):
+        """Add the elapsed times of a replayed graph's event pairs (the replay must have completed)."""
+        if self.enabled and recs:
+            self._add(self.acc, recs)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {k: dict(v) for k, v in self.acc.items()}
+        self._add(out, self.records)
         return out
 
 
@@ -341,17 +425,3 @@ def mse(a, b, *, rows, cols, lda, ldb):
     ws = torch.empty(256, device=a.device, dtype=torch.float64)
     _lib.check(l.mage_mse(a.data_ptr(), lda, b.data_ptr(), ldb, rows, cols, ws.data_ptr(), out.data_ptr(), s), l)
     return out[0]
-
-
-def mlp_fused(xn, w_fc, b_fc, w_proj, b_proj, x):
-    """x += c_proj(QuickGELU(c_fc(xn))): bf16 operands, fp32 residual stream updated in place."""
-    l, s = _dev(x)
-    assert xn.dtype == torch.bfloat16 and w_fc.dtype == torch.bfloat16 and w_proj.dtype == torch.bfloat16 and x.dtype == torch.float32
-    Cc = x.shape[-1]
-    M = x.numel() // Cc
-    ev = PROFILE.begin() if PROFILE.enabled else None
-    _lib.check(l.mage_mlp_fused(xn.data_ptr(), w_fc.data_ptr(), b_fc.data_ptr(), w_proj.data_ptr(), b_proj.data_ptr(), x.data_ptr(),
-                                M, Cc, s), l)
-    if ev is not None:
-        PROFILE.end(f"mlp_kernel<{Cc // 128}>", ev, 16.0 * M * Cc * Cc)
-    return x

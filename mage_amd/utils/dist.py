@@ -7,7 +7,10 @@ the barrier, the max-over-ranks timing and the optional gather of generated toke
 from __future__ import annotations
 
 import os
-from typing import Dict, Tuple
+import socket
+import subprocess
+import sys
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -61,3 +64,33 @@ def gather_clips(x: torch.Tensor) -> torch.Tensor:
     out = [torch.empty_like(x) for _ in range(dist.get_world_size())]
     dist.all_gather(out, x.contiguous())
     return torch.cat(out, 0)
+
+
+def ranks_seen(device: torch.device) -> int:
+    """Sum over ranks of 1 through the process group's all-reduce (RCCL on GPUs): how many ranks the collective layer
+    actually connected, as opposed to what the environment claims."""
+    if not dist.is_initialized():
+        return 1
+    t = torch.ones(1, dtype=torch.int32, device=device)
+    dist.all_reduce(t)
+    return int(t.item())
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(script_argv: List[str], nproc: int, port: Optional[int] = None, env: Optional[dict] = None) -> int:
+    """One process per GPU on this node: re-run ``script_argv`` (script path + its arguments) under
+    ``python -m torch.distributed.run`` with ``nproc`` ranks, rendezvous on 127.0.0.1.  The reference does this with
+    ``mp.spawn(main_worker, nprocs=ngpus_per_node)`` (main_mage.py:279-295); here the launcher also exports
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, which is what ``init_from_env`` reads.  Returns the exit code."""
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: required for RCCL on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port or free_port())] + list(script_argv)
+    return subprocess.call(cmd, env=e)

@@ -129,11 +129,13 @@ def _sprite(g: np.random.Generator) -> np.ndarray:
 
 
 def synth_batch_mnist(B: int, L: int, seed: int = 0, digits: int = 1, text_len: int = 11,
-                      vocab: int = 30, ragged_text: bool = False) -> Dict[str, torch.Tensor]:
+                      vocab: int = 30, ragged_text: bool = False, caption_lengths: Optional[Iterable[int]] = None) -> Dict[str, torch.Tensor]:
     """Moving-MNIST-like batch with the reference's batch contract
     (dataload.py:240-271): images f32 [B,L,1,64,64] in [-0.5, 0.5], text int64 [B,S]
     right-padded with 0, speed f32 [B].  Motion follows the bounce rule of
-    data/mnist_caption_single.py:62-109."""
+    data/mnist_caption_single.py:62-109.  ``caption_lengths`` (e.g. (16, 18, 20): the token counts of the double-digit captions
+    of data/mnist_caption_double_modified.py:218-220, each motion phrase being 1 or 3 words) draws every caption's length from
+    that set and right-pads to its maximum."""
     g = rng_for(seed, f"batch_mnist/{B}/{L}/{digits}")
     imgs = np.zeros((B, L, 1, 64, 64), np.float32)
     lim = 64 - 28
@@ -159,9 +161,15 @@ def synth_batch_mnist(B: int, L: int, seed: int = 0, digits: int = 1, text_len: 
                         sign = -sign
                         x = min(max(x, 0), lim)
     imgs -= 0.5                                                   # dataload.py:254
+    lens = sorted(int(x) for x in caption_lengths) if caption_lengths is not None else None
+    if lens:
+        text_len = lens[-1]
     text = np.zeros((B, text_len), np.int64)
     for b in range(B):
-        n = text_len if not ragged_text else int(g.integers(max(4, text_len - 6), text_len + 1))
+        if lens:
+            n = lens[int(g.integers(0, len(lens)))]
+        else:
+            n = text_len if not ragged_text else int(g.integers(max(4, text_len - 6), text_len + 1))
         text[b, 0] = 1                                            # [CLS]
         text[b, 1:n - 1] = g.integers(3, vocab, size=n - 2)
         text[b, n - 1] = 2                                        # [SEP]

@@ -399,14 +399,14 @@ def flat_axial_decoder_latent(sd: SD, p: str, motion: torch.Tensor, imgs: torch.
 
 
 def mage_generate_latent(sd: SD, batch: Dict[str, torch.Tensor], frames_length: int, lat0: torch.Tensor,
-                         noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+                         noise: Optional[torch.Tensor] = None, mage_plus: bool = False, return_motion: bool = False):
     """MAGE.autoregressive_generate for use_cids=False between the first stage's encode and decode:
     lat0 [B, E, h, w] (latents of frame 0) -> predicted latents [B, L-1, h, w, E]."""
     B, E, h, w = lat0.shape
     Lm1 = frames_length - 1
     first = _frame_features_latent(sd, lat0[:, None])[:, 0].reshape(B, h * w, -1)
     txt = text_encoder(sd, "text_encoder.", batch["text"])
-    ma = ma_encoder(sd, "ma_encoder.", first, txt).view(B, h, w, -1)
+    ma = ma_encoder(sd, "ma_encoder.", first, txt, mage_plus=mage_plus).view(B, h, w, -1)
     if noise is not None:
         ma = adain(sd, ma, noise)
     if batch.get("speed") is not None:
@@ -417,11 +417,11 @@ def mage_generate_latent(sd: SD, batch: Dict[str, torch.Tensor], frames_length: 
         pred = flat_axial_decoder_latent(sd, "generate_model.", ma, _frame_features_latent(sd, cur))
         if i != Lm1 - 1:
             cur[:, i + 1] = pred[:, i].permute(0, 3, 1, 2)
-    return pred
+    return (pred, ma) if return_motion else pred
 
 
 def mage_forward_loss_latent(sd: SD, batch: Dict[str, torch.Tensor], frames_length: int, lat: torch.Tensor, eps: torch.Tensor,
-                             v_kl: float, pid):
+                             v_kl: float, pid, mage_plus: bool = False):
     """MAGE.forward (mage_model.py:575-639) for use_cids=False with randomness=True and auto_beta=True (config/mage+_*.yaml),
     between the external first stage's encode and the loss: lat [B,L,E,h,w] = first_stage_encode(images), eps the injected
     reparameterisation noise.  Returns (final_loss, parts, predicted latents [B,L-1,h,w,E])."""
@@ -434,7 +434,7 @@ def mage_forward_loss_latent(sd: SD, batch: Dict[str, torch.Tensor], frames_leng
     video_emb = eps * (0.5 * logvar).exp() + mu
     first = _frame_features_latent(sd, lat[:, :1])[:, 0].reshape(B, h * w, -1)
     txt = text_encoder(sd, "text_encoder.", batch["text"])
-    ma = adain(sd, ma_encoder(sd, "ma_encoder.", first, txt).view(B, h, w, -1), video_emb)
+    ma = adain(sd, ma_encoder(sd, "ma_encoder.", first, txt, mage_plus=mage_plus).view(B, h, w, -1), video_emb)
     if batch.get("speed") is not None:
         ma = ma + (batch["speed"].view(B, 1) @ sd["speed_embedding"])[:, None, None, :]
     pred = flat_axial_decoder_latent(sd, "generate_model.", ma, _frame_features_latent(sd, lat[:, :frames_length - 1]))

@@ -65,3 +65,32 @@ def test_shard_range_rejects_ragged_split():
     assert shard_range(256, 3, 8) == (96, 128)
     with pytest.raises(ValueError):
         shard_range(10, 0, 4)
+
+
+def test_launch_ranks_starts_world_and_all_reduce_sees_every_rank(tmp_path):
+    """bench.py --gpus N (outside torchrun) starts its ranks with mage_amd.utils.dist.launch_ranks; the same launcher, world
+    size 2, gloo: both ranks come up, the all-reduce of ones (bench.py's `ranks_seen`) counts 2, the strong-scaling split of a
+    global batch of 256 is the contiguous halves."""
+    import json
+    sys.path.insert(0, ROOT)
+    from mage_amd.utils.dist import launch_ranks
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["OMP_NUM_THREADS"] = "1"
+    rc = launch_ranks([os.path.join(ROOT, "tests", "rank_probe.py"), str(tmp_path), "256"], 2, env=env)
+    assert rc == 0
+    got = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    assert [g["ranks_seen"] for g in got] == [2, 2] and [g["world"] for g in got] == [2, 2]
+    assert [g["shard"] for g in got] == [[0, 128], [128, 256]] and [g["tmax"] for g in got] == [1.0, 1.0]
+
+
+def test_cfg3_captions_have_the_double_mnist_lengths():
+    sys.path.insert(0, ROOT)
+    from mage_amd.utils import synth
+    b = synth.synth_batch_mnist(64, 4, seed=1, digits=2, caption_lengths=(16, 18, 20))
+    text = b["text"]
+    assert tuple(text.shape) == (64, 20)
+    lens = (text != 0).sum(1)
+    assert set(lens.tolist()) == {16, 18, 20}                      # ragged: right-padded with 0 (the padded-text quirk of a9/a10)
+    assert (text[:, 0] == 1).all() and all(text[i, lens[i] - 1] == 2 for i in range(64))

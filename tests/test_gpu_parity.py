@@ -156,6 +156,7 @@ def test_mage_plus_forward_latent_golden():
     B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
     cfg = synth.magep_model_config(frames_length=L, width=int(g["width"]), layers=int(g["layers"]))
     m = build_mage(cfg, seed, DEV)
+    m.ma_encoder.mage_plus = False          # this fixture is the reference AS SHIPPED (mage_model.py:92 active)
     db = dev_batch(synth.synth_batch_cater(B, L, seed=seed, text_len=int(g["text_len"]), vocab=50))
     db["reparam_noise"] = t(g["eps"]).to(DEV)
     loss, ld = m(db)
@@ -259,9 +260,225 @@ def test_mage_plus_latent_path_golden():
     g = golden("mage_plus_small")
     B, L = int(g["B"]), int(g["L"])
     m = build_mage(synth.magep_model_config(frames_length=L, width=64, layers=3), int(g["seed"]), DEV)
+    m.ma_encoder.mage_plus = False          # this fixture is the reference AS SHIPPED (mage_model.py:92 active)
     batch = dev_batch(synth.synth_batch_cater(B, L, seed=int(g["seed"]), text_len=int(g["text_len"]), vocab=50))
     batch["video_noise"] = t(g["noise"]).to(DEV)
     video = m.autoregressive_generate(batch)
     assert tuple(video.shape) == (B, L, 3, 128, 128)
     torch.testing.assert_close(m.last_logits.cpu(), t(g["pred_latents"]), atol=2e-4, rtol=1e-4)
     torch.testing.assert_close(video[..., ::4, ::4].cpu(), t(g["video_sub"]), atol=2e-4, rtol=0)
+
+
+def test_mage_cater_fullwidth_golden():
+    """cfg4's model at FULL width (config/mage_caterv1.yaml: d=512, 6 blocks, f8 VQ-VAE dim 256 -> codebook D=1024, K=512,
+    randomness branch with the noise injected) on a short clip, fp32 mode: the kernel dispatch of the full-size CATER runs
+    (256-wide tiles, K=1024 quantiser, f8 stack at dim 256) against the reference's own tokens / logits / frames at 1e-4."""
+    g = golden("mage_cater_fullwidth")
+    B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
+    m = build_mage(synth.cater_model_config(frames_length=L), seed, DEV)
+    db = dev_batch(synth.synth_batch_cater(B, L, seed=seed, text_len=int(g["text_len"])))
+    db["video_noise"] = t(g["noise"]).to(DEV)
+    x0 = db["images"][:, 0].contiguous()
+    z = m.first_stage_model._encode_features(x0).view(B, 16, 16, -1).permute(0, 3, 1, 2)
+    torch.testing.assert_close(z[:, :8].cpu(), t(g["z_e_slice"]), atol=LOGIT_TOL, rtol=1e-5)
+    tok0 = m.first_stage_encode(db["images"][:, 0:1])[:, 0]
+    assert assert_tokens(tok0.cpu(), g["tok0"], g["tok0_margin"], TOK_TOL, "f8 encode, D=1024") == 0
+    ma = m._motion_anchor(tok0.reshape(B, -1), db, db["video_noise"]).view(B, 16, 16, -1)
+    torch.testing.assert_close(ma[:, ::4, ::4].cpu(), t(g["motion_sub"]), atol=LOGIT_TOL, rtol=1e-5)
+    video = m.autoregressive_generate(db)
+    assert assert_tokens(m.last_tokens.cpu(), g["gen_tokens"], g["margin"], TOK_TOL, "AR tokens cater full width") == 0
+    torch.testing.assert_close(m.last_logits[:, :, ::4, ::4].cpu(), t(g["step_logits_sub"]), atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(chk(m.last_logits.cpu()), g["step_logits_chk"], rtol=1e-4)
+    torch.testing.assert_close(video[..., ::4, ::4].cpu(), t(g["video_sub"]), atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(chk(video.cpu()), g["video_chk"], rtol=1e-4)
+    # incremental decoding on this config: same tokens, same frames
+    m.ar_mode = "incremental"
+    v_inc = m.autoregressive_generate(db)
+    assert assert_tokens(m.last_tokens.cpu(), g["gen_tokens"], g["margin"], TOK_TOL, "incremental AR tokens cater full width") == 0
+    assert torch.equal(v_inc, video)
+
+
+def test_mage_plus_transformer_block_variant_golden():
+    """MAGE+ with the TransformerBlock variant of mage_model.py:93 (ln_q / ln_kv): MAGE(use_cids=False) turns it on by itself;
+    sampling (motion anchor, predicted latents, frames) and the teacher-forced loss against the reference run with that line."""
+    g = golden("mage_plus_block_small")
+    B, L = int(g["B"]), int(g["L"])
+    m = build_mage(synth.magep_model_config(frames_length=L, width=int(g["width"]), layers=int(g["layers"])), int(g["seed"]), DEV)
+    assert m.ma_encoder.mage_plus is True
+    batch = dev_batch(synth.synth_batch_cater(B, L, seed=int(g["seed"]), text_len=int(g["text_len"]), vocab=50))
+    batch["video_noise"] = t(g["noise"]).to(DEV)
+    video = m.autoregressive_generate(batch)
+    torch.testing.assert_close(m.last_logits.cpu(), t(g["pred_latents"]), atol=LOGIT_TOL, rtol=1e-4)
+    torch.testing.assert_close(video[..., ::4, ::4].cpu(), t(g["video_sub"]), atol=LOGIT_TOL, rtol=0)
+    Lf, fseed = int(g["fwd_L"]), int(g["fwd_seed"])
+    mf = build_mage(synth.magep_model_config(frames_length=Lf, width=int(g["width"]), layers=int(g["layers"])), fseed, DEV)
+    db = dev_batch(synth.synth_batch_cater(B, Lf, seed=fseed, text_len=int(g["text_len"]), vocab=50))
+    db["reparam_noise"] = t(g["fwd_eps"]).to(DEV)
+    loss, ld = mf(db)
+    pred = mf.last_logits.view(B, Lf - 1, 16, 16, -1)[..., :4].cpu()
+    torch.testing.assert_close(pred[:, ::3], t(g["fwd_pred_sub"]), atol=LOGIT_TOL, rtol=1e-4)
+    assert abs(ld["val/prediction"] - float(g["fwd_prediction"])) < 1e-4 * max(1.0, abs(float(g["fwd_prediction"])))
+    assert abs(ld["val/kl_loss"] - float(g["fwd_kl_loss"])) < 1e-4 * max(1.0, abs(float(g["fwd_kl_loss"])))
+    assert abs(ld["val/beta"] - float(g["fwd_beta"])) < 1e-6
+    assert abs(loss.item() - float(g["fwd_final_loss"])) < 1e-4 * max(1.0, abs(float(g["fwd_final_loss"])))
+
+
+# ------------------------------------------------------------------------------------------------ the benchmarked (bf16) mode
+BF16_LOGIT_TOL = 0.06    # bf16 operands (8 mantissa bits) through 6 blocks with fp32 accumulation, fp32 residual stream: measured
+                         # max |d logit| 0.02-0.03 on logits of magnitude ~2; the gate leaves 2x
+
+
+def _teacher_forced_on_tokens(m, db, tok0, gen_tokens):
+    """Decoder logits with the REFERENCE's generated tokens as context (slot 0 = frame 0's tokens, slot i = the reference's
+    frame i): by causality these are the logits the reference's AR loop saw at each step."""
+    B, L = tok0.shape[0], m.frames_length
+    ctx = torch.cat([tok0.reshape(B, 1, -1), gen_tokens.reshape(B, L - 1, -1)[:, :L - 2]], 1).contiguous()
+    dt = m._dt()
+    ma = m._motion_anchor(tok0.reshape(B, -1).contiguous(), db, db.get("video_noise"))
+    feats = m._frame_features(ctx, dt)
+    lg = m.generate_model._run(ma if dt == torch.float32 else ma.to(dt), feats, B=B, hh=16, ww=16)
+    return lg.view(B, L - 1, 16, 16, -1)
+
+
+@pytest.mark.parametrize("tag,sub", [("mage_mnist_L16", (8, 8, 4)), ("mage_mnist_L6_ragged", (4, 4, 1))])
+def test_bf16_mode_against_reference_goldens(tag, sub):
+    """The BENCHMARKED precision against the reference itself (not against this repo's fp32 mode).
+    (1) Teacher-forced on the reference's own token sequence, the bf16 logits are within BF16_LOGIT_TOL of the reference's
+        per-step logits, and the bf16 argmax IS the reference's token wherever the reference's top-2 margin exceeds twice
+        the measured bf16 error.
+    (2) Free-running, a clip's tokens equal the reference's up to the first position whose reference margin is inside the
+        bf16 error (after a flip the inputs differ, so later frames legitimately differ); the agreement rate is printed."""
+    g = golden(tag)
+    B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
+    m = build_mage(synth.mnist_model_config(frames_length=L), seed, DEV).set_precision("bf16")
+    kw = dict(digits=int(g["digits"]), text_len=int(g["text_len"]), ragged_text=bool(g["ragged"])) if "digits" in g.files else {}
+    db = dev_batch(synth.synth_batch_mnist(B, L, seed=seed, **kw))
+    want = t(g["gen_tokens"]).long().to(DEV)                       # [B, L-1, 16, 16]
+    margin = t(g["margin"]).to(DEV)
+    tok0 = m.first_stage_encode(db["images"][:, 0:1])[:, 0]
+    lg = _teacher_forced_on_tokens(m, db, tok0, want)
+    ref_sub = t(g["step_logits_sub"]).to(DEV)
+    got_sub = lg[:, :, ::sub[0], ::sub[1], ::sub[2]]
+    err = (got_sub - ref_sub).abs().max().item()
+    am = lg.argmax(-1)
+    hard = (am != want) & (margin > 2 * max(err, 1e-3))
+    agree_tf = (am == want).float().mean().item()
+    print(f"{tag}: bf16 teacher-forced vs reference: max|d logit| {err:.4f}, argmax == reference tokens {agree_tf:.4f}, "
+          f"mismatches above 2x error margin: {int(hard.sum())}")
+    assert err < BF16_LOGIT_TOL and int(hard.sum()) == 0 and agree_tf > 0.97
+    m.autoregressive_generate(db)
+    got = m.last_tokens
+    agree = (got == want).float().mean().item()
+    bad_first = 0
+    for b in range(B):
+        diff = (got[b] != want[b]).flatten(1).any(1)                # per frame
+        if diff.any():
+            f = int(diff.nonzero()[0])
+            mism = got[b, f] != want[b, f]
+            bad_first += int((mism & (margin[b, f] > BF16_LOGIT_TOL)).sum())
+    print(f"{tag}: bf16 free-running token agreement with the reference {agree:.4f}")
+    assert bad_first == 0, "a clip's first divergence from the reference is at a position the reference decides by more than the bf16 error"
+
+
+# ------------------------------------------------------------------------------------------------ CATER configs at FULL size
+def test_full_size_properties_cfg4_caterv1():
+    """BASELINE cfg4 (config/mage_caterv1.yaml, frames_length 32, 128x128, B=32, bf16) at its stated size, through
+    size-independent properties: bitwise determinism, shard == slice of the whole batch, incremental == full, range."""
+    B, L = 32, 32
+    m = build_mage(synth.cater_model_config(frames_length=L), 0, DEV).set_precision("bf16")
+    batch = dev_batch(synth.synth_batch_cater(B, L, seed=1))
+    batch["video_noise"] = torch.randn(B, 64, 16, 16, generator=torch.Generator().manual_seed(5)).to(DEV)
+    v1 = m.autoregressive_generate(batch)
+    tok1 = m.last_tokens.clone()
+    assert tuple(v1.shape) == (B, L, 3, 128, 128) and torch.isfinite(v1).all() and v1.abs().max().item() <= 1.0
+    assert torch.equal(v1[:, 0], batch["images"][:, 0])
+    assert tok1.min().item() >= 0 and tok1.max().item() < 512 and tok1.unique().numel() > 16       # not a collapsed sequence
+    v2 = m.autoregressive_generate(batch)
+    assert torch.equal(tok1, m.last_tokens) and torch.equal(v1, v2)
+    half = {k: v[B // 2:] for k, v in batch.items()}
+    vh = m.autoregressive_generate(half)
+    assert torch.equal(m.last_tokens, tok1[B // 2:]) and torch.equal(vh, v1[B // 2:])
+    del v2, vh
+    m.ar_mode = "incremental"
+    vi = m.autoregressive_generate(batch)
+    assert torch.equal(m.last_tokens, tok1) and torch.equal(vi, v1)
+
+
+def test_full_size_properties_cfg5_mage_plus():
+    """BASELINE cfg5 (config/mage+_caterv2.yaml, frames_length 32, MAGE+ over a latent first stage, 16 clips = one GPU's share
+    of the global 128), MAGE side at its stated size: determinism, shard == slice, finite latents and frames."""
+    B, L = 16, 32
+    m = build_mage(synth.magep_model_config(frames_length=L), 0, DEV).set_precision("bf16")
+    batch = dev_batch(synth.synth_batch_cater(B, L, seed=2, vocab=50, text_len=24))
+    batch["video_noise"] = torch.randn(B, 64, 16, 16, generator=torch.Generator().manual_seed(6)).to(DEV)
+    v1 = m.autoregressive_generate(batch)
+    lat1 = m.last_logits.clone()
+    assert tuple(v1.shape) == (B, L, 3, 128, 128) and tuple(lat1.shape) == (B, L - 1, 16, 16, 4)
+    assert torch.isfinite(v1).all() and torch.isfinite(lat1).all() and lat1.abs().max().item() > 0
+    v2 = m.autoregressive_generate(batch)
+    assert torch.equal(v1, v2) and torch.equal(lat1, m.last_logits)
+    half = {k: v[:B // 2] for k, v in batch.items()}
+    vh = m.autoregressive_generate(half)
+    assert torch.equal(vh, v1[:B // 2]) and torch.equal(m.last_logits, lat1[:B // 2])
+
+
+# ------------------------------------------------------------------------------------------------ HIP-graph replay of the call
+@pytest.mark.parametrize("precision,ar_mode", [("fp32", "full"), ("bf16", "full"), ("bf16", "incremental")])
+def test_graph_replay_is_bit_identical_to_eager(precision, ar_mode):
+    """MAGE.use_graph: the whole autoregressive_generate call replayed from one captured HIP graph (no allocation, no host
+    decision inside) gives bitwise the eager result, also on NEW inputs of the same shape, and the golden tokens in fp32."""
+    g = golden("mage_mnist_L6_ragged")
+    B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
+    m = build_mage(synth.mnist_model_config(frames_length=L), seed, DEV).set_precision(precision)
+    m.ar_mode = ar_mode
+    kw = dict(digits=int(g["digits"]), text_len=int(g["text_len"]), ragged_text=True)
+    b1 = dev_batch(synth.synth_batch_mnist(B, L, seed=seed, **kw))
+    b2 = dev_batch(synth.synth_batch_mnist(B, L, seed=seed + 1, **kw))
+    want = []
+    for b in (b1, b2):
+        v = m.autoregressive_generate(b)
+        want.append((v.clone(), m.last_tokens.clone()))
+    m.use_graph = True
+    for rnd_ in range(3):                                   # call 1 eager (warm), call 2 captures + replays, call 3 replays
+        for b, (wv, wt) in zip((b1, b2), want):
+            v = m.autoregressive_generate(b)
+            assert torch.equal(v, wv) and torch.equal(m.last_tokens, wt), (rnd_, m.last_call_mode)
+    assert m.last_call_mode == "graph"
+    if precision == "fp32":
+        m.autoregressive_generate(b1)
+        assert assert_tokens(m.last_tokens.cpu(), g["gen_tokens"], g["margin"], TOK_TOL, "graph-replayed AR tokens") == 0
+    # replaced weights invalidate the captured graph (its kernels point at the old derived copies)
+    synth.fill_state_dict(m, seed + 7)
+    m.use_graph = False
+    v_new = m.autoregressive_generate(b1)
+    m.use_graph = True
+    for _ in range(3):
+        v = m.autoregressive_generate(b1)
+        assert torch.equal(v, v_new)
+    assert not torch.equal(v_new, want[0][0])
+
+
+def test_graph_replay_carries_per_kernel_events():
+    """bench.py's roofline needs HIP events around the dominant kernel INSIDE the timed region: under graph replay they are
+    event-record nodes of the captured graph, re-recorded by every replay."""
+    from mage_amd import ops
+    if not ops.graph_events_supported(DEV):
+        pytest.skip("external (event-record-node) events are not supported by this runtime: bench.py then times eagerly")
+    m = build_mage(synth.mnist_model_config(frames_length=4), 5, DEV).set_precision("bf16")
+    b = dev_batch(synth.synth_batch_mnist(8, 4, seed=5))
+    try:
+        ops.PROFILE.reset(enabled=True, only=["layernorm"])
+        m.autoregressive_generate(b)           # eager, graph off: the number of bracketed launches per call
+        per_call = ops.PROFILE.summary()["layernorm"]["calls"]
+        ops.PROFILE.clear()
+        m.use_graph = True
+        m.autoregressive_generate(b)           # eager (warm)
+        m.autoregressive_generate(b)           # capture + replay
+        ops.PROFILE.clear()
+        m.autoregressive_generate(b)
+        m.autoregressive_generate(b)
+        assert m.last_call_mode == "graph"
+        s = ops.PROFILE.summary()
+        assert set(s) == {"layernorm"} and s["layernorm"]["calls"] == 2 * per_call and 0.0 < s["layernorm"]["ms"] < 1e3
+    finally:
+        ops.PROFILE.reset()

@@ -88,7 +88,7 @@ def test_mage_cater_small_randomness_branch():
     video, gen, tok0, trace = O.mage_generate(sd, batch, int(g["L"]), noise=t(g["noise"]), return_trace=True)
     ma = O.motion_anchor(sd, tok0, batch["text"], batch["speed"], t(g["noise"]))
     assert torch.allclose(ma, t(g["motion"]), atol=1e-4, rtol=1e-4)
-    assert torch.allclose(trace, t(g["step_logits"]), atol=2e-4, rtol=1e-4)
+    assert torch.allclose(trace, t(g["step_logits"]), atol=1e-5, rtol=1e-5)      # measured: 1.8e-6
     assert torch.equal(gen, t(g["gen_tokens"]).long())
     assert torch.allclose(video[..., ::4, ::4], t(g["video_sub"]), atol=1e-5)
 
@@ -154,3 +154,53 @@ def test_mage_plus_latent_path():
     assert torch.allclose(pred, t(g["pred_latents"]), atol=1e-4, rtol=1e-4)
     video = fs.decode(pred.reshape(-1, 16, 16, 4).permute(0, 3, 1, 2)).view(int(g["B"]), -1, 3, 128, 128)
     assert torch.allclose(video[..., ::4, ::4], t(g["video_sub"])[:, 1:], atol=1e-4)
+
+
+def test_mage_cater_fullwidth_golden():
+    """cfg4's model at FULL width (d=512, 6 blocks, f8 VQ-VAE dim 256 -> codebook D=1024, K=512, randomness branch) on a short
+    clip: the oracle against the reference's own tokens, logits, motion anchor and frames."""
+    g = golden("mage_cater_fullwidth")
+    B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
+    sd = cpu_sd(build_mage(synth.cater_model_config(frames_length=L), seed))
+    batch = synth.synth_batch_cater(B, L, seed=seed, text_len=int(g["text_len"]))
+    video, gen, tok0, trace = O.mage_generate(sd, batch, L, noise=t(g["noise"]), return_trace=True)
+    assert torch.equal(tok0, t(g["tok0"]).long()) and torch.equal(gen, t(g["gen_tokens"]).long())
+    ma = O.motion_anchor(sd, tok0, batch["text"], batch["speed"], t(g["noise"]))
+    assert torch.allclose(ma[:, ::4, ::4], t(g["motion_sub"]), atol=2e-5, rtol=1e-5)
+    assert torch.allclose(trace[:, :, ::4, ::4], t(g["step_logits_sub"]), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(chk(trace), g["step_logits_chk"], rtol=1e-5)
+    assert torch.allclose(video[..., ::4, ::4], t(g["video_sub"]), atol=1e-5)
+    np.testing.assert_allclose(chk(video), g["video_chk"], rtol=1e-5)
+
+
+def test_mage_plus_transformer_block_variant():
+    """The MAGE+ variant of TransformerBlock.forward (mage_model.py:93: ln_q / ln_kv applied; the fixture comes from the
+    reference with that documented line swapped in, in the generating process only): sampling and the teacher-forced loss."""
+    from modules.mage_model import PIDControl
+    from tests.standin_first_stage import StandInLatentFirstStage
+    g = golden("mage_plus_block_small")
+    B, L = int(g["B"]), int(g["L"])
+    cfg = synth.magep_model_config(frames_length=L, width=int(g["width"]), layers=int(g["layers"]))
+    sd = cpu_sd(build_mage(cfg, int(g["seed"])))
+    batch = synth.synth_batch_cater(B, L, seed=int(g["seed"]), text_len=int(g["text_len"]), vocab=50)
+    fs = StandInLatentFirstStage()
+    pred, ma = O.mage_generate_latent(sd, batch, L, fs.encode(batch["images"][:, 0]), noise=t(g["noise"]), mage_plus=True,
+                                      return_motion=True)
+    assert torch.allclose(ma, t(g["motion"]), atol=2e-5, rtol=1e-5)
+    assert torch.allclose(pred, t(g["pred_latents"]), atol=2e-5, rtol=1e-5)
+    # without the variant the same weights give a visibly different anchor: the fixture does distinguish the two lines
+    _, ma92 = O.mage_generate_latent(sd, batch, L, fs.encode(batch["images"][:, 0]), noise=t(g["noise"]), mage_plus=False,
+                                     return_motion=True)
+    assert (ma92 - t(g["motion"])).abs().max().item() > 1e-2
+    Lf, fseed = int(g["fwd_L"]), int(g["fwd_seed"])
+    cfgf = synth.magep_model_config(frames_length=Lf, width=int(g["width"]), layers=int(g["layers"]))
+    sdf = cpu_sd(build_mage(cfgf, fseed))
+    bf = synth.synth_batch_cater(B, Lf, seed=fseed, text_len=int(g["text_len"]), vocab=50)
+    lat = fs.encode(bf["images"].reshape(B * Lf, *bf["images"].shape[2:])).view(B, Lf, 4, 16, 16)
+    final, parts, predf = O.mage_forward_loss_latent(sdf, bf, Lf, lat, t(g["fwd_eps"]), v_kl=cfgf["params"]["v_kl"], pid=PIDControl(),
+                                                     mage_plus=True)
+    assert torch.allclose(predf[:, ::3], t(g["fwd_pred_sub"]), atol=2e-5, rtol=1e-5)
+    assert abs(parts["prediction"] - float(g["fwd_prediction"])) < 1e-5 * max(1.0, abs(float(g["fwd_prediction"])))
+    assert abs(parts["kl_loss"] - float(g["fwd_kl_loss"])) < 1e-4 * max(1.0, abs(float(g["fwd_kl_loss"])))
+    assert abs(parts["beta"] - float(g["fwd_beta"])) < 1e-9
+    assert abs(final.item() - float(g["fwd_final_loss"])) < 1e-5 * max(1.0, abs(float(g["fwd_final_loss"])))

@@ -99,11 +99,118 @@ def gen_forward_random(ref_mage):
          beta=np.float64(ld["val/beta"]), pred=cap["pred"])
 
 
+
+def _inject_randn(noise):
+    real_randn = torch.randn
+
+    def fake_randn(*a, **k):
+        shape = a[0] if len(a) == 1 and isinstance(a[0], (list, tuple)) else a
+        return noise.clone() if tuple(shape) == tuple(noise.shape) else real_randn(*a, **k)
+    return real_randn, fake_randn
+
+
+def gen_cater_fullwidth(ref_mage):
+    """cfg4's MODEL at full width (config/mage_caterv1.yaml: d=512, 6 blocks, f8 VQ-VAE dim 256 -> codebook D=1024, K=512,
+    randomness=True) on a short clip (B=1, L=4): pins the kernel dispatch the full-size CATER runs use (256-row tiles, K=1024
+    quantiser, f8 stack at dim 256) at the 1e-4 gate."""
+    print("mage_cater_fullwidth")
+    from oracle import mage_oracle as O
+    L, B, seed = 4, 1, 43
+    cfg = synth.cater_model_config(frames_length=L)
+    m = build_ref_mage(ref_mage, cfg, seed)
+    batch = synth.synth_batch_cater(B, L, seed=seed, text_len=14)
+    noise = torch.from_numpy(synth.rng_for(seed, "video_noise").standard_normal((B, 64, 16, 16)).astype(np.float32))
+    real_randn, fake_randn = _inject_randn(noise)
+    trace = []
+    orig_gen = m.generate_model.forward
+
+    def spy(motion, imgs):
+        out = orig_gen(motion, imgs)
+        trace.append((motion.clone(), out.clone()))
+        return out
+    m.generate_model.forward = spy
+    torch.randn = fake_randn
+    try:
+        with torch.no_grad():
+            video = m.autoregressive_generate({k: v.clone() for k, v in batch.items()})
+            x0 = batch["images"][:, 0].contiguous()
+            z_e = m.first_stage_model.encoder(x0)
+            tok0 = m.first_stage_model.encode(x0)
+            dist = O.vq_distances(z_e.permute(0, 2, 3, 1).contiguous(), m.first_stage_model.codebook.embedding.weight)
+    finally:
+        torch.randn = real_randn
+    step_logits = torch.stack([trace[i][1][:, i] for i in range(L - 1)], 1)
+    save("mage_cater_fullwidth", seed=seed, B=B, L=L, text_len=14, noise=noise, tok0=tok0.to(torch.int16),
+         tok0_margin=top2_margin(dist, largest=False).view(tok0.shape), z_e_slice=z_e[:, :8], z_e_chk=chk(z_e),
+         motion_sub=trace[0][0][:, ::4, ::4].contiguous(), motion_chk=chk(trace[0][0]),
+         gen_tokens=trace[-1][1].max(-1)[1].to(torch.int16), margin=top2_margin(step_logits),
+         step_logits_sub=step_logits[:, :, ::4, ::4].contiguous(), step_logits_chk=chk(step_logits),
+         video_sub=video[..., ::4, ::4].contiguous(), video_chk=chk(video))
+
+
+def gen_mage_plus_block(ref_mage):
+    """MAGE+ with the TransformerBlock variant the reference's comment prescribes for it (mage_model.py:93: ln_q / ln_kv
+    applied, residual from the un-normalised q).  The shipped source has :92 active; here the block's forward is replaced, in
+    this process only, by the documented MAGE+ line -- the reference tree is untouched."""
+    print("mage_plus_block_small")
+
+    def fwd93(self, q, k, v, key_mask=None, need_weights=False):
+        x = q + self.dropout(self.attention(self.ln_q(q), self.ln_kv(k), self.ln_kv(v), key_mask))
+        x = x + self.dropout(self.mlp(self.ln_2(x)))
+        return x
+    orig_fwd = ref_mage.TransformerBlock.forward
+    ref_mage.TransformerBlock.forward = fwd93
+    real_randn = torch.randn
+    real_randn_like = torch.randn_like
+    try:
+        cfg = synth.magep_model_config(frames_length=4, width=64, layers=3)
+        m = build_ref_mage(ref_mage, cfg, 52)
+        batch = synth.synth_batch_cater(2, 4, seed=52, text_len=12, vocab=50)
+        noise = torch.from_numpy(synth.rng_for(52, "video_noise").standard_normal((2, 64, 16, 16)).astype(np.float32))
+        _, fake_randn = _inject_randn(noise)
+        trace = []
+        orig_gen = m.generate_model.forward
+
+        def spyp(motion, imgs):
+            out = orig_gen(motion, imgs)
+            trace.append((motion.clone(), out.clone()))
+            return out
+        m.generate_model.forward = spyp
+        torch.randn = fake_randn
+        with torch.no_grad():
+            video = m.autoregressive_generate({k: v.clone() for k, v in batch.items()})
+        torch.randn = real_randn
+        m.generate_model.forward = orig_gen
+        # and the teacher-forced loss of the same variant (L=10 so the Conv3d prior collapses to one frame)
+        cfg10 = synth.magep_model_config(frames_length=10, width=64, layers=3)
+        m10 = build_ref_mage(ref_mage, cfg10, 72)
+        batch10 = synth.synth_batch_cater(2, 10, seed=72, text_len=12, vocab=50)
+        eps = torch.from_numpy(synth.rng_for(72, "reparam_noise").standard_normal((2, 64, 16, 16)).astype(np.float32))
+        torch.randn_like = lambda t, *a, **k: eps.clone() if tuple(t.shape) == tuple(eps.shape) else real_randn_like(t, *a, **k)
+        cap = {}
+        h = m10.generate_model.register_forward_hook(lambda mod, i, o: cap.__setitem__("pred", o.detach().clone()))
+        with torch.no_grad():
+            loss, ld = m10({k: v.clone() for k, v in batch10.items()})
+        h.remove()
+    finally:
+        torch.randn = real_randn
+        torch.randn_like = real_randn_like
+        ref_mage.TransformerBlock.forward = orig_fwd
+    save("mage_plus_block_small", seed=52, B=2, L=4, width=64, layers=3, text_len=12, noise=noise, motion=trace[0][0],
+         pred_latents=trace[-1][1], video_sub=video[..., ::4, ::4].contiguous(), video_chk=chk(video),
+         fwd_seed=72, fwd_L=10, fwd_eps=eps, fwd_final_loss=np.float64(loss.item()), fwd_prediction=np.float64(ld["val/prediction"]),
+         fwd_kl_loss=np.float64(ld["val/kl_loss"]), fwd_beta=np.float64(ld["val/beta"]), fwd_pred_sub=cap["pred"][:, ::3].contiguous())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_mage, ref_vq = import_reference()
     if "--only-forward-random" in sys.argv:      # regenerate just fixture 7c
         gen_forward_random(ref_mage)
+        return
+    if "--only-round2" in sys.argv:              # the fixtures added in round 2
+        gen_cater_fullwidth(ref_mage)
+        gen_mage_plus_block(ref_mage)
         return
 
     # ---- 1. VQ unit: exact ties, near ties, reference-init regime --------------------------
@@ -288,6 +395,8 @@ def main():
          pred_latents=trace[-1][1], pred_step0=trace[0][1], video_sub=video[..., ::4, ::4].contiguous(), video_chk=chk(video))
 
     gen_forward_random(ref_mage)
+    gen_cater_fullwidth(ref_mage)
+    gen_mage_plus_block(ref_mage)
     # ---- 8. state_dict layout (keys, shapes, dtypes) of the reference modules: the drop-in boundary ----------------
     import json
     layout = {}
