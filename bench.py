@@ -63,7 +63,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=1,
                     help="clip groups on concurrent HIP streams inside one generate call (2: +4 %% frames/s, but per-kernel "
                          "event times then overlap: the roofline object needs 1)")
-    ap.add_argument("--graph", type=int, default=1, help="1: replay the AR loop from a captured HIP graph where the model supports it")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: replay each call from ONE captured HIP graph (MAGE.use_graph).  Measured on MI355X (profiles/r02_graph_probe.txt): "
+                         "no gain in either AR mode -- the launch loop is GPU-bound (3 %% idle in incremental mode, 2 %% in full mode) -- and "
+                         "ROCm cannot capture timing events as graph nodes, so the per-kernel events of the roofline need eager launches")
     ap.add_argument("--events", default="dominant", choices=["dominant", "all"],
                     help="HIP events inside the timed region: around the dominant GEMM symbol's launches only (it is found, "
                          "and the per-kernel table filled, in the last warm-up call, which brackets every launch), or around "
