@@ -96,7 +96,14 @@ typedef struct mage_gemm_desc {
     const void* residual;
     int32_t ldr, res_dtype;
     int32_t post_relu;
-    int32_t reserved;
+    int32_t ldw;                       /* row stride of W in elements; 0 = K (W packed [N][K]) */
+    /* Split-K (the weight-gradient GEMMs dW = dY^T X of the training path, whose contraction runs over all M tokens while the
+     * output is only [N_out, K_out]): n_split > 1 computes n_split independent products in ONE launch,
+     *     Y + s*y_split_stride  =  (A + s*a_split_stride) (*) (W + s*w_split_stride)^T      s = 0 .. n_split-1
+     * (strides in elements; A and W then have lda / ldw > K and each slice contracts over K of their columns); the caller sums
+     * the n_split partial outputs (mage_sum_partials) in a fixed order.  Plain form only: no gather, no epilogue extras. */
+    int32_t n_split;                   /* 0 or 1 = no split */
+    int64_t a_split_stride, w_split_stride, y_split_stride;
 } mage_gemm_desc;
 
 int mage_gemm(const mage_gemm_desc* desc, void* stream);
@@ -244,6 +251,61 @@ int mage_reparam_kl(const float* mu, const float* logvar, const float* eps, floa
  * (F.mse_loss of the MAGE+ latent prediction, mage_model.py:620).  workspace: 256 doubles. */
 int mage_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t cols, double* workspace, float* out,
              void* stream);
+
+
+/* =============================================================================================================================
+ * Training path: backward of MAGE.forward (main_mage.py:150-153 `loss.backward(); optimizer.step()`).
+ * Dense gradients reuse mage_gemm: dX = dY W on a transposed weight copy; dW = dY^T X as transposes + ONE split-K launch
+ * (mage_gemm_desc::n_split) + mage_sum_partials.  The entry points below are the rest of the backward pass.
+ * =========================================================================================================================== */
+
+/* y[(c + y_row0)*ldy + m] = x[arow(m)*ldx + c] for m < M, 0 for M <= m < Mp (zero tail up to the padded width the split-K GEMM
+ * reads).  arow(m) is mage_gemm's implicit-GEMM row map for ONE tap: m -> (img, oy, ox) over an out_h x out_w plane,
+ * arow = img*img_stride + (oy+dy)*in_w + (ox+dx) + a_off, zero outside [0,in_h) x [0,in_w).  Plain transpose: out_h = 1,
+ * out_w = M, dy = dx = 0.  The conv3x3 weight gradient (mage_model.py:485-488) stacks nine calls (dy, dx = tap - 1,
+ * y_row0 = tap*C).  dtype: MAGE_F32 | MAGE_BF16 (x and y). */
+int mage_transpose(const void* x, int32_t dtype, int64_t ldx, void* y, int64_t ldy, int64_t y_row0, int64_t M, int64_t Mp, int32_t C,
+                   int32_t out_h, int32_t out_w, int32_t in_h, int32_t in_w, int64_t img_stride, int64_t a_off, int32_t dy, int32_t dx,
+                   void* stream);
+/* out[r] = sum_{c < n} x[r*ld + c] (fp32, fixed order): bias gradients db = column sums of dY, taken from the transposed dY. */
+int mage_row_sum(const void* x, int32_t dtype, int64_t ld, int64_t n, int32_t rows, float* out, void* stream);
+/* out[i] = (accumulate ? out[i] : 0) + sum_{s < n_part} part[s*stride + i]: the split-K partial products, the LayerNorm
+ * gamma/beta partials.  Fixed order: deterministic. */
+int mage_sum_partials(const float* part, int64_t stride, int32_t n_part, int64_t n, float* out, int32_t accumulate, void* stream);
+/* nn.LayerNorm backward (statistics recomputed from the saved input x [rows, C] fp32): dx (+)= dLN/dx, and per-workgroup
+ * partial sums partials[n_part][2][C] of (dgamma, dbeta) for mage_sum_partials.  dy in dy_dtype. */
+int mage_layernorm_bwd(const float* x, const float* gamma, const void* dy, int32_t dy_dtype, float* dx, float* partials, int32_t n_part,
+                       int64_t rows, int32_t C, float eps, int32_t accumulate, void* stream);
+/* y = act(x) and dx = dy * act'(x) elementwise (x = the saved pre-activation; QuickGELU mage_model.py:11-13, erf-GELU of the text
+ * encoder, ReLU).  n % 4 == 0. */
+int mage_act(const void* x, void* y, int32_t dtype, int64_t n, int32_t act, void* stream);
+int mage_act_bwd(const void* x, const void* dy, void* dx, int32_t dtype, int64_t n, int32_t act, void* stream);
+/* F.cross_entropy backward (mage_model.py:618): dlogits = (softmax(logits) - onehot(target)) * grad_out[0] / rows, written in
+ * dl_dtype (the A operand of the head's dX / dW GEMMs).  grad_out: device pointer to the upstream scalar gradient. */
+int mage_cross_entropy_bwd(const float* logits, const int64_t* target, int64_t rows, int32_t K, const float* grad_out, void* dlogits,
+                           int32_t dl_dtype, void* stream);
+/* nn.Embedding backward: dtable[ids[i], :] += dout[orow(i), :] (fp32 atomics; orow as in mage_embedding; ids equal to padding_idx
+ * (< 0: none) contribute nothing, as nn.Embedding(padding_idx=...) does). */
+int mage_embedding_bwd(const int64_t* ids, const void* dout, int32_t dout_dtype, float* dtable, int64_t n, int32_t C, int32_t n_table,
+                       int64_t padding_idx, int64_t group, int64_t group_stride, int64_t off, void* stream);
+/* out[g, :] = sum over rows r with (r / div) % mod == g of w(r) x[r, :], w(r) = row_scale ? row_scale[r / row_scale_div] : 1.
+ * Gradients of the broadcast row tables: T / H / W positional embeddings (mage_model.py:338,489-492), text positions, and (mod = 1,
+ * row_scale = speed) the speed embedding (:666-668). */
+int mage_group_rowsum(const void* x, int32_t dtype, int64_t rows, int32_t C, int64_t div, int64_t mod, const float* row_scale,
+                      int64_t row_scale_div, float* out, void* stream);
+/* Backward of mage_attention: same descriptor (q, k, v as in the forward call; desc->out is unused), dout addressed like the
+ * forward's out (ldo), gradients written with the addressing of q (dq, ld_dq) and of k / v (dk, dv, ld_dk, ld_dv) in desc->dtype.
+ * P is recomputed in fp32; fixed-order sums (deterministic). */
+int mage_attention_bwd(const mage_attn_desc* desc, const void* dout, void* dq, void* dk, void* dv, int32_t ld_dq, int32_t ld_dk,
+                       int32_t ld_dv, void* stream);
+/* nn.Dropout in training mode as a stateless mask: y = (accumulate ? y : 0) + x * keep(seed, i) / (1 - p).  The backward pass
+ * calls it again with the same seed (no mask tensor). */
+int mage_dropout(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, int64_t n, float p, uint64_t seed, int32_t accumulate,
+                 void* stream);
+/* torch.optim.Adam step (main_mage.py:121: betas (0.9, 0.98), eps 1e-6) over flat fp32 arenas; grad_scale multiplies the gradient
+ * first (1 / world_size after a summing reduce-scatter). */
+int mage_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int32_t step,
+              float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,8 @@ class GemmDesc(C.Structure):
         ("act", i32),
         ("rowadd", vp), ("rowadd_div", i32), ("rowadd_mod", i32),
         ("residual", vp), ("ldr", i32), ("res_dtype", i32),
-        ("post_relu", i32), ("reserved", i32),
+        ("post_relu", i32), ("ldw", i32), ("n_split", i32),
+        ("a_split_stride", i64), ("w_split_stride", i64), ("y_split_stride", i64),
     ]
 
 
@@ -75,6 +76,19 @@ SIGNATURES = {
     "mage_groupnorm_act": (C.c_int, [vp, i64, i64, i32, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, i32, i64, i64, vp]),
     "mage_reparam_kl": (C.c_int, [vp, vp, vp, vp, vp, i32, i64, vp]),
     "mage_mse": (C.c_int, [vp, i64, vp, i64, i64, i32, vp, vp, vp]),
+    # training path
+    "mage_transpose": (C.c_int, [vp, i32, i64, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i64, i64, i32, i32, vp]),
+    "mage_row_sum": (C.c_int, [vp, i32, i64, i64, i32, vp, vp]),
+    "mage_sum_partials": (C.c_int, [vp, i64, i32, i64, vp, i32, vp]),
+    "mage_layernorm_bwd": (C.c_int, [vp, vp, vp, i32, vp, vp, i32, i64, i32, f32, i32, vp]),
+    "mage_act": (C.c_int, [vp, vp, i32, i64, i32, vp]),
+    "mage_act_bwd": (C.c_int, [vp, vp, vp, i32, i64, i32, vp]),
+    "mage_cross_entropy_bwd": (C.c_int, [vp, vp, i64, i32, vp, vp, i32, vp]),
+    "mage_embedding_bwd": (C.c_int, [vp, vp, i32, vp, i64, i32, i32, i64, i64, i64, i64, vp]),
+    "mage_group_rowsum": (C.c_int, [vp, i32, i64, i32, i64, i64, vp, i64, vp, vp]),
+    "mage_attention_bwd": (C.c_int, [C.POINTER(AttnDesc), vp, vp, vp, vp, i32, i32, i32, vp]),
+    "mage_dropout": (C.c_int, [vp, i32, vp, i32, i64, f32, C.c_uint64, i32, vp]),
+    "mage_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -64,6 +64,7 @@ struct GemmArgs {
     mage_gemm_desc d;
     const char* zero;
     int ntiles_n, ntiles;
+    int tiles_per_split;                   // tiles_m * ntiles_n: tile index = split * tiles_per_split + tm * ntiles_n + tn
     int stagger_groups, stagger_sleeps;    // start group (li % groups) of an XCD's workgroups after group * sleeps s_sleep(16)
 };
 
@@ -117,7 +118,7 @@ enum { EK_BIAS = 0, EK_RES_INIT = 1, EK_GENERAL = 2 };
 
 template <int ACT, typename OT, int MT, int EK>
 __device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const ColVecs& cv, f32x4 (&acc)[MT][4], int m0, int n0,
-                                              int lane, int plane) {
+                                              int lane, int plane, long ysplit) {
     const int l15 = lane & 15;
     const bool simple_rows = d.out_h == 1 && d.out_w >= d.M;       // no regrouping: yrow = m*y_mul_x + y_off
     const float lo = d.post_relu ? 0.f : -INFINITY;                 // post-ReLU as one max
@@ -211,7 +212,7 @@ __device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const Col
             // streaming (non-temporal) stores: the output is not re-read by this kernel, keep the XCD's L2 for the
             // activation panels and W that the neighbouring workgroups re-read
             if (mq < d.M && nv[k]) {
-                OT* yp = (OT*)d.Y + (long)yrow * d.ldy + ncol[k];
+                OT* yp = (OT*)d.Y + ysplit + (long)yrow * d.ldy + ncol[k];
                 if (sizeof(OT) == 4) {
                     __builtin_nontemporal_store(v[0], (f32x4*)yp);
                     __builtin_nontemporal_store(v[1], (f32x4*)yp + 1);
@@ -269,7 +270,7 @@ __device__ unsigned long long mage_probe_seg[8 * 160];   // gemm8: workgroup 8, 
 //   bf16: one instruction = 8 rows x 128 B;   fp32: one instruction = 4 rows x 256 B.
 template <int ACT, typename OT, int MT>
 __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32x4 (&bias)[4], f32x4 (&acc)[MT][4], int m0, int n0,
-                                              int lane, int plane, char* stg) {
+                                              int lane, int plane, char* stg, long ysplit) {
     constexpr bool F32 = sizeof(OT) == 4;
     constexpr int RB = F32 ? 256 : 128;            // bytes of one staged row (64 columns)
     constexpr int NCH = RB / 16;                   // 16-byte chunks per row: 16 | 8
@@ -294,7 +295,7 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
     const bool simple_rows = d.out_h == 1 && d.out_w >= d.M;
     const bool interior = simple_rows && m0 + MT * 16 <= d.M && n0 + 64 <= d.N;     // wave-uniform
     const bool cv_ok = col < d.N;                                                    // N % 8 == 0: a chunk is all in or all out
-    OT* yp = (OT*)d.Y + (long)((m0 + rr) * d.y_mul_x + d.y_off) * d.ldy + col;      // simple rows: row m0 + rr, then steps
+    OT* yp = (OT*)d.Y + ysplit + (long)((m0 + rr) * d.y_mul_x + d.y_off) * d.ldy + col;      // simple rows: row m0 + rr, then steps
     const long step = (long)RPI * d.y_mul_x * d.ldy;
 
     auto stage = [&](int mt, u32x4 (&o)[NST]) {     // math + transpose of 16-row tile mt: results land in o[] (row-contiguous)
@@ -347,7 +348,7 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
                         const int ox = rem - oy * d.out_w;
                         yrow = img * d.y_img_stride + oy * d.y_mul_y + ox * d.y_mul_x + d.y_off;
                     }
-                    __builtin_nontemporal_store(o[i], (u32x4*)((OT*)d.Y + (long)yrow * d.ldy + col));
+                    __builtin_nontemporal_store(o[i], (u32x4*)((OT*)d.Y + ysplit + (long)yrow * d.ldy + col));
                 }
             }
         }
@@ -370,7 +371,9 @@ __device__ __forceinline__ void ring_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int DT, bool GATHER, int ACT, int MT, int EK>
+// SPLIT: the split-K form (mage_gemm_desc::n_split > 1).  A template parameter so that the kernels of the generation path keep
+// their exact code (the tile decode, two 64-bit strides and the W row stride cost the 8-phase kernel 11 spilled SGPRs otherwise).
+template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     typedef typename TT<DT>::elem E;
     constexpr int BM = Tile<MT>::BM, A_BYTES = Tile<MT>::A_BYTES, STAGE_BYTES = Tile<MT>::STAGE_BYTES, AU = Tile<MT>::AU;
@@ -406,7 +409,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     int ld_tile = chunk0 + li, ld_kt = 0, ld_stage = 0;
 
     auto loader_set_tile = [&](int tile) {
-        const int tm = tile / g.ntiles_n, tn = tile - tm * g.ntiles_n;
+        const int ts = SPLIT ? tile / g.tiles_per_split : 0, trem = SPLIT ? tile - ts * g.tiles_per_split : tile;   // split-K slice
+        const int tm = trem / g.ntiles_n, tn = trem - tm * g.ntiles_n;
+        const long a_sp = SPLIT ? (long)ts * d.a_split_stride * ES : 0, w_sp = SPLIT ? (long)ts * d.w_split_stride * ES : 0;
 #pragma unroll
         for (int i = 0; i < AU; ++i) {
             const int r = (wave * AU + i) * 8 + lr;
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                 a_ix[i] = ox * d.stride + d.dx0;
             } else {
                 const long arow = (long)img * d.a_img_stride + (long)oy * d.in_w + ox + d.a_off;
-                a_row[i] = mv ? (const char*)d.A + arow * d.lda * ES : nullptr;
+                a_row[i] = mv ? (const char*)d.A + arow * d.lda * ES + a_sp : nullptr;
             }
         }
 #pragma unroll
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
             const int r = (wave * 4 + i) * 8 + lr;
             wcs[i] = lp ^ ((r >> 1) & 7);
             const int n = tn * BN + r;
-            w_row[i] = (n < d.N) ? (const char*)d.W + (long)n * d.K * ES : nullptr;
+            w_row[i] = (n < d.N) ? (const char*)d.W + (long)n * (SPLIT ? d.ldw : d.K) * ES + w_sp : nullptr;
         }
     };
 
@@ -500,7 +505,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     int c_stage = 0;
 
     for (int it = 0; c_tile < chunk1; c_tile += nwg8, ++it) {
-        const int tm = c_tile / g.ntiles_n, tn = c_tile - tm * g.ntiles_n;
+        const int ts = SPLIT ? c_tile / g.tiles_per_split : 0, trem = SPLIT ? c_tile - ts * g.tiles_per_split : c_tile;
+        const int tm = trem / g.ntiles_n, tn = trem - tm * g.ntiles_n;
+        const long ysplit = SPLIT ? (long)ts * d.y_split_stride : 0;
         const int m0 = tm * BM + wm * MT * 16, n0 = tn * BN + wn * 64;
         if constexpr (EK == EK_RES_INIT) {
             // y = x + (A W^T + b): start the accumulators from the fp32 residual.  32 independent 16-byte loads per lane,
@@ -626,12 +633,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
         MAGE_STAMP(it, 0);
         MAGE_WSTAMP(it, 0);
         if constexpr (EK == EK_GENERAL) {
-            if (d.y_dtype == MAGE_F32) epilogue_wave<ACT, float, MT, EK>(d, cv, acc, m0, n0, lane, plane);
-            else epilogue_wave<ACT, unsigned short, MT, EK>(d, cv, acc, m0, n0, lane, plane);
+            if (d.y_dtype == MAGE_F32) epilogue_wave<ACT, float, MT, EK>(d, cv, acc, m0, n0, lane, plane, ysplit);
+            else epilogue_wave<ACT, unsigned short, MT, EK>(d, cv, acc, m0, n0, lane, plane, ysplit);
         } else {
             char* stg = smem + Tile<MT>::RING_BYTES + wave * 4096;
-            if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane, plane, stg);
-            else epilogue_lean<ACT, unsigned short, MT>(d, biasm, acc, m0, n0, lane, plane, stg);
+            if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
+            else epilogue_lean<ACT, unsigned short, MT>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
         }
         MAGE_STAMP(it, 1);
         MAGE_WSTAMP(it, 1);
@@ -660,7 +667,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
 // The loader cursors run across tile boundaries (the next tile's slabs 0 and 1 stream in under this tile's last phases and
 // its epilogue).  At a tile's end the leading half gives the trailing half one barrier (both then run the epilogue in
 // step), and the trailing half drops back by one barrier before the next tile's first phase.
-template <int ACT, int EK>
+template <int ACT, int EK, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     constexpr int MT = 8, BM = 256;
     constexpr int PIECE = 16384, KBUF = 4 * PIECE;
@@ -692,7 +699,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     unsigned voff[4][2];
     auto set_rows = [&](int P) {
         const int tile = cur_tile[P];
-        const int tm = tile / g.ntiles_n, tn = tile - tm * g.ntiles_n;
+        const int ts = SPLIT ? tile / g.tiles_per_split : 0, trem = SPLIT ? tile - ts * g.tiles_per_split : tile;   // split-K slice
+        const int tm = trem / g.ntiles_n, tn = trem - tm * g.ntiles_n;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = (2 * wave + i) * 8 + lr;                               // row of the piece
@@ -703,10 +711,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
                 const int oy = rem / d.out_w;
                 const int ox = rem - oy * d.out_w;
                 const long arow = (long)img * d.a_img_stride + (long)oy * d.in_w + ox + d.a_off;
-                voff[P][i] = (unsigned)(arow * d.lda * 2 + lc[i] * 16);
+                voff[P][i] = (unsigned)(arow * d.lda * 2 + (SPLIT ? (long)ts * d.a_split_stride * 2 : 0) + lc[i] * 16);
             } else {
                 const int n = min(tn * BN + (r >> 5) * 64 + (P == P_W1 ? 32 : 0) + (r & 31), d.N - 1);
-                voff[P][i] = (unsigned)((long)n * d.K * 2 + lc[i] * 16);
+                voff[P][i] = (unsigned)((long)n * (SPLIT ? d.ldw : d.K) * 2 + (SPLIT ? (long)ts * d.w_split_stride * 2 : 0) + lc[i] * 16);
             }
         }
     };
@@ -749,7 +757,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     int c_buf = 0;
 
     for (; c_tile < chunk1; c_tile += nwg8) {
-        const int tm = c_tile / g.ntiles_n, tn = c_tile - tm * g.ntiles_n;
+        const int ts = SPLIT ? c_tile / g.tiles_per_split : 0, trem = SPLIT ? c_tile - ts * g.tiles_per_split : c_tile;
+        const int tm = trem / g.ntiles_n, tn = trem - tm * g.ntiles_n;
+        const long ysplit = SPLIT ? (long)ts * d.y_split_stride : 0;
         const int m0 = tm * BM + wr * 128, n0 = tn * BN + wc * 64;
         if constexpr (EK == EK_RES_INIT) {
 #pragma unroll
@@ -867,12 +877,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
         char* stg = smem + 2 * KBUF + wave * 4096;
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));               // keep the epilogue's lane-derived constants out of the K loop's registers
-        if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane_e, plane, stg);
-        else epilogue_lean<ACT, unsigned short, MT>(d, biasm, acc, m0, n0, lane_e, plane, stg);
+        if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
+        else epilogue_lean<ACT, unsigned short, MT>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
     }
 }
 
-template <int DT, bool GATHER, int ACT, int MT, int EK>
+template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false>
 int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     // launch attributes are per DEVICE (a process may drive several GPUs, e.g. nn.DataParallel, main_mage.py:106): cached per
     // device index; setting one twice from two threads is harmless
@@ -880,7 +890,7 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     const int dev = mage_device_index();
     MAGE_CHECK_ARG(dev >= 0, "mage_gemm: no current device");
     if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT, MT, EK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   Tile<MT>::LDS_BYTES);
         attr_set[dev] = true;
     }
@@ -889,7 +899,8 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     a.zero = (const char*)mage_zero_page();
     const int tiles_m = (d->M + Tile<MT>::BM - 1) / Tile<MT>::BM;
     a.ntiles_n = (d->N + BN - 1) / BN;
-    a.ntiles = tiles_m * a.ntiles_n;
+    a.tiles_per_split = tiles_m * a.ntiles_n;
+    a.ntiles = a.tiles_per_split * d->n_split;
     const int grid = a.ntiles >= n_cu ? n_cu : ((a.ntiles + 7) & ~7);     // one resident workgroup per CU, multiple of 8
     // staggered start (see gemm_kernel): G groups spread over a fraction of one estimated tile period = K loop (~3.4 k clocks
     // per 64-wide slab of a 256x256 tile, measured) + the tile's HBM burst at the all-at-once rate (~10.6 B per clock per CU,
@@ -919,18 +930,20 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
         static int use8 = -1;
         if (use8 < 0) use8 = getenv("MAGE_GEMM_NO_8PHASE") ? 0 : 1;
         const long a_rows = (long)((d->M + d->out_h * d->out_w - 1) / (d->out_h * d->out_w)) * d->a_img_stride + d->a_off + 1;
-        if (use8 && d->K % 64 == 0 && a_rows * d->lda * 2 < (1L << 32) && (long)d->N * d->K * 2 < (1L << 32)) {
+        const long a_span = a_rows * d->lda + (long)(d->n_split - 1) * d->a_split_stride;       // elements reachable from A / W
+        const long w_span = (long)d->N * d->ldw + (long)(d->n_split - 1) * d->w_split_stride;
+        if (use8 && d->K % 64 == 0 && a_span * 2 < (1L << 32) && w_span * 2 < (1L << 32)) {
             static bool attr8[MAGE_MAX_DEVICES] = {false};
             if (!attr8[dev]) {
-                (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr8[dev] = true;
             }
-            hipLaunchKernelGGL((gemm8_kernel<ACT, EK>), dim3(grid), dim3(512), 160 * 1024, s, a);
+            hipLaunchKernelGGL((gemm8_kernel<ACT, EK, SPLIT>), dim3(grid), dim3(512), 160 * 1024, s, a);
             MAGE_CHECK_LAUNCH("mage_gemm");
             return MAGE_OK;
         }
     }
-    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT, MT, EK>), dim3(grid), dim3(512), Tile<MT>::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT>), dim3(grid), dim3(512), Tile<MT>::LDS_BYTES, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
     return MAGE_OK;
 }
@@ -949,7 +962,15 @@ int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
     const int n_cu = n_cu_dev[dev];
     // 256-row tiles only where there are enough of them to give every CU at least two (bf16; the fp32 8x4-accumulator
     // variant does not fit the register file)
-    const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + BN - 1) / BN);
+    const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + BN - 1) / BN) * d->n_split;
+    if constexpr (!GATHER && ACT == MAGE_ACT_NONE && EK == EK_BIAS) {
+        if (d->n_split > 1) {                      // split-K (weight gradients): its own instantiations
+            if constexpr (DT == MAGE_BF16) {
+                if (tiles256 >= 2L * n_cu) return launch_tile<DT, GATHER, ACT, 8, EK, true>(d, s, n_cu);
+            }
+            return launch_tile<DT, GATHER, ACT, 4, EK, true>(d, s, n_cu);
+        }
+    }
     if constexpr (DT == MAGE_BF16) {
         if (tiles256 >= 2L * n_cu) return launch_tile<DT, GATHER, ACT, 8, EK>(d, s, n_cu);
     }
@@ -1004,8 +1025,13 @@ extern "C" int mage_debug_read(void* dst, size_t bytes) {
 #endif
 
 
-extern "C" int mage_gemm(const mage_gemm_desc* d, void* stream) {
-    MAGE_CHECK_ARG(d != nullptr, "mage_gemm: null descriptor");
+extern "C" int mage_gemm(const mage_gemm_desc* d_in, void* stream) {
+    MAGE_CHECK_ARG(d_in != nullptr, "mage_gemm: null descriptor");
+    mage_gemm_desc dn = *d_in;                     // defaults of the optional fields
+    if (dn.ldw == 0) dn.ldw = dn.K;
+    if (dn.n_split <= 0) dn.n_split = 1;
+    const mage_gemm_desc* d = &dn;
+    MAGE_CHECK_ARG(d->ldw >= d->K, "mage_gemm: ldw=%d < K=%d", d->ldw, d->K);
     MAGE_CHECK_ARG(mage_zero_page() != nullptr, "mage_gemm: mage_init() has not been called");
     MAGE_CHECK_ARG(d->dtype == MAGE_F32 || d->dtype == MAGE_BF16, "mage_gemm: bad dtype %d", d->dtype);
     MAGE_CHECK_ARG(d->y_dtype == MAGE_F32 || d->y_dtype == MAGE_BF16, "mage_gemm: bad y_dtype %d", d->y_dtype);
@@ -1024,6 +1050,12 @@ extern "C" int mage_gemm(const mage_gemm_desc* d, void* stream) {
     MAGE_CHECK_ARG(!d->scale == !d->shift, "mage_gemm: scale and shift must be given together");
     MAGE_CHECK_ARG(!d->rowadd || (d->rowadd_div >= 1 && d->rowadd_mod >= 1), "mage_gemm: bad rowadd div/mod");
     MAGE_CHECK_ARG((((uintptr_t)d->A | (uintptr_t)d->W | (uintptr_t)d->Y) & 15) == 0, "mage_gemm: operands must be 16-byte aligned");
+    const bool gather_ = d->taps_h * d->taps_w > 1 || d->stride != 1 || d->dy0 != 0 || d->dx0 != 0 || d->in_h != d->out_h || d->in_w != d->out_w;
+    MAGE_CHECK_ARG(d->n_split == 1 || (!gather_ && !d->residual && !d->rowadd && !d->scale && !d->post_relu && !d->bias &&
+                                       d->out_h == 1 && d->out_w >= d->M && d->act == MAGE_ACT_NONE),
+                   "mage_gemm: n_split > 1 is the plain split-K form (no gather, no epilogue extras, rows not regrouped)");
+    MAGE_CHECK_ARG(d->n_split == 1 || ((d->a_split_stride | d->w_split_stride) % ch == 0 && d->y_split_stride % 4 == 0 && d->ldw % ch == 0),
+                   "mage_gemm: split strides / ldw must keep 16-byte alignment");
     hipStream_t s = (hipStream_t)stream;
     const bool gather = d->taps_h * d->taps_w > 1 || d->stride != 1 || d->dy0 != 0 || d->dx0 != 0 || d->in_h != d->out_h ||
                         d->in_w != d->out_w;

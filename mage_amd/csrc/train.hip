@@ -1,0 +1,650 @@
+// Training path: the kernels of MAGE.forward's backward pass that are not GEMMs.
+//
+// The dense gradients reuse mage_gemm: dX = dY W is the forward kernel on a transposed weight copy; dW = dY^T X contracts over
+// ALL M tokens while its output is only [N, K], so both operands are first transposed (mage_transpose: HBM-bound, one pass) and
+// the product runs as one split-K launch of the same MFMA kernel (mage_gemm_desc::n_split) whose partial outputs
+// mage_sum_partials adds in a fixed order.  Everything here is deterministic except mage_embedding_bwd (fp32 atomics, like the
+// reference's own nn.Embedding backward on a GPU).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ transpose (+ conv tap gather)
+// y[(c + y_row0) * ldy + m] = x[arow(m) * ldx + c]   for m < M,  0 for M <= m < Mp  (the split-K GEMM reads whole 64-column
+// slabs, so the tail up to the padded width is zero-filled).  arow(m) is the implicit-GEMM row map of mage_gemm: m -> (img, oy,
+// ox) over an out_h x out_w plane, row = img*img_stride + (oy+dy)*in_w + (ox+dx) + a_off, zero outside [0,in_h) x [0,in_w): a
+// plain transpose is out_h = 1, out_w = M; the nine shifted copies of the activation that the conv3x3 weight gradient
+// contracts with are nine calls with (dy, dx) = tap - 1 and y_row0 = tap * C.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, long y_row0,
+                                                        long M, long Mp, int C, int out_h, int out_w, int in_h, int in_w,
+                                                        long img_stride, long a_off, int dy, int dx) {
+    __shared__ T tile[64][65];
+    const long m0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
+    const long plane = (long)out_h * out_w;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {                           // r: m within the tile; tx: channel
+        const long m = m0 + r;
+        T v = (T)0;
+        if (m < M && c0 + tx < C) {
+            const long img = m / plane, rem = m - img * plane;
+            const int oy = (int)(rem / out_w), ox = (int)(rem - (long)oy * out_w);
+            const int iy = oy + dy, ix = ox + dx;
+            if ((unsigned)iy < (unsigned)in_h && (unsigned)ix < (unsigned)in_w)
+                v = x[(img * img_stride + (long)iy * in_w + ix + a_off) * ldx + c0 + tx];
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {                           // r: channel within the tile; tx: m
+        const long m = m0 + tx;
+        if (c0 + r < C && m < Mp) y[(y_row0 + c0 + r) * ldy + m] = tile[tx][r];
+    }
+}
+
+// out[r] = sum_c x[r*ld + c], c < n (fp32 accumulation, fixed order): bias gradients from the transposed dY.
+template <typename T>
+__global__ __launch_bounds__(256) void row_sum_kernel(const T* __restrict__ x, long ld, long n, int rows, float* __restrict__ out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const T* p = x + (long)r * ld;
+    float s = 0.f;
+    for (long c = lane; c < n; c += 64) s += to_f32<T>(p[c]);
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s;
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_s part[s*stride + i]
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, long stride, int n_part, long n,
+                                                           float* __restrict__ out, int accumulate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = accumulate ? out[i] : 0.f;
+    for (int p = 0; p < n_part; ++p) s += part[(long)p * stride + i];
+    out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// One wave per row (statistics recomputed from the saved LN input, two-pass as in the forward kernel):
+//   xhat = (x - mean) rstd;  g = dy * gamma;  dx = rstd (g - mean_c(g) - xhat mean_c(g xhat))       [+= if accumulate]
+// and per-workgroup partial sums of dgamma = sum_rows dy xhat, dbeta = sum_rows dy (part [gridDim.x][2][C], reduced by
+// mage_sum_partials: fixed order, deterministic).
+template <typename DT, int VPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const DT* __restrict__ dy, float* __restrict__ dx, float* __restrict__ part,
+                                                            long rows, int C, float eps, int accumulate) {
+    __shared__ float red[4][2][VPL * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 dg[VPL], db[VPL], gm[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        dg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c = j * 256 + lane * 4;
+        gm[j] = c < C ? *(const f32x4*)(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float* xr = x + row * C;
+        const DT* dr = dy + row * C;
+        f32x4 v[VPL], d[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const int c = j * 256 + lane * 4;
+            v[j] = c < C ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            d[j] = c < C ? load4(dr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const int c = j * 256 + lane * 4;
+            if (c < C) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = v[j][e] - mean;
+                    q += t * t;
+                }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const int c = j * 256 + lane * 4;
+            if (c < C) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (v[j][e] - mean) * rstd;
+                    const float g = d[j][e] * gm[j][e];
+                    sg += g;
+                    sgx += g * xh;
+                    dg[j][e] += d[j][e] * xh;
+                    db[j][e] += d[j][e];
+                    v[j][e] = xh;
+                    d[j][e] = g;
+                }
+            }
+        }
+        const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
+        float* dxr = dx + row * C;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const int c = j * 256 + lane * 4;
+            if (c < C) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rstd * (d[j][e] - mg - v[j][e] * mgx);
+                if (accumulate) o += *(const f32x4*)(dxr + c);
+                *(f32x4*)(dxr + c) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VPL; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[wave][0][j * 256 + lane * 4 + e] = dg[j][e];
+            red[wave][1][j * 256 + lane * 4 + e] = db[j][e];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        part[((long)blockIdx.x * 2 + 0) * C + c] = (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]);
+        part[((long)blockIdx.x * 2 + 1) * C + c] = (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ activations
+template <int ACT>
+__device__ __forceinline__ float actf(float v) {
+    if (ACT == MAGE_ACT_RELU) return fmaxf(v, 0.f);
+    if (ACT == MAGE_ACT_QUICKGELU) return v / (1.f + expf(-1.702f * v));
+    if (ACT == MAGE_ACT_GELU_ERF) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    return v;
+}
+template <int ACT>
+__device__ __forceinline__ float actdf(float v) {
+    if (ACT == MAGE_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+    if (ACT == MAGE_ACT_QUICKGELU) {
+        const float s = 1.f / (1.f + expf(-1.702f * v));
+        return s * (1.f + 1.702f * v * (1.f - s));
+    }
+    if (ACT == MAGE_ACT_GELU_ERF)
+        return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
+    return 1.f;
+}
+// BWD = 0: y = act(x);  BWD = 1: y = dy * act'(x)   (x = the saved pre-activation)
+template <typename T, int ACT, int BWD>
+__global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ y, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const f32x4 v = load4(x + i);
+    f32x4 o;
+    if (BWD) {
+        const f32x4 g = load4(dy + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = g[e] * actdf<ACT>(v[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = actf<ACT>(v[e]);
+    }
+    store4(y + i, o);
+}
+
+// ------------------------------------------------------------------------------------------------ cross entropy backward
+// dlogits[i][k] = (softmax(logits[i])[k] - [k == target[i]]) * scale   (scale = upstream gradient / rows), one wave per row
+template <typename OT>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, long rows,
+                                                     int K, const float* __restrict__ gout, float inv_rows, OT* __restrict__ dl) {
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = logits + i * K;
+    float mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, p[k]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += expf(p[k] - mx);
+    s = wave_sum(s);
+    const float scale = gout[0] * inv_rows, inv = 1.0f / s;
+    long tg = target[i];
+    if (tg < 0 || tg >= K) tg = -1;                  // reported by the forward kernel (mage_cross_entropy)
+    OT* o = dl + i * K;
+    for (int k = lane; k < K; k += 64) o[k] = from_f32<OT>((expf(p[k] - mx) * inv - (k == tg ? 1.f : 0.f)) * scale);
+}
+
+// ------------------------------------------------------------------------------------------------ embedding backward
+// dtable[ids[i]][:] += dout[orow(i)][:]   (orow as in mage_embedding; rows with ids[i] == padding_idx are skipped)
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dout,
+                                                            float* __restrict__ dtable, long n, int C, int n_table, long padding_idx,
+                                                            long group, long group_stride, long off) {
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    const long id = ids[i];
+    if (id < 0 || id >= n_table || id == padding_idx) return;
+    const long orow = (i / group) * group_stride + (i % group) + off;
+    const T* src = dout + orow * C;
+    float* dst = dtable + id * C;
+    for (int c = lane; c < C; c += 64) atomicAdd(dst + c, to_f32<T>(src[c]));
+}
+
+// ------------------------------------------------------------------------------------------------ grouped row sums
+// out[g][c] = sum over rows r with (r / div) % mod == g of w(r) * x[r][c],  w(r) = rs ? rs[r / rs_div] : 1.
+// Gradients of broadcast row tables (T / H / W positional embeddings, text positions) and of the speed embedding.
+template <typename T>
+__global__ __launch_bounds__(256) void group_rowsum_kernel(const T* __restrict__ x, long rows, int C, long div, long mod,
+                                                           const float* __restrict__ rs, long rs_div, float* __restrict__ out) {
+    const long g = blockIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    const long period = div * mod, nper = (rows + period - 1) / period;
+    for (long q = 0; q < nper; ++q)
+        for (long j = 0; j < div; ++j) {
+            const long r = q * period + g * div + j;
+            if (r < rows) s += (rs ? rs[r / rs_div] : 1.f) * to_f32<T>(x[r * C + c]);
+        }
+    out[g * C + c] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ attention backward
+// Same addressing as mage_attention (strided row sets, head_dim 32, nk <= 64).  Workgroup = (sequence, group of 4 heads), one
+// wave per head.  Per block of 64 queries (lane = query): the probabilities P and dS = P (dP - rowsum(P dP)) are recomputed in
+// fp32 and parked in LDS, dq is written by the query's lane; then lane = key accumulates dk_j = scale sum_i dS_ij q_i and
+// dv_j = sum_i P_ij dO_i over the block in registers (fixed order: deterministic).  K, V, and the block's Q, dO are staged in
+// LDS as fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const mage_attn_desc d, const T* __restrict__ dout, T* __restrict__ dq,
+                                                            T* __restrict__ dk, T* __restrict__ dv, int ld_dq, int ld_dk, int ld_dv, int qb) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = blockIdx.y * 4 + wave;
+    const int s = blockIdx.x;
+    const int nkp = d.nk + 1;
+    // per-wave LDS (qb = queries per block = min(64, nq)): K[nk][32] V[nk][32] Q[qb][33] dO[qb][33] P[qb][nkp] dS[qb][nkp]
+    const size_t per_wave = (size_t)(2 * d.nk * 32 + 2 * qb * 33 + 2 * qb * nkp) * 4;
+    float* ks = (float*)(smem_raw + wave * per_wave);
+    float* vs = ks + d.nk * 32;
+    float* qs = vs + d.nk * 32;
+    float* gs = qs + qb * 33;
+    float* ps = gs + qb * 33;
+    float* ds = ps + qb * nkp;
+    if (h >= d.n_head) return;                       // whole wave; no workgroup barriers below (waves are independent)
+    const int outer = s / d.inner, in = s - outer * d.inner;
+    const long q_base = (long)outer * d.q_outer_stride + in;
+    const long kv_base = (long)outer * d.kv_outer_stride + in;
+    const T* qp = (const T*)d.q;
+    const T* kp = (const T*)d.k;
+    const T* vp = (const T*)d.v;
+    int klen = d.nk;
+    if (d.kv_len) klen = min(klen, d.kv_len[s / d.kv_len_div]);
+    for (int e = lane; e < d.nk * 32; e += 64) {
+        const int j = e >> 5, c = e & 31;
+        const long row = kv_base + (long)j * d.kv_axis_stride;
+        ks[e] = to_f32<T>(kp[row * d.ldk + h * 32 + c]);
+        vs[e] = to_f32<T>(vp[row * d.ldv + h * 32 + c]);
+    }
+    float dka[32], dva[32];                          // lane = key j (nk <= 64)
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        dka[c] = 0.f;
+        dva[c] = 0.f;
+    }
+    for (int i0 = 0; i0 < d.nq; i0 += qb) {
+        const int nb = min(qb, d.nq - i0);
+        for (int e = lane; e < nb * 32; e += 64) {   // stage the block's Q and dO
+            const int i = e >> 5, c = e & 31;
+            const long row = q_base + (long)(i0 + i) * d.q_axis_stride;
+            qs[i * 33 + c] = to_f32<T>(qp[row * d.ldq + h * 32 + c]);
+            gs[i * 33 + c] = to_f32<T>(dout[row * d.ldo + h * 32 + c]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the wave's own LDS writes are visible to all its lanes
+        if (lane < nb) {
+            const int i = i0 + lane;
+            const int jmax = d.causal ? min(klen, i + 1 + (d.nk - d.nq)) : klen;
+            float q[32], g[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                q[c] = qs[lane * 33 + c];
+                g[c] = gs[lane * 33 + c];
+            }
+            float mx = -INFINITY;
+            for (int j = 0; j < d.nk; ++j) {
+                float a = -INFINITY;
+                if (j < jmax) {
+                    a = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 32; ++c) a += q[c] * ks[j * 32 + c];
+                    a *= d.scale;
+                }
+                ps[lane * nkp + j] = a;
+                mx = fmaxf(mx, a);
+            }
+            float den = 0.f;
+            for (int j = 0; j < d.nk; ++j) {
+                const float p = j < jmax ? expf(ps[lane * nkp + j] - mx) : 0.f;
+                ps[lane * nkp + j] = p;
+                den += p;
+            }
+            const float inv = 1.0f / den;
+            float dsum = 0.f;
+            for (int j = 0; j < d.nk; ++j) {
+                const float p = ps[lane * nkp + j] * inv;
+                float dp = 0.f;
+#pragma unroll
+                for (int c = 0; c < 32; ++c) dp += g[c] * vs[j * 32 + c];
+                ps[lane * nkp + j] = p;
+                ds[lane * nkp + j] = dp;
+                dsum += p * dp;
+            }
+            float dqa[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) dqa[c] = 0.f;
+            for (int j = 0; j < d.nk; ++j) {
+                const float t = ps[lane * nkp + j] * (ds[lane * nkp + j] - dsum);
+                ds[lane * nkp + j] = t;
+#pragma unroll
+                for (int c = 0; c < 32; ++c) dqa[c] += t * ks[j * 32 + c];
+            }
+            T* o = dq + (q_base + (long)i * d.q_axis_stride) * ld_dq + h * 32;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) o[c] = from_f32<T>(dqa[c] * d.scale);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (lane < d.nk) {
+            for (int i = 0; i < nb; ++i) {
+                const float t = ds[i * nkp + lane], p = ps[i * nkp + lane];
+#pragma unroll
+                for (int c = 0; c < 32; ++c) {
+                    dka[c] += t * qs[i * 33 + c];
+                    dva[c] += p * gs[i * 33 + c];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < d.nk) {
+        const long row = kv_base + (long)lane * d.kv_axis_stride;
+        T* ok = dk + row * ld_dk + h * 32;
+        T* ov = dv + row * ld_dv + h * 32;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            ok[c] = from_f32<T>(dka[c] * d.scale);
+            ov[c] = from_f32<T>(dva[c]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dropout
+// Stateless mask: keep(i) = hash(seed, i) >= p * 2^32, recomputed identically in the backward pass (no mask tensor).
+__device__ __forceinline__ unsigned hash32(unsigned long long v) {
+    v ^= v >> 33;
+    v *= 0xff51afd7ed558ccdULL;
+    v ^= v >> 33;
+    v *= 0xc4ceb9fe1a85ec53ULL;
+    v ^= v >> 33;
+    return (unsigned)v;
+}
+// y = (accumulate ? y : 0) + x * keep / (1 - p)      x: T, y: YT
+template <typename T, typename YT>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, YT* __restrict__ y, long n, unsigned thresh, float inv_keep,
+                                                      unsigned long long seed, int accumulate) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const f32x4 v = load4(x + i);
+    f32x4 o = accumulate ? load4(y + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (hash32(seed * 0x9e3779b97f4a7c15ULL + (unsigned long long)(i + e)) >= thresh) o[e] += v[e] * inv_keep;
+    store4(y + i, o);
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+// torch.optim.Adam semantics (main_mage.py:121: betas (0.9, 0.98), eps 1e-6, no weight decay, no amsgrad):
+//   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2_sqrt, float grad_scale) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        f32x4 pp = *(f32x4*)(p + i), gg = *(const f32x4*)(g + i), mm = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = gg[e] * grad_scale;
+            mm[e] = b1 * mm[e] + (1.f - b1) * ge;
+            vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
+            pp[e] -= (lr / bc1) * (mm[e] / (sqrtf(vv[e]) / bc2_sqrt + eps));
+        }
+        *(f32x4*)(p + i) = pp;
+        *(f32x4*)(m + i) = mm;
+        *(f32x4*)(v + i) = vv;
+    } else {
+        for (long j = i; j < n; ++j) {
+            const float ge = g[j] * grad_scale;
+            m[j] = b1 * m[j] + (1.f - b1) * ge;
+            v[j] = b2 * v[j] + (1.f - b2) * ge * ge;
+            p[j] -= (lr / bc1) * (m[j] / (sqrtf(v[j]) / bc2_sqrt + eps));
+        }
+    }
+}
+
+template <typename T>
+int transpose_launch(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t y_row0, int64_t M, int64_t Mp, int32_t C, int32_t out_h,
+                     int32_t out_w, int32_t in_h, int32_t in_w, int64_t img_stride, int64_t a_off, int32_t dy, int32_t dx, hipStream_t s) {
+    const dim3 grid((unsigned)((Mp + 63) / 64), (unsigned)((C + 63) / 64));
+    hipLaunchKernelGGL((transpose_kernel<T>), grid, dim3(256), 0, s, (const T*)x, (long)ldx, (T*)y, (long)ldy, (long)y_row0, (long)M,
+                       (long)Mp, C, out_h, out_w, in_h, in_w, (long)img_stride, (long)a_off, dy, dx);
+    MAGE_CHECK_LAUNCH("mage_transpose");
+    return MAGE_OK;
+}
+
+template <typename DT>
+int ln_bwd_launch(const float* x, const float* gamma, const void* dy, float* dx, float* part, int32_t n_part, int64_t rows, int32_t C,
+                  float eps, int32_t accumulate, hipStream_t s) {
+    const dim3 grid(n_part), blk(256);
+#define LNB(V) hipLaunchKernelGGL((layernorm_bwd_kernel<DT, V>), grid, blk, 0, s, x, gamma, (const DT*)dy, dx, part, (long)rows, C, eps, accumulate)
+    if (C <= 256) LNB(1);
+    else if (C <= 512) LNB(2);
+    else if (C <= 1024) LNB(4);
+    else LNB(8);
+#undef LNB
+    MAGE_CHECK_LAUNCH("mage_layernorm_bwd");
+    return MAGE_OK;
+}
+
+template <typename T, int BWD>
+int act_launch(const void* x, const void* dy, void* y, int64_t n, int32_t act, hipStream_t s) {
+    const dim3 grid((unsigned)((n / 4 + 255) / 256)), blk(256);
+    switch (act) {
+        case MAGE_ACT_RELU: hipLaunchKernelGGL((act_kernel<T, MAGE_ACT_RELU, BWD>), grid, blk, 0, s, (const T*)x, (const T*)dy, (T*)y, (long)n); break;
+        case MAGE_ACT_QUICKGELU: hipLaunchKernelGGL((act_kernel<T, MAGE_ACT_QUICKGELU, BWD>), grid, blk, 0, s, (const T*)x, (const T*)dy, (T*)y, (long)n); break;
+        case MAGE_ACT_GELU_ERF: hipLaunchKernelGGL((act_kernel<T, MAGE_ACT_GELU_ERF, BWD>), grid, blk, 0, s, (const T*)x, (const T*)dy, (T*)y, (long)n); break;
+        default: mage_set_error("mage_act: activation %d unsupported", act); return MAGE_EINVAL;
+    }
+    MAGE_CHECK_LAUNCH("mage_act");
+    return MAGE_OK;
+}
+
+}  // namespace
+
+#define DT_DISPATCH(dtype, CALL_F32, CALL_BF16, who)                  \
+    do {                                                              \
+        if ((dtype) == MAGE_F32) return CALL_F32;                     \
+        if ((dtype) == MAGE_BF16) return CALL_BF16;                   \
+        mage_set_error("%s: bad dtype %d", who, (int)(dtype));        \
+        return MAGE_EINVAL;                                           \
+    } while (0)
+
+extern "C" int mage_transpose(const void* x, int32_t dtype, int64_t ldx, void* y, int64_t ldy, int64_t y_row0, int64_t M, int64_t Mp,
+                              int32_t C, int32_t out_h, int32_t out_w, int32_t in_h, int32_t in_w, int64_t img_stride, int64_t a_off,
+                              int32_t dy, int32_t dx, void* stream) {
+    MAGE_CHECK_ARG(x && y && M > 0 && Mp >= M && C > 0 && out_h >= 1 && out_w >= 1 && in_h >= 1 && in_w >= 1 && ldy >= Mp,
+                   "mage_transpose: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DT_DISPATCH(dtype, (transpose_launch<float>(x, ldx, y, ldy, y_row0, M, Mp, C, out_h, out_w, in_h, in_w, img_stride, a_off, dy, dx, s)),
+                (transpose_launch<unsigned short>(x, ldx, y, ldy, y_row0, M, Mp, C, out_h, out_w, in_h, in_w, img_stride, a_off, dy, dx, s)),
+                "mage_transpose");
+}
+
+extern "C" int mage_row_sum(const void* x, int32_t dtype, int64_t ld, int64_t n, int32_t rows, float* out, void* stream) {
+    MAGE_CHECK_ARG(x && out && rows > 0 && n > 0, "mage_row_sum: bad arguments");
+    const dim3 grid((rows + 3) / 4), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MAGE_F32) hipLaunchKernelGGL((row_sum_kernel<float>), grid, blk, 0, s, (const float*)x, (long)ld, (long)n, rows, out);
+    else if (dtype == MAGE_BF16) hipLaunchKernelGGL((row_sum_kernel<unsigned short>), grid, blk, 0, s, (const unsigned short*)x, (long)ld, (long)n, rows, out);
+    else { mage_set_error("mage_row_sum: bad dtype %d", dtype); return MAGE_EINVAL; }
+    MAGE_CHECK_LAUNCH("mage_row_sum");
+    return MAGE_OK;
+}
+
+extern "C" int mage_sum_partials(const float* part, int64_t stride, int32_t n_part, int64_t n, float* out, int32_t accumulate, void* stream) {
+    MAGE_CHECK_ARG(part && out && n_part > 0 && n > 0, "mage_sum_partials: bad arguments");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, (long)stride, n_part,
+                       (long)n, out, accumulate);
+    MAGE_CHECK_LAUNCH("mage_sum_partials");
+    return MAGE_OK;
+}
+
+extern "C" int mage_layernorm_bwd(const float* x, const float* gamma, const void* dy, int32_t dy_dtype, float* dx, float* partials,
+                                  int32_t n_part, int64_t rows, int32_t C, float eps, int32_t accumulate, void* stream) {
+    MAGE_CHECK_ARG(x && gamma && dy && dx && partials, "mage_layernorm_bwd: null pointer");
+    MAGE_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048 && n_part >= 1, "mage_layernorm_bwd: rows=%ld C=%d unsupported", (long)rows, C);
+    hipStream_t s = (hipStream_t)stream;
+    DT_DISPATCH(dy_dtype, (ln_bwd_launch<float>(x, gamma, dy, dx, partials, n_part, rows, C, eps, accumulate, s)),
+                (ln_bwd_launch<unsigned short>(x, gamma, dy, dx, partials, n_part, rows, C, eps, accumulate, s)), "mage_layernorm_bwd");
+}
+
+extern "C" int mage_act(const void* x, void* y, int32_t dtype, int64_t n, int32_t act, void* stream) {
+    MAGE_CHECK_ARG(x && y && n > 0 && n % 4 == 0, "mage_act: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DT_DISPATCH(dtype, (act_launch<float, 0>(x, nullptr, y, n, act, s)), (act_launch<unsigned short, 0>(x, nullptr, y, n, act, s)), "mage_act");
+}
+
+extern "C" int mage_act_bwd(const void* x, const void* dy, void* dx, int32_t dtype, int64_t n, int32_t act, void* stream) {
+    MAGE_CHECK_ARG(x && dy && dx && n > 0 && n % 4 == 0, "mage_act_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DT_DISPATCH(dtype, (act_launch<float, 1>(x, dy, dx, n, act, s)), (act_launch<unsigned short, 1>(x, dy, dx, n, act, s)), "mage_act_bwd");
+}
+
+extern "C" int mage_cross_entropy_bwd(const float* logits, const int64_t* target, int64_t rows, int32_t K, const float* grad_out,
+                                      void* dlogits, int32_t dl_dtype, void* stream) {
+    MAGE_CHECK_ARG(logits && target && grad_out && dlogits && rows > 0 && K > 0, "mage_cross_entropy_bwd: bad arguments");
+    const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dl_dtype == MAGE_F32)
+        hipLaunchKernelGGL((ce_bwd_kernel<float>), grid, blk, 0, s, logits, target, (long)rows, K, grad_out, 1.0f / (float)rows, (float*)dlogits);
+    else if (dl_dtype == MAGE_BF16)
+        hipLaunchKernelGGL((ce_bwd_kernel<unsigned short>), grid, blk, 0, s, logits, target, (long)rows, K, grad_out, 1.0f / (float)rows,
+                           (unsigned short*)dlogits);
+    else { mage_set_error("mage_cross_entropy_bwd: bad dtype %d", dl_dtype); return MAGE_EINVAL; }
+    MAGE_CHECK_LAUNCH("mage_cross_entropy_bwd");
+    return MAGE_OK;
+}
+
+extern "C" int mage_embedding_bwd(const int64_t* ids, const void* dout, int32_t dout_dtype, float* dtable, int64_t n, int32_t C,
+                                  int32_t n_table, int64_t padding_idx, int64_t group, int64_t group_stride, int64_t off, void* stream) {
+    MAGE_CHECK_ARG(ids && dout && dtable && n > 0 && C > 0 && n_table > 0 && group > 0, "mage_embedding_bwd: bad arguments");
+    const dim3 grid((unsigned)((n + 3) / 4)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dout_dtype == MAGE_F32)
+        hipLaunchKernelGGL((embedding_bwd_kernel<float>), grid, blk, 0, s, ids, (const float*)dout, dtable, (long)n, C, n_table, (long)padding_idx,
+                           (long)group, (long)group_stride, (long)off);
+    else if (dout_dtype == MAGE_BF16)
+        hipLaunchKernelGGL((embedding_bwd_kernel<unsigned short>), grid, blk, 0, s, ids, (const unsigned short*)dout, dtable, (long)n, C, n_table,
+                           (long)padding_idx, (long)group, (long)group_stride, (long)off);
+    else { mage_set_error("mage_embedding_bwd: bad dtype %d", dout_dtype); return MAGE_EINVAL; }
+    MAGE_CHECK_LAUNCH("mage_embedding_bwd");
+    return MAGE_OK;
+}
+
+extern "C" int mage_group_rowsum(const void* x, int32_t dtype, int64_t rows, int32_t C, int64_t div, int64_t mod, const float* row_scale,
+                                 int64_t row_scale_div, float* out, void* stream) {
+    MAGE_CHECK_ARG(x && out && rows > 0 && C > 0 && div >= 1 && mod >= 1 && (!row_scale || row_scale_div >= 1), "mage_group_rowsum: bad arguments");
+    const dim3 grid((unsigned)mod, (C + 255) / 256), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MAGE_F32)
+        hipLaunchKernelGGL((group_rowsum_kernel<float>), grid, blk, 0, s, (const float*)x, (long)rows, C, (long)div, (long)mod, row_scale,
+                           (long)row_scale_div, out);
+    else if (dtype == MAGE_BF16)
+        hipLaunchKernelGGL((group_rowsum_kernel<unsigned short>), grid, blk, 0, s, (const unsigned short*)x, (long)rows, C, (long)div, (long)mod,
+                           row_scale, (long)row_scale_div, out);
+    else { mage_set_error("mage_group_rowsum: bad dtype %d", dtype); return MAGE_EINVAL; }
+    MAGE_CHECK_LAUNCH("mage_group_rowsum");
+    return MAGE_OK;
+}
+
+extern "C" int mage_attention_bwd(const mage_attn_desc* d, const void* dout, void* dq, void* dk, void* dv, int32_t ld_dq, int32_t ld_dk,
+                                  int32_t ld_dv, void* stream) {
+    MAGE_CHECK_ARG(d && d->q && d->k && d->v && dout && dq && dk && dv, "mage_attention_bwd: null pointer");
+    MAGE_CHECK_ARG(d->nk >= 1 && d->nk <= 64 && d->nq >= 1 && d->n_seq >= 1 && d->n_head >= 1 && d->inner >= 1,
+                   "mage_attention_bwd: nk=%d nq=%d unsupported", d->nk, d->nq);
+    const int qb = d->nq < 64 ? d->nq : 64;
+    const size_t per_wave = (size_t)(2 * d->nk * 32 + 2 * qb * 33 + 2 * qb * (d->nk + 1)) * 4;
+    const size_t lds = 4 * per_wave;
+    MAGE_CHECK_ARG(lds <= 160 * 1024, "mage_attention_bwd: LDS budget");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(d->n_seq, (d->n_head + 3) / 4), blk(256);
+    static bool attr_set[MAGE_MAX_DEVICES][2] = {{false}};
+    const int dev = mage_device_index();
+    MAGE_CHECK_ARG(dev >= 0, "mage_attention_bwd: no current device");
+    if (d->dtype == MAGE_F32) {
+        if (!attr_set[dev][0]) {
+            (void)hipFuncSetAttribute((const void*)attention_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set[dev][0] = true;
+        }
+        hipLaunchKernelGGL((attention_bwd_kernel<float>), grid, blk, lds, s, *d, (const float*)dout, (float*)dq, (float*)dk, (float*)dv, ld_dq,
+                           ld_dk, ld_dv, qb);
+    } else if (d->dtype == MAGE_BF16) {
+        if (!attr_set[dev][1]) {
+            (void)hipFuncSetAttribute((const void*)attention_bwd_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set[dev][1] = true;
+        }
+        hipLaunchKernelGGL((attention_bwd_kernel<unsigned short>), grid, blk, lds, s, *d, (const unsigned short*)dout, (unsigned short*)dq,
+                           (unsigned short*)dk, (unsigned short*)dv, ld_dq, ld_dk, ld_dv, qb);
+    } else {
+        mage_set_error("mage_attention_bwd: bad dtype %d", d->dtype);
+        return MAGE_EINVAL;
+    }
+    MAGE_CHECK_LAUNCH("mage_attention_bwd");
+    return MAGE_OK;
+}
+
+extern "C" int mage_dropout(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, int64_t n, float p, uint64_t seed, int32_t accumulate,
+                            void* stream) {
+    MAGE_CHECK_ARG(x && y && n > 0 && n % 4 == 0 && p >= 0.f && p < 1.f, "mage_dropout: bad arguments");
+    const unsigned thresh = (unsigned)((double)p * 4294967296.0);
+    const float inv_keep = 1.0f / (1.0f - p);
+    const dim3 grid((unsigned)((n / 4 + 255) / 256)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+#define DROP(T, YT) hipLaunchKernelGGL((dropout_kernel<T, YT>), grid, blk, 0, s, (const T*)x, (YT*)y, (long)n, thresh, inv_keep, (unsigned long long)seed, accumulate)
+    if (x_dtype == MAGE_F32 && y_dtype == MAGE_F32) DROP(float, float);
+    else if (x_dtype == MAGE_BF16 && y_dtype == MAGE_BF16) DROP(unsigned short, unsigned short);
+    else if (x_dtype == MAGE_BF16 && y_dtype == MAGE_F32) DROP(unsigned short, float);
+    else if (x_dtype == MAGE_F32 && y_dtype == MAGE_BF16) DROP(float, unsigned short);
+    else { mage_set_error("mage_dropout: bad dtypes %d %d", x_dtype, y_dtype); return MAGE_EINVAL; }
+#undef DROP
+    MAGE_CHECK_LAUNCH("mage_dropout");
+    return MAGE_OK;
+}
+
+extern "C" int mage_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                         int32_t step, float grad_scale, void* stream) {
+    MAGE_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "mage_adam: bad arguments");
+    MAGE_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "mage_adam: arenas must be 16-byte aligned");
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1,
+                       beta2, eps, bc1, bc2_sqrt, grad_scale);
+    MAGE_CHECK_LAUNCH("mage_adam");
+    return MAGE_OK;
+}

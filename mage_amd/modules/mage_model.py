@@ -1005,14 +1005,32 @@ class MAGE(nn.Module):
         tgt = rows[:, 1:L].contiguous().view(-1, LD)
         return ops.mse(pred, tgt, rows=B * (L - 1) * hw, cols=E, lda=pred.shape[1], ldb=LD), pred
 
+    def _forward_with_graph(self, batch):
+        """Grad mode (the training loop, main_mage.py:150-153): the same pass as one autograd node whose inputs are the trainable
+        parameters (mage_train.MageLossFn), so that ``loss.backward()`` fills every ``.grad`` from the HIP backward kernels."""
+        from . import mage_train
+        _need_gpu(batch["images"], "MAGE.forward")
+        with torch.cuda.device(batch["images"].device):
+            names = mage_train.trainable_names(self)
+            byname = dict(self.named_parameters())
+            loss = mage_train.MageLossFn.apply(self, batch, names, *[byname[n] for n in names])
+            prefix = "train" if self.training else "val"
+            val = loss.detach().item()
+            ops.check_device_errors(batch["images"].device)
+        return loss, {f"{prefix}/prediction": val, f"{prefix}/final_loss": val}
+
     def forward(self, batch, test_flag=False):
         """(loss, loss_dict) of the teacher-forced pass (mage_model.py:575-639), incl. the randomness=True terms (KL of the
         reparameterised video prior, the PID-controlled or fixed beta, the speed-embedding l2).  batch['reparam_noise']
-        [B,64,h,w] optionally injects the reparameterisation noise.  Values only: the HIP path builds no autograd graph yet
-        (backward kernels are a 'next' row), so ``loss.backward()`` raises."""
+        [B,64,h,w] optionally injects the reparameterisation noise.  Under ``torch.no_grad()``: values only.  In grad mode (any
+        parameter requiring grad): the returned loss carries an autograd node backed by the HIP backward kernels
+        (modules/mage_train.py; use_cids=True, randomness=False configs), so ``loss.backward(); optimizer.step()`` works."""
         if test_flag and self.randomness:
             raise NotImplementedError("forward(test_flag=True) replaces the video embedding by noise AFTER computing it; use "
                                       "autoregressive_generate for sampling")
+        if (torch.is_grad_enabled() and self.use_cids and not self.randomness
+                and any(p.requires_grad for p in self.parameters())):
+            return self._forward_with_graph(batch)        # other configs: loss VALUES only (no autograd node yet)
         extras: dict = {}
         L = self.frames_length
         if self.use_cids:

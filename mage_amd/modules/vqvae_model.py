@@ -93,9 +93,19 @@ class DecoderBlock(nn.Module):
     forward = _no_torch_forward
 
 
+_WEIGHTS_EPOCH = 0
+
+
+def bump_weights_epoch() -> None:
+    """Tell every derived cache that parameter storage was written behind torch's back (a kernel updating the flat parameter
+    arena: mage_amd.optim.FlatAdam.step): tensor version counters do not see that."""
+    global _WEIGHTS_EPOCH
+    _WEIGHTS_EPOCH += 1
+
+
 class _Derived:
     """Device-side derived caches (channels-last / transposed / bf16 weight copies, folded BN vectors).
-    Rebuilt whenever a parameter or buffer is replaced or modified in place (load_state_dict, .to())."""
+    Rebuilt whenever a parameter or buffer is replaced or modified in place (load_state_dict, .to(), an optimizer step)."""
 
     def __init__(self, module: nn.Module):
         self._m = module
@@ -104,7 +114,7 @@ class _Derived:
         self.gen = 0                   # bumped at every rebuild: captured HIP graphs that reference the old copies are stale
 
     def get(self, builder) -> Dict[str, torch.Tensor]:
-        sig = tuple((t.data_ptr(), t._version, t.device) for t in chain(self._m.parameters(), self._m.buffers()))
+        sig = (_WEIGHTS_EPOCH,) + tuple((t.data_ptr(), t._version, t.device) for t in chain(self._m.parameters(), self._m.buffers()))
         if sig != self._sig:
             with torch.no_grad():
                 self._store = builder()

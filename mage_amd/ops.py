@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc
 
 __all__ = ["gemm", "layernorm", "attention", "embedding", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
-           "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mse", "check_device_errors", "graph_events_supported", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
+           "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mse", "check_device_errors", "graph_events_supported", "transpose", "row_sum", "sum_partials", "layernorm_bwd", "act", "act_bwd", "cross_entropy_bwd", "embedding_bwd", "group_rowsum", "attention_bwd", "dropout", "adam", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
            "PROFILE", "F32", "BF16", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
 
 
@@ -173,7 +173,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
          stride: int = 1, dy0: int = 0, dx0: int = 0, dys: int = 1, dxs: int = 1,
          y_img_stride: Optional[int] = None, y_mul_y: Optional[int] = None, y_mul_x: int = 1, y_off: int = 0,
          bias=None, scale=None, shift=None, act: int = ACT_NONE, rowadd=None, rowadd_div: int = 1, rowadd_mod: int = 1,
-         residual=None, ldr: int = 0, post_relu: bool = False) -> torch.Tensor:
+         residual=None, ldr: int = 0, post_relu: bool = False, ldw: int = 0, n_split: int = 1, a_split_stride: int = 0,
+         w_split_stride: int = 0, y_split_stride: int = 0) -> torch.Tensor:
     """Y = epilogue(A (*) W^T); see mage_gemm in include/mage_hip.h for the geometry fields."""
     l, s = _dev(a)
     out_w = M if out_w is None else out_w
@@ -197,6 +198,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     d.rowadd, d.rowadd_div, d.rowadd_mod = _p(rowadd), rowadd_div, rowadd_mod
     d.residual, d.ldr, d.res_dtype = _p(residual), ldr, (code(residual) if residual is not None else 0)
     d.post_relu = int(post_relu)
+    d.ldw, d.n_split = ldw, n_split
+    d.a_split_stride, d.w_split_stride, d.y_split_stride = a_split_stride, w_split_stride, y_split_stride
     if PROFILE.enabled:
         # key = the kernel instantiation mage_gemm dispatches to (mirrors launch_act in csrc/gemm.hip), so that the
         # per-kernel averages line up with rocprofv3's per-symbol statistics
@@ -425,3 +428,120 @@ def mse(a, b, *, rows, cols, lda, ldb):
     ws = torch.empty(256, device=a.device, dtype=torch.float64)
     _lib.check(l.mage_mse(a.data_ptr(), lda, b.data_ptr(), ldb, rows, cols, ws.data_ptr(), out.data_ptr(), s), l)
     return out[0]
+
+
+# ----------------------------------------------------------------------------------------------------------------- training path
+def transpose(x, y, *, M: int, Mp: int, C: int, ldx: int, ldy: int, y_row0: int = 0, out_h: int = 1, out_w: Optional[int] = None,
+              in_h: Optional[int] = None, in_w: Optional[int] = None, img_stride: Optional[int] = None, a_off: int = 0, dy: int = 0,
+              dx: int = 0):
+    """y[(c + y_row0), m] = x[arow(m), c] (zero for M <= m < Mp and outside the plane); see mage_transpose in mage_hip.h."""
+    l, s = _dev(x)
+    assert x.dtype == y.dtype
+    out_w = M if out_w is None else out_w
+    in_h = out_h if in_h is None else in_h
+    in_w = out_w if in_w is None else in_w
+    img_stride = in_h * in_w if img_stride is None else img_stride
+    _lib.check(l.mage_transpose(x.data_ptr(), code(x), ldx, y.data_ptr(), ldy, y_row0, M, Mp, C, out_h, out_w, in_h, in_w, img_stride,
+                                a_off, dy, dx, s), l)
+    return y
+
+
+def row_sum(x, out, *, ld: int, n: int, rows: int):
+    l, s = _dev(x)
+    _lib.check(l.mage_row_sum(x.data_ptr(), code(x), ld, n, rows, out.data_ptr(), s), l)
+    return out
+
+
+def sum_partials(part, out, *, stride: int, n_part: int, n: int, accumulate: bool = False):
+    l, s = _dev(part)
+    assert part.dtype == torch.float32 and out.dtype == torch.float32
+    _lib.check(l.mage_sum_partials(part.data_ptr(), stride, n_part, n, out.data_ptr(), int(accumulate), s), l)
+    return out
+
+
+def layernorm_bwd(x, gamma, dy, dx, *, eps: float, accumulate: bool):
+    """dx (+)= dLN/dx; returns (dgamma, dbeta) fp32 [C]."""
+    l, s = _dev(x)
+    assert x.dtype == torch.float32 and dx.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous()
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    n_part = int(min(1024, (rows + 3) // 4))
+    part = torch.empty(n_part, 2, Cc, device=x.device, dtype=torch.float32)
+    _lib.check(l.mage_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), code(dy), dx.data_ptr(), part.data_ptr(), n_part, rows,
+                                    Cc, float(eps), int(accumulate), s), l)
+    gb = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
+    sum_partials(part, gb, stride=2 * Cc, n_part=n_part, n=2 * Cc)
+    return gb[0], gb[1]
+
+
+def act(x, y, kind: int):
+    l, s = _dev(x)
+    assert x.dtype == y.dtype and x.is_contiguous() and y.is_contiguous()
+    _lib.check(l.mage_act(x.data_ptr(), y.data_ptr(), code(x), x.numel(), kind, s), l)
+    return y
+
+
+def act_bwd(x, dy, dx, kind: int):
+    l, s = _dev(x)
+    assert x.dtype == dy.dtype == dx.dtype and x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous()
+    _lib.check(l.mage_act_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), code(x), x.numel(), kind, s), l)
+    return dx
+
+
+def cross_entropy_bwd(logits, target, grad_out, dlogits):
+    l, s = _dev(logits)
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and target.dtype == torch.int64 and grad_out.dtype == torch.float32
+    K = logits.shape[-1]
+    _lib.check(l.mage_cross_entropy_bwd(logits.data_ptr(), target.contiguous().data_ptr(), logits.numel() // K, K, grad_out.data_ptr(),
+                                        dlogits.data_ptr(), code(dlogits), s), l)
+    return dlogits
+
+
+def embedding_bwd(ids, dout, dtable, *, padding_idx: int = -1, group: Optional[int] = None, group_stride: Optional[int] = None, off: int = 0):
+    l, s = _dev(dout)
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and dtable.dtype == torch.float32 and dtable.is_contiguous()
+    n = ids.numel()
+    group = n if group is None else group
+    group_stride = group if group_stride is None else group_stride
+    _lib.check(l.mage_embedding_bwd(ids.data_ptr(), dout.data_ptr(), code(dout), dtable.data_ptr(), n, dtable.shape[1], dtable.shape[0],
+                                    padding_idx, group, group_stride, off, s), l)
+    return dtable
+
+
+def group_rowsum(x, out, *, rows: int, C: int, div: int, mod: int, row_scale=None, row_scale_div: int = 1):
+    l, s = _dev(x)
+    assert out.dtype == torch.float32
+    _lib.check(l.mage_group_rowsum(x.data_ptr(), code(x), rows, C, div, mod, _p(row_scale), row_scale_div, out.data_ptr(), s), l)
+    return out
+
+
+def attention_bwd(q, k, v, dout, dq, dk, dv, *, ldq, ldk, ldv, ldo, ld_dq, ld_dk, ld_dv, n_seq, inner, nq, nk, n_head, q_outer_stride,
+                  q_axis_stride, kv_outer_stride, kv_axis_stride, causal=False, kv_len=None, kv_len_div=1, scale=None):
+    l, s = _dev(q)
+    d = AttnDesc()
+    d.dtype = code(q)
+    d.q, d.k, d.v, d.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), dout.data_ptr()
+    d.ldq, d.ldk, d.ldv, d.ldo = ldq, ldk, ldv, ldo
+    d.n_seq, d.inner, d.nq, d.nk, d.n_head = n_seq, inner, nq, nk, n_head
+    d.q_outer_stride, d.q_axis_stride = q_outer_stride, q_axis_stride
+    d.kv_outer_stride, d.kv_axis_stride = kv_outer_stride, kv_axis_stride
+    d.causal = int(causal)
+    d.kv_len, d.kv_len_div = _p(kv_len), kv_len_div
+    d.scale = float(32 ** -0.5 if scale is None else scale)
+    _lib.check(l.mage_attention_bwd(C.byref(d), dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ld_dq, ld_dk, ld_dv, s), l)
+
+
+def dropout(x, y, p: float, seed: int, accumulate: bool = False):
+    l, s = _dev(x)
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    _lib.check(l.mage_dropout(x.data_ptr(), code(x), y.data_ptr(), code(y), x.numel(), float(p), int(seed) & (2 ** 64 - 1), int(accumulate), s), l)
+    return y
+
+
+def adam(p, g, m, v, *, lr: float, beta1: float, beta2: float, eps: float, step: int, grad_scale: float = 1.0):
+    l, s = _dev(p)
+    for t_ in (p, g, m, v):
+        assert t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == p.numel()
+    _lib.check(l.mage_adam(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(beta1), float(beta2),
+                           float(eps), int(step), float(grad_scale), s), l)
+    return p

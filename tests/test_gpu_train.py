@@ -1,0 +1,370 @@
+"""Training path on the GPU: every backward kernel against PyTorch autograd of the same op, the whole
+``loss.backward()`` of MAGE.forward against the CPU oracle's autograd (the oracle is a differentiable restatement of the
+reference's forward, pinned to the reference's goldens), and the fused Adam step against torch.optim.Adam."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mage_amd.utils import synth
+from oracle import mage_oracle as O
+from tests.helpers import build_mage, cpu_sd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GRAD_TOL = 1e-4          # relative to the largest entry of the reference gradient tensor
+
+
+def ops():
+    from mage_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def rel(a, b):
+    return (a.detach().float().cpu() - b.detach().float().cpu()).abs().max().item() / max(b.detach().abs().max().item(), 1e-30)
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_transpose_plain_and_conv_taps(dtype):
+    o = ops()
+    M, Cc = 1000, 72
+    x = rnd(M + 5, Cc, seed=1).to(dtype).to(DEV)
+    Mp = 1024
+    y = torch.full((Cc, Mp), 7.0, device=DEV, dtype=dtype)
+    o.transpose(x, y, M=M, Mp=Mp, C=Cc, ldx=Cc, ldy=Mp)
+    assert torch.equal(y[:, :M], x[:M].t()) and (y[:, M:] == 0).all()
+    # the x[:, 1:] rows of a [B, L, hw] stream
+    B, L, hw = 3, 4, 16
+    s = rnd(B * L * hw, 8, seed=2).to(dtype).to(DEV)
+    M1 = B * (L - 1) * hw
+    y = torch.empty(8, 192, device=DEV, dtype=dtype)
+    o.transpose(s, y, M=M1, Mp=192, C=8, ldx=8, ldy=192, out_w=(L - 1) * hw, img_stride=L * hw, a_off=hw)
+    assert torch.equal(y[:, :M1], s.view(B, L, hw, 8)[:, 1:].reshape(M1, 8).t())
+    # conv taps: y[tap*C + c, m] = x[shifted pixel, c] with zero padding
+    n, R = 2, 4
+    img = rnd(n * R * R, 8, seed=3).to(dtype).to(DEV)
+    y = torch.empty(9 * 8, 64, device=DEV, dtype=dtype)
+    for ky in range(3):
+        for kx in range(3):
+            o.transpose(img, y, M=n * R * R, Mp=64, C=8, ldx=8, ldy=64, y_row0=(ky * 3 + kx) * 8, out_h=R, out_w=R, in_h=R, in_w=R,
+                        img_stride=R * R, dy=ky - 1, dx=kx - 1)
+    pad = F.pad(img.float().view(n, R, R, 8), (0, 0, 1, 1, 1, 1))
+    for ky in range(3):
+        for kx in range(3):
+            want = pad[:, ky:ky + R, kx:kx + R].reshape(n * R * R, 8).t()
+            assert torch.equal(y[(ky * 3 + kx) * 8:(ky * 3 + kx + 1) * 8, :n * R * R].float(), want)
+
+
+@pytest.mark.parametrize("dtype,M,N,K", [(torch.float32, 5000, 64, 192), (torch.bfloat16, 70000, 512, 256), (torch.float32, 704, 1536, 512),
+                                         (torch.bfloat16, 40000, 2048, 512)])
+def test_weight_gradient_split_k(dtype, M, N, K):
+    """dW = dY^T X and db = column sums through transposes + ONE split-K launch + fixed-order partial sums."""
+    from mage_amd.modules.mage_train import _wgrad
+    dy = rnd(M, N, seed=4, scale=0.1).to(dtype)
+    x = rnd(M, K, seed=5).to(dtype)
+    dW, db = _wgrad(dy.to(DEV), x.to(DEV), M=M, N=N, K=K, ld_dy=N, ld_x=K)
+    want = dy.double().t() @ x.double()
+    tol = 2e-6 if dtype == torch.float32 else 2e-5          # fp32 accumulation of exact products (bf16 inputs are exact in fp32)
+    assert rel(dW.double(), want) < tol * np.sqrt(M)
+    assert rel(db.double(), dy.double().sum(0)) < tol * np.sqrt(M)
+    dW2, _ = _wgrad(dy.to(DEV), x.to(DEV), M=M, N=N, K=K, ld_dy=N, ld_x=K)
+    assert torch.equal(dW, dW2)                              # deterministic
+
+
+@pytest.mark.parametrize("Cc,rows,dy_dtype", [(512, 4099, torch.float32), (64, 300, torch.float32), (512, 2048, torch.bfloat16), (1024, 77, torch.float32)])
+def test_layernorm_backward(Cc, rows, dy_dtype):
+    o = ops()
+    x = (rnd(rows, Cc, seed=6) * 2 + 0.3).requires_grad_()
+    g, b = (1 + 0.1 * rnd(Cc, seed=7)).requires_grad_(), rnd(Cc, seed=8).requires_grad_()
+    dy = rnd(rows, Cc, seed=9).to(dy_dtype)
+    F.layer_norm(x, (Cc,), g, b, 1e-5).backward(dy.float())
+    dx0 = rnd(rows, Cc, seed=10)
+    dx = dx0.to(DEV).clone()
+    dg, db = o.layernorm_bwd(x.detach().to(DEV), g.detach().to(DEV), dy.to(DEV), dx, eps=1e-5, accumulate=True)
+    assert rel(dx.cpu() - dx0, x.grad) < 2e-5 and rel(dg, g.grad) < 2e-5 and rel(db, b.grad) < 2e-5
+    dx2 = torch.empty(rows, Cc, device=DEV)
+    o.layernorm_bwd(x.detach().to(DEV), g.detach().to(DEV), dy.to(DEV), dx2, eps=1e-5, accumulate=False)
+    assert rel(dx2, x.grad) < 2e-5
+
+
+@pytest.mark.parametrize("kind", ["quickgelu", "gelu", "relu"])
+def test_activation_forward_backward(kind):
+    o = ops()
+    code = {"quickgelu": o.ACT_QUICKGELU, "gelu": o.ACT_GELU_ERF, "relu": o.ACT_RELU}[kind]
+    x = (rnd(333, 64, seed=11) * 3).requires_grad_()
+    y = {"quickgelu": lambda t: t * torch.sigmoid(1.702 * t), "gelu": F.gelu, "relu": F.relu}[kind](x)
+    dy = rnd(333, 64, seed=12)
+    y.backward(dy)
+    got = o.act(x.detach().to(DEV), torch.empty(333, 64, device=DEV), code)
+    assert rel(got, y) < 2e-6
+    dx = o.act_bwd(x.detach().to(DEV), dy.to(DEV), torch.empty(333, 64, device=DEV), code)
+    assert rel(dx, x.grad) < 5e-6
+    xb = x.detach().bfloat16()
+    gb = o.act(xb.to(DEV), torch.empty(333, 64, device=DEV, dtype=torch.bfloat16), code)
+    assert rel(gb.float(), y) < 1e-2
+
+
+def test_cross_entropy_backward_and_embedding_scatter():
+    o = ops()
+    rows, K = 777, 64
+    lg = (rnd(rows, K, seed=13) * 2).requires_grad_()
+    tg = torch.randint(0, K, (rows,), generator=torch.Generator().manual_seed(14))
+    loss = F.cross_entropy(lg, tg)
+    (loss * 0.7).backward()
+    got = o.cross_entropy_bwd(lg.detach().to(DEV), tg.to(DEV), torch.tensor([0.7], device=DEV), torch.empty(rows, K, device=DEV))
+    assert rel(got, lg.grad) < 2e-6
+    # embedding scatter with a padding row and the grouped output addressing
+    V, Cc, n = 30, 64, 500
+    ids = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(15))
+    dout = rnd(n, Cc, seed=16)
+    want = torch.zeros(V, Cc).index_add_(0, ids[ids != 0], dout[ids != 0])
+    got = o.embedding_bwd(ids.to(DEV), dout.to(DEV), torch.zeros(V, Cc, device=DEV), padding_idx=0)
+    assert rel(got, want) < 1e-5
+
+
+def test_group_rowsum_tables():
+    o = ops()
+    B, L, hw, Cc = 3, 5, 16, 64
+    x = rnd(B * L * hw, Cc, seed=17)
+    got = o.group_rowsum(x.to(DEV), torch.empty(L, Cc, device=DEV), rows=B * L * hw, C=Cc, div=hw, mod=L)
+    assert rel(got, x.view(B, L, hw, Cc).sum((0, 2))) < 1e-5
+    got = o.group_rowsum(x.to(DEV), torch.empty(hw, Cc, device=DEV), rows=B * L * hw, C=Cc, div=1, mod=hw)
+    assert rel(got, x.view(B * L, hw, Cc).sum(0)) < 1e-5
+    sp = torch.rand(B * L)
+    got = o.group_rowsum(x.to(DEV), torch.empty(1, Cc, device=DEV), rows=B * L * hw, C=Cc, div=1, mod=1, row_scale=sp.to(DEV), row_scale_div=hw)
+    assert rel(got, (x.view(B * L, hw, Cc) * sp[:, None, None]).sum((0, 1))[None]) < 1e-5
+
+
+def _sdpa_ref(q, k, v, mask):
+    s = (q @ k.transpose(-1, -2)) * 32 ** -0.5
+    s = s.masked_fill(~mask, float("-inf"))
+    return torch.softmax(s, -1) @ v
+
+
+@pytest.mark.parametrize("axis,dtype", [(0, torch.float32), (1, torch.float32), (2, torch.float32), (0, torch.bfloat16), ("text", torch.float32),
+                                        ("cross", torch.float32)])
+def test_attention_backward(axis, dtype):
+    """dq, dk, dv of the strided short-sequence attention for every geometry the model uses: axial L (causal) / H / W over a
+    packed qkv, text self-attention with key padding, motion-anchor cross-attention (256 queries over S keys)."""
+    o = ops()
+    H = 2
+    Cc = H * 32
+    if axis in (0, 1, 2):
+        B, L, hh, ww = 2, 5, 4, 4
+        hw, M = hh * ww, B * L * hh * ww
+        qkv = rnd(M, 3 * Cc, seed=20).to(dtype)
+        do = rnd(M, Cc, seed=21).to(dtype)
+        geo = [dict(n_seq=B * hw, inner=hw, nq=L, nk=L, q_outer_stride=L * hw, q_axis_stride=hw, causal=True),
+               dict(n_seq=B * L * ww, inner=ww, nq=hh, nk=hh, q_outer_stride=hw, q_axis_stride=ww, causal=False),
+               dict(n_seq=B * L * hh, inner=1, nq=ww, nk=ww, q_outer_stride=ww, q_axis_stride=1, causal=False)][axis]
+        geo.update(kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], n_head=H)
+        x = qkv.float().view(B, L, hh, ww, 3, H, 32).requires_grad_()
+        perm = [(0, 2, 3, 5, 1, 6), (0, 1, 3, 5, 2, 6), (0, 1, 2, 5, 3, 6)][axis]           # -> [..., head, axis, 32]
+        q, k, v = (x[:, :, :, :, j].permute(*perm) for j in range(3))
+        n = q.shape[-2]
+        mask = torch.ones(n, n, dtype=torch.bool).tril() if axis == 0 else torch.ones(n, n, dtype=torch.bool)
+        out = _sdpa_ref(q, k, v, mask)
+        inv = np.argsort(perm).tolist()
+        out.permute(*inv).reshape(M, Cc).backward(do.float())
+        want = x.grad.reshape(M, 3 * Cc)
+        dqkv = torch.empty(M, 3 * Cc, device=DEV, dtype=dtype)
+        dq = qkv.to(DEV)
+        o.attention_bwd(dq, dq[:, Cc:], dq[:, 2 * Cc:], do.to(DEV), dqkv, dqkv[:, Cc:], dqkv[:, 2 * Cc:], ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc,
+                        ldo=Cc, ld_dq=3 * Cc, ld_dk=3 * Cc, ld_dv=3 * Cc, **geo)
+        assert rel(dqkv, want) < (1e-5 if dtype == torch.float32 else 2e-2)
+        return
+    B, S = 3, 12
+    if axis == "text":
+        lens = torch.tensor([12, 7, 9])
+        qkv = rnd(B * S, 3 * Cc, seed=22)
+        do = rnd(B * S, Cc, seed=23)
+        x = qkv.view(B, S, 3, H, 32).requires_grad_()
+        q, k, v = (x[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+        mask = (torch.arange(S)[None, :] < lens[:, None])[:, None, None, :].expand(B, H, S, S)
+        _sdpa_ref(q, k, v, mask).permute(0, 2, 1, 3).reshape(B * S, Cc).backward(do)
+        dqkv = torch.empty(B * S, 3 * Cc, device=DEV)
+        dq = qkv.to(DEV)
+        o.attention_bwd(dq, dq[:, Cc:], dq[:, 2 * Cc:], do.to(DEV), dqkv, dqkv[:, Cc:], dqkv[:, 2 * Cc:], ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc,
+                        ldo=Cc, ld_dq=3 * Cc, ld_dk=3 * Cc, ld_dv=3 * Cc, n_seq=B, inner=1, nq=S, nk=S, n_head=H, q_outer_stride=S,
+                        q_axis_stride=1, kv_outer_stride=S, kv_axis_stride=1, kv_len=lens.to(torch.int32).to(DEV), kv_len_div=1)
+        assert rel(dqkv, x.grad.reshape(B * S, 3 * Cc)) < 1e-5
+        return
+    nq = 256                                                                      # cross: 256 queries per clip over S text keys
+    qp = rnd(B * nq, Cc, seed=24).requires_grad_()
+    kvp = rnd(B * S, 2 * Cc, seed=25).requires_grad_()
+    do = rnd(B * nq, Cc, seed=26)
+    q = qp.view(B, nq, H, 32).permute(0, 2, 1, 3)
+    k, v = (kvp.view(B, S, 2, H, 32)[:, :, j].permute(0, 2, 1, 3) for j in range(2))
+    _sdpa_ref(q, k, v, torch.ones(nq, S, dtype=torch.bool)).permute(0, 2, 1, 3).reshape(B * nq, Cc).backward(do)
+    dqp, dkvp = torch.empty(B * nq, Cc, device=DEV), torch.empty(B * S, 2 * Cc, device=DEV)
+    dkv = kvp.detach().to(DEV)
+    o.attention_bwd(qp.detach().to(DEV), dkv, dkv[:, Cc:], do.to(DEV), dqp, dkvp, dkvp[:, Cc:], ldq=Cc, ldk=2 * Cc, ldv=2 * Cc, ldo=Cc, ld_dq=Cc,
+                    ld_dk=2 * Cc, ld_dv=2 * Cc, n_seq=B, inner=1, nq=nq, nk=S, n_head=H, q_outer_stride=nq, q_axis_stride=1, kv_outer_stride=S,
+                    kv_axis_stride=1)
+    assert rel(dqp, qp.grad) < 1e-5 and rel(dkvp, kvp.grad) < 1e-5
+
+
+def test_dropout_mask_is_stateless_and_scaled():
+    o = ops()
+    x = torch.ones(1 << 20, device=DEV)
+    y1 = o.dropout(x, torch.empty_like(x), 0.1, 1234)
+    y2 = o.dropout(x, torch.empty_like(x), 0.1, 1234)
+    y3 = o.dropout(x, torch.empty_like(x), 0.1, 1235)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    keep = (y1 != 0).float().mean().item()
+    assert abs(keep - 0.9) < 2e-3 and torch.allclose(y1[y1 != 0], torch.tensor(1 / 0.9, device=DEV))
+    acc = o.dropout(x, torch.full_like(x, 2.0), 0.1, 1234, accumulate=True)
+    assert torch.equal(acc, y1 + 2.0)
+    yb = o.dropout(x, torch.empty(1 << 20, device=DEV, dtype=torch.bfloat16), 0.1, 1234)       # the backward's cast + mask in one pass
+    assert torch.equal(yb != 0, y1 != 0)
+
+
+def test_fused_adam_matches_torch():
+    o = ops()
+    n = 100003
+    p0, gs = rnd(n, seed=30), [rnd(n, seed=31 + i, scale=0.1) for i in range(4)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.9, 0.98), eps=1e-6)
+    p, m, v = p0.to(DEV).clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for i, g in enumerate(gs):
+        ref.grad = g.clone()
+        opt.step()
+        o.adam(p, g.to(DEV), m, v, lr=1e-3, beta1=0.9, beta2=0.98, eps=1e-6, step=i + 1)
+    assert (p.cpu() - ref.detach()).abs().max().item() < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ the whole backward pass
+def oracle_grads(sd, batch, L):
+    """Gradients of the reference's loss (CPU oracle forward = the reference's forward, autograd of PyTorch CPU)."""
+    sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.startswith("first_stage_model.") else v) for k, v in sd.items()}
+    loss, _ = O.mage_forward_loss(sd, batch, L)
+    names = [k for k, v in sd.items() if v.requires_grad]
+    gs = torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True)
+    return loss.item(), {k: g for k, g in zip(names, gs)}
+
+
+@pytest.mark.parametrize("cfg_kw,B,L,seed,batch_kw", [
+    (dict(width=64, layers=3, vq_dim=32, K=64), 3, 5, 31, dict(text_len=9, ragged_text=True)),       # the mage_small_d64 fixture's model
+    (dict(), 1, 4, 33, dict(digits=2, caption_lengths=(16, 18, 20))),                                # full width (d=512, 6 blocks)
+])
+def test_loss_backward_matches_oracle_autograd(cfg_kw, B, L, seed, batch_kw):
+    """loss.backward() on the HIP path (fp32 mode, eval = no dropout) against autograd through the oracle: every trainable
+    parameter's gradient within 1e-4 of the tensor's largest reference entry; unused parameters (ln_q / ln_kv) get zeros."""
+    cfg = synth.mnist_model_config(frames_length=L, **cfg_kw)
+    m = build_mage(cfg, seed, DEV)
+    batch = synth.synth_batch_mnist(B, L, seed=seed, **batch_kw)
+    want_loss, want = oracle_grads(cpu_sd(m), batch, L)
+    loss, ld = m({k: v.to(DEV) for k, v in batch.items()})
+    assert abs(loss.item() - want_loss) < 1e-4 and loss.requires_grad
+    loss.backward()
+    worst = ("", 0.0)
+    n_checked = 0
+    for name, p in m.named_parameters():
+        if name.startswith("first_stage_model."):
+            assert p.grad is None
+            continue
+        g_ref = want.get(name)
+        assert p.grad is not None, name
+        if g_ref is None or g_ref.abs().max().item() == 0.0:
+            assert p.grad.abs().max().item() == 0.0, name                       # unused by the reference's forward
+            continue
+        r = rel(p.grad, g_ref)
+        n_checked += 1
+        if r > worst[1]:
+            worst = (name, r)
+    print(f"{n_checked} gradients checked, worst relative error {worst[1]:.2e} at {worst[0]}")
+    assert worst[1] < GRAD_TOL, worst
+    assert n_checked > 100
+
+
+def test_bf16_training_gradients_track_fp32():
+    cfg = synth.mnist_model_config(frames_length=4, width=64, layers=3, vq_dim=32, K=64)
+    m = build_mage(cfg, 35, DEV)
+    batch = {k: v.to(DEV) for k, v in synth.synth_batch_mnist(2, 4, seed=35).items()}
+    m(batch)[0].backward()
+    g32 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad(set_to_none=True)
+    m.set_precision("bf16")
+    loss, _ = m(batch)
+    loss.backward()
+    cos = []
+    for n, p in m.named_parameters():
+        if p.grad is not None and g32[n].abs().max() > 0:
+            cos.append(F.cosine_similarity(p.grad.flatten(), g32[n].flatten(), dim=0).item())
+    print(f"bf16 vs fp32 gradients: min cosine {min(cos):.4f}, mean {np.mean(cos):.4f}")
+    assert min(cos) > 0.98
+
+
+def test_dropout_training_mode_is_consistent_between_forward_and_backward():
+    """train(): dropout masks are stateless hashes of a per-call seed drawn from torch's RNG.  Same torch seed -> same loss; and
+    the directional derivative of that (fixed-mask) loss along a parameter direction agrees with <grad, direction>."""
+    cfg = synth.mnist_model_config(frames_length=4, width=64, layers=3, vq_dim=32, K=64)
+    m = build_mage(cfg, 37, DEV).train()
+    m.first_stage_model.eval()
+    batch = {k: v.to(DEV) for k, v in synth.synth_batch_mnist(2, 4, seed=37).items()}
+
+    def loss_at():
+        torch.manual_seed(99)
+        return m(batch)[0]
+    l0 = loss_at()
+    l0.backward()
+    assert abs(loss_at().item() - l0.item()) < 1e-6
+    torch.manual_seed(100)
+    assert abs(m(batch)[0].item() - l0.item()) > 1e-6                            # another seed: another mask
+    m.eval()
+    assert abs(m(batch)[0].item() - l0.item()) > 1e-6                            # and eval mode has none
+    m.train()
+    m.first_stage_model.eval()
+    p = m.generate_model.blocks[1].mlp.c_fc.weight
+    g = p.grad.clone()
+    d = torch.randn(p.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+    d = d / d.norm()
+    eps = 2e-2
+    with torch.no_grad():
+        p.add_(eps * d)
+        lp = loss_at().item()
+        p.sub_(2 * eps * d)
+        lm = loss_at().item()
+        p.add_(eps * d)
+    fd, an = (lp - lm) / (2 * eps), (g * d).sum().item()
+    print(f"directional derivative: finite difference {fd:.6f}, analytic {an:.6f}")
+    assert abs(fd - an) < 0.05 * max(abs(an), 1e-3) + 2e-4
+
+
+def test_flat_adam_training_steps_track_torch_adam_on_the_oracle():
+    """Three optimizer steps: HIP forward/backward + FlatAdam (one fused launch over the flat arena) against the oracle's autograd +
+    torch.optim.Adam with the reference's hyper-parameters (main_mage.py:121)."""
+    from mage_amd.optim import FlatAdam
+    L = 4
+    cfg = synth.mnist_model_config(frames_length=L, width=64, layers=3, vq_dim=32, K=64)
+    m = build_mage(cfg, 39, DEV)
+    batch = synth.synth_batch_mnist(2, L, seed=39)
+    sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.startswith("first_stage_model.") else v) for k, v in cpu_sd(m).items()}
+    ref_params = [v for v in sd.values() if v.requires_grad]
+    ref_opt = torch.optim.Adam(ref_params, lr=1e-3, betas=(0.9, 0.98), eps=1e-6)
+    opt = FlatAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-6)
+    db = {k: v.to(DEV) for k, v in batch.items()}
+    for step in range(3):
+        ref_opt.zero_grad()
+        ref_loss, _ = O.mage_forward_loss(sd, batch, L)
+        ref_loss.backward()
+        for v in ref_params:
+            if v.grad is None:
+                v.grad = torch.zeros_like(v)
+        ref_opt.step()
+        opt.zero_grad()
+        loss, _ = m(db)
+        loss.backward()
+        opt.step()
+        print(f"step {step}: loss {loss.item():.6f} (oracle {ref_loss.item():.6f})")
+        assert abs(loss.item() - ref_loss.item()) < 2e-4
+    got = m.state_dict()
+    worst = max(rel(got[k], v) for k, v in sd.items() if v.requires_grad)
+    assert worst < 2e-3, worst                                     # Adam divides by sqrt(v): tiny gradients amplify rounding
+    assert all(p.data_ptr() >= opt.flat_p.data_ptr() for p in opt.params)

@@ -1,0 +1,120 @@
+"""CPU side of the training path: the flat-arena optimizer's bookkeeping and its data-parallel step
+(reduce-scatter of the gradient arena -> Adam on the local shard -> all-gather of the parameter arena), world size 2 over gloo.
+The fused Adam kernel is HIP-only (FlatAdam raises on CPU tensors); here a test double with torch arithmetic stands in for that
+ONE launch so that the arena layout, the sharding and the collectives are what is tested."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _adam_double(self, p, g, m, v, lr, b1, b2, eps, step, grad_scale):
+    g = g * grad_scale
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.sub_((lr / (1 - b1 ** step)) * m / (v.sqrt() / (1 - b2 ** step) ** 0.5 + eps))
+
+
+def _net(seed):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.Tanh(), torch.nn.Linear(13, 5), torch.nn.LayerNorm(5))
+
+
+def test_flat_adam_refuses_cpu_tensors_and_keeps_arena_views():
+    from mage_amd.optim import FlatAdam
+    net = _net(0)
+    opt = FlatAdam(net.parameters(), lr=1e-2)
+    n = sum(p.numel() for p in net.parameters())
+    assert opt.n == n and opt.n_pad % 4 == 0
+    for p, off in zip(opt.params, opt.offsets):
+        assert p.data_ptr() == opt.flat_p.data_ptr() + 4 * off and p.grad.data_ptr() == opt.flat_g.data_ptr() + 4 * off
+    net(torch.randn(3, 7)).sum().backward()
+    assert opt.flat_g.abs().sum() > 0                       # autograd accumulated INTO the arena
+    with pytest.raises(RuntimeError, match="mage_adam"):
+        opt.step()                                          # no CPU path
+    opt.zero_grad()
+    assert opt.flat_g.abs().sum() == 0 and all(p.grad.data_ptr() == opt.flat_g.data_ptr() + 4 * off for p, off in zip(opt.params, opt.offsets))
+
+
+def test_flat_adam_matches_torch_adam_single_process(monkeypatch):
+    from mage_amd.optim import FlatAdam
+    monkeypatch.setattr(FlatAdam, "_adam", _adam_double)
+    a, b = _net(1), _net(1)
+    ref = torch.optim.Adam(a.parameters(), lr=1e-2, betas=(0.9, 0.98), eps=1e-6)
+    opt = FlatAdam(b.parameters(), lr=1e-2, betas=(0.9, 0.98), eps=1e-6)
+    for i in range(4):
+        x = torch.randn(6, 7, generator=torch.Generator().manual_seed(i))
+        for net, o in ((a, ref), (b, opt)):
+            o.zero_grad()
+            net(x).pow(2).mean().backward()
+            o.step()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, atol=1e-6)
+    sd = opt.state_dict()
+    opt2 = FlatAdam(_net(1).parameters(), lr=1e-2, betas=(0.9, 0.98), eps=1e-6)
+    opt2.load_state_dict(sd)
+    assert opt2.steps == 4 and torch.equal(opt2.m, opt.m) and opt2.param_groups[0]["lr"] == 1e-2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    from mage_amd.optim import FlatAdam
+    from mage_amd.utils import dist as D
+    FlatAdam._adam = _adam_double
+    D.init_from_env("gloo")
+    net = _net(2)
+    opt = FlatAdam(net.parameters(), lr=1e-2, betas=(0.9, 0.98), eps=1e-6)
+    assert opt.sharded and opt.shard_n * world == opt.n_pad and opt.m.numel() == opt.shard_n      # optimizer state is divided by W
+    data = torch.randn(8, 7, generator=torch.Generator().manual_seed(5))
+    mine = data[rank * 4:(rank + 1) * 4]                     # each rank sees its half of the global batch
+    for _ in range(3):
+        opt.zero_grad()
+        net(mine).pow(2).mean().backward()
+        opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    q.put((rank, flat.clone(), bool(torch.equal(gathered[0], gathered[1]))))
+    D.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_step_over_two_ranks_equals_the_global_batch_step():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][2] and res[1][2]                           # replicas stay identical after the all-gather
+    # single process on the whole batch with torch's own Adam: mean over 8 samples == mean of the two half-batch means
+    net = _net(2)
+    ref = torch.optim.Adam(net.parameters(), lr=1e-2, betas=(0.9, 0.98), eps=1e-6)
+    data = torch.randn(8, 7, generator=torch.Generator().manual_seed(5))
+    for _ in range(3):
+        ref.zero_grad()
+        (0.5 * (net(data[:4]).pow(2).mean() + net(data[4:]).pow(2).mean())).backward()
+        ref.step()
+    want = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    assert torch.allclose(res[0][1], want, atol=2e-6)
