@@ -699,7 +699,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     unsigned voff[4][2];
     auto set_rows = [&](int P) {
         const int tile = cur_tile[P];
-        const int ts = SPLIT ? tile / g.tiles_per_split : 0, trem = SPLIT ? tile - ts * g.tiles_per_split : tile;   // split-K slice
+        // split-K slice.  The loader cursors run past the end of the tile list (their DMA lands in a buffer nobody reads): rows
+        // are clamped below, and so is the slice, or its offset would leave the operand
+        const int ts_raw = SPLIT ? tile / g.tiles_per_split : 0, trem = SPLIT ? tile - ts_raw * g.tiles_per_split : tile;
+        const int ts = SPLIT ? min(ts_raw, d.n_split - 1) : 0;
         const int tm = trem / g.ntiles_n, tn = trem - tm * g.ntiles_n;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
