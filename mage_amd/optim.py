@@ -39,7 +39,9 @@ class FlatAdam(torch.optim.Optimizer):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
-        self.sharded = (self.world > 1) if shard is None else (bool(shard) and self.world > 1)
+        # shard=None: shard whenever there is more than one rank; shard=True forces the reduce-scatter / all-gather path on any
+        # initialised process group (a 1-rank group still goes through RCCL: used by the single-GPU test of the collective path)
+        self.sharded = (self.world > 1) if shard is None else (bool(shard) and dist.is_initialized())
         dev = plist[0].device
         if any(p.device != dev or p.dtype != torch.float32 for p in plist):
             raise ValueError("FlatAdam: parameters must be fp32 tensors on one device")

@@ -370,3 +370,42 @@ def test_flat_adam_training_steps_track_torch_adam_on_the_oracle():
     worst = max(rel(got[k], v) for k, v in sd.items() if v.requires_grad)
     assert worst < 2e-3, worst                                     # Adam divides by sqrt(v): tiny gradients amplify rounding
     assert all(p.data_ptr() >= opt.flat_p.data_ptr() for p in opt.params)
+
+
+def test_ddp_wrapped_model_and_rccl_sharded_step():
+    """The reference wraps the model in DistributedDataParallel(find_unused_parameters=True) (main_mage.py:95) and steps Adam.
+    One rank, backend nccl (= RCCL): the DDP-wrapped HIP model trains (its reducer sees one autograd node feeding every parameter),
+    and FlatAdam's reduce-scatter -> shard update -> all-gather path over RCCL gives the same parameters as the unsharded step."""
+    import os
+    import torch.distributed as dist
+    from mage_amd.optim import FlatAdam
+    from mage_amd.utils.dist import free_port
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        L = 4
+        cfg = synth.mnist_model_config(frames_length=L, width=64, layers=3, vq_dim=32, K=64)
+        batch = {k: v.to(DEV) for k, v in synth.synth_batch_mnist(2, L, seed=41).items()}
+        results = []
+        for mode in ("plain", "ddp+sharded"):
+            m = build_mage(cfg, 41, DEV)
+            net = m
+            if mode != "plain":
+                net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True)
+            opt = FlatAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-6, shard=(mode != "plain"))
+            assert opt.sharded == (mode != "plain")
+            for _ in range(2):
+                opt.zero_grad()
+                loss, ld = net(batch)
+                loss.backward()
+                opt.step()
+            results.append((loss.item(), {k: v.clone() for k, v in m.state_dict().items()}))
+        assert abs(results[0][0] - results[1][0]) < 1e-6
+        for k in results[0][1]:        # not bitwise: the two embedding scatters use fp32 atomics (order varies run to run)
+            assert torch.allclose(results[0][1][k].float(), results[1][1][k].float(), atol=2e-6, rtol=1e-5), k
+        assert dist.get_backend() == "nccl"
+    finally:
+        dist.destroy_process_group()
