@@ -264,8 +264,8 @@ def main():
             dom = gemms[dom_key]
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             allf, allms = sum(v["flops"] for v in all_src.values()), sum(v["ms"] for v in all_src.values())
-            roofline = {"bound": "mfma", "kernel": dom_key + "  [gemm8_kernel<act, epilogue kind>: the 8-phase ping-pong bf16 256x256 GEMM; "
-                                                             "gemm_kernel<dtype, gather, act, m-tiles/wave, epilogue kind>: the lockstep one.  "
+            roofline = {"bound": "mfma", "kernel": dom_key + "  [gemm8_kernel<act, epilogue kind, split-K>: the 8-phase ping-pong bf16 256x256 GEMM; "
+                                                             "gemm_kernel<dtype, gather, act, m-tiles/wave, epilogue kind, split-K>: the lockstep one.  "
                                                              "Epilogue kind 1 = x + Linear(.) with the fp32 residual: attention out_proj and "
                                                              "MLP c_proj of the decoder stack]",
                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),

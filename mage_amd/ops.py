@@ -205,7 +205,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
         # per-kernel averages line up with rocprofv3's per-symbol statistics
         gather = taps_h * taps_w > 1 or stride != 1 or dy0 != 0 or dx0 != 0 or d.in_h != d.out_h or d.in_w != d.out_w
         n_cu = torch.cuda.get_device_properties(a.device).multi_processor_count & ~7
-        mt = 8 if (d.dtype == BF16 and ((M + 255) // 256) * ((N + 255) // 256) >= 2 * n_cu) else 4
+        mt = 8 if (d.dtype == BF16 and ((M + 255) // 256) * ((N + 255) // 256) * max(n_split, 1) >= 2 * n_cu) else 4
         if scale is None and rowadd is None and residual is None and not post_relu:
             ek = 0
         elif (not gather and act == ACT_NONE and residual is not None and residual.dtype == torch.float32 and scale is None
@@ -213,11 +213,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
             ek = 1
         else:
             ek = 2
-        key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act}, {mt}, {ek}>"
+        sp = "true" if n_split > 1 else "false"
+        key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act}, {mt}, {ek}, {sp}>"
         a_rows = ((M + out_h * out_w - 1) // (out_h * out_w)) * d.a_img_stride + a_off + 1
         if (d.dtype == BF16 and not gather and mt == 8 and ek != 2 and K % 64 == 0 and a_rows * lda * 2 < 2 ** 32
                 and N * K * 2 < 2 ** 32 and not os.environ.get("MAGE_GEMM_NO_8PHASE")):
-            key = f"gemm8_kernel<{act}, {ek}>"          # the 8-phase ping-pong variant (launch_tile in csrc/gemm.hip)
+            key = f"gemm8_kernel<{act}, {ek}, {sp}>"    # the 8-phase ping-pong variant (launch_tile in csrc/gemm.hip)
         if PROFILE.wants(key):
             ev = PROFILE.begin()
             _lib.check(l.mage_gemm(C.byref(d), s), l)

@@ -92,12 +92,12 @@ def test_synthetic_weights_are_portable_and_keyed_by_name():
 
 
 def test_committed_bench_line_keeps_the_driver_contract():
-    """profiles/r01_bench_cfg2_bf16.json is a bench.py output line: every key the driver / judge reads is there, typed and
+    """profiles/r02_bench_cfg2_bf16.json is a bench.py output line: every key the driver / judge reads is there, typed and
     consistent (value = global_batch * frames / (ms_per_step / 1e3); roofline.frac = achieved / peak)."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = json.load(open(os.path.join(root, "profiles", "r01_bench_cfg2_bf16.json")))
+    r = json.load(open(os.path.join(root, "profiles", "r02_bench_cfg2_bf16.json")))
     for k, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                    ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                    ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
@@ -110,3 +110,12 @@ def test_committed_bench_line_keeps_the_driver_contract():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["traffic"] is not None and rf["traffic"] > 0
     cb = r["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)
+    assert cb["one_thread"]["cores"] == 1 and cb["one_thread"]["value"] > 0 and isinstance(cb["cpu"], str)
+    # round 2: the parity-gated precision beside the benchmarked one, the decode roofline, the whole-call fraction
+    pm = r["parity_mode"]
+    assert pm["dtype"] == "fp32" and pm["value"] > 0 and 0.0 <= pm["bf16_free_running_token_agreement"]["first_generated_frame"] <= 1.0
+    rd = r["roofline_decode"]
+    assert rd["bound"] == "hbm" and abs(rd["frac"] - rd["achieved"] / rd["peak"]) < 1e-3 and rd["mfma"]["frac"] > 0
+    wc = r["whole_call"]
+    assert abs(wc["frac"] - wc["flops_per_call"] / (r["ms_per_step"] * 1e-3) / 1e12 / wc["peak"]) < 1e-3
+    assert r["config"]["ranks_seen"] == r["n_gpus"] and "traffic_source" in rf
