@@ -262,11 +262,12 @@ int mage_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t r
 /* y[(c + y_row0)*ldy + m] = x[arow(m)*ldx + c] for m < M, 0 for M <= m < Mp (zero tail up to the padded width the split-K GEMM
  * reads).  arow(m) is mage_gemm's implicit-GEMM row map for ONE tap: m -> (img, oy, ox) over an out_h x out_w plane,
  * arow = img*img_stride + (oy+dy)*in_w + (ox+dx) + a_off, zero outside [0,in_h) x [0,in_w).  Plain transpose: out_h = 1,
- * out_w = M, dy = dx = 0.  The conv3x3 weight gradient (mage_model.py:485-488) stacks nine calls (dy, dx = tap - 1,
- * y_row0 = tap*C).  dtype: MAGE_F32 | MAGE_BF16 (x and y). */
+ * out_w = M, dy = dx = 0, stride = 1.  The conv3x3 weight gradient (mage_model.py:485-488) stacks nine calls (dy, dx = tap - 1,
+ * y_row0 = tap*C); with `stride` the gathered pixel is (oy*stride+dy, ox*stride+dx): the 4x4 / stride-2 convolutions and
+ * transposed convolutions of the VQ-VAE (vqvae_model.py:173-188).  dtype: MAGE_F32 | MAGE_BF16 (x and y). */
 int mage_transpose(const void* x, int32_t dtype, int64_t ldx, void* y, int64_t ldy, int64_t y_row0, int64_t M, int64_t Mp, int32_t C,
                    int32_t out_h, int32_t out_w, int32_t in_h, int32_t in_w, int64_t img_stride, int64_t a_off, int32_t dy, int32_t dx,
-                   void* stream);
+                   int32_t stride, void* stream);
 /* out[r] = sum_{c < n} x[r*ld + c] (fp32, fixed order): bias gradients db = column sums of dY, taken from the transposed dY. */
 int mage_row_sum(const void* x, int32_t dtype, int64_t ld, int64_t n, int32_t rows, float* out, void* stream);
 /* out[i] = (accumulate ? out[i] : 0) + sum_{s < n_part} part[s*stride + i]: the split-K partial products, the LayerNorm
@@ -277,7 +278,8 @@ int mage_sum_partials(const float* part, int64_t stride, int32_t n_part, int64_t
 int mage_layernorm_bwd(const float* x, const float* gamma, const void* dy, int32_t dy_dtype, float* dx, float* partials, int32_t n_part,
                        int64_t rows, int32_t C, float eps, int32_t accumulate, void* stream);
 /* y = act(x) and dx = dy * act'(x) elementwise (x = the saved pre-activation; QuickGELU mage_model.py:11-13, erf-GELU of the text
- * encoder, ReLU).  n % 4 == 0. */
+ * encoder, ReLU -- for which the post-activation output serves equally).  mage_act_bwd also takes MAGE_ACT_TANH, with x = the OUTPUT
+ * y = tanh(.): dx = dy (1 - y^2).  n % 4 == 0. */
 int mage_act(const void* x, void* y, int32_t dtype, int64_t n, int32_t act, void* stream);
 int mage_act_bwd(const void* x, const void* dy, void* dx, int32_t dtype, int64_t n, int32_t act, void* stream);
 /* F.cross_entropy backward (mage_model.py:618): dlogits = (softmax(logits) - onehot(target)) * grad_out[0] / rows, written in
@@ -302,6 +304,22 @@ int mage_attention_bwd(const mage_attn_desc* desc, const void* dout, void* dq, v
  * calls it again with the same seed (no mask tensor). */
 int mage_dropout(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, int64_t n, float p, uint64_t seed, int32_t accumulate,
                  void* stream);
+/* BatchNorm2d in TRAINING mode (stage-1 VQ-VAE training, train_vqvae.py:13-35; vqvae_model.py:112-119,174,186) on channels-last
+ * rows [rows, C] fp32: batch statistics are column reductions.  mage_bn_colreduce writes per-workgroup partial column sums
+ * partials[n_part][NOUT][C] for mage_sum_partials (fixed order): mode 0: sum x; mode 1: sum (x - mean)^2 (two-pass variance);
+ * mode 2 (backward): sum g and sum g*xhat with g = dy * (mask ? mask > 0 : 1) -- `mask` is the layer's post-ReLU output when a
+ * ReLU follows the norm.  mage_bn_apply: y = [relu]((x - mean) rstd gamma + beta [+ residual]) (the ResBlock's skip, vqvae_model.py:123).  mage_bn_bwd_apply: dx = gamma rstd (g - s1/rows
+ * - xhat s2/rows) with sums = [s1 | s2] from mode 2. */
+int mage_bn_colreduce(int32_t mode, const float* x, const float* dy, const float* mask, const float* mean, const float* rstd, int64_t rows,
+                      int32_t C, float* partials, int32_t n_part, void* stream);
+int mage_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* residual, void* y,
+                  int32_t y_dtype, int64_t rows, int32_t C, int32_t relu, void* stream);
+int mage_bn_bwd_apply(const float* x, const float* dy, const float* mask, const float* mean, const float* rstd, const float* gamma,
+                      const float* sums, float* dx, int64_t rows, int32_t C, void* stream);
+/* Backward of mage_convt_fold_tanh: dtaps[(n, iy, ix), (ky*4+kx)*cout + co] = grad_y[n, co, oy, ox] (1 - y^2), oy = 2 iy - 1 + ky
+ * (zero outside the image): the gradient of the per-input-pixel tap products of the decoder's ConvTranspose2d head.  y null: grad_y
+ * is already the gradient of the pre-tanh sum. */
+int mage_convt_unfold_tanh_bwd(const float* grad_y, const float* y, float* dtaps, int32_t N, int32_t IH, int32_t IW, int32_t cout, void* stream);
 /* torch.optim.Adam step (main_mage.py:121: betas (0.9, 0.98), eps 1e-6) over flat fp32 arenas; grad_scale multiplies the gradient
  * first (1 / world_size after a summing reduce-scatter). */
 int mage_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int32_t step,

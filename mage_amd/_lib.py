@@ -77,7 +77,11 @@ SIGNATURES = {
     "mage_reparam_kl": (C.c_int, [vp, vp, vp, vp, vp, i32, i64, vp]),
     "mage_mse": (C.c_int, [vp, i64, vp, i64, i64, i32, vp, vp, vp]),
     # training path
-    "mage_transpose": (C.c_int, [vp, i32, i64, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i64, i64, i32, i32, vp]),
+    "mage_transpose": (C.c_int, [vp, i32, i64, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i64, i64, i32, i32, i32, vp]),
+    "mage_bn_colreduce": (C.c_int, [i32, vp, vp, vp, vp, vp, i64, i32, vp, i32, vp]),
+    "mage_bn_apply": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
+    "mage_bn_bwd_apply": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
+    "mage_convt_unfold_tanh_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "mage_row_sum": (C.c_int, [vp, i32, i64, i64, i32, vp, vp]),
     "mage_sum_partials": (C.c_int, [vp, i64, i32, i64, vp, i32, vp]),
     "mage_layernorm_bwd": (C.c_int, [vp, vp, vp, i32, vp, vp, i32, i64, i32, f32, i32, vp]),

@@ -18,7 +18,7 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, long y_row0,
                                                         long M, long Mp, int C, int out_h, int out_w, int in_h, int in_w,
-                                                        long img_stride, long a_off, int dy, int dx) {
+                                                        long img_stride, long a_off, int dy, int dx, int stride) {
     __shared__ T tile[64][65];
     const long m0 = (long)blockIdx.x * 64;
     const int c0 = blockIdx.y * 64;
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x,
         if (m < M && c0 + tx < C) {
             const long img = m / plane, rem = m - img * plane;
             const int oy = (int)(rem / out_w), ox = (int)(rem - (long)oy * out_w);
-            const int iy = oy + dy, ix = ox + dx;
+            const int iy = oy * stride + dy, ix = ox * stride + dx;
             if ((unsigned)iy < (unsigned)in_h && (unsigned)ix < (unsigned)in_w)
                 v = x[(img * img_stride + (long)iy * in_w + ix + a_off) * ldx + c0 + tx];
         }
@@ -176,6 +176,7 @@ __device__ __forceinline__ float actdf(float v) {
     }
     if (ACT == MAGE_ACT_GELU_ERF)
         return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
+    if (ACT == MAGE_ACT_TANH) return 1.f - v * v;       // backward only, and v is the OUTPUT y = tanh(.)
     return 1.f;
 }
 // BWD = 0: y = act(x);  BWD = 1: y = dy * act'(x)   (x = the saved pre-activation)
@@ -438,12 +439,105 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ BatchNorm (training mode)
+// Stage-1 VQ-VAE training (train_vqvae.py:13-35) runs its BatchNorm2d layers on BATCH statistics.  Channels-last rows [rows, C]:
+// the statistics are column reductions.  One workgroup owns a slab of rows, thread = channel (coalesced rows), partial sums per
+// workgroup [gridDim.x][NOUT][C] are added in a fixed order by mage_sum_partials.
+//   MODE 0: sum x                      MODE 1: sum (x - mean)^2                (two-pass variance)
+//   MODE 2: sum g, sum g * xhat        g = dy * (mask ? mask > 0 : 1),  xhat = (x - mean) * rstd      (backward)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_colreduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ mask, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, long rows, int C, long rows_per_blk,
+                                                           float* __restrict__ part) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long r0 = (long)blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+    float a0 = 0.f, a1 = 0.f;
+    const float m = MODE >= 1 ? mean[c] : 0.f, rs = MODE == 2 ? rstd[c] : 0.f;
+    for (long r = r0; r < r1; ++r) {
+        const float v = x[r * C + c];
+        if (MODE == 0) a0 += v;
+        if (MODE == 1) a0 += (v - m) * (v - m);
+        if (MODE == 2) {
+            float g = dy[r * C + c];
+            if (mask && !(mask[r * C + c] > 0.f)) g = 0.f;
+            a0 += g;
+            a1 += g * ((v - m) * rs);
+        }
+    }
+    constexpr int NOUT = MODE == 2 ? 2 : 1;
+    part[((long)blockIdx.x * NOUT + 0) * C + c] = a0;
+    if (MODE == 2) part[((long)blockIdx.x * NOUT + 1) * C + c] = a1;
+}
+
+// y = [relu]((x - mean) * rstd * gamma + beta [+ residual])
+template <typename OT>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ residual, OT* __restrict__ y, long n, int C, int relu) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const f32x4 v = *(const f32x4*)(x + i), m = *(const f32x4*)(mean + c), rs = *(const f32x4*)(rstd + c), g = *(const f32x4*)(gamma + c),
+                b = *(const f32x4*)(beta + c);
+    f32x4 o = (v - m) * rs * g + b;
+    if (residual) o += *(const f32x4*)(residual + i);
+    if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+    }
+    store4(y + i, o);
+}
+
+// dx = gamma * rstd * (g - s1 / rows - xhat * s2 / rows),  g = dy * (mask ? mask > 0 : 1), (s1, s2) = the MODE 2 column sums
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mask,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ sums, float inv_rows,
+                                                           float* __restrict__ dx, long n, int C) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const f32x4 v = *(const f32x4*)(x + i), m = *(const f32x4*)(mean + c), rs = *(const f32x4*)(rstd + c), gm = *(const f32x4*)(gamma + c),
+                s1 = *(const f32x4*)(sums + c), s2 = *(const f32x4*)(sums + C + c);
+    f32x4 g = *(const f32x4*)(dy + i);
+    if (mask) {
+        const f32x4 mk = *(const f32x4*)(mask + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (!(mk[e] > 0.f)) g[e] = 0.f;
+    }
+    const f32x4 xh = (v - m) * rs;
+    *(f32x4*)(dx + i) = gm * rs * (g - s1 * inv_rows - xh * (s2 * inv_rows));
+}
+
+// Backward of the decoder head's fold + tanh (mage_convt_fold_tanh): ds = g * (1 - y^2) per output pixel (NCHW), scattered back to
+// the per-input-pixel tap products:  dtaps[(n, iy, ix), (ky*4 + kx)*cout + co] = ds[n, co, 2 iy - 1 + ky, 2 ix - 1 + kx]  (0 outside)
+__global__ __launch_bounds__(256) void convt_unfold_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ dtaps,
+                                                           int N, int IH, int IW, int cout) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int ld = 16 * cout;
+    if (gid >= (long)N * IH * IW * ld) return;
+    const int col = (int)(gid % ld), co = col % cout, tap = col / cout, ky = tap >> 2, kx = tap & 3;
+    const long pix = gid / ld;
+    const int ix = (int)(pix % IW), iy = (int)((pix / IW) % IH), n = (int)(pix / ((long)IW * IH));
+    const int oy = 2 * iy - 1 + ky, ox = 2 * ix - 1 + kx, OH = 2 * IH, OW = 2 * IW;
+    float v = 0.f;
+    if ((unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW) {
+        const long o = (((long)n * cout + co) * OH + oy) * OW + ox;
+        v = y ? g[o] * (1.f - y[o] * y[o]) : g[o];
+    }
+    dtaps[gid] = v;
+}
+
 template <typename T>
 int transpose_launch(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t y_row0, int64_t M, int64_t Mp, int32_t C, int32_t out_h,
-                     int32_t out_w, int32_t in_h, int32_t in_w, int64_t img_stride, int64_t a_off, int32_t dy, int32_t dx, hipStream_t s) {
+                     int32_t out_w, int32_t in_h, int32_t in_w, int64_t img_stride, int64_t a_off, int32_t dy, int32_t dx, int32_t stride,
+                     hipStream_t s) {
     const dim3 grid((unsigned)((Mp + 63) / 64), (unsigned)((C + 63) / 64));
     hipLaunchKernelGGL((transpose_kernel<T>), grid, dim3(256), 0, s, (const T*)x, (long)ldx, (T*)y, (long)ldy, (long)y_row0, (long)M,
-                       (long)Mp, C, out_h, out_w, in_h, in_w, (long)img_stride, (long)a_off, dy, dx);
+                       (long)Mp, C, out_h, out_w, in_h, in_w, (long)img_stride, (long)a_off, dy, dx, stride);
     MAGE_CHECK_LAUNCH("mage_transpose");
     return MAGE_OK;
 }
@@ -469,6 +563,9 @@ int act_launch(const void* x, const void* dy, void* y, int64_t n, int32_t act, h
         case MAGE_ACT_RELU: hipLaunchKernelGGL((act_kernel<T, MAGE_ACT_RELU, BWD>), grid, blk, 0, s, (const T*)x, (const T*)dy, (T*)y, (long)n); break;
         case MAGE_ACT_QUICKGELU: hipLaunchKernelGGL((act_kernel<T, MAGE_ACT_QUICKGELU, BWD>), grid, blk, 0, s, (const T*)x, (const T*)dy, (T*)y, (long)n); break;
         case MAGE_ACT_GELU_ERF: hipLaunchKernelGGL((act_kernel<T, MAGE_ACT_GELU_ERF, BWD>), grid, blk, 0, s, (const T*)x, (const T*)dy, (T*)y, (long)n); break;
+        case MAGE_ACT_TANH:
+            if (BWD) { hipLaunchKernelGGL((act_kernel<T, MAGE_ACT_TANH, BWD>), grid, blk, 0, s, (const T*)x, (const T*)dy, (T*)y, (long)n); break; }
+            [[fallthrough]];
         default: mage_set_error("mage_act: activation %d unsupported", act); return MAGE_EINVAL;
     }
     MAGE_CHECK_LAUNCH("mage_act");
@@ -487,13 +584,63 @@ int act_launch(const void* x, const void* dy, void* y, int64_t n, int32_t act, h
 
 extern "C" int mage_transpose(const void* x, int32_t dtype, int64_t ldx, void* y, int64_t ldy, int64_t y_row0, int64_t M, int64_t Mp,
                               int32_t C, int32_t out_h, int32_t out_w, int32_t in_h, int32_t in_w, int64_t img_stride, int64_t a_off,
-                              int32_t dy, int32_t dx, void* stream) {
-    MAGE_CHECK_ARG(x && y && M > 0 && Mp >= M && C > 0 && out_h >= 1 && out_w >= 1 && in_h >= 1 && in_w >= 1 && ldy >= Mp,
+                              int32_t dy, int32_t dx, int32_t stride, void* stream) {
+    MAGE_CHECK_ARG(x && y && M > 0 && Mp >= M && C > 0 && out_h >= 1 && out_w >= 1 && in_h >= 1 && in_w >= 1 && ldy >= Mp && stride >= 1,
                    "mage_transpose: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    DT_DISPATCH(dtype, (transpose_launch<float>(x, ldx, y, ldy, y_row0, M, Mp, C, out_h, out_w, in_h, in_w, img_stride, a_off, dy, dx, s)),
-                (transpose_launch<unsigned short>(x, ldx, y, ldy, y_row0, M, Mp, C, out_h, out_w, in_h, in_w, img_stride, a_off, dy, dx, s)),
+    DT_DISPATCH(dtype, (transpose_launch<float>(x, ldx, y, ldy, y_row0, M, Mp, C, out_h, out_w, in_h, in_w, img_stride, a_off, dy, dx, stride, s)),
+                (transpose_launch<unsigned short>(x, ldx, y, ldy, y_row0, M, Mp, C, out_h, out_w, in_h, in_w, img_stride, a_off, dy, dx, stride, s)),
                 "mage_transpose");
+}
+
+
+extern "C" int mage_bn_colreduce(int32_t mode, const float* x, const float* dy, const float* mask, const float* mean, const float* rstd,
+                                 int64_t rows, int32_t C, float* partials, int32_t n_part, void* stream) {
+    MAGE_CHECK_ARG(x && partials && rows > 0 && C > 0 && n_part >= 1 && mode >= 0 && mode <= 2, "mage_bn_colreduce: bad arguments");
+    MAGE_CHECK_ARG(mode == 0 || mean, "mage_bn_colreduce: mean missing");
+    MAGE_CHECK_ARG(mode != 2 || (dy && rstd), "mage_bn_colreduce: dy / rstd missing");
+    const long rpb = (rows + n_part - 1) / n_part;
+    const dim3 grid(n_part, (C + 255) / 256), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL((bn_colreduce_kernel<0>), grid, blk, 0, s, x, dy, mask, mean, rstd, (long)rows, C, rpb, partials);
+    else if (mode == 1) hipLaunchKernelGGL((bn_colreduce_kernel<1>), grid, blk, 0, s, x, dy, mask, mean, rstd, (long)rows, C, rpb, partials);
+    else hipLaunchKernelGGL((bn_colreduce_kernel<2>), grid, blk, 0, s, x, dy, mask, mean, rstd, (long)rows, C, rpb, partials);
+    MAGE_CHECK_LAUNCH("mage_bn_colreduce");
+    return MAGE_OK;
+}
+
+extern "C" int mage_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                             const float* residual, void* y, int32_t y_dtype, int64_t rows, int32_t C, int32_t relu, void* stream) {
+    MAGE_CHECK_ARG(x && mean && rstd && gamma && beta && y && rows > 0 && C > 0 && C % 4 == 0, "mage_bn_apply: bad arguments");
+    const long n = (long)rows * C;
+    const dim3 grid((unsigned)((n / 4 + 255) / 256)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (y_dtype == MAGE_F32) hipLaunchKernelGGL((bn_apply_kernel<float>), grid, blk, 0, s, x, mean, rstd, gamma, beta, residual, (float*)y, n, C, relu);
+    else if (y_dtype == MAGE_BF16)
+        hipLaunchKernelGGL((bn_apply_kernel<unsigned short>), grid, blk, 0, s, x, mean, rstd, gamma, beta, residual, (unsigned short*)y, n, C, relu);
+    else { mage_set_error("mage_bn_apply: bad y_dtype %d", y_dtype); return MAGE_EINVAL; }
+    MAGE_CHECK_LAUNCH("mage_bn_apply");
+    return MAGE_OK;
+}
+
+extern "C" int mage_bn_bwd_apply(const float* x, const float* dy, const float* mask, const float* mean, const float* rstd, const float* gamma,
+                                 const float* sums, float* dx, int64_t rows, int32_t C, void* stream) {
+    MAGE_CHECK_ARG(x && dy && mean && rstd && gamma && sums && dx && rows > 0 && C > 0 && C % 4 == 0, "mage_bn_bwd_apply: bad arguments");
+    const long n = (long)rows * C;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, mask, mean, rstd,
+                       gamma, sums, 1.0f / (float)rows, dx, n, C);
+    MAGE_CHECK_LAUNCH("mage_bn_bwd_apply");
+    return MAGE_OK;
+}
+
+extern "C" int mage_convt_unfold_tanh_bwd(const float* grad_y, const float* y, float* dtaps, int32_t N, int32_t IH, int32_t IW, int32_t cout,
+                                          void* stream) {
+    MAGE_CHECK_ARG(grad_y && dtaps && N > 0 && IH > 0 && IW > 0 && cout >= 1 && cout <= 4, "mage_convt_unfold_tanh_bwd: bad arguments");
+    const long total = (long)N * IH * IW * 16 * cout;
+    hipLaunchKernelGGL(convt_unfold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad_y, y, dtaps, N, IH,
+                       IW, cout);
+    MAGE_CHECK_LAUNCH("mage_convt_unfold_tanh_bwd");
+    return MAGE_OK;
 }
 
 extern "C" int mage_row_sum(const void* x, int32_t dtype, int64_t ld, int64_t n, int32_t rows, float* out, void* stream) {

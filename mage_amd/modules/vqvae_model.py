@@ -8,8 +8,9 @@ ignore_keys=[])``, ``.encode(x) -> int64 [N,h,w]``, ``.decode(latents) -> f32 [N
 key names; the arithmetic is libmage_hip.so (channels-last activations, BatchNorm(eval) + bias +
 ReLU + residual fused into the implicit-GEMM epilogues, ConvTranspose as 4 sub-pixel GEMMs).
 
-Inference only (this is how MAGE uses it: frozen + eval, mage_model.py:516-521).  Training-mode
-BatchNorm and the straight-through backward (vqvae_model.py:34-65) are not built yet and raise.
+encode / decode are the inference entry points (this is how MAGE uses the model: frozen + eval, mage_model.py:516-521).
+``forward`` in training mode (stage-1 training, train_vqvae.py:13-35: BatchNorm on batch statistics, the straight-through
+quantiser vqvae_model.py:34-65, ``loss.backward()``) runs modules/vqvae_train.py on the same kernels (f4 stack).
 """
 from __future__ import annotations
 
@@ -245,13 +246,16 @@ class VectorQuantizedVAE(nn.Module):
     def _weights(self) -> Dict[str, torch.Tensor]:
         return self._derived.get(self._build)
 
+    def _bn_training(self) -> bool:
+        return any(isinstance(m, nn.BatchNorm2d) and m.training for m in self.modules())
+
     def _check_input(self, x: torch.Tensor) -> None:
         if not x.is_cuda:
             raise RuntimeError("VectorQuantizedVAE runs on libmage_hip.so kernels: move the model and inputs to a ROCm GPU "
                                "(there is no CPU fallback)")
-        if any(isinstance(m, nn.BatchNorm2d) and m.training for m in self.modules()):
-            raise NotImplementedError("training-mode BatchNorm (batch statistics) is not built yet; call .eval() "
-                                      "(MAGE freezes the first stage: mage_model.py:516-521)")
+        if self._bn_training():
+            raise NotImplementedError("encode() / decode() use the folded eval-mode BatchNorm; in training mode call forward() (batch "
+                                      "statistics, modules/vqvae_train.py) or .eval() first (MAGE freezes the first stage: mage_model.py:516-521)")
 
     # ------------------------------------------------------------------ kernels: conv helpers
     @staticmethod
@@ -400,10 +404,27 @@ class VectorQuantizedVAE(nn.Module):
         ops.conv_out(x, w["d8.wt"], w["d8.b"], out, N=N, IH=H, IW=W, cin=dim, cout=self.input_dim, transposed=False)
 
     # ------------------------------------------------------------------ forward (values only)
-    @torch.no_grad()
     def forward(self, x: torch.Tensor):
-        """vqvae_model.py:244-248 values: (x_tilde, z_e_x, z_q_x), NCHW.  No autograd graph: the straight-through
-        backward is a 'next' row."""
+        """vqvae_model.py:244-248: (x_tilde, z_e_x, z_q_x), NCHW.  eval(): values from the inference kernels.  train(): BatchNorm on
+        batch statistics; in grad mode the three outputs hang off one autograd node (vqvae_train.VQVAEForwardFn) whose backward is
+        the straight-through estimator + every convolution / BatchNorm gradient on the HIP kernels (train_vqvae.py:13-35)."""
+        if self._bn_training():
+            from . import vqvae_train
+            if not x.is_cuda:
+                raise RuntimeError("VectorQuantizedVAE runs on libmage_hip.so kernels: move the model and inputs to a ROCm GPU")
+            with torch.cuda.device(x.device):
+                if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                    names = [n for n, p in self.named_parameters() if p.requires_grad]
+                    byname = dict(self.named_parameters())
+                    return vqvae_train.VQVAEForwardFn.apply(self, x, names, *[byname[n] for n in names])
+                with torch.no_grad():
+                    x_tilde, z_e, zq, t = vqvae_train.vq_train_forward(self, x)
+                N, hh, ww, D = t["N"], t["h"], t["wd"], self.dim
+                return x_tilde, z_e.view(N, hh, ww, D).permute(0, 3, 1, 2), zq.view(N, hh, ww, D).permute(0, 3, 1, 2)
+        with torch.no_grad():
+            return self._forward_eval(x)
+
+    def _forward_eval(self, x: torch.Tensor):
         z = self._encode_features(x)
         w = self._weights()
         N = x.shape[0]

@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc
 
 __all__ = ["gemm", "layernorm", "attention", "embedding", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
-           "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mse", "check_device_errors", "graph_events_supported", "transpose", "row_sum", "sum_partials", "layernorm_bwd", "act", "act_bwd", "cross_entropy_bwd", "embedding_bwd", "group_rowsum", "attention_bwd", "dropout", "adam", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
+           "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mse", "check_device_errors", "graph_events_supported", "transpose", "row_sum", "sum_partials", "layernorm_bwd", "act", "act_bwd", "cross_entropy_bwd", "embedding_bwd", "group_rowsum", "attention_bwd", "dropout", "adam", "bn_train_stats", "bn_apply", "bn_backward", "convt_unfold_tanh_bwd", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
            "PROFILE", "F32", "BF16", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
 
 
@@ -434,7 +434,7 @@ def mse(a, b, *, rows, cols, lda, ldb):
 # ----------------------------------------------------------------------------------------------------------------- training path
 def transpose(x, y, *, M: int, Mp: int, C: int, ldx: int, ldy: int, y_row0: int = 0, out_h: int = 1, out_w: Optional[int] = None,
               in_h: Optional[int] = None, in_w: Optional[int] = None, img_stride: Optional[int] = None, a_off: int = 0, dy: int = 0,
-              dx: int = 0):
+              dx: int = 0, stride: int = 1):
     """y[(c + y_row0), m] = x[arow(m), c] (zero for M <= m < Mp and outside the plane); see mage_transpose in mage_hip.h."""
     l, s = _dev(x)
     assert x.dtype == y.dtype
@@ -443,7 +443,7 @@ def transpose(x, y, *, M: int, Mp: int, C: int, ldx: int, ldy: int, y_row0: int 
     in_w = out_w if in_w is None else in_w
     img_stride = in_h * in_w if img_stride is None else img_stride
     _lib.check(l.mage_transpose(x.data_ptr(), code(x), ldx, y.data_ptr(), ldy, y_row0, M, Mp, C, out_h, out_w, in_h, in_w, img_stride,
-                                a_off, dy, dx, s), l)
+                                a_off, dy, dx, stride, s), l)
     return y
 
 
@@ -546,3 +546,50 @@ def adam(p, g, m, v, *, lr: float, beta1: float, beta2: float, eps: float, step:
     _lib.check(l.mage_adam(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(beta1), float(beta2),
                            float(eps), int(step), float(grad_scale), s), l)
     return p
+
+
+def _bn_reduce(mode, x, dy, mask, mean, rstd, nout):
+    l, s = _dev(x)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    n_part = int(min(1024, max(1, rows // 64)))
+    part = torch.empty(n_part, nout, Cc, device=x.device, dtype=torch.float32)
+    _lib.check(l.mage_bn_colreduce(mode, x.data_ptr(), _p(dy), _p(mask), _p(mean), _p(rstd), rows, Cc, part.data_ptr(), n_part, s), l)
+    out = torch.empty(nout, Cc, device=x.device, dtype=torch.float32)
+    return sum_partials(part, out, stride=nout * Cc, n_part=n_part, n=nout * Cc), rows
+
+
+def bn_train_stats(x, eps: float):
+    """Batch statistics of channels-last rows x [rows, C] fp32 (two passes): (mean [C], biased var [C], rstd [C])."""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    s, rows = _bn_reduce(0, x, None, None, None, None, 1)
+    mean = (s[0] / rows).contiguous()
+    q, _ = _bn_reduce(1, x, None, None, mean, None, 1)
+    var = (q[0] / rows).contiguous()
+    return mean, var, torch.rsqrt(var + eps).contiguous()        # [C]-sized vector bookkeeping
+
+
+def bn_apply(x, mean, rstd, gamma, beta, y, relu: bool, residual=None):
+    l, s = _dev(x)
+    Cc = x.shape[-1]
+    _lib.check(l.mage_bn_apply(x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), y.data_ptr(),
+                               code(y), x.numel() // Cc, Cc, int(relu), s), l)
+    return y
+
+
+def bn_backward(x, dy, mean, rstd, gamma, dx, mask=None):
+    """dx (into `dx`), dgamma, dbeta of training-mode BatchNorm; mask = the post-ReLU output when a ReLU follows the norm."""
+    l, s = _dev(x)
+    assert x.dtype == torch.float32 and dy.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous()
+    Cc = x.shape[-1]
+    sums, rows = _bn_reduce(2, x, dy, mask, mean, rstd, 2)
+    _lib.check(l.mage_bn_bwd_apply(x.data_ptr(), dy.data_ptr(), _p(mask), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), sums.data_ptr(),
+                                   dx.data_ptr(), rows, Cc, s), l)
+    return sums[1], sums[0]                                       # dgamma = sum g xhat, dbeta = sum g
+
+
+def convt_unfold_tanh_bwd(grad_y, y, dtaps, *, N, IH, IW, cout):
+    l, s = _dev(grad_y)
+    assert grad_y.dtype == torch.float32 and grad_y.is_contiguous() and (y is None or (y.dtype == torch.float32 and y.is_contiguous()))
+    _lib.check(l.mage_convt_unfold_tanh_bwd(grad_y.data_ptr(), _p(y), dtaps.data_ptr(), N, IH, IW, cout, s), l)
+    return dtaps

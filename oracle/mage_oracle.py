@@ -445,3 +445,51 @@ def mage_forward_loss_latent(sd: SD, batch: Dict[str, torch.Tensor], frames_leng
     final = recon + beta * kl
     return final, {"prediction": recon.item(), "kl_loss": kl.item(), "beta": beta, "final_loss": final.item()}, pred
 
+
+
+# ----------------------------------------------------------------------------- stage-1 training (train_vqvae.py:13-35)
+def _bn_train(sd: SD, p: str, x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """nn.BatchNorm2d in training mode: batch statistics (the running buffers are not touched here)."""
+    return F.batch_norm(x, None, None, sd[p + ".weight"], sd[p + ".bias"], True, 0.1, eps)
+
+
+def _resblock_train(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """ResBlock.forward (vqvae_model.py:111-124) with training-mode BatchNorm; the leading ReLU is in place, so the skip carries
+    relu(x) too."""
+    r = F.relu(x)
+    y = F.conv2d(r, sd[p + ".block.1.weight"], sd[p + ".block.1.bias"], padding=1)
+    y = F.relu(_bn_train(sd, p + ".block.2", y))
+    y = F.conv2d(y, sd[p + ".block.4.weight"], sd[p + ".block.4.bias"])
+    return r + _bn_train(sd, p + ".block.5", y)
+
+
+def vqvae_train_forward(sd: SD, p: str, x: torch.Tensor):
+    """VectorQuantizedVAE.forward of the f4 model in TRAINING mode (vqvae_model.py:244-248 over :171-190, straight_through :98-108,
+    VectorQuantizationStraightThrough :34-65), differentiable w.r.t. the tensors of sd: returns (x_tilde, z_e_x, z_q_x) where the
+    decoder saw the straight-through quantisation (gradient of its input goes to z_e_x) and z_q_x = codebook[ids] carries the
+    codebook gradient."""
+    h = F.conv2d(x, sd[p + "encoder.0.weight"], sd[p + "encoder.0.bias"], stride=2, padding=1)
+    h = F.relu(_bn_train(sd, p + "encoder.1", h))
+    h = F.conv2d(h, sd[p + "encoder.3.weight"], sd[p + "encoder.3.bias"], stride=2, padding=1)
+    h = _resblock_train(sd, p + "encoder.4", h)
+    z_e = _resblock_train(sd, p + "encoder.5", h)
+    cb = sd[p + "codebook.embedding.weight"]
+    zr = z_e.permute(0, 2, 3, 1).contiguous()
+    with torch.no_grad():
+        ids = vq_nearest(zr, cb)
+    codes = cb[ids.reshape(-1)].view_as(zr)
+    z_q_st = (zr + (codes.detach() - zr).detach()).permute(0, 3, 1, 2)      # value = codes, gradient -> z_e (straight-through)
+    z_q = codes.permute(0, 3, 1, 2)
+    d = _resblock_train(sd, p + "decoder.0", z_q_st)
+    d = F.relu(_resblock_train(sd, p + "decoder.1", d))
+    d = F.conv_transpose2d(d, sd[p + "decoder.3.weight"], sd[p + "decoder.3.bias"], stride=2, padding=1)
+    d = F.relu(_bn_train(sd, p + "decoder.4", d))
+    x_tilde = torch.tanh(F.conv_transpose2d(d, sd[p + "decoder.6.weight"], sd[p + "decoder.6.bias"], stride=2, padding=1))
+    return x_tilde, z_e, z_q
+
+
+def vqvae_train_loss(sd: SD, p: str, x: torch.Tensor, beta: float = 2.0):
+    """The objective of train_vqvae.py:20-27 (reconstruction + vector-quantisation + beta * commitment)."""
+    x_tilde, z_e, z_q = vqvae_train_forward(sd, p, x)
+    rec, vql, com = F.mse_loss(x_tilde, x), F.mse_loss(z_q, z_e.detach()), F.mse_loss(z_e, z_q.detach())
+    return rec + vql + beta * com, (rec, vql, com), (x_tilde, z_e, z_q)

@@ -409,3 +409,76 @@ def test_ddp_wrapped_model_and_rccl_sharded_step():
         assert dist.get_backend() == "nccl"
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ stage-1 VQ-VAE training
+def test_batchnorm_training_kernels():
+    o = ops()
+    rows, Cc = 3000, 64
+    x = (rnd(rows, Cc, seed=50) * 2 + 1).requires_grad_()
+    g, b = (1 + 0.2 * rnd(Cc, seed=51)).requires_grad_(), rnd(Cc, seed=52).requires_grad_()
+    res = rnd(rows, Cc, seed=53)
+    xn = x.t().reshape(1, Cc, rows, 1)                                       # channels-last rows as an NCHW tensor for torch
+    y = F.relu(F.batch_norm(xn, None, None, g, b, True, 0.1, 1e-5)[0, :, :, 0].t() + res)
+    dy = rnd(rows, Cc, seed=54)
+    y.backward(dy)
+    mean, var, rstd = o.bn_train_stats(x.detach().to(DEV), 1e-5)
+    assert rel(mean, x.detach().mean(0)) < 1e-6 and rel(var, x.detach().var(0, unbiased=False)) < 1e-5
+    got = o.bn_apply(x.detach().to(DEV), mean, rstd, g.detach().to(DEV), b.detach().to(DEV), torch.empty(rows, Cc, device=DEV), True, residual=res.to(DEV))
+    assert rel(got, y) < 2e-6
+    dx = torch.empty(rows, Cc, device=DEV)
+    dg, db = o.bn_backward(x.detach().to(DEV), dy.to(DEV), mean, rstd, g.detach().to(DEV), dx, mask=got)
+    assert rel(dx, x.grad) < 2e-5 and rel(dg, g.grad) < 2e-5 and rel(db, b.grad) < 2e-5
+
+
+@pytest.mark.parametrize("tag", ["vqvae_f4_train_small", "vqvae_f4_train"])
+def test_vqvae_stage1_training_step_matches_the_reference(tag):
+    """train_vqvae.py:13-27 on the HIP path: model.train(); x_tilde, z_e_x, z_q_x = model(images); the three-term loss (computed by
+    the caller with torch, as the script does); loss.backward().  Loss terms, outputs, EVERY parameter gradient and the BatchNorm
+    running buffers against the reference's own step."""
+    from tests.helpers import golden, t
+    from tests.test_oracle_golden import check_vq_train_grads
+    g = golden(tag)
+    from tests.helpers import build_vqvae
+    m = build_vqvae(1, 4, int(g["dim"]), int(g["K"]), int(g["seed"]), DEV).train()
+    x = synth.synth_batch_mnist(int(g["n_img"]), 1, seed=int(g["seed"]))["images"][:, 0].contiguous().to(DEV)
+    x_tilde, z_e, z_q = m(x)
+    assert x_tilde.requires_grad and z_e.requires_grad and z_q.requires_grad
+    rec, vql, com = F.mse_loss(x_tilde, x), F.mse_loss(z_q, z_e.detach()), F.mse_loss(z_e, z_q.detach())
+    loss = rec + vql + float(g["beta"]) * com
+    assert abs(rec.item() - float(g["rec"])) < 1e-5 and abs(vql.item() - float(g["vq"])) < 1e-5 * max(1, float(g["vq"]))
+    assert abs(com.item() - float(g["commit"])) < 1e-5 * max(1, float(g["commit"])) and abs(loss.item() - float(g["loss"])) < 1e-4
+    torch.testing.assert_close(x_tilde.detach()[:, :, ::4, ::4].cpu(), t(g["x_tilde_sub"]), atol=1e-4, rtol=0)
+    loss.backward()
+    grads = {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters()}
+    worst = check_vq_train_grads(g, grads, GRAD_TOL)
+    print(f"{tag}: worst relative gradient error {worst:.2e}")
+    for n, b in m.named_buffers():
+        if n.endswith("running_mean") or n.endswith("running_var"):
+            torch.testing.assert_close(b.cpu(), t(g["buf." + n]), atol=2e-5, rtol=1e-4)
+        if n.endswith("num_batches_tracked"):
+            assert int(b) == 1
+    # the eval-mode entry points are untouched by the training pass (and refuse training-mode BatchNorm)
+    with pytest.raises(NotImplementedError):
+        m.encode(x)
+    m.eval()
+    assert m.encode(x).dtype == torch.int64
+
+
+def test_vqvae_stage1_training_loop_reduces_the_loss():
+    """A few steps of train_vqvae.py's loop (Adam lr 1e-4 as its default is too slow to show in 5 steps: 1e-3) with FlatAdam."""
+    from mage_amd.optim import FlatAdam
+    from tests.helpers import build_vqvae
+    m = build_vqvae(1, 4, 32, 64, 15, DEV).train()
+    opt = FlatAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    x = synth.synth_batch_mnist(8, 1, seed=15)["images"][:, 0].contiguous().to(DEV)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        x_tilde, z_e, z_q = m(x)
+        loss = F.mse_loss(x_tilde, x) + F.mse_loss(z_q, z_e.detach()) + 2.0 * F.mse_loss(z_e, z_q.detach())
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    print("stage-1 losses:", [round(l, 4) for l in losses])
+    assert losses[-1] < losses[0] and all(np.isfinite(losses))

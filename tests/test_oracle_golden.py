@@ -204,3 +204,52 @@ def test_mage_plus_transformer_block_variant():
     assert abs(parts["kl_loss"] - float(g["fwd_kl_loss"])) < 1e-4 * max(1.0, abs(float(g["fwd_kl_loss"])))
     assert abs(parts["beta"] - float(g["fwd_beta"])) < 1e-9
     assert abs(final.item() - float(g["fwd_final_loss"])) < 1e-5 * max(1.0, abs(float(g["fwd_final_loss"])))
+
+
+def _vq_train_sd(dim, K, seed):
+    from mage_amd.modules.vqvae_model import VectorQuantizedVAE
+    m = VectorQuantizedVAE(1, 4, dim, K)
+    synth.fill_state_dict(m, seed)
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def check_vq_train_grads(g, grads, tol):
+    """Every parameter gradient of the reference's training step: in full where the fixture holds it, else slices + checksums."""
+    worst = 0.0
+    names = g["param_names"].tolist()
+    gmax_all = max(float(g["gmax." + n]) for n in names)
+    for n in names:
+        got = grads[n].detach().float().cpu()
+        scale = float(g["gmax." + n])
+        if scale < 1e-4 * gmax_all:
+            # a bias in front of a training-mode BatchNorm has an analytically ZERO gradient (the norm removes the mean): the
+            # reference's own values there are rounding noise (1e-10 .. 1e-6); ours must be noise too
+            assert got.abs().max().item() < 1e-4 * gmax_all, n
+            continue
+        if ("g." + n) in g.files:
+            err = (got - t(g["g." + n])).abs().max().item() / scale
+        else:
+            want = t(g["gs." + n])
+            err = (got.flatten()[::max(1, got.numel() // 1024)][:1024] - want).abs().max().item() / scale
+            np.testing.assert_allclose(chk(got)[1:], g["gchk." + n][1:], rtol=max(tol * 20, 1e-4), atol=1e-5)
+        worst = max(worst, err)
+        assert err < tol, (n, err)
+    return worst
+
+
+@pytest.mark.parametrize("tag", ["vqvae_f4_train_small", "vqvae_f4_train"])
+def test_vqvae_stage1_training_step(tag):
+    """The oracle's training-mode VQ-VAE (BatchNorm on batch statistics, straight-through quantiser, in-place-ReLU ResBlocks) and
+    its autograd against the reference's own train_vqvae.py step: the three loss terms and every parameter gradient."""
+    g = golden(tag)
+    sd = {k: (v.requires_grad_() if v.is_floating_point() and "running" not in k else v) for k, v in _vq_train_sd(int(g["dim"]), int(g["K"]),
+                                                                                                                   int(g["seed"])).items()}
+    x = synth.synth_batch_mnist(int(g["n_img"]), 1, seed=int(g["seed"]))["images"][:, 0].contiguous()
+    loss, (rec, vql, com), (x_tilde, z_e, z_q) = O.vqvae_train_loss(sd, "", x, beta=float(g["beta"]))
+    assert abs(loss.item() - float(g["loss"])) < 1e-6 and abs(rec.item() - float(g["rec"])) < 1e-6
+    assert abs(vql.item() - float(g["vq"])) < 1e-6 * max(1, float(g["vq"])) and abs(com.item() - float(g["commit"])) < 1e-6 * max(1, float(g["commit"]))
+    assert torch.allclose(x_tilde[:, :, ::4, ::4], t(g["x_tilde_sub"]), atol=1e-5)
+    names = g["param_names"].tolist()
+    gs = torch.autograd.grad(loss, [sd[n] for n in names], allow_unused=True)
+    grads = {n: (gg if gg is not None else torch.zeros_like(sd[n])) for n, gg in zip(names, gs)}
+    assert check_vq_train_grads(g, grads, 2e-5) < 2e-5

@@ -202,6 +202,42 @@ def gen_mage_plus_block(ref_mage):
          fwd_kl_loss=np.float64(ld["val/kl_loss"]), fwd_beta=np.float64(ld["val/beta"]), fwd_pred_sub=cap["pred"][:, ::3].contiguous())
 
 
+
+def gen_vqvae_train(ref_vq):
+    """Stage-1 training step of the reference itself (train_vqvae.py:13-27): VectorQuantizedVAE in train() mode (BatchNorm on
+    batch statistics, straight-through quantiser), the three-term loss, loss.backward(): loss values, every parameter's gradient
+    (dim 32: in full; dim 256: checksums + slices) and the BatchNorm running buffers after the step."""
+    import torch.nn.functional as F
+    for tag, dim, K, n_img, seed, full in (("vqvae_f4_train_small", 32, 64, 4, 13, True), ("vqvae_f4_train", 256, 512, 2, 14, False)):
+        print(tag)
+        m = ref_vq.VectorQuantizedVAE(1, 4, dim, K)
+        synth.fill_state_dict(m, seed)
+        m.train()
+        x = synth.synth_batch_mnist(n_img, 1, seed=seed)["images"][:, 0].contiguous()
+        x_tilde, z_e, z_q = m(x.clone())
+        rec, vql, com = F.mse_loss(x_tilde, x), F.mse_loss(z_q, z_e.detach()), F.mse_loss(z_e, z_q.detach())
+        loss = rec + vql + 2.0 * com
+        loss.backward()
+        out = dict(seed=seed, dim=dim, K=K, n_img=n_img, beta=2.0, loss=np.float64(loss.item()), rec=np.float64(rec.item()),
+                   vq=np.float64(vql.item()), commit=np.float64(com.item()), x_tilde_chk=chk(x_tilde.detach()), z_e_chk=chk(z_e.detach()),
+                   z_q_chk=chk(z_q.detach()), x_tilde_sub=x_tilde.detach()[:, :, ::4, ::4].contiguous())
+        names = []
+        for n, p_ in m.named_parameters():
+            names.append(n)
+            g = p_.grad if p_.grad is not None else torch.zeros_like(p_)
+            out["gchk." + n] = chk(g)
+            out["gmax." + n] = np.float64(g.abs().max().item())
+            if full or g.numel() <= 4096:
+                out["g." + n] = g.clone()
+            else:
+                out["gs." + n] = g.flatten()[::max(1, g.numel() // 1024)][:1024].clone()
+        for n, b in m.named_buffers():
+            if n.endswith("running_mean") or n.endswith("running_var"):
+                out["buf." + n] = b.clone()
+        out["param_names"] = np.array(names)
+        save(tag, **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_mage, ref_vq = import_reference()
@@ -211,6 +247,10 @@ def main():
     if "--only-round2" in sys.argv:              # the fixtures added in round 2
         gen_cater_fullwidth(ref_mage)
         gen_mage_plus_block(ref_mage)
+        gen_vqvae_train(ref_vq)
+        return
+    if "--only-vqvae-train" in sys.argv:
+        gen_vqvae_train(ref_vq)
         return
 
     # ---- 1. VQ unit: exact ties, near ties, reference-init regime --------------------------
@@ -397,6 +437,7 @@ def main():
     gen_forward_random(ref_mage)
     gen_cater_fullwidth(ref_mage)
     gen_mage_plus_block(ref_mage)
+    gen_vqvae_train(ref_vq)
     # ---- 8. state_dict layout (keys, shapes, dtypes) of the reference modules: the drop-in boundary ----------------
     import json
     layout = {}
