@@ -418,8 +418,9 @@ def test_batchnorm_training_kernels():
     x = (rnd(rows, Cc, seed=50) * 2 + 1).requires_grad_()
     g, b = (1 + 0.2 * rnd(Cc, seed=51)).requires_grad_(), rnd(Cc, seed=52).requires_grad_()
     res = rnd(rows, Cc, seed=53)
-    xn = x.t().reshape(1, Cc, rows, 1)                                       # channels-last rows as an NCHW tensor for torch
-    y = F.relu(F.batch_norm(xn, None, None, g, b, True, 0.1, 1e-5)[0, :, :, 0].t() + res)
+    # training-mode BatchNorm over the rows, spelled out (autograd of plain tensor ops: F.batch_norm's CPU backward on a
+    # channel-fastest strided view of these rows was found unreliable while writing this test)
+    y = F.relu((x - x.mean(0)) / (x.var(0, unbiased=False) + 1e-5).sqrt() * g + b + res)
     dy = rnd(rows, Cc, seed=54)
     y.backward(dy)
     mean, var, rstd = o.bn_train_stats(x.detach().to(DEV), 1e-5)
