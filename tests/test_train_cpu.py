@@ -91,7 +91,7 @@ def _worker(rank, world, port, q):
     flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
-    q.put((rank, flat.clone(), bool(torch.equal(gathered[0], gathered[1]))))
+    q.put((rank, flat.tolist(), bool(torch.equal(gathered[0], gathered[1]))))    # plain lists: no shared-memory handles outlive the worker
     D.barrier()
     dist.destroy_process_group()
 
@@ -117,4 +117,4 @@ def test_sharded_step_over_two_ranks_equals_the_global_batch_step():
         (0.5 * (net(data[:4]).pow(2).mean() + net(data[4:]).pow(2).mean())).backward()
         ref.step()
     want = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
-    assert torch.allclose(res[0][1], want, atol=2e-6)
+    assert torch.allclose(torch.tensor(res[0][1]), want, atol=2e-6)
