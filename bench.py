@@ -45,6 +45,21 @@ def call_flops(B, L, d=512, K=512, hw=256):
     return (L - 1) * (f_step + f_conv) + B * DEC_FLOP_PER_FRAME + B * (L - 1) * DEC_FLOP_PER_FRAME, f_step
 
 
+def hbm_view(key, dom, B, L, d=512):
+    """The same launches against the HBM roof.  The dominant symbol of cfg2 (x + Linear(.) with the fp32 residual: out_proj K = d and
+    c_proj K = 4d, alternating) moves, per launch, A (bf16 [M, K]) + the residual in + the stream out (fp32 [M, d] each): 197 FLOP/B on
+    average, below the machine balance (2.5 PF / 8 TB/s = 312 FLOP/B): by the roofline model it is HBM-bound."""
+    if not key.startswith("gemm8_kernel<0, 1"):
+        return None
+    M = B * L * 256
+    bytes_per_launch = 0.5 * ((M * d * 2 + 2 * M * d * 4) + (M * 4 * d * 2 + 2 * M * d * 4))          # mean of out_proj and c_proj
+    us = dom["ms"] * 1e3 / dom["calls"]
+    gbs = bytes_per_launch / (us * 1e-6) / 1e9
+    return {"bound": "hbm", "algorithmic_bytes_per_launch": bytes_per_launch, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(gbs / PEAK_HBM_GBS, 4), "flop_per_byte": round(dom["flops"] / dom["calls"] / bytes_per_launch, 1),
+            "machine_balance_flop_per_byte": round(PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9), 1)}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +287,7 @@ def main():
                         "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": dom["calls"] // args.steps,
                         "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
                         "flops_per_launch": dom["flops"] / dom["calls"],
+                        "hbm_view": hbm_view(dom_key, dom, B, L),
                         "all_gemm_kernels": {"achieved": round(allf / (allms * 1e-3) / 1e12, 2), "frac": round(allf / (allms * 1e-3) / 1e12 / peak, 4),
                                              "ms_per_step": round(allms / all_div, 3),
                                              "measured_in": "timed region" if args.events == "all" else "last warm-up call"}}
