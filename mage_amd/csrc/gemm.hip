@@ -758,8 +758,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     const int w_off = (wc * 32 + l15) * 128;                                     // + n*2048 inside a W piece
     f32x4 acc[MT][4];
     int c_buf = 0;
+    [[maybe_unused]] int it = 0;                       // probe build: tile counter of this workgroup
 
-    for (; c_tile < chunk1; c_tile += nwg8) {
+    for (; c_tile < chunk1; c_tile += nwg8, ++it) {
         const int ts = SPLIT ? c_tile / g.tiles_per_split : 0, trem = SPLIT ? c_tile - ts * g.tiles_per_split : c_tile;
         const int tm = trem / g.ntiles_n, tn = trem - tm * g.ntiles_n;
         const long ysplit = SPLIT ? (long)ts * d.y_split_stride : 0;
@@ -862,7 +863,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             if (kt == nk - 1) __builtin_amdgcn_s_waitcnt(0x0F72);
             else __builtin_amdgcn_s_waitcnt(0x0F74);
             asm volatile("" ::: "memory");
+            if (kt == 0) MAGE_STAMP(it, 2);             // probe: the tile's first counted wait has completed
             mfma_quadrant(1, 0);
+            if (kt == 0) MAGE_STAMP(it, 3);             // probe: end of the tile's first slab
             c_buf ^= 1;
         }
         if (!wr) ring_barrier();                       // the leading half waits for the trailing half's last MFMA section
@@ -877,11 +880,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             continue;
         }
 #endif
+        MAGE_STAMP(it, 0);                             // probe: K loop done
         char* stg = smem + 2 * KBUF + wave * 4096;
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));               // keep the epilogue's lane-derived constants out of the K loop's registers
         if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
         else epilogue_lean<ACT, unsigned short, MT>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
+        MAGE_STAMP(it, 1);                             // probe: epilogue issued
     }
 }
 
