@@ -268,8 +268,9 @@ int mage_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t r
 int mage_transpose(const void* x, int32_t dtype, int64_t ldx, void* y, int64_t ldy, int64_t y_row0, int64_t M, int64_t Mp, int32_t C,
                    int32_t out_h, int32_t out_w, int32_t in_h, int32_t in_w, int64_t img_stride, int64_t a_off, int32_t dy, int32_t dx,
                    int32_t stride, void* stream);
-/* out[r] = sum_{c < n} x[r*ld + c] (fp32, fixed order): bias gradients db = column sums of dY, taken from the transposed dY. */
-int mage_row_sum(const void* x, int32_t dtype, int64_t ld, int64_t n, int32_t rows, float* out, void* stream);
+/* Row sums (fp32, fixed order): bias gradients db = column sums of dY, taken from the transposed dY.  The n columns are cut into
+ * n_chunk chunks: out[chunk*rows + r] = sum over chunk of x[r*ld + c]; n_chunk > 1 is finished by mage_sum_partials. */
+int mage_row_sum(const void* x, int32_t dtype, int64_t ld, int64_t n, int32_t rows, float* out, int32_t n_chunk, void* stream);
 /* out[i] = (accumulate ? out[i] : 0) + sum_{s < n_part} part[s*stride + i]: the split-K partial products, the LayerNorm
  * gamma/beta partials.  Fixed order: deterministic. */
 int mage_sum_partials(const float* part, int64_t stride, int32_t n_part, int64_t n, float* out, int32_t accumulate, void* stream);
@@ -292,9 +293,10 @@ int mage_embedding_bwd(const int64_t* ids, const void* dout, int32_t dout_dtype,
                        int64_t padding_idx, int64_t group, int64_t group_stride, int64_t off, void* stream);
 /* out[g, :] = sum over rows r with (r / div) % mod == g of w(r) x[r, :], w(r) = row_scale ? row_scale[r / row_scale_div] : 1.
  * Gradients of the broadcast row tables: T / H / W positional embeddings (mage_model.py:338,489-492), text positions, and (mod = 1,
- * row_scale = speed) the speed embedding (:666-668). */
+ * row_scale = speed) the speed embedding (:666-668).  The rows of a group are cut into n_chunk chunks, out[chunk][g][c] holds the
+ * partial sums (n_chunk > 1: finished by mage_sum_partials). */
 int mage_group_rowsum(const void* x, int32_t dtype, int64_t rows, int32_t C, int64_t div, int64_t mod, const float* row_scale,
-                      int64_t row_scale_div, float* out, void* stream);
+                      int64_t row_scale_div, float* out, int32_t n_chunk, void* stream);
 /* Backward of mage_attention: same descriptor (q, k, v as in the forward call; desc->out is unused), dout addressed like the
  * forward's out (ldo), gradients written with the addressing of q (dq, ld_dq) and of k / v (dk, dv, ld_dk, ld_dv) in desc->dtype.
  * P is recomputed in fp32; fixed-order sums (deterministic). */

@@ -45,17 +45,65 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x,
     }
 }
 
+
+// 16-byte variant for bf16 with C % 8 == 0: a thread loads 8 consecutive channels of one (gathered) row, the 64 x 64 tile sits in LDS
+// row-major (pitch 132 B: the column reads below touch distinct banks), then every thread assembles 8 consecutive m of one channel
+// and stores 16 bytes: both sides of the transposition move whole 128-byte segments (the 2-byte version ran at 1.1 TB/s).
+__global__ __launch_bounds__(256) void transpose8_kernel(const unsigned short* __restrict__ x, long ldx, unsigned short* __restrict__ y,
+                                                         long ldy, long y_row0, long M, long Mp, int C, int out_h, int out_w, int in_h,
+                                                         int in_w, long img_stride, long a_off, int dy, int dx, int stride) {
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64 * 66];
+    const long m0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const long plane = (long)out_h * out_w;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = threadIdx.x + 256 * k;          // 512 (row, 8-channel chunk) pairs
+        const int r = e >> 3, cc = (e & 7) * 8;
+        const long m = m0 + r;
+        uint4 v = uint4{0u, 0u, 0u, 0u};
+        if (m < M && c0 + cc < C) {
+            const long img = m / plane, rem = m - img * plane;
+            const int oy = (int)(rem / out_w), ox = (int)(rem - (long)oy * out_w);
+            const int iy = oy * stride + dy, ix = ox * stride + dx;
+            if ((unsigned)iy < (unsigned)in_h && (unsigned)ix < (unsigned)in_w)
+                v = *(const uint4*)(x + (img * img_stride + (long)iy * in_w + ix + a_off) * ldx + c0 + cc);
+        }
+        unsigned* t32 = (unsigned*)(tile + r * 66 + cc);      // 66-element pitch: 4-byte aligned
+        t32[0] = v.x; t32[1] = v.y; t32[2] = v.z; t32[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = threadIdx.x + 256 * k;          // 512 (channel, 8-row chunk) pairs
+        const int c = e >> 3, mm = (e & 7) * 8;
+        if (c0 + c < C && m0 + mm < Mp) {
+            unsigned short h[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = tile[(mm + j) * 66 + c];
+            uint4 o;
+            o.x = h[0] | ((unsigned)h[1] << 16); o.y = h[2] | ((unsigned)h[3] << 16);
+            o.z = h[4] | ((unsigned)h[5] << 16); o.w = h[6] | ((unsigned)h[7] << 16);
+            *(uint4*)(y + (y_row0 + c0 + c) * ldy + m0 + mm) = o;
+        }
+    }
+}
+
 // out[r] = sum_c x[r*ld + c], c < n (fp32 accumulation, fixed order): bias gradients from the transposed dY.
+// blockIdx.y = column chunk (a row of 10^5 columns on ONE wave was 0.76 ms per call: 19 % of a training step): partial sums
+// out[chunk][r] for mage_sum_partials.
 template <typename T>
 __global__ __launch_bounds__(256) void row_sum_kernel(const T* __restrict__ x, long ld, long n, int rows, float* __restrict__ out) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const int lane = threadIdx.x & 63;
+    const long per = ((n + gridDim.y - 1) / gridDim.y + 7) / 8 * 8;
+    const long c0 = (long)blockIdx.y * per, c1 = min(n, c0 + per);
     const T* p = x + (long)r * ld;
     float s = 0.f;
-    for (long c = lane; c < n; c += 64) s += to_f32<T>(p[c]);
+    for (long c = c0 + lane; c < c1; c += 64) s += to_f32<T>(p[c]);
     s = wave_sum(s);
-    if (lane == 0) out[r] = s;
+    if (lane == 0) out[(long)blockIdx.y * rows + r] = s;
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_s part[s*stride + i]
@@ -247,12 +295,15 @@ __global__ __launch_bounds__(256) void group_rowsum_kernel(const T* __restrict__
     if (c >= C) return;
     float s = 0.f;
     const long period = div * mod, nper = (rows + period - 1) / period;
-    for (long q = 0; q < nper; ++q)
-        for (long j = 0; j < div; ++j) {
-            const long r = q * period + g * div + j;
-            if (r < rows) s += (rs ? rs[r / rs_div] : 1.f) * to_f32<T>(x[r * C + c]);
-        }
-    out[g * C + c] = s;
+    // blockIdx.z = chunk of the (period, row-in-group) index space: partial sums out[chunk][g][c] for mage_sum_partials
+    const long total = nper * div, per = (total + gridDim.z - 1) / gridDim.z;
+    const long i0 = (long)blockIdx.z * per, i1 = min(total, i0 + per);
+    for (long i = i0; i < i1; ++i) {
+        const long q = i / div, j = i - q * div;
+        const long r = q * period + g * div + j;
+        if (r < rows) s += (rs ? rs[r / rs_div] : 1.f) * to_f32<T>(x[r * C + c]);
+    }
+    out[((long)blockIdx.z * mod + g) * C + c] = s;
 }
 
 // ------------------------------------------------------------------------------------------------ attention backward
@@ -536,6 +587,14 @@ int transpose_launch(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t y
                      int32_t out_w, int32_t in_h, int32_t in_w, int64_t img_stride, int64_t a_off, int32_t dy, int32_t dx, int32_t stride,
                      hipStream_t s) {
     const dim3 grid((unsigned)((Mp + 63) / 64), (unsigned)((C + 63) / 64));
+    if constexpr (sizeof(T) == 2) {
+        if (C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && Mp % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+            hipLaunchKernelGGL(transpose8_kernel, grid, dim3(256), 0, s, (const unsigned short*)x, (long)ldx, (unsigned short*)y, (long)ldy,
+                               (long)y_row0, (long)M, (long)Mp, C, out_h, out_w, in_h, in_w, (long)img_stride, (long)a_off, dy, dx, stride);
+            MAGE_CHECK_LAUNCH("mage_transpose");
+            return MAGE_OK;
+        }
+    }
     hipLaunchKernelGGL((transpose_kernel<T>), grid, dim3(256), 0, s, (const T*)x, (long)ldx, (T*)y, (long)ldy, (long)y_row0, (long)M,
                        (long)Mp, C, out_h, out_w, in_h, in_w, (long)img_stride, (long)a_off, dy, dx, stride);
     MAGE_CHECK_LAUNCH("mage_transpose");
@@ -643,9 +702,9 @@ extern "C" int mage_convt_unfold_tanh_bwd(const float* grad_y, const float* y, f
     return MAGE_OK;
 }
 
-extern "C" int mage_row_sum(const void* x, int32_t dtype, int64_t ld, int64_t n, int32_t rows, float* out, void* stream) {
-    MAGE_CHECK_ARG(x && out && rows > 0 && n > 0, "mage_row_sum: bad arguments");
-    const dim3 grid((rows + 3) / 4), blk(256);
+extern "C" int mage_row_sum(const void* x, int32_t dtype, int64_t ld, int64_t n, int32_t rows, float* out, int32_t n_chunk, void* stream) {
+    MAGE_CHECK_ARG(x && out && rows > 0 && n > 0 && n_chunk >= 1, "mage_row_sum: bad arguments");
+    const dim3 grid((rows + 3) / 4, n_chunk), blk(256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MAGE_F32) hipLaunchKernelGGL((row_sum_kernel<float>), grid, blk, 0, s, (const float*)x, (long)ld, (long)n, rows, out);
     else if (dtype == MAGE_BF16) hipLaunchKernelGGL((row_sum_kernel<unsigned short>), grid, blk, 0, s, (const unsigned short*)x, (long)ld, (long)n, rows, out);
@@ -715,9 +774,10 @@ extern "C" int mage_embedding_bwd(const int64_t* ids, const void* dout, int32_t 
 }
 
 extern "C" int mage_group_rowsum(const void* x, int32_t dtype, int64_t rows, int32_t C, int64_t div, int64_t mod, const float* row_scale,
-                                 int64_t row_scale_div, float* out, void* stream) {
-    MAGE_CHECK_ARG(x && out && rows > 0 && C > 0 && div >= 1 && mod >= 1 && (!row_scale || row_scale_div >= 1), "mage_group_rowsum: bad arguments");
-    const dim3 grid((unsigned)mod, (C + 255) / 256), blk(256);
+                                 int64_t row_scale_div, float* out, int32_t n_chunk, void* stream) {
+    MAGE_CHECK_ARG(x && out && rows > 0 && C > 0 && div >= 1 && mod >= 1 && n_chunk >= 1 && n_chunk <= 65535 && (!row_scale || row_scale_div >= 1),
+                   "mage_group_rowsum: bad arguments");
+    const dim3 grid((unsigned)mod, (C + 255) / 256, n_chunk), blk(256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MAGE_F32)
         hipLaunchKernelGGL((group_rowsum_kernel<float>), grid, blk, 0, s, (const float*)x, (long)rows, C, (long)div, (long)mod, row_scale,

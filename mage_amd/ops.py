@@ -449,8 +449,13 @@ def transpose(x, y, *, M: int, Mp: int, C: int, ldx: int, ldy: int, y_row0: int 
 
 def row_sum(x, out, *, ld: int, n: int, rows: int):
     l, s = _dev(x)
-    _lib.check(l.mage_row_sum(x.data_ptr(), code(x), ld, n, rows, out.data_ptr(), s), l)
-    return out
+    n_chunk = int(max(1, min(64, n // 2048, 16384 // max(rows, 1))))      # enough waves to fill the chip, >= 2048 columns each
+    if n_chunk == 1:
+        _lib.check(l.mage_row_sum(x.data_ptr(), code(x), ld, n, rows, out.data_ptr(), 1, s), l)
+        return out
+    part = torch.empty(n_chunk, rows, device=x.device, dtype=torch.float32)
+    _lib.check(l.mage_row_sum(x.data_ptr(), code(x), ld, n, rows, part.data_ptr(), n_chunk, s), l)
+    return sum_partials(part, out, stride=rows, n_part=n_chunk, n=rows)
 
 
 def sum_partials(part, out, *, stride: int, n_part: int, n: int, accumulate: bool = False):
@@ -512,8 +517,14 @@ def embedding_bwd(ids, dout, dtable, *, padding_idx: int = -1, group: Optional[i
 def group_rowsum(x, out, *, rows: int, C: int, div: int, mod: int, row_scale=None, row_scale_div: int = 1):
     l, s = _dev(x)
     assert out.dtype == torch.float32
-    _lib.check(l.mage_group_rowsum(x.data_ptr(), code(x), rows, C, div, mod, _p(row_scale), row_scale_div, out.data_ptr(), s), l)
-    return out
+    per_group = rows // max(mod, 1)
+    n_chunk = int(max(1, min(256, per_group // 64, 2048 // max(mod, 1))))
+    if n_chunk == 1:
+        _lib.check(l.mage_group_rowsum(x.data_ptr(), code(x), rows, C, div, mod, _p(row_scale), row_scale_div, out.data_ptr(), 1, s), l)
+        return out
+    part = torch.empty(n_chunk, mod, C, device=x.device, dtype=torch.float32)
+    _lib.check(l.mage_group_rowsum(x.data_ptr(), code(x), rows, C, div, mod, _p(row_scale), row_scale_div, part.data_ptr(), n_chunk, s), l)
+    return sum_partials(part, out, stride=mod * C, n_part=n_chunk, n=mod * C)
 
 
 def attention_bwd(q, k, v, dout, dq, dk, dv, *, ldq, ldk, ldv, ldo, ld_dq, ld_dk, ld_dv, n_seq, inner, nq, nk, n_head, q_outer_stride,
