@@ -914,10 +914,11 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     // per 64-wide slab of a 256x256 tile, measured) + the tile's HBM burst at the all-at-once rate (~10.6 B per clock per CU,
     // measured).  Only when every workgroup has enough tiles for the idle start to pay.  MAGE_GEMM_STAGGER="G,percent"
     // overrides (tuning), "0" disables.  Measured on the decoder's 4-GEMM block: 775 -> 800 TFLOP/s with 8 groups over 60 %.
-    static int st_groups = -1, st_percent = 60;
+    static int st_groups = -1, st_percent = 60, st_env = 0;
     if (st_groups < 0) {
         st_groups = 8;
         if (const char* e = getenv("MAGE_GEMM_STAGGER")) {
+            st_env = 1;
             if (sscanf(e, "%d,%d", &st_groups, &st_percent) < 2) st_percent = 60;
             if (st_groups < 0) st_groups = 0;
         }
@@ -925,7 +926,11 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     a.stagger_groups = 0;
     a.stagger_sleeps = 0;
     const int tiles_per_wg = a.ntiles / grid;
-    if (st_groups > 1 && a.ntiles >= n_cu && tiles_per_wg >= 6) {
+    // Only the residual kind by default: its tile ends in a 512 KB read + write burst per CU that the stagger spreads (out_proj
+    // 0.307 -> 0.276 ms, c_proj 0.567 -> 0.542 ms).  The bias kinds (QKV, c_fc) have no drain stall to hide (round-2 tile probe); an
+    // interleaved A/B with and without it is inside +-0.5 %, so they skip the idle start.  MAGE_GEMM_STAGGER applies to every kind.
+    const bool kind_wants = st_env || EK == EK_RES_INIT;
+    if (kind_wants && st_groups > 1 && a.ntiles >= n_cu && tiles_per_wg >= 6) {
         const int es = d->dtype == MAGE_BF16 ? 2 : 4;
         const long nk = ((long)d->K * es + 127) / 128;
         const long out_b = (long)Tile<MT>::BM * BN * (d->y_dtype == MAGE_BF16 ? 2 : 4);
