@@ -71,6 +71,12 @@ int mage_check_device_errors(void* stream);
  * v = act(v);  v += rowadd[((yrow / rowadd_div) % rowadd_mod), n];  v += residual[yrow, n];
  * v = relu(v) if post_relu;  store as y_dtype.  Null pointers skip a stage.  Y may alias residual.
  *
+ * Padded-taps form (bf16): when the input is ZERO-PADDED (in_h = out_h + taps_h - 1, in_w = out_w + taps_w - 1, stride 1, dy0 = dx0 = 0,
+ * cin % 64 == 0, M and N multiples of 256, packed output rows) every tap is a valid row and the convolution runs on the 8-phase
+ * ping-pong kernel with one scalar offset per K slab; epilogue y = act(acc + bias) (act none / ReLU) or y = rowadd[..] + acc
+ * (rowadd set, no bias / residual: the table is loaded into the accumulators before the K loop).  Anything else takes the generic
+ * gather kernel.
+ *
  * Requirements: lda and cin multiples of 8 (bf16) / 4 (f32); N multiple of 8; ldy/ldr multiples of 4 (fp32) / 8 (bf16);
  * A, W, Y 16-byte aligned; W is [N][K] row-major in `dtype`.
  * ------------------------------------------------------------------------------------------- */
@@ -146,14 +152,17 @@ typedef struct mage_attn_desc {
 
 int mage_attention(const mage_attn_desc* desc, void* stream);
 
-/* out[orow(i), :] = act(table[ids[i], :]),  orow(i) = (i / group)*group_stride + i % group + off.
+/* out[orow(i), :] = act(table[ids[i], :]),  orow(i) = (i / group)*group_stride + ((i % group) / inner)*inner_stride + (i % group) % inner + off
+ * (inner <= 0: one level, orow = (i / group)*group_stride + i % group + off).  Two levels write an image's h x w tokens into the
+ * interior of a zero-padded (h+2) x (w+2) frame buffer (group = h*w, group_stride = (h+2)(w+2), inner = w, inner_stride = w+2,
+ * off = w+3): the input layout of the padded-taps convolution of mage_gemm.
  * Replaces nn.Embedding lookups: visual_token_embedding (mage_model.py:581,644,682), the codebook
  * gather of VectorQuantizedVAE.decode (vqvae_model.py:240; relu=1 folds the in-place ReLU that
  * opens the first decoder ResBlock :113), text token embedding (:226).  An id outside [0, n_table) is read as the nearest valid
  * row AND recorded for mage_check_device_errors (the reference raises IndexError). */
 int mage_embedding(const int64_t* ids, const float* table, void* out, int32_t out_dtype, int64_t n,
                    int32_t C, int32_t n_table, int32_t relu, int64_t group, int64_t group_stride, int64_t off,
-                   void* stream);
+                   int64_t inner, int64_t inner_stride, void* stream);
 
 /* Nearest codebook entry, reference formula and tie-break (vqvae_model.py:8-25):
  *   dist[m,k] = (|c_k|^2 + |z_m|^2) - 2 * <z_m, c_k>,  idx[m] = first k attaining the minimum.

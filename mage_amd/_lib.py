@@ -57,7 +57,7 @@ SIGNATURES = {
     "mage_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "mage_layernorm": (C.c_int, [vp, vp, vp, vp, i32, i64, i32, f32, vp]),
     "mage_attention": (C.c_int, [C.POINTER(AttnDesc), vp]),
-    "mage_embedding": (C.c_int, [vp, vp, vp, i32, i64, i32, i32, i32, i64, i64, i64, vp]),
+    "mage_embedding": (C.c_int, [vp, vp, vp, i32, i64, i32, i32, i32, i64, i64, i64, i64, i64, vp]),
     "mage_vq_nearest": (C.c_int, [vp, vp, vp, i64, i32, i32, vp, vp, vp]),
     "mage_vq_prepare": (C.c_int, [vp, i32, i32, vp, vp, vp]),
     "mage_argmax": (C.c_int, [vp, i64, i32, i64, i64, i64, i64, vp, i64, i64, vp, vp]),

@@ -667,7 +667,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
 // The loader cursors run across tile boundaries (the next tile's slabs 0 and 1 stream in under this tile's last phases and
 // its epilogue).  At a tile's end the leading half gives the trailing half one barrier (both then run the epilogue in
 // step), and the trailing half drops back by one barrier before the next tile's first phase.
-template <int ACT, int EK, bool SPLIT = false>
+// TAPS: implicit-GEMM convolution over a ZERO-PADDED input (in_h = out_h + taps_h - 1, in_w = out_w + taps_w - 1, stride 1): every tap
+// of every output pixel is a valid row, so the gather is the plain loader plus ONE scalar offset per K slab -- slab kt lies in tap
+// kt / (cin/64), whose rows sit (ky*in_w + kx) rows further -- kept as three scalar cursors per A piece (no vector instruction in a
+// load section, which is what this kernel's schedule depends on).  The lockstep kernel's generic gather decodes the tap per lane
+// and per slab and re-tests the bounds (frame conv3x3: 773 TFLOP/s, 6.7x its algorithmic bytes fetched: round-1 PMC).
+template <int ACT, int EK, bool SPLIT = false, bool TAPS = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     constexpr int MT = 8, BM = 256;
     constexpr int PIECE = 16384, KBUF = 4 * PIECE;
@@ -721,14 +726,36 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             }
         }
     };
+    // TAPS cursors of the two A piece types: slab inside the tap, kx, and the tap's byte offset ((ky*in_w + kx) rows)
+    int tap_ci[2] = {0, 0}, tap_kx[2] = {0, 0};
+    long tap_off[2] = {0, 0};
+    const int spt = TAPS ? d.cin >> 6 : 1;             // 64-wide slabs per tap
     auto issue = [&](int P) {
         char* dst = smem + cur_buf[P] * KBUF + P * PIECE + (2 * wave) * 1024;
-        const char* sbase = (const char*)((P == P_A0 || P == P_A1) ? d.A : d.W) + cur_kt[P] * 128;
+        const bool isA = P == P_A0 || P == P_A1;
+        const char* sbase;
+        if (TAPS && isA) sbase = (const char*)d.A + tap_off[P] + tap_ci[P] * 128;       // P_A0 = 0, P_A1 = 1 index the cursors
+        else sbase = (const char*)(isA ? d.A : d.W) + cur_kt[P] * 128;
 #pragma unroll
         for (int i = 0; i < 2; ++i) glds16(sbase + voff[P][i], dst + i * 1024);
         cur_buf[P] ^= 1;
+        if (TAPS && isA) {
+            if (++tap_ci[P] == spt) {
+                tap_ci[P] = 0;
+                tap_off[P] += (long)d.lda * 2;
+                if (++tap_kx[P] == d.taps_w) {
+                    tap_kx[P] = 0;
+                    tap_off[P] += (long)(d.in_w - d.taps_w) * d.lda * 2;
+                }
+            }
+        }
         if (++cur_kt[P] == nk) {
             cur_kt[P] = 0;
+            if (TAPS && isA) {
+                tap_ci[P] = 0;
+                tap_kx[P] = 0;
+                tap_off[P] = 0;
+            }
             cur_tile[P] += nwg8;
             set_rows(P);
         }
@@ -766,10 +793,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
         const long ysplit = SPLIT ? (long)ts * d.y_split_stride : 0;
         const int m0 = tm * BM + wr * 128, n0 = tn * BN + wc * 64;
         if constexpr (EK == EK_RES_INIT) {
+            // y = r + (A W^T + b): the accumulators start from r.  r is the fp32 residual stream, or (rowadd set, residual null) a
+            // broadcast row table: r[m] = rowadd[(yrow / div) % mod] -- the H/W positional table of the frame convolution
+            // (the table form exists in the TAPS instantiation only: the Linear layers' kernel keeps its exact code)
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int m = min(m0 + a * 16 + l15, d.M - 1);
-                const float* rp = (const float*)d.residual + (long)(m * d.y_mul_x + d.y_off) * d.ldr;
+                const float* rp;
+                if constexpr (TAPS) rp = d.rowadd + (long)(((m * d.y_mul_x + d.y_off) / d.rowadd_div) % d.rowadd_mod) * d.N;
+                else rp = (const float*)d.residual + (long)(m * d.y_mul_x + d.y_off) * d.ldr;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int n = n0 + b * 16 + grp * 4;
@@ -961,6 +993,61 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     return MAGE_OK;
 }
 
+
+// Padded-taps convolutions on the 8-phase kernel (gemm8_kernel TAPS): eligible shapes only; returns 1 if launched, 0 if not
+// eligible (the caller falls through to the generic gather kernel), < 0 on error.
+template <int ACT, int EK>
+int launch_taps8(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
+    const int dev = mage_device_index();
+    MAGE_CHECK_ARG(dev >= 0, "mage_gemm: no current device");
+    static bool attr[MAGE_MAX_DEVICES] = {false};
+    if (!attr[dev]) {
+        (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr[dev] = true;
+    }
+    GemmArgs a;
+    a.d = *d;
+    a.zero = (const char*)mage_zero_page();
+    const int tiles_m = (d->M + 255) / 256;
+    a.ntiles_n = (d->N + BN - 1) / BN;
+    a.tiles_per_split = tiles_m * a.ntiles_n;
+    a.ntiles = a.tiles_per_split;
+    a.stagger_groups = 0;
+    a.stagger_sleeps = 0;
+    const int grid = a.ntiles >= n_cu ? n_cu : ((a.ntiles + 7) & ~7);
+    hipLaunchKernelGGL((gemm8_kernel<ACT, EK, false, true>), dim3(grid), dim3(512), 160 * 1024, s, a);
+    MAGE_CHECK_LAUNCH("mage_gemm");
+    return 1;
+}
+
+int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
+    static int use8 = -1;
+    if (use8 < 0) use8 = (getenv("MAGE_GEMM_NO_8PHASE") || getenv("MAGE_GEMM_NO_TAPS8")) ? 0 : 1;
+    if (!use8 || d->dtype != MAGE_BF16 || d->n_split != 1) return 0;
+    if (d->taps_h * d->taps_w <= 1 || d->stride != 1 || d->dys != 1 || d->dxs != 1 || d->dy0 != 0 || d->dx0 != 0) return 0;
+    if (d->in_h != d->out_h + d->taps_h - 1 || d->in_w != d->out_w + d->taps_w - 1) return 0;          // zero-padded input only
+    if (d->cin % 64 != 0 || d->K % 64 != 0 || d->scale || d->post_relu) return 0;
+    if (d->y_mul_x != 1 || d->y_mul_y != d->out_w || d->y_img_stride != d->out_h * d->out_w) return 0;   // packed output rows
+    int dev = mage_device_index();
+    if (dev < 0) return 0;
+    hipDeviceProp_t p;
+    static int n_cu_dev[MAGE_MAX_DEVICES] = {0};
+    if (!n_cu_dev[dev]) n_cu_dev[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= 8) ? (p.multiProcessorCount & ~7) : 256;
+    const int n_cu = n_cu_dev[dev];
+    // any tile count (also the 64-image conv of the incremental AR mode: both modes must run the SAME arithmetic, their tokens
+    // are compared bitwise), but only the widths the 8-phase kernel is exercised at
+    if (d->N % 256 != 0 || d->M % 256 != 0) return 0;
+    const long n_img = (d->M + (long)d->out_h * d->out_w - 1) / ((long)d->out_h * d->out_w);
+    const long a_span = (n_img * d->a_img_stride + d->a_off + (long)d->in_h * d->in_w) * d->lda;
+    if (a_span * 2 >= (1L << 32) || (long)d->N * d->K * 2 >= (1L << 32)) return 0;
+    const bool table = d->rowadd && !d->residual && !d->bias;                                             // y = table[row] + conv
+    const bool plain = !d->rowadd && !d->residual;
+    if (table && d->act == MAGE_ACT_NONE && (((uintptr_t)d->rowadd) & 15) == 0) return launch_taps8<MAGE_ACT_NONE, EK_RES_INIT>(d, s, n_cu);
+    if (plain && d->act == MAGE_ACT_NONE) return launch_taps8<MAGE_ACT_NONE, EK_BIAS>(d, s, n_cu);
+    if (plain && d->act == MAGE_ACT_RELU) return launch_taps8<MAGE_ACT_RELU, EK_BIAS>(d, s, n_cu);
+    return 0;
+}
+
 template <int DT, bool GATHER, int ACT, int EK>
 int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
     static int n_cu_dev[MAGE_MAX_DEVICES] = {0};
@@ -1070,6 +1157,7 @@ extern "C" int mage_gemm(const mage_gemm_desc* d_in, void* stream) {
     MAGE_CHECK_ARG(d->n_split == 1 || ((d->a_split_stride | d->w_split_stride) % ch == 0 && d->y_split_stride % 4 == 0 && d->ldw % ch == 0),
                    "mage_gemm: split strides / ldw must keep 16-byte alignment");
     hipStream_t s = (hipStream_t)stream;
+    if (const int r = try_taps8(d, s)) return r < 0 ? r : MAGE_OK;
     const bool gather = d->taps_h * d->taps_w > 1 || d->stride != 1 || d->dy0 != 0 || d->dx0 != 0 || d->in_h != d->out_h ||
                         d->in_w != d->out_w;
     if (d->dtype == MAGE_BF16) return gather ? launch<MAGE_BF16, true>(d, s) : launch<MAGE_BF16, false>(d, s);

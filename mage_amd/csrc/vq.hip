@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict
 template <typename OT>
 __global__ __launch_bounds__(256) void embedding_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
                                                         OT* __restrict__ out, long n, int C, int n_table, int relu,
-                                                        long group, long group_stride, long off, int* __restrict__ err) {
+                                                        long group, long group_stride, long off, long inner, long inner_stride,
+                                                        int* __restrict__ err) {
     const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const int lane = threadIdx.x & 63;
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(256) void embedding_kernel(const int64_t* __restric
         if (lane == 0) mage_raise(err, MAGE_DEVERR_EMBEDDING_ID, id, n_table);
         id = id < 0 ? 0 : n_table - 1;      // stay memory-safe meanwhile
     }
-    const long orow = (i / group) * group_stride + (i % group) + off;
+    const long ig = i % group;
+    const long orow = (i / group) * group_stride + (ig / inner) * inner_stride + (ig % inner) + off;
     const float* src = table + id * C;
     OT* dst = out + orow * C;
     for (int c = lane * 4; c < C; c += 256) {
@@ -226,19 +228,24 @@ extern "C" int mage_vq_nearest(const float* z, const float* codebook_t, const fl
 }
 
 extern "C" int mage_embedding(const int64_t* ids, const float* table, void* out, int32_t out_dtype, int64_t n, int32_t C,
-                              int32_t n_table, int32_t relu, int64_t group, int64_t group_stride, int64_t off, void* stream) {
+                              int32_t n_table, int32_t relu, int64_t group, int64_t group_stride, int64_t off, int64_t inner,
+                              int64_t inner_stride, void* stream) {
     MAGE_CHECK_ARG(ids && table && out, "mage_embedding: null pointer");
     MAGE_CHECK_ARG(n > 0 && C > 0 && C % 4 == 0 && n_table > 0 && group > 0, "mage_embedding: bad sizes n=%ld C=%d", (long)n, C);
+    if (inner <= 0) {                      // one-level grouping
+        inner = group;
+        inner_stride = group;
+    }
     const dim3 grid((unsigned)((n + 3) / 4)), blk(256);
     hipStream_t s = (hipStream_t)stream;
     int* err = mage_error_word();
     MAGE_CHECK_ARG(err != nullptr, "mage_embedding: mage_init() has not been called");
     if (out_dtype == MAGE_F32)
         hipLaunchKernelGGL((embedding_kernel<float>), grid, blk, 0, s, ids, table, (float*)out, (long)n, C, n_table, relu,
-                           (long)group, (long)group_stride, (long)off, err);
+                           (long)group, (long)group_stride, (long)off, (long)inner, (long)inner_stride, err);
     else if (out_dtype == MAGE_BF16)
         hipLaunchKernelGGL((embedding_kernel<unsigned short>), grid, blk, 0, s, ids, table, (unsigned short*)out, (long)n, C,
-                           n_table, relu, (long)group, (long)group_stride, (long)off, err);
+                           n_table, relu, (long)group, (long)group_stride, (long)off, (long)inner, (long)inner_stride, err);
     else {
         mage_set_error("mage_embedding: bad out_dtype %d", out_dtype);
         return MAGE_EINVAL;

@@ -583,6 +583,7 @@ class MAGE(nn.Module):
         self.ar_mode = "full"          # 'full' = the reference's per-iteration full recompute (mage_model.py:673-684);
                                        # 'incremental' = temporal KV cache, each position once
         self.last_call_mode = "eager"
+        self._pad_frames: dict = {}    # zero-padded frame buffers of _frame_features (bf16 mode), by (images, device, stream)
         self.use_graph = False         # True: autoregressive_generate replays a captured HIP graph of the whole call (see there)
         self._graphs: dict = {}
         self._derived = _Derived(self)
@@ -661,13 +662,31 @@ class MAGE(nn.Module):
 
     # ------------------------------------------------------------------ shared pieces
     def _frame_features(self, tokens: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
-        """ids [n, hw] -> conv3x3(embedding) + (H_pos + W_pos) as rows [n*hw, C] (mage_model.py:581,586-588,674-676)."""
+        """ids [n, hw] -> conv3x3(embedding) + (H_pos + W_pos) as rows [n*hw, C] (mage_model.py:581,586-588,674-676).
+
+        bf16 mode: the embedding rows are written into the interior of a zero-padded (R+2) x (R+2) frame buffer, so that the
+        convolution is the padded-taps form of mage_gemm (every tap a valid row: the 8-phase ping-pong kernel with one scalar
+        offset per K slab, the positional table loaded into the accumulators) instead of the generic per-lane gather.  The buffer
+        is kept between calls: its border is written once (zeros), its interior on every call."""
         d = self._derived.get(self._build)
         R, Cc = self.image_resolution, self.vision_width
         n = tokens.numel() // (R * R)
-        emb = ops.embedding(tokens.reshape(-1), d["emb"], torch.empty(n * R * R, Cc, device=tokens.device, dtype=dt))
-        return VectorQuantizedVAE._conv(emb, d["conv" + _sfx(dt)], torch.empty_like(emb), n_img=n, H=R, W=R, cin=Cc, cout=Cc,
-                                        k=3, rowadd=d["hwpos"], rowadd_div=1, rowadd_mod=R * R)
+        if dt == F32 or Cc % 64:
+            emb = ops.embedding(tokens.reshape(-1), d["emb"], torch.empty(n * R * R, Cc, device=tokens.device, dtype=dt))
+            return VectorQuantizedVAE._conv(emb, d["conv" + _sfx(dt)], torch.empty_like(emb), n_img=n, H=R, W=R, cin=Cc, cout=Cc,
+                                            k=3, rowadd=d["hwpos"], rowadd_div=1, rowadd_mod=R * R)
+        P = R + 2
+        key = (n, str(tokens.device), torch.cuda.current_stream(tokens.device).cuda_stream if tokens.is_cuda else 0)
+        pad = self._pad_frames.get(key)
+        if pad is None:
+            if len(self._pad_frames) > 8:
+                self._pad_frames.clear()
+            pad = self._pad_frames[key] = torch.zeros((n * P * P + 1) * Cc, device=tokens.device, dtype=dt).view(-1, Cc)
+        ops.embedding(tokens.reshape(-1), d["emb"], pad, group=R * R, group_stride=P * P, off=P + 1, inner=R, inner_stride=P)
+        out = torch.empty(n * R * R, Cc, device=tokens.device, dtype=dt)
+        return ops.gemm(pad, d["conv" + _sfx(dt)], out, M=n * R * R, N=Cc, K=9 * Cc, lda=Cc, ldy=Cc, out_h=R, out_w=R, in_h=P, in_w=P,
+                        a_img_stride=P * P, taps_h=3, taps_w=3, cin=Cc, stride=1, dy0=0, dx0=0, rowadd=d["hwpos"], rowadd_div=1,
+                        rowadd_mod=R * R)
 
     def _frame_features_latent(self, lat: torch.Tensor, ld: int, dt: torch.dtype) -> torch.Tensor:
         """use_cids=False: latents as fp32 rows [n*hw, ld] (first embed_dim columns valid) -> Linear(embed_dim -> C)

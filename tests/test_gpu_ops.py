@@ -408,3 +408,45 @@ def test_out_of_range_ids_and_targets_are_reported():
     o.cross_entropy(logits, torch.full((8,), 32, device=DEV, dtype=torch.int64))
     with pytest.raises(ValueError, match="target out of range"):
         o.check_device_errors(DEV)
+
+
+@pytest.mark.parametrize("n_img,Cc,mode", [(8, 256, "table"), (3, 512, "table"), (6, 256, "relu_bias"), (5, 256, "plain")])
+def test_padded_taps_conv_on_the_8phase_kernel(n_img, Cc, mode):
+    """conv3x3 over a zero-padded frame buffer (every tap a valid row): the padded-taps form of mage_gemm runs on the 8-phase
+    ping-pong kernel (one scalar offset per K slab); y = table[row % 256] + conv (the frame convolution + H/W positions), or
+    act(conv + bias).  Against torch's conv2d on the same bf16-rounded operands, and against the generic gather kernel's result."""
+    import torch.nn.functional as F
+    o = ops()
+    R, P = 16, 18
+    x = rnd(n_img, R, R, Cc, seed=70).bfloat16()
+    w = rnd(Cc, 3, 3, Cc, seed=71, scale=(9 * Cc) ** -0.5).bfloat16()                      # [co, ky, kx, ci]
+    table = rnd(R * R, Cc, seed=72)
+    bias = rnd(Cc, seed=73, scale=0.1)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1).reshape(n_img * R * R, Cc)
+    kw = {}
+    if mode == "table":
+        ref = ref + table.repeat(n_img, 1)
+        kw = dict(rowadd=table.to(DEV), rowadd_div=1, rowadd_mod=R * R)
+    elif mode == "relu_bias":
+        ref = torch.relu(ref + bias)
+        kw = dict(bias=bias.to(DEV), act=o.ACT_RELU)
+    pad = torch.zeros(n_img, P, P, Cc, dtype=torch.bfloat16)
+    pad[:, 1:-1, 1:-1] = x
+    wd = w.reshape(Cc, 9 * Cc).to(DEV)
+    y = torch.empty(n_img * R * R, Cc, device=DEV, dtype=torch.bfloat16)
+    o.gemm(pad.view(-1, Cc).to(DEV), wd, y, M=n_img * R * R, N=Cc, K=9 * Cc, lda=Cc, ldy=Cc, out_h=R, out_w=R, in_h=P, in_w=P,
+           a_img_stride=P * P, taps_h=3, taps_w=3, cin=Cc, stride=1, dy0=0, dx0=0, **kw)
+    torch.testing.assert_close(y.float().cpu(), ref, atol=3e-2, rtol=2e-2)
+    # the generic gather kernel on the unpadded input: the same sums in another order, rounded to bf16
+    y2 = torch.empty_like(y)
+    o.gemm(x.view(-1, Cc).to(DEV), wd, y2, M=n_img * R * R, N=Cc, K=9 * Cc, lda=Cc, ldy=Cc, out_h=R, out_w=R, in_h=R, in_w=R, taps_h=3,
+           taps_w=3, cin=Cc, stride=1, dy0=-1, dx0=-1, **kw)
+    assert (y.float() - y2.float()).abs().max().item() <= 2 ** -6 * max(1.0, ref.abs().max().item())
+    # and the embedding kernel's two-level addressing fills exactly the interior of the padded buffer
+    ids = torch.randint(0, 50, (n_img * R * R,), generator=torch.Generator().manual_seed(74))
+    tab = rnd(50, Cc, seed=75)
+    buf = torch.zeros(n_img * P * P, Cc, device=DEV, dtype=torch.bfloat16)
+    o.embedding(ids.to(DEV), tab.to(DEV), buf, group=R * R, group_stride=P * P, off=P + 1, inner=R, inner_stride=P)
+    want = torch.zeros(n_img, P, P, Cc, dtype=torch.bfloat16)
+    want[:, 1:-1, 1:-1] = tab[ids].bfloat16().view(n_img, R, R, Cc)
+    assert torch.equal(buf.cpu().view(n_img, P, P, Cc), want)
