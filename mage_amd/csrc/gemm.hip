@@ -268,7 +268,10 @@ __device__ unsigned long long mage_probe_seg[8 * 160];   // gemm8: workgroup 8, 
 // So each wave transposes its 16x64 block through a private 4 KiB LDS window (XOR-swizzled, conflict-free both ways; DS
 // operations of one wave execute in order, so no barrier and no wait between its writes and reads) and stores whole rows:
 //   bf16: one instruction = 8 rows x 128 B;   fp32: one instruction = 4 rows x 256 B.
-template <int ACT, typename OT, int MT>
+// AFFINE (the TAPS instantiations of the 8-phase kernel): rows regrouped P at a time (out_h = 1, out_w = P, y_img_stride != P: the
+// decoder stream's x[:, 1:] slots) still take the fast path when P % 256 == 0 -- a wave's 128 rows then lie in ONE group and
+// yrow = m + group*(y_img_stride - P) + y_off.  A template parameter so that the Linear layers' kernels keep their exact code.
+template <int ACT, typename OT, int MT, bool AFFINE = false>
 __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32x4 (&bias)[4], f32x4 (&acc)[MT][4], int m0, int n0,
                                               int lane, int plane, char* stg, long ysplit) {
     constexpr bool F32 = sizeof(OT) == 4;
@@ -293,9 +296,11 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
     }
     const int col = n0 + cc * CPC;
     const bool simple_rows = d.out_h == 1 && d.out_w >= d.M;
-    const bool interior = simple_rows && m0 + MT * 16 <= d.M && n0 + 64 <= d.N;     // wave-uniform
+    const bool affine_rows = AFFINE && d.out_h == 1 && d.y_mul_x == 1 && d.out_w % 256 == 0;
+    const bool interior = (simple_rows || affine_rows) && m0 + MT * 16 <= d.M && n0 + 64 <= d.N;     // wave-uniform
     const bool cv_ok = col < d.N;                                                    // N % 8 == 0: a chunk is all in or all out
-    OT* yp = (OT*)d.Y + ysplit + (long)((m0 + rr) * d.y_mul_x + d.y_off) * d.ldy + col;      // simple rows: row m0 + rr, then steps
+    const long row_shift = (AFFINE && !simple_rows && affine_rows) ? (long)(m0 / d.out_w) * (d.y_img_stride - d.out_w) : 0;
+    OT* yp = (OT*)d.Y + ysplit + ((long)((m0 + rr) * d.y_mul_x + d.y_off) + row_shift) * d.ldy + col;      // row m0 + rr, then steps
     const long step = (long)RPI * d.y_mul_x * d.ldy;
 
     auto stage = [&](int mt, u32x4 (&o)[NST]) {     // math + transpose of 16-row tile mt: results land in o[] (row-contiguous)
@@ -800,8 +805,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             for (int a = 0; a < MT; ++a) {
                 const int m = min(m0 + a * 16 + l15, d.M - 1);
                 const float* rp;
-                if constexpr (TAPS) rp = d.rowadd + (long)(((m * d.y_mul_x + d.y_off) / d.rowadd_div) % d.rowadd_mod) * d.N;
-                else rp = (const float*)d.residual + (long)(m * d.y_mul_x + d.y_off) * d.ldr;
+                if constexpr (TAPS) {
+                    const int img = m / plane, rem = m - img * plane;
+                    const int oy = rem / d.out_w, ox = rem - oy * d.out_w;
+                    const int yrow = img * d.y_img_stride + oy * d.y_mul_y + ox * d.y_mul_x + d.y_off;       // regrouped rows allowed
+                    rp = d.rowadd + (long)((yrow / d.rowadd_div) % d.rowadd_mod) * d.N;
+                } else {
+                    rp = (const float*)d.residual + (long)(m * d.y_mul_x + d.y_off) * d.ldr;
+                }
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int n = n0 + b * 16 + grp * 4;
@@ -916,8 +927,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
         char* stg = smem + 2 * KBUF + wave * 4096;
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));               // keep the epilogue's lane-derived constants out of the K loop's registers
-        if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
-        else epilogue_lean<ACT, unsigned short, MT>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
+        if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
+        else epilogue_lean<ACT, unsigned short, MT, TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
         MAGE_STAMP(it, 1);                             // probe: epilogue issued
     }
 }
@@ -1024,10 +1035,15 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
     static int use8 = -1;
     if (use8 < 0) use8 = (getenv("MAGE_GEMM_NO_8PHASE") || getenv("MAGE_GEMM_NO_TAPS8")) ? 0 : 1;
     if (!use8 || d->dtype != MAGE_BF16 || d->n_split != 1) return 0;
-    if (d->taps_h * d->taps_w <= 1 || d->stride != 1 || d->dys != 1 || d->dxs != 1 || d->dy0 != 0 || d->dx0 != 0) return 0;
+    const bool table = d->rowadd && !d->residual;                                                         // y = table[row] + conv (+ bias)
+    const bool plain = !d->rowadd && !d->residual;
+    const int ntaps = d->taps_h * d->taps_w;
+    // convolutions over a zero-padded input, and (taps 1x1) the Linear layers that add a broadcast row table (in_linear /
+    // context_linear + T positions, written into regrouped rows of the decoder stream)
+    if (ntaps <= 1 && !table) return 0;
+    if (d->stride != 1 || d->dys != 1 || d->dxs != 1 || d->dy0 != 0 || d->dx0 != 0) return 0;
     if (d->in_h != d->out_h + d->taps_h - 1 || d->in_w != d->out_w + d->taps_w - 1) return 0;          // zero-padded input only
     if (d->cin % 64 != 0 || d->K % 64 != 0 || d->scale || d->post_relu) return 0;
-    if (d->y_mul_x != 1 || d->y_mul_y != d->out_w || d->y_img_stride != d->out_h * d->out_w) return 0;   // packed output rows
     int dev = mage_device_index();
     if (dev < 0) return 0;
     hipDeviceProp_t p;
@@ -1040,8 +1056,6 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
     const long n_img = (d->M + (long)d->out_h * d->out_w - 1) / ((long)d->out_h * d->out_w);
     const long a_span = (n_img * d->a_img_stride + d->a_off + (long)d->in_h * d->in_w) * d->lda;
     if (a_span * 2 >= (1L << 32) || (long)d->N * d->K * 2 >= (1L << 32)) return 0;
-    const bool table = d->rowadd && !d->residual && !d->bias;                                             // y = table[row] + conv
-    const bool plain = !d->rowadd && !d->residual;
     if (table && d->act == MAGE_ACT_NONE && (((uintptr_t)d->rowadd) & 15) == 0) return launch_taps8<MAGE_ACT_NONE, EK_RES_INIT>(d, s, n_cu);
     if (plain && d->act == MAGE_ACT_NONE) return launch_taps8<MAGE_ACT_NONE, EK_BIAS>(d, s, n_cu);
     if (plain && d->act == MAGE_ACT_RELU) return launch_taps8<MAGE_ACT_RELU, EK_BIAS>(d, s, n_cu);

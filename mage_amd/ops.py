@@ -219,14 +219,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
         if (d.dtype == BF16 and not gather and mt == 8 and ek != 2 and K % 64 == 0 and a_rows * lda * 2 < 2 ** 32
                 and N * K * 2 < 2 ** 32 and not os.environ.get("MAGE_GEMM_NO_8PHASE")):
             key = f"gemm8_kernel<{act}, {ek}, {sp}, false>"    # the 8-phase ping-pong variant (launch_tile in csrc/gemm.hip)
-        # padded-taps convolutions on the 8-phase kernel (try_taps8 in csrc/gemm.hip)
-        if (d.dtype == BF16 and n_split == 1 and taps_h * taps_w > 1 and stride == 1 and dys == 1 and dxs == 1 and dy0 == 0 and dx0 == 0
+        # padded-taps convolutions and row-table Linears on the 8-phase kernel (try_taps8 in csrc/gemm.hip)
+        ntaps = taps_h * taps_w
+        table, plain = rowadd is not None and residual is None, rowadd is None and residual is None
+        if (d.dtype == BF16 and n_split == 1 and (ntaps > 1 or table) and stride == 1 and dys == 1 and dxs == 1 and dy0 == 0 and dx0 == 0
                 and d.in_h == out_h + taps_h - 1 and d.in_w == out_w + taps_w - 1 and d.cin % 64 == 0 and K % 64 == 0 and scale is None
-                and not post_relu and N % 256 == 0 and M % 256 == 0 and d.y_mul_x == 1 and d.y_mul_y == out_w
-                and d.y_img_stride == out_h * out_w and not os.environ.get("MAGE_GEMM_NO_8PHASE") and not os.environ.get("MAGE_GEMM_NO_TAPS8")):
-            if rowadd is not None and residual is None and bias is None and act == ACT_NONE:
+                and not post_relu and N % 256 == 0 and M % 256 == 0
+                and not os.environ.get("MAGE_GEMM_NO_8PHASE") and not os.environ.get("MAGE_GEMM_NO_TAPS8")):
+            if table and act == ACT_NONE:
                 key = "gemm8_kernel<0, 1, false, true>"
-            elif rowadd is None and residual is None and act in (ACT_NONE, ACT_RELU):
+            elif plain and act in (ACT_NONE, ACT_RELU):
                 key = f"gemm8_kernel<{act}, 0, false, true>"
         if PROFILE.wants(key):
             ev = PROFILE.begin()
