@@ -110,9 +110,23 @@ typedef struct mage_gemm_desc {
      * the n_split partial outputs (mage_sum_partials) in a fixed order.  Plain form only: no gather, no epilogue extras. */
     int32_t n_split;                   /* 0 or 1 = no split */
     int64_t a_split_stride, w_split_stride, y_split_stride;
+    /* LayerNorm folded around the decoder's GEMMs (bf16, plain rows, M and N multiples of 256; mage_model.py:35-53: the
+     * x + dropout(attn(ln_1(x))) / x + mlp(ln_2(x)) chain).  Producer -- the x + Linear(.) GEMM that writes the fp32 stream: with y2
+     * set it also writes a bf16 copy of the new rows (ldy2 elements per row) and ln_part[row][N/64][2] = (sum, sum of squares) of each
+     * 64-column slice; mage_ln_stats reduces those to ln_stats[row][2] = (mean, rstd).  Consumer -- the Linear that follows the norm:
+     * A = that bf16 copy, W = gamma * W (per input channel), bias = W beta + b, ln_colsum[n] = sum_k W'[n, k]; with ln_stats set the
+     * epilogue computes rstd_m (acc - mean_m ln_colsum[n]) + bias[n] before the activation: LN(x) W^T + b without the LayerNorm pass. */
+    void* y2;
+    int32_t ldy2, reserved2;
+    float* ln_part;
+    const float* ln_stats;
+    const float* ln_colsum;
 } mage_gemm_desc;
 
 int mage_gemm(const mage_gemm_desc* desc, void* stream);
+/* stats[row] = (mean, rstd) from the producer GEMM's partial sums: mean = sum_s part[row][s][0] / C,
+ * var = sum_s part[row][s][1] / C - mean^2, rstd = 1 / sqrt(max(var, 0) + eps); fixed order. */
+int mage_ln_stats(const float* part, int64_t rows, int32_t n_slices, int32_t C, float eps, float* stats, void* stream);
 
 /* LayerNorm over the last dim of fp32 rows; y may be fp32 (may alias x) or bf16.
  * Replaces nn.LayerNorm at mage_model.py:21,27,84,204,206 and inside nn.TransformerEncoderLayer. */

@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("residual", vp), ("ldr", i32), ("res_dtype", i32),
         ("post_relu", i32), ("ldw", i32), ("n_split", i32),
         ("a_split_stride", i64), ("w_split_stride", i64), ("y_split_stride", i64),
+        ("y2", vp), ("ldy2", i32), ("reserved2", i32), ("ln_part", vp), ("ln_stats", vp), ("ln_colsum", vp),
     ]
 
 
@@ -55,6 +56,7 @@ SIGNATURES = {
     "mage_init": (C.c_int, [C.c_int]),
     "mage_check_device_errors": (C.c_int, [vp]),
     "mage_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "mage_ln_stats": (C.c_int, [vp, i64, i32, i32, f32, vp, vp]),
     "mage_layernorm": (C.c_int, [vp, vp, vp, vp, i32, i64, i32, f32, vp]),
     "mage_attention": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "mage_embedding": (C.c_int, [vp, vp, vp, i32, i64, i32, i32, i32, i64, i64, i64, i64, i64, vp]),

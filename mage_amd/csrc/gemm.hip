@@ -271,9 +271,22 @@ __device__ unsigned long long mage_probe_seg[8 * 160];   // gemm8: workgroup 8, 
 // AFFINE (the TAPS instantiations of the 8-phase kernel): rows regrouped P at a time (out_h = 1, out_w = P, y_img_stride != P: the
 // decoder stream's x[:, 1:] slots) still take the fast path when P % 256 == 0 -- a wave's 128 rows then lie in ONE group and
 // yrow = m + group*(y_img_stride - P) + y_off.  A template parameter so that the Linear layers' kernels keep their exact code.
-template <int ACT, typename OT, int MT, bool AFFINE = false>
+// LN: LayerNorm folded around the GEMMs (bf16 mode of the decoder stack; interior tiles and simple rows only -- the host checks).
+//   LN_PRODUCE (x + Linear(.), fp32 stream out): the epilogue also writes a bf16 copy of the new x (y2) and, per row and per
+//     64-column wave slice, the partial sums (sum x, sum x^2) of the fp32 values it holds anyway (ln_part[row][N/64][2]):
+//     mage_ln_stats turns them into (mean, rstd) per row.  The standalone LayerNorm pass (read 4 B + write 2 B per element) is gone.
+//   LN_CONSUME (the Linear that follows the norm): A is that bf16 copy of x, W carries gamma (W' = gamma * W, rounded to bf16),
+//     and the epilogue finishes the norm algebraically:   LN(x) W^T + b = rstd_m (x W'^T - mean_m s_n) + c_n,
+//     s_n = sum_k W'_nk, c_n = sum_k beta_k W_nk + b_n (c arrives as `bias`).
+struct LnConsume {
+    float mean[8], rstd[8];            // per 16-row tile of the wave: the stats of this lane's row (row l15 of tile mt)
+    f32x4 s[4];                        // s_n of this lane's 16 columns (MFMA layout)
+};
+enum { LN_NONE = 0, LN_PRODUCE = 1, LN_CONSUME = 2 };
+
+template <int ACT, typename OT, int MT, bool AFFINE = false, int LN = LN_NONE>
 __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32x4 (&bias)[4], f32x4 (&acc)[MT][4], int m0, int n0,
-                                              int lane, int plane, char* stg, long ysplit) {
+                                              int lane, int plane, char* stg, long ysplit, const LnConsume* lnc = nullptr) {
     constexpr bool F32 = sizeof(OT) == 4;
     constexpr int RB = F32 ? 256 : 128;            // bytes of one staged row (64 columns)
     constexpr int NCH = RB / 16;                   // 16-byte chunks per row: 16 | 8
@@ -302,11 +315,25 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
     const long row_shift = (AFFINE && !simple_rows && affine_rows) ? (long)(m0 / d.out_w) * (d.y_img_stride - d.out_w) : 0;
     OT* yp = (OT*)d.Y + ysplit + ((long)((m0 + rr) * d.y_mul_x + d.y_off) + row_shift) * d.ldy + col;      // row m0 + rr, then steps
     const long step = (long)RPI * d.y_mul_x * d.ldy;
+    // LN_PRODUCE (fp32 out): the bf16 copy of the same rows (8 bytes per lane: 4 rows x 128 B per instruction)
+    [[maybe_unused]] unsigned short* y2p = nullptr;
+    [[maybe_unused]] long step2 = 0;
+    if constexpr (LN == LN_PRODUCE) {
+        y2p = (unsigned short*)d.y2 + (long)((m0 + rr) * d.y_mul_x + d.y_off) * d.ldy2 + col;
+        step2 = (long)RPI * d.y_mul_x * d.ldy2;
+    }
 
     auto stage = [&](int mt, u32x4 (&o)[NST]) {     // math + transpose of 16-row tile mt: results land in o[] (row-contiguous)
+        [[maybe_unused]] float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            f32x4 v = acc[mt][nt] + bias[nt];
+            f32x4 v;
+            if constexpr (LN == LN_CONSUME) v = (acc[mt][nt] - lnc->s[nt] * lnc->mean[mt]) * lnc->rstd[mt] + bias[nt];
+            else v = acc[mt][nt] + bias[nt];
+            if constexpr (LN == LN_PRODUCE) {
+                s1 += (v[0] + v[1]) + (v[2] + v[3]);
+                s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            }
             if constexpr (ACT == MAGE_ACT_QUICKGELU) {
                 // x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)): the two transcendentals (quarter rate) are the cost;
                 // everything around them as 4-wide vector arithmetic, which hipcc packs into v_pk_* (one multiply fewer per
@@ -329,6 +356,18 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
                 *(uint2*)(stg + woff[nt]) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             }
         }
+        if constexpr (LN == LN_PRODUCE) {
+            // the four lane groups hold four 16-column pieces of row l15: fixed-order sum, written by group 0
+            s1 += __shfl_xor(s1, 16);
+            s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (grp == 0) {
+                const long row = (long)(m0 + mt * 16 + l15) * d.y_mul_x + d.y_off;
+                float* pp = d.ln_part + (row * (d.N >> 6) + (n0 >> 6)) * 2;
+                *(float2*)pp = float2{s1, s2};
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NST; ++i) o[i] = *(const u32x4*)(stg + roff[i]);
     };
@@ -340,6 +379,13 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
             if (interior) {
                 __builtin_nontemporal_store(o[i], (u32x4*)yp);
                 yp += step;
+                if constexpr (LN == LN_PRODUCE && F32) {
+                    const uint2 pk = uint2{pack_bf16x2(__uint_as_float(o[i][0]), __uint_as_float(o[i][1])),
+                                           pack_bf16x2(__uint_as_float(o[i][2]), __uint_as_float(o[i][3]))};
+                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                    __builtin_nontemporal_store(u32x2_t{pk.x, pk.y}, (u32x2_t*)y2p);
+                    y2p += step2;
+                }
             } else {
                 const int m = m0 + mt * 16 + rr + RPI * i;
                 if (m < d.M && cv_ok) {
@@ -378,7 +424,7 @@ __device__ __forceinline__ void ring_barrier() {
 
 // SPLIT: the split-K form (mage_gemm_desc::n_split > 1).  A template parameter so that the kernels of the generation path keep
 // their exact code (the tile decode, two 64-bit strides and the W row stride cost the 8-phase kernel 11 spilled SGPRs otherwise).
-template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false>
+template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     typedef typename TT<DT>::elem E;
     constexpr int BM = Tile<MT>::BM, A_BYTES = Tile<MT>::A_BYTES, STAGE_BYTES = Tile<MT>::STAGE_BYTES, AU = Tile<MT>::AU;
@@ -545,6 +591,20 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                 biasm[b] = d.bias ? *(const f32x4*)(d.bias + (n < d.N ? n : 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+        [[maybe_unused]] LnConsume lnc;                // LN_CONSUME: (mean, rstd) of this lane's rows, s_n of its columns
+        if constexpr (LN == LN_CONSUME) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const float2 st = *(const float2*)(d.ln_stats + 2 * (long)min(m0 + a * 16 + l15, d.M - 1));
+                lnc.mean[a] = st.x;
+                lnc.rstd[a] = st.y;
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int n = n0 + b * 16 + grp * 4;
+                lnc.s[b] = *(const f32x4*)(d.ln_colsum + (n < d.N ? n : 0));
+            }
+        }
         for (int kt = 0; kt < nk; ++kt) {
             // The slab to multiply was issued one whole iteration (or one epilogue) ago; nothing younger is in flight.
             // (the builtin, not inline asm: hipcc's own wait-count pass must SEE this wait, or it guards every later use of
@@ -642,8 +702,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
             else epilogue_wave<ACT, unsigned short, MT, EK>(d, cv, acc, m0, n0, lane, plane, ysplit);
         } else {
             char* stg = smem + Tile<MT>::RING_BYTES + wave * 4096;
-            if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
-            else epilogue_lean<ACT, unsigned short, MT>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
+            if constexpr (LN == LN_CONSUME) {
+                if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit, &lnc);
+                else epilogue_lean<ACT, unsigned short, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit, &lnc);
+            } else if constexpr (LN == LN_PRODUCE) {
+                epilogue_lean<ACT, float, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);       // fp32 stream out (host check)
+            } else {
+                if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
+                else epilogue_lean<ACT, unsigned short, MT>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
+            }
         }
         MAGE_STAMP(it, 1);
         MAGE_WSTAMP(it, 1);
@@ -677,7 +744,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
 // kt / (cin/64), whose rows sit (ky*in_w + kx) rows further -- kept as three scalar cursors per A piece (no vector instruction in a
 // load section, which is what this kernel's schedule depends on).  The lockstep kernel's generic gather decodes the tap per lane
 // and per slab and re-tests the bounds (frame conv3x3: 773 TFLOP/s, 6.7x its algorithmic bytes fetched: round-1 PMC).
-template <int ACT, int EK, bool SPLIT = false, bool TAPS = false>
+template <int ACT, int EK, bool SPLIT = false, bool TAPS = false, int LN = LN_NONE>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     constexpr int MT = 8, BM = 256;
     constexpr int PIECE = 16384, KBUF = 4 * PIECE;
@@ -826,6 +893,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
                 for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         f32x4 biasm[4];
+        [[maybe_unused]] LnConsume lnc;                // LN_CONSUME: requested with the bias vector in the tile's last slab
         [[maybe_unused]] const bool seg_on = c_tile == chunk0 + li + 2 * nwg8;     // probe build: stamp the third tile
         if (wr) ring_barrier();                        // the trailing half drops one barrier behind
         for (int kt = 0; kt < nk; ++kt) {
@@ -895,6 +963,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
                 for (int b = 0; b < 4; ++b) {
                     const int n = n0 + b * 16 + grp * 4;
                     biasm[b] = d.bias ? *(const f32x4*)(d.bias + (n < d.N ? n : 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (LN == LN_CONSUME) lnc.s[b] = *(const f32x4*)(d.ln_colsum + (n < d.N ? n : 0));
+                }
+                if constexpr (LN == LN_CONSUME) {
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) {
+                        const float2 st = *(const float2*)(d.ln_stats + 2 * (long)min(m0 + a * 16 + l15, d.M - 1));
+                        lnc.mean[a] = st.x;
+                        lnc.rstd[a] = st.y;
+                    }
                 }
             }
             mfma_quadrant(1, 1);
@@ -927,13 +1004,20 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
         char* stg = smem + 2 * KBUF + wave * 4096;
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));               // keep the epilogue's lane-derived constants out of the K loop's registers
-        if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
-        else epilogue_lean<ACT, unsigned short, MT, TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
+        if constexpr (LN == LN_CONSUME) {
+            if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit, &lnc);
+            else epilogue_lean<ACT, unsigned short, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit, &lnc);
+        } else if constexpr (LN == LN_PRODUCE) {
+            epilogue_lean<ACT, float, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);          // fp32 stream out (host check)
+        } else {
+            if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
+            else epilogue_lean<ACT, unsigned short, MT, TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
+        }
         MAGE_STAMP(it, 1);                             // probe: epilogue issued
     }
 }
 
-template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false>
+template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE>
 int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     // launch attributes are per DEVICE (a process may drive several GPUs, e.g. nn.DataParallel, main_mage.py:106): cached per
     // device index; setting one twice from two threads is harmless
@@ -941,7 +1025,7 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     const int dev = mage_device_index();
     MAGE_CHECK_ARG(dev >= 0, "mage_gemm: no current device");
     if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   Tile<MT>::LDS_BYTES);
         attr_set[dev] = true;
     }
@@ -991,15 +1075,16 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
         if (use8 && d->K % 64 == 0 && a_span * 2 < (1L << 32) && w_span * 2 < (1L << 32)) {
             static bool attr8[MAGE_MAX_DEVICES] = {false};
             if (!attr8[dev]) {
-                (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK, SPLIT, false, LN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          160 * 1024);
                 attr8[dev] = true;
             }
-            hipLaunchKernelGGL((gemm8_kernel<ACT, EK, SPLIT>), dim3(grid), dim3(512), 160 * 1024, s, a);
+            hipLaunchKernelGGL((gemm8_kernel<ACT, EK, SPLIT, false, LN>), dim3(grid), dim3(512), 160 * 1024, s, a);
             MAGE_CHECK_LAUNCH("mage_gemm");
             return MAGE_OK;
         }
     }
-    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT>), dim3(grid), dim3(512), Tile<MT>::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT, LN>), dim3(grid), dim3(512), Tile<MT>::LDS_BYTES, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
     return MAGE_OK;
 }
@@ -1062,7 +1147,7 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
     return 0;
 }
 
-template <int DT, bool GATHER, int ACT, int EK>
+template <int DT, bool GATHER, int ACT, int EK, int LN = LN_NONE>
 int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
     static int n_cu_dev[MAGE_MAX_DEVICES] = {0};
     const int dev = mage_device_index();
@@ -1086,14 +1171,34 @@ int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
         }
     }
     if constexpr (DT == MAGE_BF16) {
-        if (tiles256 >= 2L * n_cu) return launch_tile<DT, GATHER, ACT, 8, EK>(d, s, n_cu);
+        if (tiles256 >= 2L * n_cu) return launch_tile<DT, GATHER, ACT, 8, EK, false, LN>(d, s, n_cu);
     }
-    return launch_tile<DT, GATHER, ACT, 4, EK>(d, s, n_cu);
+    return launch_tile<DT, GATHER, ACT, 4, EK, false, LN>(d, s, n_cu);
 }
 
 template <int DT, bool GATHER, int ACT>
 int launch_act(const mage_gemm_desc* d, hipStream_t s) {
     const bool extras = d->scale || d->rowadd || d->residual || d->post_relu;
+    if constexpr (DT == MAGE_BF16 && !GATHER && (ACT == MAGE_ACT_NONE || ACT == MAGE_ACT_QUICKGELU)) {
+        // LayerNorm folded around the GEMM (see epilogue_lean): whole interior tiles, rows not regrouped
+        if (d->y2 || d->ln_stats) {
+            MAGE_CHECK_ARG(d->M % 256 == 0 && d->N % 256 == 0 && d->n_split == 1,
+                           "mage_gemm: the LayerNorm-folded forms need M and N multiples of 256");
+            MAGE_CHECK_ARG(d->ln_stats || (d->out_h == 1 && d->out_w >= d->M && d->y_mul_x == 1),
+                           "mage_gemm: y2 (bf16 copy + LayerNorm partial sums) needs plain output rows");
+            if (d->ln_stats) {
+                MAGE_CHECK_ARG(!extras && d->ln_colsum && d->bias && !d->y2, "mage_gemm: ln_stats goes with ln_colsum and bias, nothing else");
+                return launch_ek<DT, GATHER, ACT, EK_BIAS, LN_CONSUME>(d, s);
+            }
+            if constexpr (ACT == MAGE_ACT_NONE) {
+                MAGE_CHECK_ARG(d->residual && d->res_dtype == MAGE_F32 && !d->scale && !d->rowadd && !d->post_relu && d->y_dtype == MAGE_F32 &&
+                                   d->ln_part && d->ldy2 % 8 == 0 && (((uintptr_t)d->residual | (uintptr_t)d->y2) & 15) == 0,
+                               "mage_gemm: y2 (bf16 copy + LayerNorm partial sums) goes with the fp32 residual form");
+                return launch_ek<DT, GATHER, ACT, EK_RES_INIT, LN_PRODUCE>(d, s);
+            }
+        }
+    }
+    MAGE_CHECK_ARG(!d->y2 && !d->ln_stats, "mage_gemm: y2 / ln_stats are bf16 plain-GEMM options (act none or QuickGELU)");
     if (!extras) return launch_ek<DT, GATHER, ACT, EK_BIAS>(d, s);
     if constexpr (!GATHER && ACT == MAGE_ACT_NONE) {
         // the transformer's "x + Linear(.)": fp32 residual, nothing else after the bias, rows not regrouped

@@ -612,3 +612,30 @@ extern "C" int mage_mse(const float* a, int64_t lda, const float* b, int64_t ldb
     MAGE_CHECK_LAUNCH("mage_mse");
     return MAGE_OK;
 }
+
+// ------------------------------------------------------------------------------------ LayerNorm statistics from GEMM partial sums
+namespace {
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ part, long rows, int n_slices, float inv_c, float eps,
+                                                       float* __restrict__ stats) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float2* p = (const float2*)part + r * n_slices;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < n_slices; ++i) {
+        const float2 v = p[i];
+        s1 += v.x;
+        s2 += v.y;
+    }
+    const float mean = s1 * inv_c;
+    const float var = fmaxf(s2 * inv_c - mean * mean, 0.f);
+    *(float2*)(stats + 2 * r) = float2{mean, 1.0f / sqrtf(var + eps)};
+}
+}  // namespace
+
+extern "C" int mage_ln_stats(const float* part, int64_t rows, int32_t n_slices, int32_t C, float eps, float* stats, void* stream) {
+    MAGE_CHECK_ARG(part && stats && rows > 0 && n_slices > 0 && C > 0, "mage_ln_stats: bad arguments");
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, (long)rows, n_slices,
+                       1.0f / (float)C, eps, stats);
+    MAGE_CHECK_LAUNCH("mage_ln_stats");
+    return MAGE_OK;
+}

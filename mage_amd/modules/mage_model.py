@@ -13,6 +13,7 @@ LayerNorm, softmax, logits, the once-per-clip prologue and the VQ-VAE encode + q
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from math import exp
 from typing import Dict, Optional
@@ -375,7 +376,29 @@ class FlatAxialDecoder(nn.Module):
         d["tpos"] = self.T_positional_embedding.float().reshape(self.frames_length, self.model_channels).contiguous()
         for i, blk in enumerate(self.blocks):
             _pack_block(d, f"b{i}", blk)
+            # LayerNorm folded into the Linear that follows it (bf16 path, see _fold): W' = gamma * W per input channel,
+            # s_n = sum_k W'[n, k] (of the ROUNDED weights: what the MFMA multiplies), c_n = W beta + b
+            for ln, lin in (("ln_1", "in_proj"), ("ln_2", "c_fc")):
+                w, g, bt = d[f"b{i}.{lin}.f32"], d[f"b{i}.{ln}.w"], d[f"b{i}.{ln}.b"]
+                wq = (w * g[None, :]).to(BF16)
+                d[f"b{i}.{lin}.lnw"] = wq
+                d[f"b{i}.{lin}.lns"] = wq.float().sum(dim=1).contiguous()
+                d[f"b{i}.{lin}.lnc"] = (w.double() @ bt.double() + d[f"b{i}.{lin}.b"].double()).float().contiguous()
         return d
+
+    def _fold(self, dt, B: int, hw: int) -> bool:
+        """bf16 path: the standalone LayerNorm launches between the GEMMs are folded into them (csrc/gemm.hip, epilogue_lean):
+        the x + Linear(.) GEMM also writes a bf16 copy of x and per-row partial (sum, sum of squares); the next Linear takes that
+        copy with gamma folded into its weights and finishes the normalisation in its epilogue.  Needs whole 256-row tiles per
+        frame slot (so that the full pass and the incremental loop take the same route: their tokens stay bit-identical)."""
+        return (dt == BF16 and (B * hw) % 256 == 0 and self.model_channels % 256 == 0 and not os.environ.get("MAGE_NO_LN_FOLD"))
+
+    def _ln_linear(self, d, p, lin, xb, stats, y, *, M, N, lo=0, hi=None, **kw):
+        """y = Linear(LN(x)) from the bf16 copy of x and its row statistics (rows lo:hi of the Linear's outputs)."""
+        Cc = self.model_channels
+        hi = N + lo if hi is None else hi
+        return ops.gemm(xb, d[f"{p}.{lin}.lnw"][lo:hi], y, M=M, N=hi - lo, K=Cc, lda=Cc, ldy=kw.pop("ldy", hi - lo),
+                        bias=d[f"{p}.{lin}.lnc"][lo:hi], ln_stats=stats, ln_colsum=d[f"{p}.{lin}.lns"][lo:hi], **kw)
 
     @torch.no_grad()
     def _run(self, motion: torch.Tensor, imgs: torch.Tensor, *, B: int, hh: int, ww: int) -> torch.Tensor:
@@ -396,6 +419,11 @@ class FlatAxialDecoder(nn.Module):
         qkv = torch.empty(M, 3 * Cc, device=dev, dtype=dt)
         ao = torch.empty(M, Cc, device=dev, dtype=dt)
         hdn = torch.empty(M, 4 * Cc, device=dev, dtype=dt)
+        fold, have_stats = self._fold(dt, B, hw), False
+        if fold:
+            xb = torch.empty(M, Cc, device=dev, dtype=dt)                          # bf16 copy of the stream, written by its producers
+            part = torch.empty(M, Cc // 64, 2, device=dev, dtype=F32)
+            stats = torch.empty(M, 2, device=dev, dtype=F32)
         for i in range(self.layers):
             p = f"b{i}"
             axis = i % 3                                                            # 0: L (causal), 1: H, 2: W  (:344,:382)
@@ -405,18 +433,31 @@ class FlatAxialDecoder(nn.Module):
                 geo = dict(n_seq=B * L * ww, inner=ww, nq=hh, nk=hh, q_outer_stride=hw, q_axis_stride=ww, causal=False)
             else:
                 geo = dict(n_seq=B * L * hh, inner=1, nq=ww, nk=ww, q_outer_stride=ww, q_axis_stride=1, causal=False)
-            ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], xn, 1e-5)
-            _linear(xn, d, p + ".in_proj", qkv, dt, M=M, N=3 * Cc, K=Cc)
+            if have_stats:
+                self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=3 * Cc)
+            else:
+                ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], xn, 1e-5)
+                _linear(xn, d, p + ".in_proj", qkv, dt, M=M, N=3 * Cc, K=Cc)
             ops.attention(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], ao, ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=Cc, n_head=H,
                           kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], **geo)
-            _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc)
-            ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5)
-            _linear(xn, d, p + ".c_fc", hdn, dt, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU)
-            if i == self.layers - 1 and self.use_cids and dt != F32:
+            if fold:
+                _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc, y2=xb, ldy2=Cc, ln_part=part)
+                ops.ln_stats(part, Cc, 1e-5, stats)
+                self._ln_linear(d, p, "c_fc", xb, stats, hdn, M=M, N=4 * Cc, act=ops.ACT_QUICKGELU)
+            else:
+                _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc)
+                ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5)
+                _linear(xn, d, p + ".c_fc", hdn, dt, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU)
+            last = i == self.layers - 1
+            if last and self.use_cids and dt != F32:
                 # the last block's x + c_proj(.) is only read by the head GEMM: the epilogue rounds it to the compute dtype on the
                 # way out (same fp32 sum, same round-to-nearest-even as a separate cast pass: bit-identical) instead of writing
                 # the fp32 stream and converting it in another launch
                 _linear(hdn, d, p + ".c_proj", xn, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
+            elif fold and not last:
+                _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc, y2=xb, ldy2=Cc, ln_part=part)
+                ops.ln_stats(part, Cc, 1e-5, stats)
+                have_stats = True
             else:
                 _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
         if not self.use_cids:
@@ -467,32 +508,58 @@ class FlatAxialDecoder(nn.Module):
         qkv = torch.empty(M, 3 * Cc, device=dev, dtype=dt)
         ao = torch.empty(M, Cc, device=dev, dtype=dt)
         hdn = torch.empty(M, 4 * Cc, device=dev, dtype=dt)
+        fold, have_stats = self._fold(dt, B, hw), False
+        if fold:                                                             # see _run
+            xb = torch.empty(M, Cc, device=dev, dtype=dt)
+            part = torch.empty(M, Cc // 64, 2, device=dev, dtype=F32)
+            stats = torch.empty(M, 2, device=dev, dtype=F32)
         for i in range(self.layers):
             p = f"b{i}"
             axis = i % 3
-            ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], xn, 1e-5)
+            if not have_stats:
+                ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], xn, 1e-5)
             w, b = d[p + ".in_proj" + _sfx(dt)], d[p + ".in_proj.b"]
             if axis == 0:
                 kv = st["kv"][i]                                             # [B, L, hw, K|V]
-                ops.gemm(xn, w[:Cc], qkv, M=M, N=Cc, K=Cc, lda=Cc, ldy=Cc, bias=b[:Cc])          # q, packed [M, C]
-                ops.gemm(xn, w[Cc:], kv, M=M, N=2 * Cc, K=Cc, lda=Cc, ldy=2 * Cc, bias=b[Cc:], out_w=P * hw,
-                         y_img_stride=L * hw, y_off=p0 * hw)                                       # k, v -> cache slots
+                if have_stats:
+                    self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=Cc)                   # q, packed [M, C]
+                    self._ln_linear(d, p, "in_proj", xb, stats, kv, M=M, N=2 * Cc, lo=Cc, hi=3 * Cc, out_w=P * hw,
+                                    y_img_stride=L * hw, y_off=p0 * hw)                           # k, v -> cache slots
+                else:
+                    ops.gemm(xn, w[:Cc], qkv, M=M, N=Cc, K=Cc, lda=Cc, ldy=Cc, bias=b[:Cc])
+                    ops.gemm(xn, w[Cc:], kv, M=M, N=2 * Cc, K=Cc, lda=Cc, ldy=2 * Cc, bias=b[Cc:], out_w=P * hw,
+                             y_img_stride=L * hw, y_off=p0 * hw)
                 ops.attention(qkv, kv, kv[:, Cc:], ao, ldq=Cc, ldk=2 * Cc, ldv=2 * Cc, ldo=Cc, n_seq=B * hw, inner=hw, nq=P,
                               nk=p0 + P, n_head=H, q_outer_stride=P * hw, q_axis_stride=hw, kv_outer_stride=L * hw,
                               kv_axis_stride=hw, causal=True)
             else:
-                ops.gemm(xn, w, qkv, M=M, N=3 * Cc, K=Cc, lda=Cc, ldy=3 * Cc, bias=b)
+                if have_stats:
+                    self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=3 * Cc)
+                else:
+                    ops.gemm(xn, w, qkv, M=M, N=3 * Cc, K=Cc, lda=Cc, ldy=3 * Cc, bias=b)
                 if axis == 1:
                     geo = dict(n_seq=B * P * ww, inner=ww, nq=hh, nk=hh, q_outer_stride=hw, q_axis_stride=ww)
                 else:
                     geo = dict(n_seq=B * P * hh, inner=1, nq=ww, nk=ww, q_outer_stride=ww, q_axis_stride=1)
                 ops.attention(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], ao, ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=Cc, n_head=H,
                               kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], **geo)
-            _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc)
-            ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5)
-            _linear(xn, d, p + ".c_fc", hdn, dt, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU)
-            last_bf16 = i == self.layers - 1 and dt != F32          # see _run: the head's input straight from the epilogue
-            _linear(hdn, d, p + ".c_proj", xn if last_bf16 else x, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
+            if fold:
+                _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc, y2=xb, ldy2=Cc, ln_part=part)
+                ops.ln_stats(part, Cc, 1e-5, stats)
+                self._ln_linear(d, p, "c_fc", xb, stats, hdn, M=M, N=4 * Cc, act=ops.ACT_QUICKGELU)
+            else:
+                _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc)
+                ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5)
+                _linear(xn, d, p + ".c_fc", hdn, dt, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU)
+            last = i == self.layers - 1
+            if last and dt != F32:                                  # see _run: the head's input straight from the epilogue
+                _linear(hdn, d, p + ".c_proj", xn, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
+            elif fold and not last:
+                _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc, y2=xb, ldy2=Cc, ln_part=part)
+                ops.ln_stats(part, Cc, 1e-5, stats)
+                have_stats = True
+            else:
+                _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
         xa = x if dt == F32 else xn
         logits = torch.empty(B * hw, self.out_channels, device=dev, dtype=F32)
         _linear(xa, d, "out", logits, dt, M=B * hw, N=self.out_channels, K=Cc, out_w=hw, a_img_stride=P * hw, a_off=(P - 1) * hw)

@@ -174,7 +174,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
          y_img_stride: Optional[int] = None, y_mul_y: Optional[int] = None, y_mul_x: int = 1, y_off: int = 0,
          bias=None, scale=None, shift=None, act: int = ACT_NONE, rowadd=None, rowadd_div: int = 1, rowadd_mod: int = 1,
          residual=None, ldr: int = 0, post_relu: bool = False, ldw: int = 0, n_split: int = 1, a_split_stride: int = 0,
-         w_split_stride: int = 0, y_split_stride: int = 0) -> torch.Tensor:
+         w_split_stride: int = 0, y_split_stride: int = 0, y2=None, ldy2: int = 0, ln_part=None, ln_stats=None,
+         ln_colsum=None) -> torch.Tensor:
     """Y = epilogue(A (*) W^T); see mage_gemm in include/mage_hip.h for the geometry fields."""
     l, s = _dev(a)
     out_w = M if out_w is None else out_w
@@ -200,6 +201,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     d.post_relu = int(post_relu)
     d.ldw, d.n_split = ldw, n_split
     d.a_split_stride, d.w_split_stride, d.y_split_stride = a_split_stride, w_split_stride, y_split_stride
+    d.y2, d.ldy2, d.ln_part, d.ln_stats, d.ln_colsum = _p(y2), ldy2, _p(ln_part), _p(ln_stats), _p(ln_colsum)
+    ln = 2 if ln_stats is not None else (1 if y2 is not None else 0)      # LN_CONSUME / LN_PRODUCE (csrc/gemm.hip)
     if PROFILE.enabled:
         # key = the kernel instantiation mage_gemm dispatches to (mirrors launch_act in csrc/gemm.hip), so that the
         # per-kernel averages line up with rocprofv3's per-symbol statistics
@@ -214,11 +217,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
         else:
             ek = 2
         sp = "true" if n_split > 1 else "false"
-        key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act}, {mt}, {ek}, {sp}>"
+        key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act}, {mt}, {ek}, {sp}, {ln}>"
         a_rows = ((M + out_h * out_w - 1) // (out_h * out_w)) * d.a_img_stride + a_off + 1
         if (d.dtype == BF16 and not gather and mt == 8 and ek != 2 and K % 64 == 0 and a_rows * lda * 2 < 2 ** 32
                 and N * K * 2 < 2 ** 32 and not os.environ.get("MAGE_GEMM_NO_8PHASE")):
-            key = f"gemm8_kernel<{act}, {ek}, {sp}, false>"    # the 8-phase ping-pong variant (launch_tile in csrc/gemm.hip)
+            key = f"gemm8_kernel<{act}, {ek}, {sp}, false, {ln}>"    # the 8-phase ping-pong variant (launch_tile in csrc/gemm.hip)
         # padded-taps convolutions and row-table Linears on the 8-phase kernel (try_taps8 in csrc/gemm.hip)
         ntaps = taps_h * taps_w
         table, plain = rowadd is not None and residual is None, rowadd is None and residual is None
@@ -227,9 +230,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
                 and not post_relu and N % 256 == 0 and M % 256 == 0
                 and not os.environ.get("MAGE_GEMM_NO_8PHASE") and not os.environ.get("MAGE_GEMM_NO_TAPS8")):
             if table and act == ACT_NONE:
-                key = "gemm8_kernel<0, 1, false, true>"
+                key = "gemm8_kernel<0, 1, false, true, 0>"
             elif plain and act in (ACT_NONE, ACT_RELU):
-                key = f"gemm8_kernel<{act}, 0, false, true>"
+                key = f"gemm8_kernel<{act}, 0, false, true, 0>"
         if PROFILE.wants(key):
             ev = PROFILE.begin()
             _lib.check(l.mage_gemm(C.byref(d), s), l)
@@ -237,6 +240,20 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
             return y
     _lib.check(l.mage_gemm(C.byref(d), s), l)
     return y
+
+
+def ln_stats(part: torch.Tensor, C_: int, eps: float, stats: torch.Tensor) -> torch.Tensor:
+    """(mean, rstd) per row from a producer GEMM's partial sums ``part[rows, n_slices, 2]`` (mage_ln_stats)."""
+    l, s = _dev(part)
+    rows, n_slices = part.shape[0], part.shape[1]
+    assert part.dtype == torch.float32 and part.is_contiguous() and stats.is_contiguous() and stats.numel() >= 2 * rows
+    if PROFILE.wants("ln_stats_kernel"):
+        ev = PROFILE.begin()
+        _lib.check(l.mage_ln_stats(part.data_ptr(), rows, n_slices, C_, eps, stats.data_ptr(), s), l)
+        PROFILE.end("ln_stats_kernel", ev, 0.0)
+        return stats
+    _lib.check(l.mage_ln_stats(part.data_ptr(), rows, n_slices, C_, eps, stats.data_ptr(), s), l)
+    return stats
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch.Tensor, eps: float) -> torch.Tensor:

@@ -450,3 +450,61 @@ def test_padded_taps_conv_on_the_8phase_kernel(n_img, Cc, mode):
     want = torch.zeros(n_img, P, P, Cc, dtype=torch.bfloat16)
     want[:, 1:-1, 1:-1] = tab[ids].bfloat16().view(n_img, R, R, Cc)
     assert torch.equal(buf.cpu().view(n_img, P, P, Cc), want)
+
+
+@pytest.mark.parametrize("M", [512, 32768])
+def test_layernorm_folded_around_the_gemms(M):
+    """bf16: the x + Linear(.) GEMM that also writes a bf16 copy of x and per-row partial (sum, sum of squares); mage_ln_stats;
+    the Linear that consumes (copy, stats) with gamma folded into its weights = Linear(LayerNorm(x)) (mage_model.py:35-53).
+    M = 512 runs the lockstep kernel, M = 32768 the 8-phase one; the same rows give the same bits on both."""
+    o = ops()
+    C_, eps = 1024, 1e-5
+    x0 = rnd(M, C_, seed=1) + 0.3
+    ao = rnd(M, C_, seed=2).bfloat16()
+    wo, bo = rnd(C_, C_, seed=3, scale=C_ ** -0.5).bfloat16(), rnd(C_, seed=4, scale=0.1)
+    g, bt = 1.0 + 0.2 * rnd(C_, seed=5), 0.1 * rnd(C_, seed=6)
+    wf, bf = rnd(4 * C_, C_, seed=7, scale=C_ ** -0.5), rnd(4 * C_, seed=8, scale=0.1)
+    xd, aod, wod, bod = x0.to(DEV), ao.to(DEV), wo.to(DEV), bo.to(DEV)
+    # producer against the same GEMM without the extra outputs: the fp32 stream must not change by a bit
+    x_plain = xd.clone()
+    o.gemm(aod, wod, x_plain, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bod, residual=x_plain, ldr=C_)
+    x_new = xd.clone()
+    xb = torch.empty(M, C_, device=DEV, dtype=torch.bfloat16)
+    part = torch.empty(M, C_ // 64, 2, device=DEV, dtype=torch.float32)
+    o.gemm(aod, wod, x_new, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bod, residual=x_new, ldr=C_, y2=xb, ldy2=C_, ln_part=part)
+    assert torch.equal(x_new, x_plain)
+    assert torch.equal(xb, x_new.to(torch.bfloat16))
+    xs = x_new.double().view(M, C_ // 64, 64)
+    torch.testing.assert_close(part[..., 0].double(), xs.sum(-1), atol=1e-4, rtol=1e-5)
+    torch.testing.assert_close(part[..., 1].double(), (xs * xs).sum(-1), atol=1e-3, rtol=1e-5)
+    stats = torch.empty(M, 2, device=DEV, dtype=torch.float32)
+    o.ln_stats(part, C_, eps, stats)
+    mean = x_new.double().mean(-1)
+    var = x_new.double().var(-1, unbiased=False)
+    torch.testing.assert_close(stats[:, 0].double(), mean, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(stats[:, 1].double(), (var + eps).rsqrt(), atol=1e-4, rtol=1e-4)
+    # consumer
+    wq = (wf * g[None, :]).bfloat16()
+    s = wq.float().sum(1)
+    c = (wf.double() @ bt.double() + bf.double()).float()
+    want = F.layer_norm(x_new.cpu().double(), (C_,), g.double(), bt.double(), eps) @ wf.double().t() + bf.double()
+    for act in (o.ACT_NONE, o.ACT_QUICKGELU):
+        y = torch.empty(M, 4 * C_, device=DEV, dtype=torch.bfloat16)
+        o.gemm(xb, wq.to(DEV), y, M=M, N=4 * C_, K=C_, lda=C_, ldy=4 * C_, bias=c.to(DEV), act=act, ln_stats=stats,
+               ln_colsum=s.to(DEV))
+        w_ = want if act == o.ACT_NONE else want * torch.sigmoid(1.702 * want)
+        torch.testing.assert_close(y.cpu().double(), w_, atol=6e-2, rtol=3e-2)
+        # the same rows through the other kernel (fewer rows: lockstep 128-row tiles): bit-identical
+        y_s = torch.empty(256, 4 * C_, device=DEV, dtype=torch.bfloat16)
+        o.gemm(xb[:256], wq.to(DEV), y_s, M=256, N=4 * C_, K=C_, lda=C_, ldy=4 * C_, bias=c.to(DEV), act=act, ln_stats=stats[:256],
+               ln_colsum=s.to(DEV))
+        assert torch.equal(y_s, y[:256])
+    # ... and the producer's extra outputs do not depend on the kernel either
+    x_s = xd[:256].clone()
+    xb_s = torch.empty(256, C_, device=DEV, dtype=torch.bfloat16)
+    part_s = torch.empty(256, C_ // 64, 2, device=DEV, dtype=torch.float32)
+    o.gemm(aod[:256], wod, x_s, M=256, N=C_, K=C_, lda=C_, ldy=C_, bias=bod, residual=x_s, ldr=C_, y2=xb_s, ldy2=C_, ln_part=part_s)
+    assert torch.equal(x_s, x_new[:256]) and torch.equal(xb_s, xb[:256]) and torch.equal(part_s, part[:256])
+    # loud on shapes the folded forms do not take
+    with pytest.raises(Exception):
+        o.gemm(xb[:100], wq.to(DEV), y, M=100, N=4 * C_, K=C_, lda=C_, ldy=4 * C_, bias=c.to(DEV), ln_stats=stats, ln_colsum=s.to(DEV))
