@@ -53,6 +53,9 @@ def hbm_view(key, dom, B, L, d=512):
         return None
     M = B * L * 256
     bytes_per_launch = 0.5 * ((M * d * 2 + 2 * M * d * 4) + (M * 4 * d * 2 + 2 * M * d * 4))          # mean of out_proj and c_proj
+    if key.rstrip(">").endswith(", 1"):
+        # the LayerNorm-producing form also writes the bf16 copy of the stream and the per-row partial (sum, sum of squares)
+        bytes_per_launch += M * d * 2 + M * (d // 64) * 8
     us = dom["ms"] * 1e3 / dom["calls"]
     gbs = bytes_per_launch / (us * 1e-6) / 1e9
     return {"bound": "hbm", "algorithmic_bytes_per_launch": bytes_per_launch, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -279,10 +282,11 @@ def main():
             dom = gemms[dom_key]
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             allf, allms = sum(v["flops"] for v in all_src.values()), sum(v["ms"] for v in all_src.values())
-            roofline = {"bound": "mfma", "kernel": dom_key + "  [gemm8_kernel<act, epilogue kind, split-K>: the 8-phase ping-pong bf16 256x256 GEMM; "
-                                                             "gemm_kernel<dtype, gather, act, m-tiles/wave, epilogue kind, split-K>: the lockstep one.  "
-                                                             "Epilogue kind 1 = x + Linear(.) with the fp32 residual: attention out_proj and "
-                                                             "MLP c_proj of the decoder stack]",
+            roofline = {"bound": "mfma", "kernel": dom_key + "  [gemm8_kernel<act, epilogue kind, split-K, padded taps, LayerNorm fold>: the 8-phase ping-pong bf16 256x256 GEMM; "
+                                                             "gemm_kernel<dtype, gather, act, m-tiles/wave, epilogue kind, split-K, LayerNorm fold>: the "
+                                                             "lockstep one.  Epilogue kind 1 = x + Linear(.) with the fp32 residual: attention out_proj "
+                                                             "and MLP c_proj of the decoder stack; LayerNorm fold 1 = it also writes the bf16 copy of x "
+                                                             "and the row partial sums the next Linear normalises with (2 = that consumer)]",
                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": dom["calls"] // args.steps,
                         "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
