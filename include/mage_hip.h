@@ -345,6 +345,24 @@ int mage_bn_bwd_apply(const float* x, const float* dy, const float* mask, const 
  * (zero outside the image): the gradient of the per-input-pixel tap products of the decoder's ConvTranspose2d head.  y null: grad_y
  * is already the gradient of the pre-tanh sum. */
 int mage_convt_unfold_tanh_bwd(const float* grad_y, const float* y, float* dtaps, int32_t N, int32_t IH, int32_t IW, int32_t cout, void* stream);
+/* Backward of the randomness branch of MAGE.forward (mage_model.py:601-609).
+ * mage_groupnorm_bwd: GroupNorm (+ residual, + ReLU / SiLU) of BasicBlock (:264-297) and of the MAGE+ head (:350-354), the row maps of
+ * mage_groupnorm_act: x rows b*sample_stride_rows + row_off + r (dx is written with the same map; rows outside it are left alone),
+ * dy rows b*dy_sample_stride_rows + dy_row_off + r, residual / dres packed (b*rows_per_sample + r).  stats = the forward's (mean, rstd)
+ * [n_samples, groups, 2]; red = workspace of that shape; dgamma_part / dbeta_part [n_samples, C] are per-sample sums (the caller adds
+ * them over samples).  Channels per group must divide 256.
+ * mage_adain_bwd: ADAIN2D (:299-314) out = gamma_map * InstanceNorm(x) + beta_map: dx and dgamma_map = dout * xhat (dbeta_map = dout).
+ * mage_reparam_kl_bwd: reparameterize (:569-573) + the KL term (:623): dmu = dz + c mu, dlogvar = dz eps exp(logvar/2)/2 - c (1 - exp(logvar))/2
+ * with c = coef[0] = dL/dkl / B (a device scalar). */
+int mage_groupnorm_bwd(const float* x, int64_t sample_stride_rows, int64_t row_off, int32_t n_samples, int32_t rows_per_sample, int32_t C,
+                       int32_t groups, const float* stats, const float* gamma, const float* beta, const float* residual, int32_t act,
+                       const float* dy, int64_t dy_sample_stride_rows, int64_t dy_row_off, float* red, float* dx, float* dres,
+                       float* dgamma_part, float* dbeta_part, void* stream);
+int mage_adain_bwd(const float* x, const float* gamma_map, const float* dout, float* dx, float* dgamma_map, int32_t B, int32_t P, int32_t C,
+                   float eps, void* stream);
+int mage_reparam_kl_bwd(const float* mu, const float* logvar, const float* eps, const float* dz, const float* coef, float* dmu, float* dlogvar,
+                        int64_t n, void* stream);
+
 /* torch.optim.Adam step (main_mage.py:121: betas (0.9, 0.98), eps 1e-6) over flat fp32 arenas; grad_scale multiplies the gradient
  * first (1 / world_size after a summing reduce-scatter). */
 int mage_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int32_t step,

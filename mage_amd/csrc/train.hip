@@ -855,3 +855,194 @@ extern "C" int mage_adam(float* p, const float* g, float* m, float* v, int64_t n
     MAGE_CHECK_LAUNCH("mage_adam");
     return MAGE_OK;
 }
+
+// =================================================================================================================================
+// Backward of the randomness branch of MAGE.forward (mage_model.py:601-609): GroupNorm of the Conv3d video prior (:264-297), the
+// instance norm of ADAIN2D (:299-314), the reparameterisation + KL term (:569-573, :623).
+// =================================================================================================================================
+namespace {
+
+// d act(t) / dt * dy;  act: 0 none, 1 ReLU, 2 SiLU
+__device__ __forceinline__ float gn_dact(int act, float t, float dy) {
+    if (act == 1) return t > 0.f ? dy : 0.f;
+    if (act == 2) {
+        const float sg = 1.0f / (1.0f + expf(-t));
+        return dy * sg * (1.0f + t * (1.0f - sg));
+    }
+    return dy;
+}
+
+// y = act(xhat * gamma + beta + residual), xhat = (x - mean_{b,g}) * rstd_{b,g}.  With g = dy * act'(.):
+//   dgamma_c = sum_{b,r} g xhat,  dbeta_c = sum_{b,r} g,  dx = rstd (gamma g - m1 - xhat m2),  m1 = mean_{(b,g)}(gamma g), m2 = mean(gamma g xhat).
+// Pass 1: one workgroup per (sample, group); thread = (channel of the group, row phase); writes the per-(sample, channel) sums
+// (fixed order) and red[b][g] = (m1, m2).  Row maps: x rows b*xs + xo + r, dy rows b*ds + dof + r, residual packed b*rows + r.
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, long xs, long xo, int rows_per_sample, int C, int groups,
+                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ residual, int act,
+                                                            const float* __restrict__ dy, long ds, long dof, float* __restrict__ red,
+                                                            float* __restrict__ dgam_part, float* __restrict__ dbet_part) {
+    __shared__ double sm[2][256];
+    const int b = blockIdx.x, g = blockIdx.y, cpg = C / groups;
+    const int cl = threadIdx.x % cpg, ph = threadIdx.x / cpg, nph = 256 / cpg;
+    const int c = g * cpg + cl;
+    const float mean = stats[((long)b * groups + g) * 2], rstd = stats[((long)b * groups + g) * 2 + 1];
+    const float gm = gamma[c], bt = beta[c];
+    double sg = 0.0, sgx = 0.0;
+    for (int r = ph; r < rows_per_sample; r += nph) {
+        const float xh = (x[((long)b * xs + xo + r) * C + c] - mean) * rstd;
+        float t = xh * gm + bt;
+        if (residual) t += residual[((long)b * rows_per_sample + r) * C + c];
+        const float ge = gn_dact(act, t, dy[((long)b * ds + dof + r) * C + c]);
+        sg += (double)ge;
+        sgx += (double)ge * (double)xh;
+    }
+    sm[0][threadIdx.x] = sg;
+    sm[1][threadIdx.x] = sgx;
+    __syncthreads();
+    if (threadIdx.x < cpg) {
+        double a = 0.0, q = 0.0;
+        for (int p = 0; p < nph; ++p) {
+            a += sm[0][p * cpg + threadIdx.x];
+            q += sm[1][p * cpg + threadIdx.x];
+        }
+        dbet_part[(long)b * C + c] = (float)a;
+        dgam_part[(long)b * C + c] = (float)q;
+        sm[0][threadIdx.x] = a * (double)gm;
+        sm[1][threadIdx.x] = q * (double)gm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, q = 0.0;
+        for (int i = 0; i < cpg; ++i) {
+            a += sm[0][i];
+            q += sm[1][i];
+        }
+        const double n = (double)rows_per_sample * cpg;
+        red[((long)b * groups + g) * 2] = (float)(a / n);
+        red[((long)b * groups + g) * 2 + 1] = (float)(q / n);
+    }
+}
+
+// Pass 2 (elementwise): dx rows in x's row map; dres (optional, packed) = g.
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, long xs, long xo, int rows_per_sample, int C, int groups,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ residual, int act,
+                                                           const float* __restrict__ dy, long ds, long dof, const float* __restrict__ red,
+                                                           float* __restrict__ dx, float* __restrict__ dres, long total) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    const long orow = i / C;
+    const int c = (int)(i - orow * C);
+    const long b = orow / rows_per_sample, r = orow - b * rows_per_sample;
+    const int cpg = C / groups;
+    const f32x4 v = *(const f32x4*)(x + ((b * xs + xo + r) * C + c));
+    const f32x4 gy = *(const f32x4*)(dy + ((b * ds + dof + r) * C + c));
+    const f32x4 gm = *(const f32x4*)(gamma + c), bt = *(const f32x4*)(beta + c);
+    f32x4 res = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (residual) res = *(const f32x4*)(residual + i);
+    f32x4 o, ge4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long sg = (b * groups + (c + e) / cpg) * 2;
+        const float mean = stats[sg], rstd = stats[sg + 1];
+        const float xh = (v[e] - mean) * rstd;
+        const float ge = gn_dact(act, xh * gm[e] + bt[e] + res[e], gy[e]);
+        ge4[e] = ge;
+        o[e] = rstd * (gm[e] * ge - red[sg] - xh * red[sg + 1]);
+    }
+    *(f32x4*)(dx + ((b * xs + xo + r) * C + c)) = o;
+    if (dres) *(f32x4*)(dres + i) = ge4;
+}
+
+// out = gamma_map * IN(x) + beta_map over the P positions of (b, c) (adain_kernel in norm_attn.hip).  Given dout:
+//   dgamma_map = dout * xhat, dbeta_map = dout (no kernel), dx = rstd (g - mean_p(g) - xhat mean_p(g xhat)), g = dout * gamma_map.
+// grid = (B, C/64); block 256 = 64 channels x 4 position phases.
+__global__ __launch_bounds__(256) void adain_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gmap, const float* __restrict__ dout,
+                                                        float* __restrict__ dx, float* __restrict__ dgmap, int P, int C, float eps) {
+    __shared__ float red[4][4][64];
+    const int b = blockIdx.x, cl = threadIdx.x & 63, c = blockIdx.y * 64 + cl, ph = threadIdx.x >> 6;
+    const long base = (long)b * P * C + c;
+    float s = 0.f;
+    for (int p = ph; p < P; p += 4) s += x[base + (long)p * C];
+    red[0][ph][cl] = s;
+    __syncthreads();
+    const float mean = (red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]) / (float)P;
+    float q = 0.f;
+    for (int p = ph; p < P; p += 4) {
+        const float dlt = x[base + (long)p * C] - mean;
+        q += dlt * dlt;
+    }
+    red[1][ph][cl] = q;
+    __syncthreads();
+    const float var = (red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]) / (float)P;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = ph; p < P; p += 4) {
+        const long i = base + (long)p * C;
+        const float xh = (x[i] - mean) * rstd, g = dout[i] * gmap[i];
+        s1 += g;
+        s2 += g * xh;
+    }
+    red[2][ph][cl] = s1;
+    red[3][ph][cl] = s2;
+    __syncthreads();
+    const float m1 = (red[2][0][cl] + red[2][1][cl] + red[2][2][cl] + red[2][3][cl]) / (float)P;
+    const float m2 = (red[3][0][cl] + red[3][1][cl] + red[3][2][cl] + red[3][3][cl]) / (float)P;
+    for (int p = ph; p < P; p += 4) {
+        const long i = base + (long)p * C;
+        const float xh = (x[i] - mean) * rstd, go = dout[i];
+        dgmap[i] = go * xh;
+        dx[i] = rstd * (go * gmap[i] - m1 - xh * m2);
+    }
+}
+
+// z = eps exp(logvar / 2) + mu; kl = -1/2 mean_b sum(1 + logvar - mu^2 - exp(logvar)).  With dz and c = dL/dkl / B:
+//   dmu = dz + c mu,  dlogvar = dz eps exp(logvar / 2) / 2 - c (1 - exp(logvar)) / 2
+__global__ void reparam_kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, const float* __restrict__ eps,
+                                      const float* __restrict__ dz, const float* __restrict__ coef, float* __restrict__ dmu,
+                                      float* __restrict__ dlogvar, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float c = coef[0], lv = logvar[i];
+    dmu[i] = dz[i] + c * mu[i];
+    dlogvar[i] = 0.5f * dz[i] * eps[i] * expf(0.5f * lv) - 0.5f * c * (1.0f - expf(lv));
+}
+
+}  // namespace
+
+extern "C" int mage_groupnorm_bwd(const float* x, int64_t sample_stride_rows, int64_t row_off, int32_t n_samples, int32_t rows_per_sample,
+                                  int32_t C, int32_t groups, const float* stats, const float* gamma, const float* beta, const float* residual,
+                                  int32_t act, const float* dy, int64_t dy_sample_stride_rows, int64_t dy_row_off, float* red, float* dx,
+                                  float* dres, float* dgamma_part, float* dbeta_part, void* stream) {
+    MAGE_CHECK_ARG(x && stats && gamma && beta && dy && red && dx && dgamma_part && dbeta_part, "mage_groupnorm_bwd: null pointer");
+    MAGE_CHECK_ARG(n_samples > 0 && rows_per_sample > 0 && groups > 0 && C % groups == 0 && C % 4 == 0 && (C / groups) <= 256 &&
+                       256 % (C / groups) == 0 && act >= 0 && act <= 2,
+                   "mage_groupnorm_bwd: C=%d groups=%d act=%d unsupported (channels per group must divide 256)", C, groups, act);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(n_samples, groups), dim3(256), 0, s, x, (long)sample_stride_rows, (long)row_off, rows_per_sample,
+                       C, groups, stats, gamma, beta, residual, act, dy, (long)dy_sample_stride_rows, (long)dy_row_off, red, dgamma_part,
+                       dbeta_part);
+    const long total = (long)n_samples * rows_per_sample * C;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, x, (long)sample_stride_rows,
+                       (long)row_off, rows_per_sample, C, groups, stats, gamma, beta, residual, act, dy, (long)dy_sample_stride_rows,
+                       (long)dy_row_off, red, dx, dres, total);
+    MAGE_CHECK_LAUNCH("mage_groupnorm_bwd");
+    return MAGE_OK;
+}
+
+extern "C" int mage_adain_bwd(const float* x, const float* gamma_map, const float* dout, float* dx, float* dgamma_map, int32_t B, int32_t P,
+                              int32_t C, float eps, void* stream) {
+    MAGE_CHECK_ARG(x && gamma_map && dout && dx && dgamma_map && B > 0 && P > 0 && C > 0 && C % 64 == 0, "mage_adain_bwd: bad arguments");
+    hipLaunchKernelGGL(adain_bwd_kernel, dim3(B, C / 64), dim3(256), 0, (hipStream_t)stream, x, gamma_map, dout, dx, dgamma_map, P, C, eps);
+    MAGE_CHECK_LAUNCH("mage_adain_bwd");
+    return MAGE_OK;
+}
+
+extern "C" int mage_reparam_kl_bwd(const float* mu, const float* logvar, const float* eps, const float* dz, const float* coef, float* dmu,
+                                   float* dlogvar, int64_t n, void* stream) {
+    MAGE_CHECK_ARG(mu && logvar && eps && dz && coef && dmu && dlogvar && n > 0, "mage_reparam_kl_bwd: bad arguments");
+    hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mu, logvar, eps, dz, coef, dmu,
+                       dlogvar, (long)n);
+    MAGE_CHECK_LAUNCH("mage_reparam_kl_bwd");
+    return MAGE_OK;
+}

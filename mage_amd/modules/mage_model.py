@@ -969,13 +969,15 @@ class MAGE(nn.Module):
     # ------------------------------------------------------------------ teacher-forced pass (mage_model.py:575-639)
     @torch.no_grad()
     @torch.no_grad()
-    def _video_prior(self, tok: Optional[torch.Tensor], lat_rows: Optional[torch.Tensor] = None, B: int = 0, L: int = 0) -> torch.Tensor:
+    def _video_prior(self, tok: Optional[torch.Tensor], lat_rows: Optional[torch.Tensor] = None, B: int = 0, L: int = 0,
+                     tape: Optional[list] = None) -> torch.Tensor:
         """self.conv3d over the token embeddings of ALL frames (mage_model.py:496-501,602-603): tok int64 [B, L, hw] (or, for
         use_cids=False, lat_rows [B*L*hw, 8] fp32 latents whose Linear(E -> C) embedding is taken) -> rows [B*hw, d_model] fp32.  Each Conv3d(3x3x3, temporal stride s, pad 1) is three implicit-GEMM launches, one per temporal tap,
         accumulating in place: the block input lives in a zero-padded frame buffer in which clip b owns frames
         [b*Lp, (b+1)*Lp) (frame 0 = the leading zero pad) with Lp = s * (virtual output frames per clip), so that output image
         i' = b*Lv + t' gathers from frame s*i' + kd: one affine image stride for the whole batch, the clip boundaries and the
-        temporal padding are zero frames.  The Lv - Lout virtual frames per clip are never normalised or read."""
+        temporal padding are zero frames.  The Lv - Lout virtual frames per clip are never normalised or read.
+        `tape` (a list, training path): receives per block what the backward pass needs (modules/mage_train_prior.py)."""
         d = self._derived.get(self._build)
         R, Cc = self.image_resolution, self.vision_width
         hw = R * R
@@ -1007,24 +1009,31 @@ class MAGE(nn.Module):
             Lout = (Lin + 1) // 2
             Lv = Lout + 1
             gn = dict(n_samples=B, rows_per_sample=Lout * hw, groups=16)
+            st1, std, st2 = (torch.empty(B, 16, 2, device=dev, dtype=F32) for _ in range(3))
             c1 = conv3(xa, f"p{i}.c1", Lv, 2, cin, cout)
             cd = conv3(xa, f"p{i}.ds", Lv, 2, cin, cout)
             xb = torch.zeros((B * (Lout + 2) + 2) * hw, cout, device=dev, dtype=F32)           # conv2 input: stride-1 layout
             ops.groupnorm_act(c1, d[f"p{i}.g1.w"], d[f"p{i}.g1.b"], xb, sample_stride_rows=Lv * hw, row_off=0, eps=blk.bn1.eps,
-                              act=1, y_sample_stride_rows=(Lout + 2) * hw, y_row_off=hw, **gn)
+                              act=1, y_sample_stride_rows=(Lout + 2) * hw, y_row_off=hw, stats=st1, **gn)
             res = ops.groupnorm_act(cd, d[f"p{i}.gd.w"], d[f"p{i}.gd.b"], torch.empty(B * Lout * hw, cout, device=dev, dtype=F32),
-                                    sample_stride_rows=Lv * hw, row_off=0, eps=blk.downsample[1].eps, act=0, **gn)
+                                    sample_stride_rows=Lv * hw, row_off=0, eps=blk.downsample[1].eps, act=0, stats=std, **gn)
             c2 = conv3(xb, f"p{i}.c2", Lout + 2, 1, cout, cout)
             if i + 1 < len(self.conv3d):                                                       # next block's stride-2 input
                 Lp2 = 2 * ((Lout + 1) // 2 + 1)
                 nxt = torch.zeros((B * Lp2 + 1) * hw, cout, device=dev, dtype=F32)
                 ops.groupnorm_act(c2, d[f"p{i}.g2.w"], d[f"p{i}.g2.b"], nxt, sample_stride_rows=(Lout + 2) * hw, row_off=0,
-                                  eps=blk.bn2.eps, act=1, residual=res, y_sample_stride_rows=Lp2 * hw, y_row_off=hw, **gn)
+                                  eps=blk.bn2.eps, act=1, residual=res, y_sample_stride_rows=Lp2 * hw, y_row_off=hw, stats=st2, **gn)
+                out_map = (Lp2 * hw, hw)
             else:
                 if Lout != 1:
                     raise ValueError(f"the Conv3d video prior needs 9 <= frames <= 16 to collapse to one frame (got {L})")
                 nxt = ops.groupnorm_act(c2, d[f"p{i}.g2.w"], d[f"p{i}.g2.b"], torch.empty(B * hw, cout, device=dev, dtype=F32),
-                                        sample_stride_rows=(Lout + 2) * hw, row_off=0, eps=blk.bn2.eps, act=1, residual=res, **gn)
+                                        sample_stride_rows=(Lout + 2) * hw, row_off=0, eps=blk.bn2.eps, act=1, residual=res, stats=st2,
+                                        **gn)
+                out_map = (hw, 0)
+            if tape is not None:
+                tape.append(dict(xa=xa, c1=c1, cd=cd, xb=xb, c2=c2, res=res, st1=st1, std=std, st2=st2, Lin=Lin, Lout=Lout, Lv=Lv, cin=cin,
+                                 cout=cout, out_map=out_map))
             xa, cin, Lin = nxt, cout, Lout
         return xa
 
@@ -1101,22 +1110,21 @@ class MAGE(nn.Module):
             byname = dict(self.named_parameters())
             loss = mage_train.MageLossFn.apply(self, batch, names, *[byname[n] for n in names])
             prefix = "train" if self.training else "val"
-            val = loss.detach().item()
             ops.check_device_errors(batch["images"].device)
-        return loss, {f"{prefix}/prediction": val, f"{prefix}/final_loss": val}
+        return loss, {f"{prefix}/{k}": v for k, v in self._last_train_parts.items()}
 
     def forward(self, batch, test_flag=False):
         """(loss, loss_dict) of the teacher-forced pass (mage_model.py:575-639), incl. the randomness=True terms (KL of the
         reparameterised video prior, the PID-controlled or fixed beta, the speed-embedding l2).  batch['reparam_noise']
         [B,64,h,w] optionally injects the reparameterisation noise.  Under ``torch.no_grad()``: values only.  In grad mode (any
         parameter requiring grad): the returned loss carries an autograd node backed by the HIP backward kernels
-        (modules/mage_train.py; use_cids=True, randomness=False configs), so ``loss.backward(); optimizer.step()`` works."""
+        (modules/mage_train.py, mage_train_prior.py: the use_cids=True configs, with or without the randomness branch), so
+        ``loss.backward(); optimizer.step()`` works."""
         if test_flag and self.randomness:
             raise NotImplementedError("forward(test_flag=True) replaces the video embedding by noise AFTER computing it; use "
                                       "autoregressive_generate for sampling")
-        if (torch.is_grad_enabled() and self.use_cids and not self.randomness
-                and any(p.requires_grad for p in self.parameters())):
-            return self._forward_with_graph(batch)        # other configs: loss VALUES only (no autograd node yet)
+        if torch.is_grad_enabled() and self.use_cids and any(p.requires_grad for p in self.parameters()):
+            return self._forward_with_graph(batch)        # MAGE+ (use_cids=False): loss VALUES only (no autograd node yet)
         extras: dict = {}
         L = self.frames_length
         if self.use_cids:

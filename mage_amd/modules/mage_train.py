@@ -11,8 +11,9 @@ tokens into a small [N, K] matrix, so both operands are transposed once (mage_tr
 (mage_gemm n_split) whose partials are summed in a fixed order.  LayerNorm / attention / activation / cross-entropy backward,
 the embedding scatter and the positional-table reductions are the kernels of csrc/train.hip.
 
-Built for the use_cids=True, randomness=False family (config of BASELINE cfg1-3: MNIST f4 VQ-VAE + MAGE); the first stage
-is frozen, as in the reference (mage_model.py:516-521).  Dropout (training mode only) is a stateless mask recomputed in the
+Built for the use_cids=True family: the MNIST configs of BASELINE cfg1-3 and, with the randomness branch of
+modules/mage_train_prior.py (Conv3d video prior, reparameterisation + KL, ADAIN), config/mage_caterv1.yaml / mage_caterv2.yaml; the
+first stage is frozen, as in the reference (mage_model.py:516-521).  Dropout (training mode only) is a stateless mask recomputed in the
 backward pass from a per-call seed.
 """
 from __future__ import annotations
@@ -424,9 +425,9 @@ def _text_backward(te, run32: _Run, tape, dout, grads, pre: str = "text_encoder"
 def train_forward(model, batch):
     """Teacher-forced pass of MAGE.forward (mage_model.py:575-639) with the activations the backward pass needs.
     Returns (loss 0-dim fp32 tensor, tape)."""
-    if not model.use_cids or model.randomness:
-        raise NotImplementedError("the HIP training backward is built for use_cids=True, randomness=False (MNIST-family configs); "
-                                  "run this config under torch.no_grad() for loss values")
+    if not model.use_cids:
+        raise NotImplementedError("the HIP training backward is built for the use_cids=True configs (MAGE; with or without the "
+                                  "randomness branch); run MAGE+ configs under torch.no_grad() for loss values")
     images = batch["images"]
     B = images.shape[0]
     R, L, Cc = model.image_resolution, model.frames_length, model.vision_width
@@ -449,6 +450,10 @@ def train_forward(model, batch):
     txt, t_text = _text_forward(model.text_encoder, run32, batch["text"])
     S = batch["text"].shape[1]
     ma, t_ma = _ma_forward(model.ma_encoder, run32, first, txt, B, hw, S)
+    t_rand = None
+    if model.randomness:                                                     # :601-609: ADAIN modulation by the reparameterised video prior
+        from . import mage_train_prior
+        ma, t_rand = mage_train_prior.rand_forward(model, batch, tok, ma, B)
     speed = None
     if "speed" in batch:
         speed = batch["speed"].float().contiguous()
@@ -457,9 +462,26 @@ def train_forward(model, batch):
     ma_dt = ma if dt == F32 else ma.to(dt)
     logits, t_dec = _dec_forward(model.generate_model, run, ma_dt, feats, B, R, R)
     target = tok[:, 1:L].reshape(-1).contiguous()
-    loss = ops.cross_entropy(logits, target)
+    recon = ops.cross_entropy(logits, target)
+    loss, parts = recon, {"prediction": recon.item()}
+    beta = alpha = 0.0
+    if model.randomness:                                                     # :622-632 ([B]-element reductions and scalars)
+        kl = -0.5 * t_rand["kl_sum"].mean()
+        parts["kl_loss"] = kl.item()
+        if model.auto_beta:
+            model.beta, _ = model.PID.pid(model.KL_loss, parts["kl_loss"])
+            parts["beta"] = model.beta
+            beta = float(model.beta)
+            loss = recon + beta * kl
+        else:
+            if speed is None:
+                raise KeyError("MAGE.forward with randomness=True and auto_beta=False needs batch['speed'] (mage_model.py:631)")
+            beta, alpha = float(model.beta), float(model.alpha)
+            l2 = (speed ** 2).mean() * (d["speed"] ** 2).sum()
+            loss = recon + beta * kl + alpha * l2
+    parts["final_loss"] = loss.item()
     tape = dict(run=run, run32=run32, tok_in=tok_in, tok0=tok0, emb=emb, emb0=emb0, text=t_text, ma=t_ma, dec=t_dec, logits=logits,
-                target=target, speed=speed, B=B)
+                target=target, speed=speed, B=B, rand=t_rand, beta=beta, alpha=alpha, parts=parts)
     return loss, tape
 
 
@@ -482,7 +504,15 @@ def train_backward(model, tape, grad_out: torch.Tensor) -> Dict[str, torch.Tenso
     if tape["speed"] is not None:                                            # ma += speed_b * speed_embedding  (:666-668)
         gs = ops.group_rowsum(dma, torch.empty(1, Cc, device=dev, dtype=F32), rows=B * hw, C=Cc, div=1, mod=1, row_scale=tape["speed"],
                               row_scale_div=hw)
+        if tape["alpha"] != 0.0:                                             # alpha * mean_b(speed_b^2) * |speed_embedding|^2  (:631)
+            d = model._derived.get(model._build)
+            gs = gs + (2.0 * tape["alpha"]) * gout * (tape["speed"] ** 2).mean() * d["speed"].view(1, Cc)
         grads["speed_embedding"] = gs
+    if tape["rand"] is not None:
+        from . import mage_train_prior
+        kl_coef = (gout * (tape["beta"] / B)).contiguous()
+        dma = mage_train_prior.rand_backward(model, tape["rand"], dma, kl_coef, grads, acc)
+        tape["rand"] = None
     dfirst, dtxt = _ma_backward(model.ma_encoder, run32, tape["ma"], dma, grads)
     _text_backward(model.text_encoder, run32, tape["text"], dtxt, grads)
     _frame_backward(model, F32, tape["tok0"].reshape(-1), tape["emb0"], dfirst, grads, acc)
@@ -507,6 +537,7 @@ class MageLossFn(torch.autograd.Function):
     def forward(ctx, model, batch, names, *params):
         with torch.no_grad():
             loss, tape = train_forward(model, batch)
+        model._last_train_parts = tape["parts"]                              # the reference's loss_dict values (without the prefix)
         ctx.model, ctx.tape, ctx.names, ctx.shapes = model, tape, names, [p.shape for p in params]
         ctx.devices = [p.device for p in params]
         return loss.clone()

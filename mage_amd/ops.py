@@ -424,14 +424,15 @@ def groupnorm_silu(x, gamma, beta, y, *, n_samples, rows_per_sample, sample_stri
 
 
 def groupnorm_act(x, gamma, beta, y, *, n_samples, rows_per_sample, sample_stride_rows, row_off, groups, eps=1e-5, act=0,
-                  residual=None, y_sample_stride_rows=None, y_row_off=0):
+                  residual=None, y_sample_stride_rows=None, y_row_off=0, stats=None):
     """y rows (b*y_sample_stride_rows + y_row_off + r) = act(GroupNorm(x rows (b*sample_stride_rows + row_off + r)) + residual);
     act 0 none / 1 ReLU / 2 SiLU (see mage_hip.h)."""
     l, s = _dev(x)
     assert x.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous()
     assert residual is None or (residual.dtype == torch.float32 and residual.is_contiguous())
     Cc = x.shape[-1]
-    stats = torch.empty(n_samples, groups, 2, device=x.device, dtype=torch.float32)
+    if stats is None:                                   # (mean, rstd) per (sample, group): kept by the training path for the backward
+        stats = torch.empty(n_samples, groups, 2, device=x.device, dtype=torch.float32)
     _lib.check(l.mage_groupnorm_act(x.data_ptr(), sample_stride_rows, row_off, n_samples, rows_per_sample, Cc, groups,
                                     gamma.data_ptr(), beta.data_ptr(), float(eps), stats.data_ptr(), _p(residual), act, y.data_ptr(),
                                     code(y), rows_per_sample if y_sample_stride_rows is None else y_sample_stride_rows, y_row_off, s), l)
@@ -447,6 +448,46 @@ def reparam_kl(mu, logvar, eps, out, kl_sum):
         assert t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == B * n
     _lib.check(l.mage_reparam_kl(mu.data_ptr(), logvar.data_ptr(), eps.data_ptr(), out.data_ptr(), kl_sum.data_ptr(), B, n, s), l)
     return out
+
+
+def groupnorm_bwd(x, gamma, beta, stats, dy, dx, *, n_samples, rows_per_sample, sample_stride_rows, row_off, groups, act=0, residual=None,
+                  dy_sample_stride_rows=None, dy_row_off=0, want_dres=False):
+    """Backward of groupnorm_act (same row maps): writes dx (x's row map; other rows untouched), returns (dgamma [C], dbeta [C], dres|None)."""
+    l, s = _dev(x)
+    Cc = x.shape[-1]
+    for t_ in (x, dy, dx, stats):
+        assert t_.dtype == torch.float32 and t_.is_contiguous()
+    dev = x.device
+    red = torch.empty(n_samples, groups, 2, device=dev, dtype=torch.float32)
+    dgp = torch.empty(n_samples, Cc, device=dev, dtype=torch.float32)
+    dbp = torch.empty(n_samples, Cc, device=dev, dtype=torch.float32)
+    dres = torch.empty(n_samples * rows_per_sample, Cc, device=dev, dtype=torch.float32) if want_dres else None
+    _lib.check(l.mage_groupnorm_bwd(x.data_ptr(), sample_stride_rows, row_off, n_samples, rows_per_sample, Cc, groups, stats.data_ptr(),
+                                    gamma.data_ptr(), beta.data_ptr(), _p(residual), act, dy.data_ptr(),
+                                    rows_per_sample if dy_sample_stride_rows is None else dy_sample_stride_rows, dy_row_off,
+                                    red.data_ptr(), dx.data_ptr(), _p(dres), dgp.data_ptr(), dbp.data_ptr(), s), l)
+    if n_samples == 1:
+        return dgp[0], dbp[0], dres
+    dg = sum_partials(dgp, torch.empty(Cc, device=dev, dtype=torch.float32), stride=Cc, n_part=n_samples, n=Cc)
+    db = sum_partials(dbp, torch.empty(Cc, device=dev, dtype=torch.float32), stride=Cc, n_part=n_samples, n=Cc)
+    return dg, db, dres
+
+
+def adain_bwd(x, gamma_map, dout, *, B, P, Cc, eps=1e-5):
+    """Backward of adain: (dx, dgamma_map); dbeta_map is dout itself."""
+    l, s = _dev(x)
+    dx, dg = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(l.mage_adain_bwd(x.data_ptr(), gamma_map.data_ptr(), dout.data_ptr(), dx.data_ptr(), dg.data_ptr(), B, P, Cc, float(eps), s), l)
+    return dx, dg
+
+
+def reparam_kl_bwd(mu, logvar, eps, dz, coef):
+    """(dmu, dlogvar) of z = eps exp(logvar/2) + mu and the KL term; coef = 1-element fp32 device tensor dL/dkl / B."""
+    l, s = _dev(mu)
+    dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+    _lib.check(l.mage_reparam_kl_bwd(mu.data_ptr(), logvar.data_ptr(), eps.data_ptr(), dz.data_ptr(), coef.data_ptr(), dmu.data_ptr(),
+                                     dlv.data_ptr(), mu.numel(), s), l)
+    return dmu, dlv
 
 
 def mse(a, b, *, rows, cols, lda, ldb):

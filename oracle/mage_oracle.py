@@ -249,7 +249,13 @@ def adain(sd: SD, motion: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
     """Sampling-time randomness branch (mage_model.py:660-664, ADAIN2D :299-314).
     motion [B,H,W,C]; noise [B,64,H,W] is injected (the reference draws torch.randn)."""
     y = F.conv2d(noise, sd["conv_d2.weight"], None, padding=1)
-    m = F.instance_norm(motion.permute(0, 3, 1, 2))
+    # nn.InstanceNorm2d(affine=False) written out (biased variance, eps 1e-5): F.instance_norm's CPU BACKWARD is wrong for a batch
+    # of one (checked against the closed form and against autograd of this expression), and the training tests differentiate
+    # through the oracle; the forward values are the same
+    mp = motion.permute(0, 3, 1, 2).contiguous()                          # :606
+    mean = mp.mean(dim=(2, 3), keepdim=True)
+    var = mp.var(dim=(2, 3), unbiased=False, keepdim=True)
+    m = (mp - mean) / torch.sqrt(var + 1e-5)
     gam = F.conv2d(F.conv2d(y, sd["adain.conv_mu.0.weight"], sd["adain.conv_mu.0.bias"], padding=1),
                    sd["adain.conv_mu.1.weight"], sd["adain.conv_mu.1.bias"], padding=1)
     bet = F.conv2d(F.conv2d(y, sd["adain.conv_var.0.weight"], sd["adain.conv_var.0.bias"], padding=1),
@@ -327,7 +333,7 @@ def basic_block(sd: SD, p: str, x: torch.Tensor, stride_t: int = 2) -> torch.Ten
 def video_prior(sd: SD, x_emb: torch.Tensor) -> torch.Tensor:
     """self.conv3d (mage_model.py:496-501,602-603): four temporal-stride-2 BasicBlocks over the token embeddings of ALL frames,
     [B,L,C,h,w] -> [B,C,h,w] (L in 9..16 collapses to one frame; squeeze(2))."""
-    v = x_emb.permute(0, 2, 1, 3, 4)
+    v = x_emb.permute(0, 2, 1, 3, 4).contiguous()                        # :602
     for i in range(4):
         v = basic_block(sd, f"conv3d.{i}.", v, 2)
     return v.squeeze(2)
