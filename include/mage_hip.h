@@ -362,6 +362,10 @@ int mage_adain_bwd(const float* x, const float* gamma_map, const float* dout, fl
                    float eps, void* stream);
 int mage_reparam_kl_bwd(const float* mu, const float* logvar, const float* eps, const float* dz, const float* coef, float* dmu, float* dlogvar,
                         int64_t n, void* stream);
+/* da = d mean((a - b)^2) / da * gout[0] over the first `cols` columns (zeros in the padding columns up to ld_da): backward of mage_mse
+ * (F.mse_loss of the MAGE+ latent prediction, mage_model.py:620). */
+int mage_mse_bwd(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t cols, const float* gout, float* da,
+                 int64_t ld_da, void* stream);
 
 /* torch.optim.Adam step (main_mage.py:121: betas (0.9, 0.98), eps 1e-6) over flat fp32 arenas; grad_scale multiplies the gradient
  * first (1 / world_size after a summing reduce-scatter). */

@@ -1046,3 +1046,26 @@ extern "C" int mage_reparam_kl_bwd(const float* mu, const float* logvar, const f
     MAGE_CHECK_LAUNCH("mage_reparam_kl_bwd");
     return MAGE_OK;
 }
+
+// d mean((a - b)^2) / da = 2 (a - b) / (rows * cols) * gout for the first `cols` columns of each row of a (row stride lda), zero for the
+// padding columns up to ld_da (F.mse_loss of the MAGE+ latent prediction, mage_model.py:620).
+namespace {
+__global__ void mse_bwd_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb, long rows, int cols,
+                               const float* __restrict__ gout, float* __restrict__ da, long ld_da, float inv_n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * ld_da) return;
+    const long r = i / ld_da;
+    const int c = (int)(i - r * ld_da);
+    da[i] = c < cols ? 2.0f * (a[r * lda + c] - b[r * ldb + c]) * inv_n * gout[0] : 0.f;
+}
+}  // namespace
+
+extern "C" int mage_mse_bwd(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t cols, const float* gout, float* da,
+                            int64_t ld_da, void* stream) {
+    MAGE_CHECK_ARG(a && b && gout && da && rows > 0 && cols > 0 && ld_da >= cols, "mage_mse_bwd: bad arguments");
+    const long n = rows * ld_da;
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, (long)lda, b, (long)ldb, (long)rows,
+                       cols, gout, da, (long)ld_da, (float)(1.0 / ((double)rows * cols)));
+    MAGE_CHECK_LAUNCH("mage_mse_bwd");
+    return MAGE_OK;
+}

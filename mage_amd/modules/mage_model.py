@@ -1118,13 +1118,13 @@ class MAGE(nn.Module):
         reparameterised video prior, the PID-controlled or fixed beta, the speed-embedding l2).  batch['reparam_noise']
         [B,64,h,w] optionally injects the reparameterisation noise.  Under ``torch.no_grad()``: values only.  In grad mode (any
         parameter requiring grad): the returned loss carries an autograd node backed by the HIP backward kernels
-        (modules/mage_train.py, mage_train_prior.py: the use_cids=True configs, with or without the randomness branch), so
+        (modules/mage_train.py, mage_train_prior.py: every config family -- MNIST, CATER with the randomness branch, MAGE+), so
         ``loss.backward(); optimizer.step()`` works."""
         if test_flag and self.randomness:
             raise NotImplementedError("forward(test_flag=True) replaces the video embedding by noise AFTER computing it; use "
                                       "autoregressive_generate for sampling")
-        if torch.is_grad_enabled() and self.use_cids and any(p.requires_grad for p in self.parameters()):
-            return self._forward_with_graph(batch)        # MAGE+ (use_cids=False): loss VALUES only (no autograd node yet)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_with_graph(batch)
         extras: dict = {}
         L = self.frames_length
         if self.use_cids:

@@ -11,9 +11,11 @@ tokens into a small [N, K] matrix, so both operands are transposed once (mage_tr
 (mage_gemm n_split) whose partials are summed in a fixed order.  LayerNorm / attention / activation / cross-entropy backward,
 the embedding scatter and the positional-table reductions are the kernels of csrc/train.hip.
 
-Built for the use_cids=True family: the MNIST configs of BASELINE cfg1-3 and, with the randomness branch of
-modules/mage_train_prior.py (Conv3d video prior, reparameterisation + KL, ADAIN), config/mage_caterv1.yaml / mage_caterv2.yaml; the
-first stage is frozen, as in the reference (mage_model.py:516-521).  Dropout (training mode only) is a stateless mask recomputed in the
+Built for every config family of the reference: the MNIST configs of BASELINE cfg1-3; with the randomness branch of
+modules/mage_train_prior.py (Conv3d video prior, reparameterisation + KL, ADAIN) config/mage_caterv1.yaml / mage_caterv2.yaml; and
+MAGE+ (config/mage+_*.yaml: use_cids=False -- Linear token embedding of the first stage's latents, GroupNorm + SiLU + Conv3d head,
+MSE loss, the ln_q / ln_kv TransformerBlock variant, PID-controlled beta).  The first stage is frozen, as in the reference
+(mage_model.py:516-521).  Dropout (training mode only) is a stateless mask recomputed in the
 backward pass from a per-call seed.
 """
 from __future__ import annotations
@@ -149,6 +151,15 @@ def _dec_forward(gm, run: _Run, motion, feats, B: int, hh: int, ww: int):
         del hdn
         blocks.append(dict(x0=x, xn1=xn1, qkv=qkv, ao=ao, x1=x1, xn2=xn2, hpre=hpre, geo=geo, s_attn=s_attn, s_mlp=s_mlp))
         x = x2
+    if not gm.use_cids:
+        # MAGE+ head (mage_model.py:350-354,387-388): GroupNorm(32) over all L-1 predicted frames of a clip -> SiLU -> Conv3d 1x1x1
+        M1 = B * (L - 1) * hw
+        st = torch.empty(B, 32, 2, device=dev, dtype=F32)
+        y = ops.groupnorm_act(x, d["gn.w"], d["gn.b"], torch.empty(M1, Cc, device=dev, dtype=dt), n_samples=B, rows_per_sample=(L - 1) * hw,
+                              sample_stride_rows=L * hw, row_off=hw, groups=32, eps=gm.out[0].eps, act=2, stats=st)
+        n8 = d["out.f32"].shape[0]
+        pred = ops.gemm(y, d["out" + _sfx(dt)], torch.empty(M1, n8, device=dev, dtype=F32), M=M1, N=n8, K=Cc, lda=Cc, ldy=n8, bias=d["out.b"])
+        return pred, dict(blocks=blocks, x_last=x, y=y, gn_stats=st, motion=motion, feats=feats, B=B, hh=hh, ww=ww)
     xa = x if dt == F32 else ops.cast(x, torch.empty(M, Cc, device=dev, dtype=dt))
     Kc = gm.out_channels
     logits = torch.empty(B * (L - 1) * hw, Kc, device=dev, dtype=F32)
@@ -182,9 +193,19 @@ def _dec_backward(gm, run: _Run, tape, dlogits, grads: Dict[str, torch.Tensor], 
     hw = hh * ww
     M, Kc, M1 = B * L * hw, gm.out_channels, B * (L - 1) * hw
     tail = dict(out_w=(L - 1) * hw, img_stride=L * hw, a_off=hw)            # the x[:, 1:] rows of a [B, L, hw, C] stream
-    grads[pre + ".out.weight"], grads[pre + ".out.bias"] = _wgrad(dlogits, tape["xa"], M=M1, N=Kc, K=Cc, ld_dy=Kc, ld_x=Cc, x_geo=tail)
     dx = torch.zeros(M, Cc, device=dev, dtype=F32)
-    _gemm_x(dlogits, _wt(d, "out", dt), dx, M=M1, N=Cc, K=Kc, out_w=(L - 1) * hw, y_img_stride=L * hw, y_off=hw)
+    if gm.use_cids:
+        grads[pre + ".out.weight"], grads[pre + ".out.bias"] = _wgrad(dlogits, tape["xa"], M=M1, N=Kc, K=Cc, ld_dy=Kc, ld_x=Cc, x_geo=tail)
+        _gemm_x(dlogits, _wt(d, "out", dt), dx, M=M1, N=Cc, K=Kc, out_w=(L - 1) * hw, y_img_stride=L * hw, y_off=hw)
+    else:                                                                    # dlogits = d loss / d pred [M1, n8] (padding columns zero)
+        n8 = d["out.f32"].shape[0]
+        dWo, dbo = _wgrad(dlogits, tape["y"], M=M1, N=n8, K=Cc, ld_dy=n8, ld_x=Cc)
+        grads[pre + ".out.2.weight"], grads[pre + ".out.2.bias"] = dWo[:Kc].reshape(Kc, Cc, 1, 1, 1), dbo[:Kc]
+        dy = _gemm_x(dlogits, _wt(d, "out", dt), torch.empty(M1, Cc, device=dev, dtype=F32), M=M1, N=Cc, K=n8)
+        dg, db, _ = ops.groupnorm_bwd(tape["x_last"], d["gn.w"], d["gn.b"], tape["gn_stats"], dy, dx, n_samples=B, rows_per_sample=(L - 1) * hw,
+                                      sample_stride_rows=L * hw, row_off=hw, groups=32, act=2)       # slot 0 rows stay zero
+        grads[pre + ".out.0.weight"], grads[pre + ".out.0.bias"] = dg, db
+        del dy
     for i in reversed(range(gm.layers)):
         p, bp, t = f"b{i}", f"{pre}.blocks.{i}", tape["blocks"][i]
         _block_mlp_bwd(run, d, p, bp, grads, dx, t["x1"], t["xn2"], t["hpre"], M, Cc, t["s_mlp"])
@@ -228,9 +249,11 @@ def _conv_flip(model, d, dt):
     return d[key]
 
 
-def _frame_backward(model, run_dt, tok_rows, emb, dfeats, grads, acc):
+def _frame_backward(model, run_dt, tok_rows, emb, dfeats, grads, acc, lat_rows=None):
     """feats = conv3x3(emb[tok]) + (H_pos + W_pos): gradients of the conv weight, the positional tables and the token table
-    (accumulated into acc['conv'], acc['hwpos'], acc['emb']: the fp32 prologue pass and the decoder pass both land here)."""
+    (accumulated into acc['conv'], acc['hwpos'], acc['emb']: the fp32 prologue pass and the decoder pass both land here).
+    use_cids=False: emb = Linear(latents) (mage_model.py:583): lat_rows [rows, LD] fp32 instead of tok_rows, the Linear's gradients
+    accumulate in acc['emb_lin.w'] [C, LD] / acc['emb_lin.b']."""
     d = model._derived.get(model._build)
     R, Cc, dev = model.image_resolution, model.vision_width, dfeats.device
     hw = R * R
@@ -259,6 +282,12 @@ def _frame_backward(model, run_dt, tok_rows, emb, dfeats, grads, acc):
     # d emb = the transposed convolution of dfeats
     demb = VectorQuantizedVAE._conv(dfe, _conv_flip(model, d, run_dt), torch.empty(rows, Cc, device=dev, dtype=F32), n_img=n_img, H=R, W=R,
                                     cin=Cc, cout=Cc, k=3)
+    if lat_rows is not None:
+        LD = lat_rows.shape[1]
+        dW, db = _wgrad(demb, lat_rows, M=rows, N=Cc, K=LD, ld_dy=Cc, ld_x=LD)
+        acc["emb_lin.w"] = dW if acc.get("emb_lin.w") is None else acc["emb_lin.w"] + dW
+        acc["emb_lin.b"] = db if acc.get("emb_lin.b") is None else acc["emb_lin.b"] + db
+        return
     if acc.get("emb") is None:
         acc["emb"] = torch.zeros(model.codebook_size, Cc, device=dev, dtype=F32)
     ops.embedding_bwd(tok_rows, demb, acc["emb"])
@@ -267,8 +296,6 @@ def _frame_backward(model, run_dt, tok_rows, emb, dfeats, grads, acc):
 # ----------------------------------------------------------------------------------------------------------------- MA encoder
 def _ma_forward(ma, run: _Run, q, kv, B: int, nq: int, nk: int):
     """MAEncoder (one or more TransformerBlocks, the MAGE variant mage_model.py:92), batch-first rows, fp32."""
-    if ma.mage_plus:
-        raise NotImplementedError("training backward: the MAGE+ TransformerBlock variant is not built")
     d = ma._derived.get(ma._build)
     Cc, dev, H = ma.d_model, q.device, ma.d_model // 32
     x = q
@@ -276,8 +303,12 @@ def _ma_forward(ma, run: _Run, q, kv, B: int, nq: int, nk: int):
     for i in range(ma.layers):
         p = f"b{i}"
         w, b = d[p + ".in_proj.f32"], d[p + ".in_proj.b"]
-        qp = ops.gemm(x, w[:Cc], torch.empty(B * nq, Cc, device=dev, dtype=F32), M=B * nq, N=Cc, K=Cc, lda=Cc, ldy=Cc, bias=b[:Cc])
-        kvp = ops.gemm(kv, w[Cc:], torch.empty(B * nk, 2 * Cc, device=dev, dtype=F32), M=B * nk, N=2 * Cc, K=Cc, lda=Cc, ldy=2 * Cc, bias=b[Cc:])
+        qin, kvin = x, kv
+        if ma.mage_plus:                                                     # the ln_q / ln_kv line of mage_model.py:93 (MAGE+)
+            qin = ops.layernorm(x, d[p + ".ln_q.w"], d[p + ".ln_q.b"], torch.empty_like(x), 1e-5)
+            kvin = ops.layernorm(kv, d[p + ".ln_kv.w"], d[p + ".ln_kv.b"], torch.empty_like(kv), 1e-5)
+        qp = ops.gemm(qin, w[:Cc], torch.empty(B * nq, Cc, device=dev, dtype=F32), M=B * nq, N=Cc, K=Cc, lda=Cc, ldy=Cc, bias=b[:Cc])
+        kvp = ops.gemm(kvin, w[Cc:], torch.empty(B * nk, 2 * Cc, device=dev, dtype=F32), M=B * nk, N=2 * Cc, K=Cc, lda=Cc, ldy=2 * Cc, bias=b[Cc:])
         geo = dict(n_seq=B, inner=1, nq=nq, nk=nk, n_head=H, q_outer_stride=nq, q_axis_stride=1, kv_outer_stride=nk, kv_axis_stride=1)
         ao = torch.empty(B * nq, Cc, device=dev, dtype=F32)
         ops.attention(qp, kvp, kvp[:, Cc:], ao, ldq=Cc, ldk=2 * Cc, ldv=2 * Cc, ldo=Cc, **geo)
@@ -288,7 +319,7 @@ def _ma_forward(ma, run: _Run, q, kv, B: int, nq: int, nk: int):
                         ldy=4 * Cc, bias=d[p + ".c_fc.b"])
         hdn = ops.act(hpre, torch.empty_like(hpre), ops.ACT_QUICKGELU)
         x2 = _res_linear(run, hdn, d, p + ".c_proj", x1, F32, M=B * nq, N=Cc, K=4 * Cc, seed=s_mlp)
-        layers.append(dict(x0=x, qp=qp, kvp=kvp, ao=ao, x1=x1, xn=xn, hpre=hpre, geo=geo, s_attn=s_attn, s_mlp=s_mlp))
+        layers.append(dict(x0=x, qin=qin, kvin=kvin, qp=qp, kvp=kvp, ao=ao, x1=x1, xn=xn, hpre=hpre, geo=geo, s_attn=s_attn, s_mlp=s_mlp))
         x = x2
     return x, dict(layers=layers, kv=kv, B=B, nq=nq, nk=nk)
 
@@ -310,16 +341,24 @@ def _ma_backward(ma, run32: _Run, tape, dx, grads, pre: str = "ma_encoder"):
         kvp = t["kvp"]
         ops.attention_bwd(t["qp"], kvp, kvp[:, Cc:], dao, dqp, dkvp, dkvp[:, Cc:], ldq=Cc, ldk=2 * Cc, ldv=2 * Cc, ldo=Cc, ld_dq=Cc,
                           ld_dk=2 * Cc, ld_dv=2 * Cc, **t["geo"])
-        dWq, dbq = _wgrad(dqp, t["x0"], M=B * nq, N=Cc, K=Cc, ld_dy=Cc, ld_x=Cc)
-        dWkv, dbkv = _wgrad(dkvp, kv, M=B * nk, N=2 * Cc, K=Cc, ld_dy=2 * Cc, ld_x=Cc)
+        dWq, dbq = _wgrad(dqp, t["qin"], M=B * nq, N=Cc, K=Cc, ld_dy=Cc, ld_x=Cc)
+        dWkv, dbkv = _wgrad(dkvp, t["kvin"], M=B * nk, N=2 * Cc, K=Cc, ld_dy=2 * Cc, ld_x=Cc)
         grads[bp + ".attn.in_proj_weight"] = torch.cat([dWq, dWkv], 0)                      # [3C, C] assembly (layout plumbing)
         grads[bp + ".attn.in_proj_bias"] = torch.cat([dbq, dbkv], 0)
         wT = _wt(d, p + ".in_proj", F32)                                                    # [C, 3C]
         wqT, wkvT = wT[:, :Cc].contiguous(), wT[:, Cc:].contiguous()
-        dx = _gemm_x(dqp, wqT, torch.empty(B * nq, Cc, device=dev, dtype=F32), M=B * nq, N=Cc, K=Cc, residual=dx, ldr=Cc)
-        dkv = _gemm_x(dkvp, wkvT, torch.empty(B * nk, Cc, device=dev, dtype=F32), M=B * nk, N=Cc, K=2 * Cc)
+        if ma.mage_plus:
+            dqin = _gemm_x(dqp, wqT, torch.empty(B * nq, Cc, device=dev, dtype=F32), M=B * nq, N=Cc, K=Cc)
+            grads[bp + ".ln_q.weight"], grads[bp + ".ln_q.bias"] = ops.layernorm_bwd(t["x0"], d[p + ".ln_q.w"], dqin, dx, eps=1e-5, accumulate=True)
+            dkvin = _gemm_x(dkvp, wkvT, torch.empty(B * nk, Cc, device=dev, dtype=F32), M=B * nk, N=Cc, K=2 * Cc)
+            dkv = torch.empty_like(dkvin)
+            grads[bp + ".ln_kv.weight"], grads[bp + ".ln_kv.bias"] = ops.layernorm_bwd(kv, d[p + ".ln_kv.w"], dkvin, dkv, eps=1e-5,
+                                                                                      accumulate=False)
+        else:
+            dx = _gemm_x(dqp, wqT, torch.empty(B * nq, Cc, device=dev, dtype=F32), M=B * nq, N=Cc, K=Cc, residual=dx, ldr=Cc)
+            dkv = _gemm_x(dkvp, wkvT, torch.empty(B * nk, Cc, device=dev, dtype=F32), M=B * nk, N=Cc, K=2 * Cc)
+            # ln_q / ln_kv exist in the checkpoint but are not applied by MAGE (mage_model.py:92): zero gradients
         dkv_total = dkv if dkv_total is None else dkv_total + dkv
-        # ln_q / ln_kv exist in the checkpoint but are not applied by MAGE (mage_model.py:92): zero gradients
     return dx, dkv_total
 
 
@@ -425,9 +464,6 @@ def _text_backward(te, run32: _Run, tape, dout, grads, pre: str = "text_encoder"
 def train_forward(model, batch):
     """Teacher-forced pass of MAGE.forward (mage_model.py:575-639) with the activations the backward pass needs.
     Returns (loss 0-dim fp32 tensor, tape)."""
-    if not model.use_cids:
-        raise NotImplementedError("the HIP training backward is built for the use_cids=True configs (MAGE; with or without the "
-                                  "randomness branch); run MAGE+ configs under torch.no_grad() for loss values")
     images = batch["images"]
     B = images.shape[0]
     R, L, Cc = model.image_resolution, model.frames_length, model.vision_width
@@ -437,14 +473,30 @@ def train_forward(model, batch):
     run32 = _Run(F32, model.dropout, model.training)
     run32.seed, run32.p = run.seed, run.p
     d = model._derived.get(model._build)
-    tok = model.first_stage_encode(images).reshape(B, -1, hw)                         # frozen first stage: no gradient
-    tok_in = tok[:, :L - 1].contiguous()
-    tok0 = tok[:, 0].contiguous()
-    # frame features for the decoder (compute dtype) and, as the inference prologue does, frame 0's in fp32 for the MA encoder
-    emb = ops.embedding(tok_in.reshape(-1), d["emb"], torch.empty(B * (L - 1) * hw, Cc, device=images.device, dtype=dt))
+    dev = images.device
+    tok = tok_in = tok0 = lat_all = lat_in = lat0 = None
+    if model.use_cids:
+        tok = model.first_stage_encode(images).reshape(B, -1, hw)                     # frozen first stage: no gradient
+        tok_in = tok[:, :L - 1].contiguous()
+        tok0 = tok[:, 0].contiguous()
+        # frame features for the decoder (compute dtype) and, as the inference prologue does, frame 0's in fp32 for the MA encoder
+        emb = ops.embedding(tok_in.reshape(-1), d["emb"], torch.empty(B * (L - 1) * hw, Cc, device=dev, dtype=dt))
+        emb0 = ops.embedding(tok0.reshape(-1), d["emb"], torch.empty(B * hw, Cc, device=dev, dtype=F32))
+    else:
+        # MAGE+ (mage_model.py:579,583): latents of ALL frames from the external first stage as zero-padded rows [., LD], token
+        # embedding = Linear(embed_dim -> C)
+        E, LD = model.first_stage_model.embed_dim, 8
+        lat = model.first_stage_encode(images)                                        # [B, Lb, E, h, w]
+        Lb = lat.shape[1]
+        lat_all = torch.zeros(B, Lb, hw, LD, device=dev, dtype=F32)
+        lat_all[..., :E] = lat.permute(0, 1, 3, 4, 2).reshape(B, Lb, hw, E).float()   # layout plumbing (channels last)
+        lat_in = lat_all[:, :L - 1].contiguous().view(-1, LD)
+        lat0 = lat_all[:, 0].contiguous().view(-1, LD)
+        lin = dict(N=Cc, K=E, lda=LD, ldy=Cc, bias=d["emb_lin.b"])
+        emb = ops.gemm(lat_in, d["emb_lin.w"], torch.empty(B * (L - 1) * hw, Cc, device=dev, dtype=dt), M=B * (L - 1) * hw, **lin)
+        emb0 = ops.gemm(lat0, d["emb_lin.w"], torch.empty(B * hw, Cc, device=dev, dtype=F32), M=B * hw, **lin)
     feats = VectorQuantizedVAE._conv(emb, d["conv" + _sfx(dt)], torch.empty_like(emb), n_img=B * (L - 1), H=R, W=R, cin=Cc, cout=Cc, k=3,
                                      rowadd=d["hwpos"], rowadd_div=1, rowadd_mod=hw)
-    emb0 = ops.embedding(tok0.reshape(-1), d["emb"], torch.empty(B * hw, Cc, device=images.device, dtype=F32))
     first = VectorQuantizedVAE._conv(emb0, d["conv.f32"], torch.empty_like(emb0), n_img=B, H=R, W=R, cin=Cc, cout=Cc, k=3,
                                      rowadd=d["hwpos"], rowadd_div=1, rowadd_mod=hw)
     txt, t_text = _text_forward(model.text_encoder, run32, batch["text"])
@@ -453,7 +505,8 @@ def train_forward(model, batch):
     t_rand = None
     if model.randomness:                                                     # :601-609: ADAIN modulation by the reparameterised video prior
         from . import mage_train_prior
-        ma, t_rand = mage_train_prior.rand_forward(model, batch, tok, ma, B)
+        ma, t_rand = mage_train_prior.rand_forward(model, batch, tok, ma, B, lat_rows=None if model.use_cids else lat_all.view(-1, 8),
+                                                   L=0 if model.use_cids else lat_all.shape[1])
     speed = None
     if "speed" in batch:
         speed = batch["speed"].float().contiguous()
@@ -461,8 +514,13 @@ def train_forward(model, batch):
         ops.add_scaled_rowvec(ma, speed, d["speed"], B=B, P=hw, Cc=Cc)
     ma_dt = ma if dt == F32 else ma.to(dt)
     logits, t_dec = _dec_forward(model.generate_model, run, ma_dt, feats, B, R, R)
-    target = tok[:, 1:L].reshape(-1).contiguous()
-    recon = ops.cross_entropy(logits, target)
+    if model.use_cids:
+        target = tok[:, 1:L].reshape(-1).contiguous()
+        recon = ops.cross_entropy(logits, target)                                                            # :618
+    else:
+        target = lat_all[:, 1:L].contiguous().view(-1, 8)
+        recon = ops.mse(logits, target, rows=B * (L - 1) * hw, cols=model.first_stage_model.embed_dim, lda=logits.shape[1], ldb=8)   # :620
+        model.last_logits = logits
     loss, parts = recon, {"prediction": recon.item()}
     beta = alpha = 0.0
     if model.randomness:                                                     # :622-632 ([B]-element reductions and scalars)
@@ -480,8 +538,8 @@ def train_forward(model, batch):
             l2 = (speed ** 2).mean() * (d["speed"] ** 2).sum()
             loss = recon + beta * kl + alpha * l2
     parts["final_loss"] = loss.item()
-    tape = dict(run=run, run32=run32, tok_in=tok_in, tok0=tok0, emb=emb, emb0=emb0, text=t_text, ma=t_ma, dec=t_dec, logits=logits,
-                target=target, speed=speed, B=B, rand=t_rand, beta=beta, alpha=alpha, parts=parts)
+    tape = dict(run=run, run32=run32, tok_in=tok_in, tok0=tok0, lat_in=lat_in, lat0=lat0, emb=emb, emb0=emb0, text=t_text, ma=t_ma, dec=t_dec,
+                logits=logits, target=target, speed=speed, B=B, rand=t_rand, beta=beta, alpha=alpha, parts=parts)
     return loss, tape
 
 
@@ -494,12 +552,18 @@ def train_backward(model, tape, grad_out: torch.Tensor) -> Dict[str, torch.Tenso
     dev = tape["logits"].device
     grads: Dict[str, torch.Tensor] = {}
     gout = grad_out.detach().to(device=dev, dtype=F32).reshape(1).contiguous()
-    dlogits = ops.cross_entropy_bwd(tape["logits"], tape["target"], gout, torch.empty(tape["logits"].shape, device=dev, dtype=dt))
+    if model.use_cids:
+        dlogits = ops.cross_entropy_bwd(tape["logits"], tape["target"], gout, torch.empty(tape["logits"].shape, device=dev, dtype=dt))
+    else:
+        pred = tape["logits"]
+        dlogits = _to_dt(run, ops.mse_bwd(pred, tape["target"], gout, rows=pred.shape[0], cols=model.first_stage_model.embed_dim,
+                                          lda=pred.shape[1], ldb=8))
     tape["logits"] = None
     dfeats, dma = _dec_backward(model.generate_model, run, tape["dec"], dlogits, grads)
     del dlogits
     acc: Dict[str, Optional[torch.Tensor]] = {}
-    _frame_backward(model, dt, tape["tok_in"].reshape(-1), tape["emb"], dfeats, grads, acc)
+    _frame_backward(model, dt, None if tape["tok_in"] is None else tape["tok_in"].reshape(-1), tape["emb"], dfeats, grads, acc,
+                    lat_rows=tape["lat_in"])
     del dfeats
     if tape["speed"] is not None:                                            # ma += speed_b * speed_embedding  (:666-668)
         gs = ops.group_rowsum(dma, torch.empty(1, Cc, device=dev, dtype=F32), rows=B * hw, C=Cc, div=1, mod=1, row_scale=tape["speed"],
@@ -515,8 +579,14 @@ def train_backward(model, tape, grad_out: torch.Tensor) -> Dict[str, torch.Tenso
         tape["rand"] = None
     dfirst, dtxt = _ma_backward(model.ma_encoder, run32, tape["ma"], dma, grads)
     _text_backward(model.text_encoder, run32, tape["text"], dtxt, grads)
-    _frame_backward(model, F32, tape["tok0"].reshape(-1), tape["emb0"], dfirst, grads, acc)
-    grads["visual_token_embedding.weight"] = acc["emb"]
+    _frame_backward(model, F32, None if tape["tok0"] is None else tape["tok0"].reshape(-1), tape["emb0"], dfirst, grads, acc,
+                    lat_rows=tape["lat0"])
+    if model.use_cids:
+        grads["visual_token_embedding.weight"] = acc["emb"]
+    else:
+        E = model.first_stage_model.embed_dim
+        grads["visual_token_embedding.weight"] = acc["emb_lin.w"][:, :E].contiguous()
+        grads["visual_token_embedding.bias"] = acc["emb_lin.b"]
     grads["conv.0.weight"] = acc["conv"].view(Cc, 3, 3, Cc).permute(0, 3, 1, 2).contiguous()       # [Cout, Cin, kh, kw] layout
     hp = acc["hwpos"].contiguous()                                           # [R*R, C] -> H table (sum over w), W table (sum over h)
     grads["H_positional_embedding"] = ops.group_rowsum(hp, torch.empty(R, Cc, device=dev, dtype=F32), rows=hw, C=Cc, div=R,

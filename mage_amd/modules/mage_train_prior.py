@@ -86,14 +86,15 @@ def _conv2d_bwd(d, key, dy, x, *, B: int, R: int, cin: int, cout: int, want_bias
 
 
 # ----------------------------------------------------------------------------------------------------------------- forward
-def rand_forward(model, batch, tok, ma, B: int):
-    """tok int64 [B, L, hw] (all frames), ma [B*hw, C] fp32 (MA encoder output) -> (modulated ma, tape).  tape['kl_sum'] [B]."""
+def rand_forward(model, batch, tok, ma, B: int, lat_rows=None, L: int = 0):
+    """tok int64 [B, L, hw] (all frames; MAGE+: lat_rows [B*L*hw, 8] fp32 latents instead), ma [B*hw, C] fp32 (MA encoder output)
+    -> (modulated ma, tape).  tape['kl_sum'] [B]."""
     d = model._derived.get(model._build)
     da = model.adain._derived.get(model.adain._build)
     R, Cc = model.image_resolution, model.vision_width
     hw, dev = R * R, ma.device
     blocks: list = []
-    prior = model._video_prior(tok, tape=blocks)                                            # [B*hw, Cp]
+    prior = model._video_prior(tok, lat_rows, B, L, tape=blocks)                            # [B*hw, Cp]
     Cp = prior.shape[1]
     mu = _conv(prior, d["mu2.w"], torch.empty(B * hw, 64, device=dev, dtype=F32), n_img=B, H=R, W=R, cin=Cp, cout=64, k=3, bias=d["mu2.b"])
     logvar = _conv(prior, d["var2.w"], torch.empty_like(mu), n_img=B, H=R, W=R, cin=Cp, cout=64, k=3, bias=d["var2.b"])
@@ -109,7 +110,8 @@ def rand_forward(model, batch, tok, ma, B: int):
     b0 = _conv(y, da["var0.w"], torch.empty_like(g0), n_img=B, H=R, W=R, cin=Cc, cout=Cc, k=3, bias=da["var0.b"])
     bet = _conv(b0, da["var1.w"], torch.empty_like(g0), n_img=B, H=R, W=R, cin=Cc, cout=Cc, k=3, bias=da["var1.b"])
     out = ops.adain(ma, gam, bet, torch.empty_like(ma), B=B, P=hw, Cc=Cc, eps=model.adain.norm.eps)
-    tape = dict(blocks=blocks, prior=prior, mu=mu, logvar=logvar, eps=eps, z=z, y=y, g0=g0, gam=gam, b0=b0, ma=ma, kl_sum=kl_sum, tok=tok, B=B)
+    tape = dict(blocks=blocks, prior=prior, mu=mu, logvar=logvar, eps=eps, z=z, y=y, g0=g0, gam=gam, b0=b0, ma=ma, kl_sum=kl_sum, tok=tok,
+                lat_rows=lat_rows, L=L if tok is None else tok.shape[1], B=B)
     return out, tape
 
 
@@ -173,7 +175,7 @@ def _prior_backward(model, d, blocks, dprior, grads: Dict[str, torch.Tensor], B:
 
 def rand_backward(model, tape, dout_ma, kl_coef: torch.Tensor, grads: Dict[str, torch.Tensor], acc: Dict[str, Optional[torch.Tensor]]):
     """dout_ma = d loss / d (ADAIN output) [B*hw, C]; kl_coef = 1-element device tensor (d loss / d kl) / B.  Fills the gradients of
-    conv3d.*, conv_mu2 / conv_var2, conv_d2, adain.*; adds the video prior's share to acc['emb']; returns d loss / d (MA encoder output)."""
+    conv3d.*, conv_mu2 / conv_var2, conv_d2, adain.*; adds the video prior's share to acc['emb'] (MAGE+: acc['emb_lin.*']); returns d loss / d (MA encoder output)."""
     d = model._derived.get(model._build)
     da = model.adain._derived.get(model.adain._build)
     R, Cc, B = model.image_resolution, model.vision_width, tape["B"]
@@ -199,9 +201,16 @@ def rand_backward(model, tape, dout_ma, kl_coef: torch.Tensor, grads: Dict[str, 
     gw, gb, dprior = _conv2d_bwd(d, "var2.w", dlv, tape["prior"], B=B, R=R, cin=Cp, cout=64, want_bias=True, dx_acc=dprior)
     grads["conv_var2.weight"], grads["conv_var2.bias"] = gw, gb
     dxa, ds = _prior_backward(model, d, tape["blocks"], dprior, grads, B)
-    tok = tape["tok"]
-    L = tok.shape[1]
-    if acc.get("emb") is None:
-        acc["emb"] = torch.zeros(model.codebook_size, Cc, device=dev, dtype=F32)
-    ops.embedding_bwd(tok.reshape(-1).contiguous(), dxa, acc["emb"], group=L * hw, group_stride=ds, off=hw)
+    tok, L = tape["tok"], tape["L"]
+    if tok is not None:
+        if acc.get("emb") is None:
+            acc["emb"] = torch.zeros(model.codebook_size, Cc, device=dev, dtype=F32)
+        ops.embedding_bwd(tok.reshape(-1).contiguous(), dxa, acc["emb"], group=L * hw, group_stride=ds, off=hw)
+    else:                                                   # MAGE+: the embeddings are Linear(latents), written into the same frame slots
+        from .mage_train import _wgrad
+        lat = tape["lat_rows"]
+        dW, db = _wgrad(dxa, lat, M=B * L * hw, N=Cc, K=lat.shape[1], ld_dy=Cc, ld_x=lat.shape[1],
+                        dy_geo=dict(out_w=L * hw, img_stride=ds, a_off=hw))
+        acc["emb_lin.w"] = dW if acc.get("emb_lin.w") is None else acc["emb_lin.w"] + dW
+        acc["emb_lin.b"] = db if acc.get("emb_lin.b") is None else acc["emb_lin.b"] + db
     return dma

@@ -490,6 +490,14 @@ def reparam_kl_bwd(mu, logvar, eps, dz, coef):
     return dmu, dlv
 
 
+def mse_bwd(a, b, gout, *, rows, cols, lda, ldb):
+    """d mse / da * gout as [rows, lda] fp32 (zeros in the padding columns)."""
+    l, s = _dev(a)
+    da = torch.empty(rows, lda, device=a.device, dtype=torch.float32)
+    _lib.check(l.mage_mse_bwd(a.data_ptr(), lda, b.data_ptr(), ldb, rows, cols, gout.data_ptr(), da.data_ptr(), lda, s), l)
+    return da
+
+
 def mse(a, b, *, rows, cols, lda, ldb):
     """mean((a[:, :cols] - b[:, :cols])^2) over `rows` rows with row strides lda / ldb (fp32) -> 0-dim fp32 tensor."""
     l, s = _dev(a)

@@ -399,7 +399,7 @@ def flat_axial_decoder_latent(sd: SD, p: str, motion: torch.Tensor, imgs: torch.
     while (p + f"blocks.{i}.ln_1.weight") in sd:
         x = axial_block(sd, p + f"blocks.{i}", x, axis=i % 3 + 1, causal=(i % 3 == 0))
         i += 1
-    y = x[:, 1:].permute(0, 4, 1, 2, 3)
+    y = x[:, 1:].permute(0, 4, 1, 2, 3).contiguous()                     # :386
     y = F.silu(F.group_norm(y, 32, sd[p + "out.0.weight"], sd[p + "out.0.bias"], 1e-5))
     return F.conv3d(y, sd[p + "out.2.weight"], sd[p + "out.2.bias"]).permute(0, 2, 3, 4, 1)
 

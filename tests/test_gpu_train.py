@@ -493,10 +493,15 @@ def oracle_grads_random(sd, batch, L, eps, alpha, beta):
     return loss.item(), parts, {k: g for k, g in zip(names, gs)}
 
 
-def prior_relu_margin(sd, tok):
-    """Smallest |pre-activation| over the ReLUs of the Conv3d video prior (BasicBlock, mage_model.py:280-297), float64."""
+def prior_relu_margin(sd, tok=None, lat=None):
+    """Smallest |pre-activation| over the ReLUs of the Conv3d video prior (BasicBlock, mage_model.py:280-297), float64; the prior's
+    input is the token embedding of tok [B, L, h, w] or (MAGE+) the Linear embedding of lat [B, L, E, h, w]."""
     sd = {k: v.double() for k, v in sd.items() if k.startswith(("conv3d.", "visual_token_embedding."))}
-    v = sd["visual_token_embedding.weight"][tok].permute(0, 4, 1, 2, 3).contiguous()
+    if tok is not None:
+        v = sd["visual_token_embedding.weight"][tok].permute(0, 4, 1, 2, 3).contiguous()
+    else:
+        v = F.linear(lat.double().permute(0, 1, 3, 4, 2), sd["visual_token_embedding.weight"], sd["visual_token_embedding.bias"])
+        v = v.permute(0, 4, 1, 2, 3).contiguous()
     mn = float("inf")
     for i in range(4):
         p = f"conv3d.{i}."
@@ -547,10 +552,10 @@ def test_loss_backward_with_the_randomness_branch_matches_oracle_autograd(B, L, 
         if g_ref is None or g_ref.abs().max().item() == 0.0:
             assert p.grad.abs().max().item() == 0.0, name
             continue
-        if g_ref.abs().max().item() < 1e-6 * gmax:
+        if name == "ma_encoder.blocks.0.mlp.c_proj.bias":
             # a per-channel constant in front of ADAIN's instance norm (the MA encoder's last bias): the exact gradient is zero, the
             # reference's is rounding noise; bounded against the scale of the real gradients instead
-            assert p.grad.abs().max().item() < 1e-5 * gmax, name
+            assert g_ref.abs().max().item() < 1e-6 * gmax and p.grad.abs().max().item() < 1e-6 * gmax, name
             continue
         r = rel(p.grad, g_ref)
         n_checked += 1
@@ -559,7 +564,57 @@ def test_loss_backward_with_the_randomness_branch_matches_oracle_autograd(B, L, 
             worst = (name, r)
     print(f"{n_checked} gradients checked ({prior_checked} of the randomness branch), worst relative error {worst[1]:.2e} at {worst[0]}")
     assert worst[1] < GRAD_TOL, worst
-    assert prior_checked == 4 * 9 + 8 + 4 + 1 and n_checked >= 100
+    assert prior_checked == 4 * 9 + 8 + 4 + 1 and n_checked >= 130
+
+
+@pytest.mark.parametrize("B,L,seed,min_margin", [(1, 10, 69, 1e-5), (2, 9, 62, 5e-6)])
+def test_loss_backward_mage_plus_matches_oracle_autograd(B, L, seed, min_margin):
+    """config/mage+_*.yaml's family (use_cids=False: Linear embedding of the first stage's latents, the ln_q / ln_kv TransformerBlock
+    variant, GroupNorm(32) + SiLU + Conv3d head, MSE loss, randomness branch with the PID-controlled beta) over the stand-in latent first
+    stage: loss.backward() on the HIP path (fp32, eval) against autograd through the oracle.  Seeds chosen for their ReLU margin, see
+    test_loss_backward_with_the_randomness_branch_matches_oracle_autograd."""
+    from mage_amd.modules.mage_model import PIDControl
+    cfg = synth.magep_model_config(frames_length=L, width=64, layers=3)
+    m = build_mage(cfg, seed, DEV)
+    assert m.ma_encoder.mage_plus
+    batch = synth.synth_batch_cater(B, L, seed=seed, text_len=9, vocab=50)
+    eps = torch.randn(B, 64, 16, 16, generator=torch.Generator().manual_seed(seed))
+    lat = m.first_stage_model.encode(batch["images"].reshape(B * L, *batch["images"].shape[2:])).view(B, L, 4, 16, 16).cpu()
+    sd0 = cpu_sd(m)
+    assert prior_relu_margin(sd0, lat=lat) >= min_margin
+    sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.startswith("first_stage_model.") else v) for k, v in sd0.items()}
+    final, parts, pred = O.mage_forward_loss_latent(sd, batch, L, lat, eps, v_kl=cfg["params"]["v_kl"], pid=PIDControl(), mage_plus=True)
+    names = [k for k, v in sd.items() if v.requires_grad]
+    want = dict(zip(names, torch.autograd.grad(final, [sd[k] for k in names], allow_unused=True)))
+    db = {k: v.to(DEV) for k, v in batch.items()}
+    db["reparam_noise"] = eps.to(DEV)
+    loss, ld = m(db)
+    assert loss.requires_grad and abs(loss.item() - final.item()) < 1e-4 * max(1.0, abs(final.item()))
+    assert abs(ld["val/prediction"] - parts["prediction"]) < 1e-4 * max(1.0, parts["prediction"]) and abs(ld["val/beta"] - parts["beta"]) < 1e-7
+    torch.testing.assert_close(m.last_logits.view(B, L - 1, 16, 16, -1)[..., :4].cpu(), pred.detach(), atol=1e-4, rtol=1e-4)
+    loss.backward()
+    gmax = max(g.abs().max().item() for g in want.values() if g is not None)
+    worst, n_checked, seen = ("", 0.0), 0, set()
+    for name, p in m.named_parameters():
+        g_ref = want.get(name)
+        if name.startswith("first_stage_model.") or g_ref is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, name
+            continue
+        assert p.grad is not None, name
+        if name == "ma_encoder.blocks.0.mlp.c_proj.bias":                   # a constant in front of ADAIN's instance norm: zero gradient
+            assert g_ref.abs().max().item() < 1e-6 * gmax and p.grad.abs().max().item() < 1e-6 * gmax, name
+            continue
+        r = rel(p.grad, g_ref)
+        n_checked += 1
+        seen.add(name)
+        if r > worst[1]:
+            worst = (name, r)
+    print(f"{n_checked} gradients checked, worst relative error {worst[1]:.2e} at {worst[0]}")
+    assert worst[1] < GRAD_TOL, worst
+    for must in ("visual_token_embedding.weight", "visual_token_embedding.bias", "generate_model.out.0.weight", "generate_model.out.2.weight",
+                 "generate_model.out.2.bias", "ma_encoder.blocks.0.ln_q.weight", "ma_encoder.blocks.0.ln_kv.bias", "conv3d.0.conv1.weight",
+                 "adain.conv_mu.0.weight", "conv_d2.weight"):
+        assert must in seen, must
 
 
 @pytest.mark.parametrize("B,Cc,P", [(1, 64, 256), (2, 64, 256), (3, 512, 64)])
