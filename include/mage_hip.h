@@ -362,6 +362,11 @@ int mage_adain_bwd(const float* x, const float* gamma_map, const float* dout, fl
                    float eps, void* stream);
 int mage_reparam_kl_bwd(const float* mu, const float* logvar, const float* eps, const float* dz, const float* coef, float* dmu, float* dlogvar,
                         int64_t n, void* stream);
+/* Backward of mage_maxpool2 (x = the pooling input [N,H,W,C] fp32 channels-last; the gradient goes to the first maximum of each 2x2
+ * window in scan order, PyTorch's tie rule) and of mage_upsample2 (dx [N,H,W,C] = the sum of each 2x2 block of dy [N,2H,2W,C]):
+ * nn.MaxPool2d(2) / nn.Upsample(scale_factor=2) of the f8 VQ-VAE (vqvae_model.py:194-210) in stage-1 training. */
+int mage_maxpool2_bwd(const float* x, const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int mage_upsample2_bwd(const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 /* da = d mean((a - b)^2) / da * gout[0] over the first `cols` columns (zeros in the padding columns up to ld_da): backward of mage_mse
  * (F.mse_loss of the MAGE+ latent prediction, mage_model.py:620). */
 int mage_mse_bwd(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t cols, const float* gout, float* da,

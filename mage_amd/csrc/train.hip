@@ -1069,3 +1069,72 @@ extern "C" int mage_mse_bwd(const float* a, int64_t lda, const float* b, int64_t
     MAGE_CHECK_LAUNCH("mage_mse_bwd");
     return MAGE_OK;
 }
+
+// Backward of MaxPool2d(2) and of Upsample(scale 2, nearest) of the f8 VQ-VAE (vqvae_model.py:194-210), channels-last fp32.
+namespace {
+// dx of the 2x2 window = dy at the FIRST maximum in scan order (PyTorch's tie rule), zero elsewhere; one thread per output pixel x 4 channels.
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int N,
+                                                           int H, int W, int C) {
+    const int cq = C / 4, OH = H / 2, OW = W / 2;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)N * OH * OW * cq) return;
+    const int c = (int)(gid % cq) * 4;
+    const long pix = gid / cq;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), n = (int)(pix / ((long)OW * OH));
+    const long base = (((long)n * H + oy * 2) * W + ox * 2) * C + c;
+    const long off[4] = {0, (long)C, (long)W * C, (long)W * C + C};
+    f32x4 v[4], o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = *(const f32x4*)(x + base + off[k]);
+        o[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const f32x4 g = *(const f32x4*)(dy + pix * C + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int best = 0;
+        float m = v[0][e];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (v[k][e] > m) {
+                m = v[k][e];
+                best = k;
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k == best) o[k][e] = g[e];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *(f32x4*)(dx + base + off[k]) = o[k];
+}
+
+// dx[n, y, x] = sum of the 2x2 block of dy it was copied to.
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C) {
+    const int cq = C / 4;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)N * H * W * cq) return;
+    const int c = (int)(gid % cq) * 4;
+    const long pix = gid / cq;
+    const int ix = (int)(pix % W), iy = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+    const long base = (((long)n * 2 * H + iy * 2) * 2 * W + ix * 2) * C + c;
+    const f32x4 s = (*(const f32x4*)(dy + base) + *(const f32x4*)(dy + base + C)) +
+                    (*(const f32x4*)(dy + base + (long)2 * W * C) + *(const f32x4*)(dy + base + (long)2 * W * C + C));
+    *(f32x4*)(dx + pix * C + c) = s;
+}
+}  // namespace
+
+extern "C" int mage_maxpool2_bwd(const float* x, const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    MAGE_CHECK_ARG(x && dy && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "mage_maxpool2_bwd: bad arguments");
+    const long items = (long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C);
+    MAGE_CHECK_LAUNCH("mage_maxpool2_bwd");
+    return MAGE_OK;
+}
+
+extern "C" int mage_upsample2_bwd(const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    MAGE_CHECK_ARG(dy && dx && N > 0 && H > 0 && W > 0 && C % 4 == 0, "mage_upsample2_bwd: bad arguments");
+    const long items = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W, C);
+    MAGE_CHECK_LAUNCH("mage_upsample2_bwd");
+    return MAGE_OK;
+}

@@ -407,8 +407,10 @@ class VectorQuantizedVAE(nn.Module):
     def forward(self, x: torch.Tensor):
         """vqvae_model.py:244-248: (x_tilde, z_e_x, z_q_x), NCHW.  eval(): values from the inference kernels.  train(): BatchNorm on
         batch statistics; in grad mode the three outputs hang off one autograd node (vqvae_train.VQVAEForwardFn) whose backward is
-        the straight-through estimator + every convolution / BatchNorm gradient on the HIP kernels (train_vqvae.py:13-35)."""
-        if self._bn_training():
+        the straight-through estimator + every convolution / BatchNorm gradient on the HIP kernels (train_vqvae.py:13-35; both the
+        f4 and the f8 stack)."""
+        f8_graph = (self.down_ratio == 8 and self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+        if self._bn_training() or f8_graph:                       # the f8 stack has no BatchNorm: train() + grad mode asks for the graph
             from . import vqvae_train
             if not x.is_cuda:
                 raise RuntimeError("VectorQuantizedVAE runs on libmage_hip.so kernels: move the model and inputs to a ROCm GPU")

@@ -12,7 +12,13 @@ back-propagates into it, and its ``backward`` produces every parameter gradient 
   transposes + one split-K launch (mage_train._wgrad machinery);
 * the in-place-ReLU quirk of ResBlock (out = relu(x) + f(relu(x)), vqvae_model.py:111-124) exactly as in inference.
 
-fp32 throughout (stage-1 training is small: 2 x 2.4 M parameters).  down_ratio 8 (CATER) training is not built.
+fp32 throughout (stage-1 training is small: 2 x 2.4 M parameters).
+
+The f8 (CATER) stack (vqvae_model.py:126-165,192-214; ``train_vqvae.py --dataset cater-gen``) has no BatchNorm: its training pass is
+the inference kernels with the activations kept, and its backward adds the gradients of the bottleneck blocks (1x1 / 3x3 convolutions
+behind out-of-place ReLUs, the 1x1 identity path), of MaxPool2d(2) (first maximum of the window, PyTorch's tie rule) and nearest
+Upsample (2x2 block sums), of the 7x7 three-channel stem (weight gradient over the image padded to 8 channels) and of the 1x1
+three-channel tanh head.
 """
 from __future__ import annotations
 
@@ -26,7 +32,7 @@ from .mage_train import _split_plan
 
 F32 = torch.float32
 
-__all__ = ["VQVAEForwardFn", "vq_train_forward", "vq_train_backward"]
+__all__ = ["VQVAEForwardFn", "vq_train_forward", "vq_train_backward", "vq8_train_forward", "vq8_train_backward"]
 
 
 # ----------------------------------------------------------------------------------------------------------------- helpers
@@ -138,8 +144,7 @@ def _convt_forward(x_rows, subw, bias, n_img: int, h: int, wd: int, cin: int, co
 # ----------------------------------------------------------------------------------------------------------------- forward
 def vq_train_forward(vq, x: torch.Tensor):
     """VectorQuantizedVAE.forward in training mode (vqvae_model.py:244-248): (x_tilde NCHW, z_e rows, z_q rows, tape)."""
-    if vq.down_ratio != 4:
-        raise NotImplementedError("training-mode forward / backward is built for the f4 (MNIST) VQ-VAE; the f8 stack runs in eval mode")
+    assert vq.down_ratio == 4
     w = vq._weights()
     x = x.float().contiguous()
     N, Cin, H, W = x.shape
@@ -251,14 +256,165 @@ def vq_train_backward(vq, tape, g_xt, g_ze_rows, g_zq_rows) -> Dict[str, torch.T
     return grads
 
 
+# ================================================================================================================= f8 (CATER) stack
+def _kconv_bwd(w, wkey: str, dy, x, *, n_img: int, H: int, W: int, cin: int, cout: int, k: int, want_dx: bool = True, dx_res=None):
+    """Backward of y = Conv2d(cin, cout, k, 1, k // 2)(x) on channels-last rows: (dW [cout, cin, k, k], db, dx [+ dx_res])."""
+    M, r = n_img * H * W, k // 2
+    taps = [dict(dy=ky - r, dx=kx - r) for ky in range(k) for kx in range(k)]
+    dW, db = _wgrad_taps(dy, x, M=M, N=cout, Cin=cin, taps=taps, grid=dict(out_h=H, out_w=W, in_h=H, in_w=W))
+    dW = dW.view(cout, k, k, cin).permute(0, 3, 1, 2).contiguous()
+    dx = None
+    if want_dx:
+        dx = torch.empty(M, cin, device=dy.device, dtype=F32)
+        extra = dict(residual=dx_res, ldr=cin) if dx_res is not None else {}
+        if k == 1:
+            ops.gemm(dy, w[wkey].t().contiguous(), dx, M=M, N=cin, K=cout, lda=cout, ldy=cin, **extra)
+        else:
+            wf = w[wkey].view(cout, k, k, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, k * k * cout).contiguous()
+            _conv(dy, wf, dx, n_img=n_img, H=H, W=W, cin=cout, cout=cin, k=k, **extra)
+    return dW, db, dx
+
+
+def _bott_forward(vq, w, p: str, x, n_img: int, H: int, W: int, cin: int, cout: int, ks, post_relu: bool):
+    """EncoderBlock / DecoderBlock (vqvae_model.py:126-165): id_path(x) + conv(relu(conv(relu(conv(relu(conv(relu(x)))))))), the ReLUs
+    out of place (the identity path sees x itself).  ks = the four kernel sizes.  Returns (out, tape)."""
+    hid, dev = cout // 4, x.device
+    M = n_img * H * W
+    xr = ops.relu(x, torch.empty_like(x))
+    chans = [cin, hid, hid, hid, cout]
+    hs = [xr]
+    for j in range(3):
+        hs.append(_conv(hs[-1], w[f"{p}.w{2 * j + 1}.f32"], torch.empty(M, chans[j + 1], device=dev, dtype=F32), n_img=n_img, H=H, W=W,
+                        cin=chans[j], cout=chans[j + 1], k=ks[j], bias=w[f"{p}.b{2 * j + 1}"], act=ops.ACT_RELU))
+    has_id = (p + ".wid.f32") in w
+    idp = _conv(x, w[p + ".wid.f32"], torch.empty(M, cout, device=dev, dtype=F32), n_img=n_img, H=H, W=W, cin=cin, cout=cout, k=1,
+                bias=w[p + ".bid"]) if has_id else x
+    out = _conv(hs[3], w[p + ".w7.f32"], torch.empty(M, cout, device=dev, dtype=F32), n_img=n_img, H=H, W=W, cin=hid, cout=cout, k=ks[3],
+                bias=w[p + ".b7"], residual=idp, ldr=cout, post_relu=post_relu)
+    return out, dict(x=x, hs=hs, out=out if post_relu else None, has_id=has_id, geo=(n_img, H, W, cin, cout), ks=ks)
+
+
+def _bott_backward(vq, w, p: str, key: str, t, dout, grads: Dict[str, torch.Tensor]):
+    """d/dx of the block; fills `key`.block.{1,3,5,7}.* and `key`.id_path.*."""
+    n_img, H, W, cin, cout = t["geo"]
+    hid, ks, hs = cout // 4, t["ks"], t["hs"]
+    geo = dict(n_img=n_img, H=H, W=W)
+    do = ops.act_bwd(t["out"], dout, torch.empty_like(dout), ops.ACT_RELU) if t["out"] is not None else dout
+    chans = [cin, hid, hid, hid, cout]
+    g = do
+    for j in (3, 2, 1, 0):
+        dW, db, dh = _kconv_bwd(w, f"{p}.w{2 * j + 1}.f32", g, hs[j], cin=chans[j], cout=chans[j + 1], k=ks[j], **geo)
+        grads[f"{key}.block.{2 * j + 1}.weight"], grads[f"{key}.block.{2 * j + 1}.bias"] = dW, db
+        g = ops.act_bwd(hs[j], dh, dh, ops.ACT_RELU)                       # hs[j] = relu(.): its sign is the mask (hs[0] = relu(x))
+    if t["has_id"]:
+        dW, db, dx = _kconv_bwd(w, p + ".wid.f32", do, t["x"], cin=cin, cout=cout, k=1, dx_res=g, **geo)
+        grads[f"{key}.id_path.weight"], grads[f"{key}.id_path.bias"] = dW, db
+        return dx
+    return ops.dropout(do, g, 0.0, 0, accumulate=True)                     # g += do (p = 0: a plain add)
+
+
+_F8_ENC = ((1, 1, 1), (3, 1, 1), (5, 1, 2), (7, 2, 4))                      # (module index, cin / dim, cout / dim)
+_F8_DEC = ((0, 4, 2), (2, 2, 1), (4, 1, 1), (6, 1, 1))
+
+
+def vq8_train_forward(vq, x: torch.Tensor):
+    """VectorQuantizedVAE.forward of the f8 stack with the activations kept: (x_tilde NCHW, z_e rows, z_q rows, tape)."""
+    w = vq._weights()
+    x = x.float().contiguous()
+    N, Cin, H, W = x.shape
+    if H % 8 or W % 8:
+        raise ValueError(f"f8 VQ-VAE input {H}x{W} must be a multiple of 8 in both dimensions")
+    dim, dev = vq.dim, x.device
+    h = ops.conv_in(x, w["e0.wt"], w["e0.b"], None, None, torch.empty(N * H * W, dim, device=dev, dtype=F32), cin=Cin, H=H, W=W, cout=dim,
+                    kh=7, kw=7, stride=1, pad=3)
+    enc_t, pools = [], []
+    hh, ww = H, W
+    for bi, ci, co in _F8_ENC:
+        last = bi == 7
+        h, t = _bott_forward(vq, w, f"e{bi}", h, N, hh, ww, ci * dim, co * dim, (3, 3, 3, 1), post_relu=last)      # trailing nn.ReLU (:201)
+        enc_t.append(t)
+        if not last:
+            pools.append((h, hh, ww, co * dim))
+            h = ops.maxpool2(h, torch.empty(N * (hh // 2) * (ww // 2), co * dim, device=dev, dtype=F32), N=N, H=hh, W=ww, Cc=co * dim)
+            hh, ww = hh // 2, ww // 2
+    z_e, D = h, 4 * dim
+    ids = ops.vq_nearest(z_e, w["cbt"], w["c2"])
+    zq = ops.embedding(ids, w["cb"], torch.empty(N * hh * ww, D, device=dev, dtype=F32))
+    dec_t, ups = [], []
+    h = zq
+    for bi, ci, co in _F8_DEC:
+        last = bi == 6
+        h, t = _bott_forward(vq, w, f"d{bi}", h, N, hh, ww, ci * dim, co * dim, (1, 3, 3, 3), post_relu=last)      # decoder[7] ReLU folded
+        dec_t.append(t)
+        if not last:
+            ups.append((hh, ww, co * dim))
+            h = ops.upsample2(h, torch.empty(N * 4 * hh * ww, co * dim, device=dev, dtype=F32), N=N, H=hh, W=ww, Cc=co * dim)
+            hh, ww = hh * 2, ww * 2
+    x_tilde = ops.conv_out(h, w["d8.wt"], w["d8.b"], torch.empty(N, Cin, H, W, device=dev, dtype=F32), N=N, IH=H, IW=W, cin=dim, cout=Cin,
+                           transposed=False)
+    tape = dict(f8=True, x=x, enc=enc_t, pools=pools, ids=ids, dec=dec_t, ups=ups, last=h, x_tilde=x_tilde, N=N, H=H, W=W, h=H // 8, wd=W // 8,
+                Cin=Cin)
+    return x_tilde, z_e, zq, tape
+
+
+def vq8_train_backward(vq, tape, g_xt, g_ze_rows, g_zq_rows) -> Dict[str, torch.Tensor]:
+    w = vq._weights()
+    N, H, W, Cin, dim = tape["N"], tape["H"], tape["W"], tape["Cin"], vq.dim
+    D, dev = 4 * dim, tape["x"].device
+    grads: Dict[str, torch.Tensor] = {}
+    M8 = N * tape["h"] * tape["wd"]
+    dz_e = g_ze_rows.clone() if g_ze_rows is not None else torch.zeros(M8, D, device=dev, dtype=F32)
+    if g_zq_rows is not None:                                      # z_q_x_bar: index_add into the codebook (vqvae_model.py:54-62)
+        gcb = torch.zeros(vq.K, D, device=dev, dtype=F32)
+        ops.embedding_bwd(tape["ids"].reshape(-1), g_zq_rows, gcb)
+        grads["codebook.embedding.weight"] = gcb
+    if g_xt is not None:
+        M = N * H * W
+        g_xt = g_xt.float().contiguous()
+        ds = ops.act_bwd(tape["x_tilde"], g_xt, torch.empty_like(g_xt), ops.ACT_TANH)               # d tanh from its output, NCHW
+        grads["decoder.8.bias"] = ops.row_sum(ds, torch.empty(N * Cin, device=dev, dtype=F32), ld=H * W, n=H * W,
+                                              rows=N * Cin).view(N, Cin).sum(0)
+        dsr = torch.zeros(M, 8, device=dev, dtype=F32)                                              # channels-last rows, padded to 8 (plumbing)
+        dsr[:, :Cin] = ds.permute(0, 2, 3, 1).reshape(M, Cin)
+        dW8, _ = _wgrad_taps(dsr, tape["last"], M=M, N=8, Cin=dim, taps=[dict(dy=0, dx=0)], grid=dict(out_h=H, out_w=W, in_h=H, in_w=W))
+        grads["decoder.8.weight"] = dW8[:Cin].reshape(Cin, dim, 1, 1).contiguous()
+        w8 = torch.zeros(8, dim, device=dev, dtype=F32)
+        w8[:Cin] = w["d8.wt"]
+        g = ops.gemm(dsr, w8.t().contiguous(), torch.empty(M, dim, device=dev, dtype=F32), M=M, N=dim, K=8, lda=8, ldy=dim)
+        for (bi, ci, co), t in zip(reversed(_F8_DEC), reversed(tape["dec"])):
+            if bi != 6:
+                hh, ww, cc = tape["ups"].pop()
+                g = ops.upsample2_bwd(g, N=N, H=hh, W=ww, Cc=cc)
+            g = _bott_backward(vq, w, f"d{bi}", f"decoder.{bi}", t, g, grads)
+        if g_ze_rows is not None:                                                                   # straight-through (vqvae_model.py:47-49)
+            ops.dropout(g, dz_e, 0.0, 0, accumulate=True)
+        else:
+            dz_e = g
+    g = dz_e
+    for (bi, ci, co), t in zip(reversed(_F8_ENC), reversed(tape["enc"])):
+        if bi != 7:
+            xin, hh, ww, cc = tape["pools"].pop()
+            g = ops.maxpool2_bwd(xin, g, N=N, H=hh, W=ww, Cc=cc)
+        g = _bott_backward(vq, w, f"e{bi}", f"encoder.{bi}", t, g, grads)
+    # 7x7 stem over the Cin-channel image: weight gradient on the image as channels-last rows padded to 8 channels (layout plumbing)
+    M = N * H * W
+    xr = torch.zeros(M, 8, device=dev, dtype=F32)
+    xr[:, :Cin] = tape["x"].permute(0, 2, 3, 1).reshape(M, Cin)
+    taps = [dict(dy=ky - 3, dx=kx - 3) for ky in range(7) for kx in range(7)]
+    dW0, db0 = _wgrad_taps(g, xr, M=M, N=dim, Cin=8, taps=taps, grid=dict(out_h=H, out_w=W, in_h=H, in_w=W))
+    grads["encoder.0.weight"] = dW0.view(dim, 7, 7, 8)[..., :Cin].permute(0, 3, 1, 2).contiguous()
+    grads["encoder.0.bias"] = db0
+    return grads
+
+
 class VQVAEForwardFn(torch.autograd.Function):
     """(x_tilde, z_e_x, z_q_x) = VQVAEForwardFn.apply(model, images, names, *params): NCHW outputs as the reference returns them."""
 
     @staticmethod
     def forward(ctx, vq, x, names, *params):
         with torch.no_grad():
-            x_tilde, z_e, zq, tape = vq_train_forward(vq, x)
-        N, h, wd, D = tape["N"], tape["h"], tape["wd"], vq.dim
+            x_tilde, z_e, zq, tape = (vq_train_forward if vq.down_ratio == 4 else vq8_train_forward)(vq, x)
+        N, h, wd, D = tape["N"], tape["h"], tape["wd"], z_e.shape[1]
         ctx.vq, ctx.tape, ctx.names, ctx.shapes = vq, tape, names, [p.shape for p in params]
         return x_tilde, z_e.view(N, h, wd, D).permute(0, 3, 1, 2), zq.view(N, h, wd, D).permute(0, 3, 1, 2)
 
@@ -266,12 +422,13 @@ class VQVAEForwardFn(torch.autograd.Function):
     def backward(ctx, g_xt, g_ze, g_zq):
         if ctx.tape is None:
             raise RuntimeError("VQ-VAE training graph: backward through the same forward a second time")
-        vq, D = ctx.vq, ctx.vq.dim
+        vq = ctx.vq
+        D = vq.dim if vq.down_ratio == 4 else 4 * vq.dim
 
         def rows(g):                                               # NCHW gradient -> channels-last rows (layout plumbing)
             return None if g is None else g.float().permute(0, 2, 3, 1).reshape(-1, D).contiguous()
         with torch.no_grad(), torch.cuda.device(ctx.tape["x"].device):
-            grads = vq_train_backward(vq, ctx.tape, g_xt, rows(g_ze), rows(g_zq))
+            grads = (vq8_train_backward if ctx.tape.get("f8") else vq_train_backward)(vq, ctx.tape, g_xt, rows(g_ze), rows(g_zq))
         ctx.tape = None
         dev = next(vq.parameters()).device
         out = [grads[n].reshape(s) if n in grads else torch.zeros(s, device=dev, dtype=F32) for n, s in zip(ctx.names, ctx.shapes)]

@@ -490,6 +490,24 @@ def reparam_kl_bwd(mu, logvar, eps, dz, coef):
     return dmu, dlv
 
 
+def maxpool2_bwd(x, dy, *, N, H, W, Cc):
+    """dx [N*H*W, C] of y = maxpool2(x): dy [N*(H/2)*(W/2), C] routed to the first maximum of each window."""
+    l, s = _dev(x)
+    assert x.dtype == torch.float32 and dy.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty_like(x)
+    _lib.check(l.mage_maxpool2_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, H, W, Cc, s), l)
+    return dx
+
+
+def upsample2_bwd(dy, *, N, H, W, Cc):
+    """dx [N*H*W, C] of y = upsample2(x) (nearest): the sum of each 2x2 block of dy [N*2H*2W, C]."""
+    l, s = _dev(dy)
+    assert dy.dtype == torch.float32 and dy.is_contiguous()
+    dx = torch.empty(N * H * W, Cc, device=dy.device, dtype=torch.float32)
+    _lib.check(l.mage_upsample2_bwd(dy.data_ptr(), dx.data_ptr(), N, H, W, Cc, s), l)
+    return dx
+
+
 def mse_bwd(a, b, gout, *, rows, cols, lda, ldb):
     """d mse / da * gout as [rows, lda] fp32 (zeros in the padding columns)."""
     l, s = _dev(a)

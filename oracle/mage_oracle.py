@@ -494,8 +494,43 @@ def vqvae_train_forward(sd: SD, p: str, x: torch.Tensor):
     return x_tilde, z_e, z_q
 
 
+def _block8_train(sd: SD, p: str, x: torch.Tensor, ks) -> torch.Tensor:
+    """EncoderBlock / DecoderBlock.forward (vqvae_model.py:126-165): id_path(x) + block(x), ReLUs out of place; ks = kernel sizes."""
+    idp = F.conv2d(x, sd[p + ".id_path.weight"], sd[p + ".id_path.bias"]) if (p + ".id_path.weight") in sd else x
+    h = x
+    for j, k in zip((1, 3, 5, 7), ks):
+        h = F.conv2d(F.relu(h), sd[f"{p}.block.{j}.weight"], sd[f"{p}.block.{j}.bias"], padding=k // 2)
+    return idp + h
+
+
+def vqvae8_train_forward(sd: SD, p: str, x: torch.Tensor):
+    """VectorQuantizedVAE.forward of the f8 (CATER) model (vqvae_model.py:244-248 over :192-214; no BatchNorm, so train() and eval()
+    compute the same values), differentiable w.r.t. the tensors of sd, straight-through quantiser as in vqvae_train_forward."""
+    h = F.conv2d(x, sd[p + "encoder.0.weight"], sd[p + "encoder.0.bias"], padding=3)
+    for bi in (1, 3, 5, 7):
+        h = _block8_train(sd, p + f"encoder.{bi}", h, (3, 3, 3, 1))
+        if bi != 7:
+            h = F.max_pool2d(h, 2)
+    z_e = F.relu(h)
+    cb = sd[p + "codebook.embedding.weight"]
+    zr = z_e.permute(0, 2, 3, 1).contiguous()
+    with torch.no_grad():
+        ids = vq_nearest(zr, cb)
+    codes = cb[ids.reshape(-1)].view_as(zr)
+    z_q_st = (zr + (codes.detach() - zr).detach()).permute(0, 3, 1, 2)
+    z_q = codes.permute(0, 3, 1, 2)
+    d = z_q_st
+    for bi in (0, 2, 4, 6):
+        d = _block8_train(sd, p + f"decoder.{bi}", d, (1, 3, 3, 3))
+        if bi != 6:
+            d = F.interpolate(d, scale_factor=2, mode="nearest")
+    x_tilde = torch.tanh(F.conv2d(F.relu(d), sd[p + "decoder.8.weight"], sd[p + "decoder.8.bias"]))
+    return x_tilde, z_e, z_q
+
+
 def vqvae_train_loss(sd: SD, p: str, x: torch.Tensor, beta: float = 2.0):
     """The objective of train_vqvae.py:20-27 (reconstruction + vector-quantisation + beta * commitment)."""
-    x_tilde, z_e, z_q = vqvae_train_forward(sd, p, x)
+    f8 = (p + "encoder.7.block.1.weight") in sd
+    x_tilde, z_e, z_q = (vqvae8_train_forward if f8 else vqvae_train_forward)(sd, p, x)
     rec, vql, com = F.mse_loss(x_tilde, x), F.mse_loss(z_q, z_e.detach()), F.mse_loss(z_e, z_q.detach())
     return rec + vql + beta * com, (rec, vql, com), (x_tilde, z_e, z_q)

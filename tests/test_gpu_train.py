@@ -466,6 +466,51 @@ def test_vqvae_stage1_training_step_matches_the_reference(tag):
     assert m.encode(x).dtype == torch.int64
 
 
+@pytest.mark.parametrize("tag", ["vqvae_f8_train_small", "vqvae_f8_train"])
+def test_vqvae8_stage1_training_step_matches_the_reference(tag):
+    """train_vqvae.py:13-27 with --dataset cater-gen (down_ratio 8: bottleneck blocks, MaxPool2d, nearest Upsample, 7x7 RGB stem, 1x1
+    tanh head, codebook dimension 4*dim) on the HIP path: outputs, loss terms and EVERY parameter gradient against the reference's
+    own step."""
+    from tests.helpers import build_vqvae, golden, t
+    from tests.test_oracle_golden import check_vq_train_grads
+    g = golden(tag)
+    m = build_vqvae(3, 8, int(g["dim"]), int(g["K"]), int(g["seed"]), DEV).train()
+    x = synth.synth_batch_cater(int(g["n_img"]), 1, seed=int(g["seed"]), res=64)["images"][:, 0].contiguous().to(DEV)
+    x_tilde, z_e, z_q = m(x)
+    assert x_tilde.requires_grad and z_e.requires_grad and z_q.requires_grad and z_e.shape[1] == 4 * int(g["dim"])
+    rec, vql, com = F.mse_loss(x_tilde, x), F.mse_loss(z_q, z_e.detach()), F.mse_loss(z_e, z_q.detach())
+    loss = rec + vql + float(g["beta"]) * com
+    assert abs(rec.item() - float(g["rec"])) < 1e-5 and abs(vql.item() - float(g["vq"])) < 1e-5 * max(1, float(g["vq"]))
+    assert abs(com.item() - float(g["commit"])) < 1e-5 * max(1, float(g["commit"])) and abs(loss.item() - float(g["loss"])) < 1e-4 * max(1, float(g["loss"]))
+    torch.testing.assert_close(x_tilde.detach()[:, :, ::4, ::4].cpu(), t(g["x_tilde_sub"]), atol=1e-4, rtol=0)
+    loss.backward()
+    grads = {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters()}
+    worst = check_vq_train_grads(g, grads, GRAD_TOL)
+    print(f"{tag}: worst relative gradient error {worst:.2e}")
+    m.eval()                                                       # eval mode: values only, the inference path
+    with torch.no_grad():
+        xt2, _, _ = m(x)
+    torch.testing.assert_close(xt2, x_tilde.detach(), atol=1e-5, rtol=0)
+
+
+def test_pooling_backward_kernels():
+    o = ops()
+    N, H, W, Cc = 2, 8, 12, 8
+    x = rnd(N, Cc, H, W, seed=1)
+    x[0, :, 0, 0] = x[0, :, 0, 1]                                  # a tie inside a window: the first maximum takes the gradient
+    x = x.requires_grad_()
+    dy = rnd(N, Cc, H // 2, W // 2, seed=2)
+    F.max_pool2d(x, 2).backward(dy)
+    rows = lambda t_: t_.permute(0, 2, 3, 1).reshape(-1, Cc).contiguous().to(DEV)
+    dx = o.maxpool2_bwd(rows(x.detach()), rows(dy), N=N, H=H, W=W, Cc=Cc)
+    assert torch.equal(dx.view(N, H, W, Cc).permute(0, 3, 1, 2).cpu(), x.grad)
+    u = rnd(N, Cc, H, W, seed=3).requires_grad_()
+    du = rnd(N, Cc, 2 * H, 2 * W, seed=4)
+    F.interpolate(u, scale_factor=2, mode="nearest").backward(du)
+    dxu = o.upsample2_bwd(rows(du), N=N, H=H, W=W, Cc=Cc)
+    torch.testing.assert_close(dxu.view(N, H, W, Cc).permute(0, 3, 1, 2).cpu(), u.grad, atol=1e-6, rtol=1e-6)
+
+
 def test_vqvae_stage1_training_loop_reduces_the_loss():
     """A few steps of train_vqvae.py's loop (Adam lr 1e-4 as its default is too slow to show in 5 steps: 1e-3) with FlatAdam."""
     from mage_amd.optim import FlatAdam

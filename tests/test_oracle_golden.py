@@ -253,3 +253,21 @@ def test_vqvae_stage1_training_step(tag):
     gs = torch.autograd.grad(loss, [sd[n] for n in names], allow_unused=True)
     grads = {n: (gg if gg is not None else torch.zeros_like(sd[n])) for n, gg in zip(names, gs)}
     assert check_vq_train_grads(g, grads, 2e-5) < 2e-5
+
+
+@pytest.mark.parametrize("tag", ["vqvae_f8_train_small", "vqvae_f8_train"])
+def test_vqvae8_stage1_training_step(tag):
+    """The oracle's f8 (CATER) VQ-VAE forward with the straight-through quantiser and its autograd against the reference's own
+    train_vqvae.py step (--dataset cater-gen: down_ratio 8): the three loss terms and every parameter gradient."""
+    from tests.helpers import build_vqvae
+    g = golden(tag)
+    sd = {k: (v.requires_grad_() if v.is_floating_point() else v) for k, v in cpu_sd(build_vqvae(3, 8, int(g["dim"]), int(g["K"]), int(g["seed"]))).items()}
+    x = synth.synth_batch_cater(int(g["n_img"]), 1, seed=int(g["seed"]), res=64)["images"][:, 0].contiguous()
+    loss, (rec, vql, com), (x_tilde, z_e, z_q) = O.vqvae_train_loss(sd, "", x, beta=float(g["beta"]))
+    assert abs(loss.item() - float(g["loss"])) < 1e-6 * max(1, float(g["loss"])) and abs(rec.item() - float(g["rec"])) < 1e-6
+    assert abs(vql.item() - float(g["vq"])) < 1e-6 * max(1, float(g["vq"])) and abs(com.item() - float(g["commit"])) < 1e-6 * max(1, float(g["commit"]))
+    assert torch.allclose(x_tilde[:, :, ::4, ::4], t(g["x_tilde_sub"]), atol=1e-5)
+    names = g["param_names"].tolist()
+    gs = torch.autograd.grad(loss, [sd[n] for n in names], allow_unused=True)
+    grads = {n: (gg if gg is not None else torch.zeros_like(sd[n])) for n, gg in zip(names, gs)}
+    assert check_vq_train_grads(g, grads, 2e-5) < 2e-5

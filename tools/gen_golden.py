@@ -208,17 +208,24 @@ def gen_vqvae_train(ref_vq):
     batch statistics, straight-through quantiser), the three-term loss, loss.backward(): loss values, every parameter's gradient
     (dim 32: in full; dim 256: checksums + slices) and the BatchNorm running buffers after the step."""
     import torch.nn.functional as F
-    for tag, dim, K, n_img, seed, full in (("vqvae_f4_train_small", 32, 64, 4, 13, True), ("vqvae_f4_train", 256, 512, 2, 14, False)):
+    cases = (("vqvae_f4_train_small", 4, 32, 64, 4, 13, True), ("vqvae_f4_train", 4, 256, 512, 2, 14, False),
+             ("vqvae_f8_train_small", 8, 32, 64, 2, 15, True), ("vqvae_f8_train", 8, 128, 256, 1, 16, False))
+    if "--only-vqvae8-train" in sys.argv:
+        cases = cases[2:]
+    for tag, ratio, dim, K, n_img, seed, full in cases:
         print(tag)
-        m = ref_vq.VectorQuantizedVAE(1, 4, dim, K)
+        m = ref_vq.VectorQuantizedVAE(1 if ratio == 4 else 3, ratio, dim, K)
         synth.fill_state_dict(m, seed)
         m.train()
-        x = synth.synth_batch_mnist(n_img, 1, seed=seed)["images"][:, 0].contiguous()
+        if ratio == 4:
+            x = synth.synth_batch_mnist(n_img, 1, seed=seed)["images"][:, 0].contiguous()
+        else:                                                  # CATER-like RGB frames, 64x64 (any multiple of 8 works; train_vqvae.py:97)
+            x = synth.synth_batch_cater(n_img, 1, seed=seed, res=64)["images"][:, 0].contiguous()
         x_tilde, z_e, z_q = m(x.clone())
         rec, vql, com = F.mse_loss(x_tilde, x), F.mse_loss(z_q, z_e.detach()), F.mse_loss(z_e, z_q.detach())
         loss = rec + vql + 2.0 * com
         loss.backward()
-        out = dict(seed=seed, dim=dim, K=K, n_img=n_img, beta=2.0, loss=np.float64(loss.item()), rec=np.float64(rec.item()),
+        out = dict(seed=seed, dim=dim, K=K, n_img=n_img, ratio=ratio, beta=2.0, loss=np.float64(loss.item()), rec=np.float64(rec.item()),
                    vq=np.float64(vql.item()), commit=np.float64(com.item()), x_tilde_chk=chk(x_tilde.detach()), z_e_chk=chk(z_e.detach()),
                    z_q_chk=chk(z_q.detach()), x_tilde_sub=x_tilde.detach()[:, :, ::4, ::4].contiguous())
         names = []
@@ -249,7 +256,7 @@ def main():
         gen_mage_plus_block(ref_mage)
         gen_vqvae_train(ref_vq)
         return
-    if "--only-vqvae-train" in sys.argv:
+    if "--only-vqvae-train" in sys.argv or "--only-vqvae8-train" in sys.argv:
         gen_vqvae_train(ref_vq)
         return
 
