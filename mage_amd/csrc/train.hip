@@ -790,16 +790,254 @@ extern "C" int mage_group_rowsum(const void* x, int32_t dtype, int64_t rows, int
     return MAGE_OK;
 }
 
+namespace {
+// ------------------------------------------------------------------------------------------------ attention backward on the matrix cores
+// bf16, nq <= 32, nk <= 32 (the decoder's axial attentions): the backward twin of attention_mfma_kernel (norm_attn.hip), one wave per
+// (sequence, head), 4 heads per workgroup.  K, Q, dO of the head are staged in wave-private LDS (bf16, 80-byte rows); V fragments come
+// straight from global.  Per 16-query block and 16-key block, with the MFMA conventions of the forward kernel
+// (16x16x32: D[m][n] = sum_c A[m][c] B[n][c], lane (r, g) feeds row r's bytes [16g, 16g+16) of A and of B, result lane (n, g) holds
+//  D[4g+e][n];  16x16x16: A lane (m, g) holds A[m][4g+e], B lane (n, g) holds B[n][4g+e], result lane (n, g) holds D[4g+e][n]):
+//   query-major  S^T = K Q^T, dP^T = V dO^T: lane (i, g) holds 4 keys of ITS query: softmax statistics (max, sum) and D_i = sum_j P dP
+//                as in-lane sums + two xor-shuffles; dS = P (dP - D) scale;  dQ^T = K^T dS^T  (A = K^T read from LDS, B = dS in the lane);
+//   key-major    S = Q K^T, dP = dO V^T: lane (j, g) holds 4 queries of ITS key; P and dS are rebuilt with the statistics fetched from
+//                the lanes that own those queries;  dV^T += dO^T P, dK^T += Q^T dS  (A = dO^T / Q^T from LDS).
+// P and dS enter the 16x16x16 MFMAs as bf16 hi + lo pairs (fp32-class weights, as in the forward).  dK / dV accumulate over the query
+// blocks in registers; every output row leaves as one 16-byte store per lane (lane-group swap as in the forward).
+typedef __attribute__((ext_vector_type(8))) __bf16 tbf16x8;
+typedef __attribute__((ext_vector_type(4))) short tshort4;
+
+__device__ __forceinline__ void split_hi_lo(float v, short& hi, short& lo) {
+    const unsigned hb = __float_as_uint(v) & 0xffff0000u;
+    hi = (short)(hb >> 16);
+    lo = (short)(__float_as_uint(v - __uint_as_float(hb)) >> 16);
+}
+
+template <int NKB>
+__global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const mage_attn_desc d, const unsigned short* __restrict__ dout,
+                                                                 unsigned short* __restrict__ dq, unsigned short* __restrict__ dk,
+                                                                 unsigned short* __restrict__ dv, int ld_dq, int ld_dk, int ld_dv) {
+    constexpr int PITCH = 40;                                  // shorts per staged row (64 data bytes + 16): conflict-free transposed reads
+    __shared__ __attribute__((aligned(16))) unsigned short lds[4][(16 * NKB + 64) * PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = blockIdx.y * 4 + wave;
+    if (h >= d.n_head) return;                                 // whole wave; waves are independent (no workgroup barrier below)
+    unsigned short* ks = lds[wave];
+    unsigned short* qs = ks + 16 * NKB * PITCH;
+    unsigned short* gs = qs + 32 * PITCH;
+    const int s = blockIdx.x;
+    const int outer = s / d.inner, in = s - outer * d.inner;
+    const long q_base = (long)outer * d.q_outer_stride + in;
+    const long kv_base = (long)outer * d.kv_outer_stride + in;
+    const unsigned short* qp = (const unsigned short*)d.q;
+    const unsigned short* kp = (const unsigned short*)d.k;
+    const unsigned short* vp = (const unsigned short*)d.v;
+    const int r = lane & 15, g = lane >> 4;
+    const int sr = lane >> 2, sc = (lane & 3) * 8;             // staging: 16 rows x 4 chunks of 16 bytes per pass
+    const int nqb = (d.nq + 15) >> 4;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const int j = kb * 16 + sr;
+        uint4 val = uint4{0u, 0u, 0u, 0u};
+        if (j < d.nk) val = *(const uint4*)(kp + (kv_base + (long)j * d.kv_axis_stride) * d.ldk + h * 32 + sc);
+        *(uint4*)(ks + j * PITCH + sc) = val;
+    }
+    for (int qb = 0; qb < nqb; ++qb) {
+        const int i = qb * 16 + sr;
+        uint4 vq = uint4{0u, 0u, 0u, 0u}, vg = vq;
+        if (i < d.nq) {
+            const long row = q_base + (long)i * d.q_axis_stride;
+            vq = *(const uint4*)(qp + row * d.ldq + h * 32 + sc);
+            vg = *(const uint4*)(dout + row * d.ldo + h * 32 + sc);
+        }
+        *(uint4*)(qs + i * PITCH + sc) = vq;
+        *(uint4*)(gs + i * PITCH + sc) = vg;
+    }
+    uint4 vf[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const long vrow = kv_base + (long)min(kb * 16 + r, d.nk - 1) * d.kv_axis_stride;      // rows >= nk: clamped, masked below
+        vf[kb] = *(const uint4*)(vp + vrow * d.ldv + h * 32 + g * 8);
+    }
+    int klen = d.nk;
+    if (d.kv_len) klen = min(klen, d.kv_len[s / d.kv_len_div]);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0): the wave's own LDS writes are visible to all its lanes
+    uint4 kf[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) kf[kb] = *(const uint4*)(ks + (kb * 16 + r) * PITCH + g * 8);
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 dka[NKB][2], dva[NKB][2];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) dka[kb][b] = dva[kb][b] = zero4;
+
+    for (int qb = 0; qb < nqb; ++qb) {
+        const uint4 qf = *(const uint4*)(qs + (qb * 16 + r) * PITCH + g * 8);
+        const uint4 gf = *(const uint4*)(gs + (qb * 16 + r) * PITCH + g * 8);
+        // ---------------- query-major: this lane's query qi, keys kb*16 + 4g + e
+        const int qi = qb * 16 + r;
+        const int jmax = d.causal ? min(klen, qi + 1 + (d.nk - d.nq)) : klen;
+        f32x4 st[NKB], dpt[NKB];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tbf16x8, kf[kb]), __builtin_bit_cast(tbf16x8, qf), zero4, 0, 0, 0);
+            dpt[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tbf16x8, vf[kb]), __builtin_bit_cast(tbf16x8, gf), zero4, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                st[kb][e] = (kb * 16 + 4 * g + e < jmax) ? st[kb][e] * d.scale : -INFINITY;
+                mx = fmaxf(mx, st[kb][e]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float den = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                st[kb][e] = (kb * 16 + 4 * g + e < jmax) ? expf(st[kb][e] - mx) : 0.f;
+                den += st[kb][e];
+            }
+        den += __shfl_xor(den, 16);
+        den += __shfl_xor(den, 32);
+        const float inv = 1.0f / den;
+        float dsum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                st[kb][e] *= inv;                                             // P
+                dsum += st[kb][e] * dpt[kb][e];
+            }
+        dsum += __shfl_xor(dsum, 16);
+        dsum += __shfl_xor(dsum, 32);
+        tshort4 shi[NKB], slo[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                short hi, lo;
+                split_hi_lo(st[kb][e] * (dpt[kb][e] - dsum) * d.scale, hi, lo);    // dS
+                shi[kb][e] = hi;
+                slo[kb][e] = lo;
+            }
+        f32x4 o[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            o[b] = zero4;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const unsigned short* kr = ks + (kb * 16 + 4 * g) * PITCH + b * 16 + r;
+                tshort4 kt;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kt[e] = (short)kr[e * PITCH];
+                o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt, shi[kb], o[b], 0, 0, 0);
+                o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt, slo[kb], o[b], 0, 0, 0);
+            }
+        }
+        {
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[0][e]), __float_as_uint(o[1][e]), false, false);
+                v0[e] = __uint_as_float(sw[0]);
+                v1[e] = __uint_as_float(sw[1]);
+            }
+            if (qi < d.nq) store8(dq + (q_base + (long)qi * d.q_axis_stride) * ld_dq + h * 32 + 16 * (g & 1) + 8 * (g >> 1), v0, v1);
+        }
+        // ---------------- key-major: this lane's key kb*16 + r, queries qb*16 + 4g + e (their statistics live in lanes 4g + e)
+        float mxq[4], invq[4], dsq[4];
+        int jmq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mxq[e] = __shfl(mx, 4 * g + e);
+            invq[e] = __shfl(inv, 4 * g + e);
+            dsq[e] = __shfl(dsum, 4 * g + e);
+            const int i2 = qb * 16 + 4 * g + e;
+            jmq[e] = d.causal ? min(klen, i2 + 1 + (d.nk - d.nq)) : klen;
+        }
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const f32x4 s2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tbf16x8, qf), __builtin_bit_cast(tbf16x8, kf[kb]), zero4, 0, 0, 0);
+            const f32x4 dp2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tbf16x8, gf), __builtin_bit_cast(tbf16x8, vf[kb]), zero4, 0, 0, 0);
+            tshort4 phi, plo, dhi, dlo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = (kb * 16 + r < jmq[e]) ? expf(s2[e] * d.scale - mxq[e]) * invq[e] : 0.f;
+                short hi, lo;
+                split_hi_lo(p, hi, lo);
+                phi[e] = hi;
+                plo[e] = lo;
+                split_hi_lo(p * (dp2[e] - dsq[e]) * d.scale, hi, lo);
+                dhi[e] = hi;
+                dlo[e] = lo;
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const unsigned short* gr = gs + (qb * 16 + 4 * g) * PITCH + b * 16 + r;
+                const unsigned short* qr = qs + (qb * 16 + 4 * g) * PITCH + b * 16 + r;
+                tshort4 gt, qt;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gt[e] = (short)gr[e * PITCH];
+                    qt[e] = (short)qr[e * PITCH];
+                }
+                dva[kb][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gt, phi, dva[kb][b], 0, 0, 0);
+                dva[kb][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gt, plo, dva[kb][b], 0, 0, 0);
+                dka[kb][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qt, dhi, dka[kb][b], 0, 0, 0);
+                dka[kb][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qt, dlo, dka[kb][b], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        f32x4 k0, k1, w0, w1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const auto sk = __builtin_amdgcn_permlane16_swap(__float_as_uint(dka[kb][0][e]), __float_as_uint(dka[kb][1][e]), false, false);
+            const auto sv = __builtin_amdgcn_permlane16_swap(__float_as_uint(dva[kb][0][e]), __float_as_uint(dva[kb][1][e]), false, false);
+            k0[e] = __uint_as_float(sk[0]);
+            k1[e] = __uint_as_float(sk[1]);
+            w0[e] = __uint_as_float(sv[0]);
+            w1[e] = __uint_as_float(sv[1]);
+        }
+        const int j = kb * 16 + r;
+        if (j < d.nk) {
+            const long row = kv_base + (long)j * d.kv_axis_stride;
+            const int col = h * 32 + 16 * (g & 1) + 8 * (g >> 1);
+            store8(dk + row * ld_dk + col, k0, k1);
+            store8(dv + row * ld_dv + col, w0, w1);
+        }
+    }
+}
+
+}  // namespace
+
 extern "C" int mage_attention_bwd(const mage_attn_desc* d, const void* dout, void* dq, void* dk, void* dv, int32_t ld_dq, int32_t ld_dk,
                                   int32_t ld_dv, void* stream) {
     MAGE_CHECK_ARG(d && d->q && d->k && d->v && dout && dq && dk && dv, "mage_attention_bwd: null pointer");
     MAGE_CHECK_ARG(d->nk >= 1 && d->nk <= 64 && d->nq >= 1 && d->n_seq >= 1 && d->n_head >= 1 && d->inner >= 1,
                    "mage_attention_bwd: nk=%d nq=%d unsupported", d->nk, d->nq);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == MAGE_BF16 && d->nq <= 32 && d->nk <= 32 && !getenv("MAGE_ATTN_NO_MFMA") && d->ldq % 8 == 0 && d->ldk % 8 == 0 &&
+        d->ldv % 8 == 0 && d->ldo % 8 == 0 && ld_dq % 8 == 0 && ld_dk % 8 == 0 && ld_dv % 8 == 0 &&
+        ((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0)) {
+        const dim3 grid(d->n_seq, (d->n_head + 3) / 4), blk(256);
+        if (d->nk <= 16)
+            hipLaunchKernelGGL((attention_bwd_mfma_kernel<1>), grid, blk, 0, s, *d, (const unsigned short*)dout, (unsigned short*)dq,
+                               (unsigned short*)dk, (unsigned short*)dv, ld_dq, ld_dk, ld_dv);
+        else
+            hipLaunchKernelGGL((attention_bwd_mfma_kernel<2>), grid, blk, 0, s, *d, (const unsigned short*)dout, (unsigned short*)dq,
+                               (unsigned short*)dk, (unsigned short*)dv, ld_dq, ld_dk, ld_dv);
+        MAGE_CHECK_LAUNCH("mage_attention_bwd");
+        return MAGE_OK;
+    }
     const int qb = d->nq < 64 ? d->nq : 64;
     const size_t per_wave = (size_t)(2 * d->nk * 32 + 2 * qb * 33 + 2 * qb * (d->nk + 1)) * 4;
     const size_t lds = 4 * per_wave;
     MAGE_CHECK_ARG(lds <= 160 * 1024, "mage_attention_bwd: LDS budget");
-    hipStream_t s = (hipStream_t)stream;
     const dim3 grid(d->n_seq, (d->n_head + 3) / 4), blk(256);
     static bool attr_set[MAGE_MAX_DEVICES][2] = {{false}};
     const int dev = mage_device_index();

@@ -210,6 +210,47 @@ def test_attention_backward(axis, dtype):
     assert rel(dqp, qp.grad) < 1e-5 and rel(dkvp, kvp.grad) < 1e-5
 
 
+@pytest.mark.parametrize("axis,L,hh,ww,H", [(0, 16, 4, 4, 6), (0, 20, 2, 3, 4), (0, 5, 4, 4, 2), (1, 3, 16, 4, 5), (2, 2, 4, 16, 16), (1, 2, 32, 2, 4)])
+def test_attention_backward_on_the_matrix_cores(axis, L, hh, ww, H):
+    """bf16 axial attention backward (attention_bwd_mfma_kernel): 1-2 blocks of 16 queries / keys, causal and full, head counts that do
+    not fill the last workgroup, against autograd of the fp32 formula on the same bf16 inputs (the outputs are bf16: 1e-2 of the largest
+    entry) and against the thread-per-query kernel."""
+    import os
+    o = ops()
+    Cc, B = H * 32, 2
+    hw, M = hh * ww, B * L * hh * ww
+    qkv = rnd(M, 3 * Cc, seed=30).bfloat16()
+    do = rnd(M, Cc, seed=31).bfloat16()
+    geo = [dict(n_seq=B * hw, inner=hw, nq=L, nk=L, q_outer_stride=L * hw, q_axis_stride=hw, causal=True),
+           dict(n_seq=B * L * ww, inner=ww, nq=hh, nk=hh, q_outer_stride=hw, q_axis_stride=ww, causal=False),
+           dict(n_seq=B * L * hh, inner=1, nq=ww, nk=ww, q_outer_stride=ww, q_axis_stride=1, causal=False)][axis]
+    geo.update(kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], n_head=H)
+    x = qkv.float().view(B, L, hh, ww, 3, H, 32).requires_grad_()
+    perm = [(0, 2, 3, 4, 1, 5), (0, 1, 3, 4, 2, 5), (0, 1, 2, 4, 3, 5)][axis]
+    q, k, v = (x[:, :, :, :, j].permute(*perm) for j in range(3))
+    n = q.shape[-2]
+    mask = torch.ones(n, n, dtype=torch.bool).tril() if axis == 0 else torch.ones(n, n, dtype=torch.bool)
+    _sdpa_ref(q, k, v, mask).permute(*np.argsort(perm).tolist()).reshape(M, Cc).backward(do.float())
+    want = x.grad.reshape(M, 3 * Cc)
+
+    def run():
+        dqkv = torch.full((M, 3 * Cc), float("nan"), device=DEV, dtype=torch.bfloat16)
+        dq = qkv.to(DEV)
+        o.attention_bwd(dq, dq[:, Cc:], dq[:, 2 * Cc:], do.to(DEV), dqkv, dqkv[:, Cc:], dqkv[:, 2 * Cc:], ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc,
+                        ldo=Cc, ld_dq=3 * Cc, ld_dk=3 * Cc, ld_dv=3 * Cc, **geo)
+        return dqkv
+    got = run()
+    assert torch.isfinite(got.float()).all()
+    for j, nm in enumerate(("dq", "dk", "dv")):
+        assert rel(got[:, j * Cc:(j + 1) * Cc], want[:, j * Cc:(j + 1) * Cc]) < 1e-2, nm
+    os.environ["MAGE_ATTN_NO_MFMA"] = "1"
+    try:
+        old = run()
+    finally:
+        del os.environ["MAGE_ATTN_NO_MFMA"]
+    assert rel(got, old.float()) < 1e-2
+
+
 def test_dropout_mask_is_stateless_and_scaled():
     o = ops()
     x = torch.ones(1 << 20, device=DEV)
