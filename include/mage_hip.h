@@ -291,6 +291,12 @@ int mage_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t r
 int mage_transpose(const void* x, int32_t dtype, int64_t ldx, void* y, int64_t ldy, int64_t y_row0, int64_t M, int64_t Mp, int32_t C,
                    int32_t out_h, int32_t out_w, int32_t in_h, int32_t in_w, int64_t img_stride, int64_t a_off, int32_t dy, int32_t dx,
                    int32_t stride, void* stream);
+/* mage_transpose of bf16 rows (out_h = 1: row m -> (m / out_w) * img_stride + m % out_w + a_off, no tap shift) that also returns the
+ * column sums of x: colsum[p][c] = sum over the p-th group of 16 consecutive 64-row tiles of x[., c] (n_part = ceil(ceil(Mp / 64) / 16)
+ * partial rows for mage_sum_partials): the bias gradient db = sum_m dY[m, :] of a Linear in the same pass as the transposed copy of dY
+ * that its weight gradient needs. */
+int mage_transpose_colsum(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int64_t Mp, int32_t C, int32_t out_w,
+                          int64_t img_stride, int64_t a_off, float* colsum, int32_t n_part, void* stream);
 /* Row sums (fp32, fixed order): bias gradients db = column sums of dY, taken from the transposed dY.  The n columns are cut into
  * n_chunk chunks: out[chunk*rows + r] = sum over chunk of x[r*ld + c]; n_chunk > 1 is finished by mage_sum_partials. */
 int mage_row_sum(const void* x, int32_t dtype, int64_t ld, int64_t n, int32_t rows, float* out, int32_t n_chunk, void* stream);

@@ -61,6 +61,7 @@ SIGNATURES = {
     "mage_adain_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "mage_reparam_kl_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "mage_mse_bwd": (C.c_int, [vp, i64, vp, i64, i64, i32, vp, vp, i64, vp]),
+    "mage_transpose_colsum": (C.c_int, [vp, i64, vp, i64, i64, i64, i32, i32, i64, i64, vp, i32, vp]),
     "mage_maxpool2_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "mage_upsample2_bwd": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "mage_layernorm": (C.c_int, [vp, vp, vp, vp, i32, i64, i32, f32, vp]),

@@ -89,6 +89,68 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const unsigned short* _
     }
 }
 
+// The same transposition with the column sums of x folded in (the bias gradient db = sum_m dY[m, :] of a Linear, which used to be a
+// second pass over the transposed copy: 7 ms of a 119 ms training step): a workgroup walks TPW consecutive 64-row tiles, every thread adds
+// up the 8 rows it assembles per channel, the 8 threads of a channel combine by xor-shuffles, and the workgroup's sums land in
+// colsum[blockIdx.x][c] (fixed order; mage_sum_partials adds the ceil(tiles / TPW) partial rows).
+constexpr int TRANSPOSE_TPW = 16;
+__global__ __launch_bounds__(256) void transpose8_colsum_kernel(const unsigned short* __restrict__ x, long ldx, unsigned short* __restrict__ y,
+                                                                long ldy, long M, long Mp, int C, int out_h, int out_w, int in_h, int in_w,
+                                                                long img_stride, long a_off, float* __restrict__ colsum) {
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64 * 66];
+    const int c0 = blockIdx.y * 64;
+    const long plane = (long)out_h * out_w;
+    float cs[2] = {0.f, 0.f};
+    for (int t = 0; t < TRANSPOSE_TPW; ++t) {
+        const long m0 = ((long)blockIdx.x * TRANSPOSE_TPW + t) * 64;
+        if (m0 >= Mp) break;                                              // block-uniform
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int r = e >> 3, cc = (e & 7) * 8;
+            const long m = m0 + r;
+            uint4 v = uint4{0u, 0u, 0u, 0u};
+            if (m < M && c0 + cc < C) {
+                const long img = m / plane, rem = m - img * plane;
+                const int oy = (int)(rem / out_w), ox = (int)(rem - (long)oy * out_w);
+                if ((unsigned)oy < (unsigned)in_h && (unsigned)ox < (unsigned)in_w)
+                    v = *(const uint4*)(x + (img * img_stride + (long)oy * in_w + ox + a_off) * ldx + c0 + cc);
+            }
+            unsigned* t32 = (unsigned*)(tile + r * 66 + cc);
+            t32[0] = v.x; t32[1] = v.y; t32[2] = v.z; t32[3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int c = e >> 3, mm = (e & 7) * 8;
+            if (c0 + c < C && m0 + mm < Mp) {
+                unsigned short h[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    h[j] = tile[(mm + j) * 66 + c];
+                    cs[k] += bf_bits2f(h[j]);
+                }
+                uint4 o;
+                o.x = h[0] | ((unsigned)h[1] << 16); o.y = h[2] | ((unsigned)h[3] << 16);
+                o.z = h[4] | ((unsigned)h[5] << 16); o.w = h[6] | ((unsigned)h[7] << 16);
+                *(uint4*)(y + (long)(c0 + c) * ldy + m0 + mm) = o;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float v = cs[k];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        const int e = threadIdx.x + 256 * k;
+        const int c = e >> 3;
+        if ((e & 7) == 0 && c0 + c < C) colsum[(long)blockIdx.x * C + c0 + c] = v;
+    }
+}
+
 // out[r] = sum_c x[r*ld + c], c < n (fp32 accumulation, fixed order): bias gradients from the transposed dY.
 // blockIdx.y = column chunk (a row of 10^5 columns on ONE wave was 0.76 ms per call: 19 % of a training step): partial sums
 // out[chunk][r] for mage_sum_partials.
@@ -282,6 +344,32 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __res
     const T* src = dout + orow * C;
     float* dst = dtable + id * C;
     for (int c = lane; c < C; c += 64) atomicAdd(dst + c, to_f32<T>(src[c]));
+}
+
+// The same scatter for small tables (n_table * 256 B of LDS: the 512-entry visual token table): a workgroup owns a 64-channel slice and
+// a chunk of the rows, accumulates into its private LDS copy of the slice with LDS atomics, and flushes the non-zero entries with one
+// global atomic each: 262144 x 512 global atomics on 512 hot rows (2.1 ms per call) become 64 x 512 x 512.
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_bwd_lds_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dout,
+                                                                float* __restrict__ dtable, long n, int C, int n_table, long padding_idx,
+                                                                long group, long group_stride, long off, long rows_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* tab = (float*)smem_raw;                                        // [n_table][64]
+    const int c0 = blockIdx.y * 64, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < n_table * 64; e += 256) tab[e] = 0.f;
+    __syncthreads();
+    const long i0 = (long)blockIdx.x * rows_per_chunk, i1 = min(n, i0 + rows_per_chunk);
+    for (long i = i0 + wave; i < i1; i += 4) {
+        const long id = ids[i];
+        if (id < 0 || id >= n_table || id == padding_idx) continue;
+        const long orow = (i / group) * group_stride + (i % group) + off;
+        atomicAdd(&tab[id * 64 + lane], to_f32<T>(dout[orow * C + c0 + lane]));
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_table * 64; e += 256) {
+        const float v = tab[e];
+        if (v != 0.f) atomicAdd(dtable + (long)(e >> 6) * C + c0 + (e & 63), v);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ grouped row sums
@@ -653,6 +741,21 @@ extern "C" int mage_transpose(const void* x, int32_t dtype, int64_t ldx, void* y
 }
 
 
+extern "C" int mage_transpose_colsum(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int64_t Mp, int32_t C, int32_t out_w,
+                                     int64_t img_stride, int64_t a_off, float* colsum, int32_t n_part, void* stream) {
+    const long tiles = (Mp + 63) / 64;
+    MAGE_CHECK_ARG(x && y && colsum && M > 0 && Mp >= M && C > 0 && out_w >= 1 && ldy >= Mp, "mage_transpose_colsum: bad arguments");
+    MAGE_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && Mp % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0,
+                   "mage_transpose_colsum: bf16 operands with 16-byte rows");
+    MAGE_CHECK_ARG(n_part == (int)((tiles + TRANSPOSE_TPW - 1) / TRANSPOSE_TPW), "mage_transpose_colsum: n_part must be ceil(ceil(Mp/64)/%d)",
+                   TRANSPOSE_TPW);
+    // rows regrouped like mage_transpose with out_h = 1 (row m -> (m / out_w) * img_stride + m % out_w + a_off), no tap shift
+    hipLaunchKernelGGL(transpose8_colsum_kernel, dim3(n_part, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
+                       (long)ldx, (unsigned short*)y, (long)ldy, (long)M, (long)Mp, C, 1, out_w, 1, out_w, (long)img_stride, (long)a_off, colsum);
+    MAGE_CHECK_LAUNCH("mage_transpose_colsum");
+    return MAGE_OK;
+}
+
 extern "C" int mage_bn_colreduce(int32_t mode, const float* x, const float* dy, const float* mask, const float* mean, const float* rstd,
                                  int64_t rows, int32_t C, float* partials, int32_t n_part, void* stream) {
     MAGE_CHECK_ARG(x && partials && rows > 0 && C > 0 && n_part >= 1 && mode >= 0 && mode <= 2, "mage_bn_colreduce: bad arguments");
@@ -760,8 +863,35 @@ extern "C" int mage_cross_entropy_bwd(const float* logits, const int64_t* target
 extern "C" int mage_embedding_bwd(const int64_t* ids, const void* dout, int32_t dout_dtype, float* dtable, int64_t n, int32_t C,
                                   int32_t n_table, int64_t padding_idx, int64_t group, int64_t group_stride, int64_t off, void* stream) {
     MAGE_CHECK_ARG(ids && dout && dtable && n > 0 && C > 0 && n_table > 0 && group > 0, "mage_embedding_bwd: bad arguments");
-    const dim3 grid((unsigned)((n + 3) / 4)), blk(256);
     hipStream_t s = (hipStream_t)stream;
+    if (n_table <= 512 && C % 64 == 0 && n >= 8192 && (dout_dtype == MAGE_F32 || dout_dtype == MAGE_BF16)) {
+        const int n_chunk = (int)(n / 4096 < 64 ? (n + 4095) / 4096 : 64);
+        const long rpc = (n + n_chunk - 1) / n_chunk;
+        const dim3 grid(n_chunk, C / 64), blk(256);
+        const size_t lds = (size_t)n_table * 64 * sizeof(float);
+        static bool attr_set[MAGE_MAX_DEVICES][2] = {{false}};
+        const int dev = mage_device_index();
+        MAGE_CHECK_ARG(dev >= 0, "mage_embedding_bwd: no current device");
+        if (dout_dtype == MAGE_F32) {
+            if (!attr_set[dev][0]) {
+                (void)hipFuncSetAttribute((const void*)embedding_bwd_lds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                attr_set[dev][0] = true;
+            }
+            hipLaunchKernelGGL((embedding_bwd_lds_kernel<float>), grid, blk, lds, s, ids, (const float*)dout, dtable, (long)n, C, n_table,
+                               (long)padding_idx, (long)group, (long)group_stride, (long)off, rpc);
+        } else {
+            if (!attr_set[dev][1]) {
+                (void)hipFuncSetAttribute((const void*)embedding_bwd_lds_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          128 * 1024);
+                attr_set[dev][1] = true;
+            }
+            hipLaunchKernelGGL((embedding_bwd_lds_kernel<unsigned short>), grid, blk, lds, s, ids, (const unsigned short*)dout, dtable, (long)n, C,
+                               n_table, (long)padding_idx, (long)group, (long)group_stride, (long)off, rpc);
+        }
+        MAGE_CHECK_LAUNCH("mage_embedding_bwd");
+        return MAGE_OK;
+    }
+    const dim3 grid((unsigned)((n + 3) / 4)), blk(256);
     if (dout_dtype == MAGE_F32)
         hipLaunchKernelGGL((embedding_bwd_kernel<float>), grid, blk, 0, s, ids, (const float*)dout, dtable, (long)n, C, n_table, (long)padding_idx,
                            (long)group, (long)group_stride, (long)off);

@@ -83,7 +83,12 @@ def _wgrad(dy, x, *, M: int, N: int, K: int, ld_dy: int, ld_x: int, dy_geo: Opti
     S, Mc = _split_plan(M, N, K)
     Mp = S * Mc
     dyT = torch.empty(N, Mp, device=dev, dtype=dt)
-    ops.transpose(dy, dyT, M=M, Mp=Mp, C=N, ldx=ld_dy, ldy=Mp, **(dy_geo or {}))
+    db = None
+    fused = want_bias and dt == BF16 and N % 8 == 0 and ld_dy % 8 == 0 and Mp % 8 == 0
+    if fused:                                       # db in the same pass as the transposed copy (bf16)
+        db = ops.transpose_colsum(dy, dyT, M=M, Mp=Mp, C=N, ldx=ld_dy, ldy=Mp, **(dy_geo or {}))
+    else:
+        ops.transpose(dy, dyT, M=M, Mp=Mp, C=N, ldx=ld_dy, ldy=Mp, **(dy_geo or {}))
     xT = torch.empty(K, Mp, device=dev, dtype=dt)
     ops.transpose(x, xT, M=M, Mp=Mp, C=K, ldx=ld_x, ldy=Mp, **(x_geo or {}))
     part = torch.empty(S, N, K, device=dev, dtype=F32)
@@ -92,7 +97,8 @@ def _wgrad(dy, x, *, M: int, N: int, K: int, ld_dy: int, ld_x: int, dy_geo: Opti
         dW = part[0]
     else:
         dW = ops.sum_partials(part, torch.empty(N, K, device=dev, dtype=F32), stride=N * K, n_part=S, n=N * K)
-    db = ops.row_sum(dyT, torch.empty(N, device=dev, dtype=F32), ld=Mp, n=M, rows=N) if want_bias else None
+    if want_bias and not fused:
+        db = ops.row_sum(dyT, torch.empty(N, device=dev, dtype=F32), ld=Mp, n=M, rows=N)
     return dW, db
 
 
@@ -148,8 +154,8 @@ def _dec_forward(gm, run: _Run, motion, feats, B: int, hh: int, ww: int):
                         ldy=4 * Cc, bias=d[p + ".c_fc.b"])
         hdn = ops.act(hpre, torch.empty_like(hpre), ops.ACT_QUICKGELU)
         x2 = _res_linear(run, hdn, d, p + ".c_proj", x1, dt, M=M, N=Cc, K=4 * Cc, seed=s_mlp)
-        del hdn
-        blocks.append(dict(x0=x, xn1=xn1, qkv=qkv, ao=ao, x1=x1, xn2=xn2, hpre=hpre, geo=geo, s_attn=s_attn, s_mlp=s_mlp))
+        # hdn is kept for the c_proj weight gradient (recomputing it was one more pass over [M, 4C] per block; 288 GB of HBM)
+        blocks.append(dict(x0=x, xn1=xn1, qkv=qkv, ao=ao, x1=x1, xn2=xn2, hpre=hpre, hdn=hdn, geo=geo, s_attn=s_attn, s_mlp=s_mlp))
         x = x2
     if not gm.use_cids:
         # MAGE+ head (mage_model.py:350-354,387-388): GroupNorm(32) over all L-1 predicted frames of a clip -> SiLU -> Conv3d 1x1x1
@@ -169,13 +175,14 @@ def _dec_forward(gm, run: _Run, motion, feats, B: int, hh: int, ww: int):
 
 
 def _block_mlp_bwd(run, d, p, pre, grads, dx, x1, xn2, hpre, M, Cc, seed, ln_key="ln_2", fc="c_fc", proj="c_proj", act=ops.ACT_QUICKGELU,
-                   names=None):
+                   names=None, hdn=None):
     """Backward of x2 = x1 + drop(proj(act(fc(LN(x1))))) given dx = d/dx2 (fp32, updated in place to d/dx1)."""
     dt, dev = run.dt, dx.device
     names = names or {"fc_w": f"{pre}.mlp.c_fc.weight", "fc_b": f"{pre}.mlp.c_fc.bias", "proj_w": f"{pre}.mlp.c_proj.weight",
                       "proj_b": f"{pre}.mlp.c_proj.bias", "ln_w": f"{pre}.ln_2.weight", "ln_b": f"{pre}.ln_2.bias"}
     dxb = _to_dt(run, dx, seed)
-    hdn = ops.act(hpre, torch.empty_like(hpre), act)
+    if hdn is None:
+        hdn = ops.act(hpre, torch.empty_like(hpre), act)
     grads[names["proj_w"]], grads[names["proj_b"]] = _wgrad(dxb, hdn, M=M, N=Cc, K=4 * Cc, ld_dy=Cc, ld_x=4 * Cc)
     del hdn
     dh = _gemm_x(dxb, _wt(d, f"{p}.{proj}", dt), torch.empty(M, 4 * Cc, device=dev, dtype=dt), M=M, N=4 * Cc, K=Cc)
@@ -208,7 +215,7 @@ def _dec_backward(gm, run: _Run, tape, dlogits, grads: Dict[str, torch.Tensor], 
         del dy
     for i in reversed(range(gm.layers)):
         p, bp, t = f"b{i}", f"{pre}.blocks.{i}", tape["blocks"][i]
-        _block_mlp_bwd(run, d, p, bp, grads, dx, t["x1"], t["xn2"], t["hpre"], M, Cc, t["s_mlp"])
+        _block_mlp_bwd(run, d, p, bp, grads, dx, t["x1"], t["xn2"], t["hpre"], M, Cc, t["s_mlp"], hdn=t.pop("hdn"))
         dxb = _to_dt(run, dx, t["s_attn"])
         grads[bp + ".attn.out_proj.weight"], grads[bp + ".attn.out_proj.bias"] = _wgrad(dxb, t["ao"], M=M, N=Cc, K=Cc, ld_dy=Cc, ld_x=Cc)
         dao = _gemm_x(dxb, _wt(d, p + ".out_proj", dt), torch.empty(M, Cc, device=dev, dtype=dt), M=M, N=Cc, K=Cc)

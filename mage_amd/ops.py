@@ -490,6 +490,22 @@ def reparam_kl_bwd(mu, logvar, eps, dz, coef):
     return dmu, dlv
 
 
+def transpose_colsum(x, y, *, M: int, Mp: int, C: int, ldx: int, ldy: int, out_w: Optional[int] = None, img_stride: Optional[int] = None,
+                     a_off: int = 0):
+    """y[c, m] = x[arow(m), c] (bf16, zero for M <= m < Mp) and the column sums of the gathered rows in the same pass: returns
+    db [C] fp32 (mage_transpose_colsum + mage_sum_partials)."""
+    l, s = _dev(x)
+    assert x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16
+    out_w = M if out_w is None else out_w
+    n_part = ((Mp + 63) // 64 + 15) // 16
+    part = torch.empty(n_part, C, device=x.device, dtype=torch.float32)
+    _lib.check(l.mage_transpose_colsum(x.data_ptr(), ldx, y.data_ptr(), ldy, M, Mp, C, out_w, out_w if img_stride is None else img_stride,
+                                       a_off, part.data_ptr(), n_part, s), l)
+    if n_part == 1:
+        return part[0]
+    return sum_partials(part, torch.empty(C, device=x.device, dtype=torch.float32), stride=C, n_part=n_part, n=C)
+
+
 def maxpool2_bwd(x, dy, *, N, H, W, Cc):
     """dx [N*H*W, C] of y = maxpool2(x): dy [N*(H/2)*(W/2), C] routed to the first maximum of each window."""
     l, s = _dev(x)

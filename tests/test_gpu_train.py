@@ -251,6 +251,30 @@ def test_attention_backward_on_the_matrix_cores(axis, L, hh, ww, H):
     assert rel(got, old.float()) < 1e-2
 
 
+def test_transpose_with_fused_column_sums_and_lds_embedding_scatter():
+    """mage_transpose_colsum (the transposed bf16 copy of dY and db = its column sums in one pass, plain and regrouped rows) and the
+    LDS-table form of mage_embedding_bwd (small tables, many rows)."""
+    o = ops()
+    for M, Cc, geo in ((70000, 520, {}), (3 * 5 * 64, 64, dict(out_w=5 * 64, img_stride=6 * 64, a_off=64))):
+        rows_src = M if not geo else 3 * 6 * 64
+        x = rnd(rows_src, Cc, seed=5).bfloat16()
+        Mp = (M + 63) // 64 * 64 + 64
+        y = torch.full((Cc, Mp), 7.0, device=DEV, dtype=torch.bfloat16)
+        db = o.transpose_colsum(x.to(DEV), y, M=M, Mp=Mp, C=Cc, ldx=Cc, ldy=Mp, **geo)
+        src = x.float() if not geo else x.float().view(3, 6 * 64, Cc)[:, 64:].reshape(M, Cc)
+        assert torch.equal(y[:, :M].float().cpu(), src.t()) and (y[:, M:] == 0).all()
+        torch.testing.assert_close(db.cpu(), src.sum(0), atol=1e-2, rtol=1e-4)
+    n, K, Cc = 40000, 512, 128
+    ids = torch.randint(0, K, (n,), generator=torch.Generator().manual_seed(6))
+    ids[::7] = 3                                                   # a hot row
+    g = rnd(n, Cc, seed=7)
+    for dt in (torch.float32, torch.bfloat16):
+        tab = torch.zeros(K, Cc, device=DEV)
+        o.embedding_bwd(ids.to(DEV), g.to(DEV).to(dt), tab)
+        want = torch.zeros(K, Cc).index_add_(0, ids, g.to(dt).float())
+        torch.testing.assert_close(tab.cpu(), want, atol=2e-3, rtol=1e-4)
+
+
 def test_dropout_mask_is_stateless_and_scaled():
     o = ops()
     x = torch.ones(1 << 20, device=DEV)
