@@ -739,7 +739,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
 // The loader cursors run across tile boundaries (the next tile's slabs 0 and 1 stream in under this tile's last phases and
 // its epilogue).  At a tile's end the leading half gives the trailing half one barrier (both then run the epilogue in
 // step), and the trailing half drops back by one barrier before the next tile's first phase.
-// TAPS: implicit-GEMM convolution over a ZERO-PADDED input (in_h = out_h + taps_h - 1, in_w = out_w + taps_w - 1, stride 1): every tap
+// TAPS: implicit-GEMM convolution over a ZERO-PADDED input (in_h >= out_h + taps_h - 1, in_w = row pitch >= out_w + taps_w - 1, stride 1): every tap
 // of every output pixel is a valid row, so the gather is the plain loader plus ONE scalar offset per K slab -- slab kt lies in tap
 // kt / (cin/64), whose rows sit (ky*in_w + kx) rows further -- kept as three scalar cursors per A piece (no vector instruction in a
 // load section, which is what this kernel's schedule depends on).  The lockstep kernel's generic gather decodes the tap per lane
@@ -1127,7 +1127,9 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
     // context_linear + T positions, written into regrouped rows of the decoder stream)
     if (ntaps <= 1 && !table) return 0;
     if (d->stride != 1 || d->dys != 1 || d->dxs != 1 || d->dy0 != 0 || d->dx0 != 0) return 0;
-    if (d->in_h != d->out_h + d->taps_h - 1 || d->in_w != d->out_w + d->taps_w - 1) return 0;          // zero-padded input only
+    // zero-padded input only: every tap of every output pixel is a row of the buffer (in_w is the buffer's row pitch: a window that
+    // starts inside the padding -- the sub-pixel phases of a transposed convolution -- comes with a_off and a wider pitch)
+    if (d->in_h < d->out_h + d->taps_h - 1 || d->in_w < d->out_w + d->taps_w - 1) return 0;
     if (d->cin % 64 != 0 || d->K % 64 != 0 || d->scale || d->post_relu) return 0;
     int dev = mage_device_index();
     if (dev < 0) return 0;
@@ -1139,6 +1141,7 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
     // are compared bitwise), but only the widths the 8-phase kernel is exercised at
     if (d->N % 256 != 0 || d->M % 256 != 0) return 0;
     const long n_img = (d->M + (long)d->out_h * d->out_w - 1) / ((long)d->out_h * d->out_w);
+    if (d->a_img_stride < (long)(d->out_h + d->taps_h - 2) * d->in_w + d->out_w + d->taps_w - 1) return 0;   // the caller's padded image
     const long a_span = (n_img * d->a_img_stride + d->a_off + (long)d->in_h * d->in_w) * d->lda;
     if (a_span * 2 >= (1L << 32) || (long)d->N * d->K * 2 >= (1L << 32)) return 0;
     if (table && d->act == MAGE_ACT_NONE && (((uintptr_t)d->rowadd) & 15) == 0) return launch_taps8<MAGE_ACT_NONE, EK_RES_INIT>(d, s, n_cu);

@@ -14,6 +14,8 @@ quantiser vqvae_model.py:34-65, ``loss.backward()``) runs modules/vqvae_train.py
 """
 from __future__ import annotations
 
+import os
+
 from itertools import chain
 from typing import Dict, List, Optional
 
@@ -161,6 +163,7 @@ class VectorQuantizedVAE(nn.Module):
         self.apply(weights_init)
         self.decode_dtype = torch.float32          # torch.bfloat16 = MFMA-bf16 performance mode for decode
         self.decode_chunk = 1024                   # frames per decode launch group (bounds workspace: 0.8 GB at dim 256)
+        self._pad_bufs = {}                        # zero-padded frame buffers of the bf16 decode, keyed by (frames, grid, device, stream)
         self._derived = _Derived(self)
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
@@ -227,6 +230,18 @@ class VectorQuantizedVAE(nn.Module):
                     both(f"d3.w{py}{px}", sub.permute(1, 2, 3, 0).reshape(wt.shape[1], -1).contiguous())
             d["d3.b"] = dec[3].bias.float().contiguous()
             d["d3.s"], d["d3.t"] = _bn_vectors(dec[4])
+            # bf16 decode on the 8-phase kernel's padded-taps form (_decode_chunk): eval BatchNorm folded into the weights and the
+            # bias (W' = alpha W per output channel, b' = alpha b + beta), inputs in zero-padded (h+2) x (w+2) frame buffers.  The
+            # sub-pixel taps in forward window order: tap a' = 1 - a of the window that starts at padded (y + py, x + px).
+            for rp in ("d0", "d1"):
+                d[rp + ".w3f.bf16"] = (d[rp + ".w3.f32"] * d[rp + ".s3"][:, None]).to(torch.bfloat16)
+                d[rp + ".b3f"] = (d[rp + ".b3"] * d[rp + ".s3"] + d[rp + ".t3"]).contiguous()
+            co = wt.shape[1]
+            for py in range(2):
+                for px in range(2):
+                    wsub = d[f"d3.w{py}{px}.f32"].view(co, 2, 2, -1).flip(1, 2).reshape(co, -1)
+                    d[f"d3.w{py}{px}f.bf16"] = (wsub * d["d3.s"][:, None]).to(torch.bfloat16)
+            d["d3.bf"] = (d["d3.b"] * d["d3.s"] + d["d3.t"]).contiguous()
             d["d6.wt"] = dec[6].weight.float().permute(2, 3, 1, 0).contiguous()         # [4,4,cout,cin]
             # the same taps as GEMM rows [(ky*4+kx)*cout + co, cin], padded to a multiple of 8 rows (mage_gemm: N % 8 == 0)
             taps = d["d6.wt"].reshape(16 * self.input_dim, -1)
@@ -373,6 +388,37 @@ class VectorQuantizedVAE(nn.Module):
         s = "." + ("f32" if dt == torch.float32 else "bf16")
         N, dev, dim = ids.shape[0], ids.device, self.dim
         h, wd = ids.shape[1], ids.shape[2]
+        if self.down_ratio == 4 and dt == torch.bfloat16 and dim % 256 == 0 and (N * h * wd) % 256 == 0 and not os.environ.get("MAGE_DECODE_NO_TAPS8"):
+            # the two 3x3 convolutions and the four sub-pixel convolutions on the 8-phase GEMM kernel (padded-taps form): every
+            # activation that a windowed layer reads lives in a zero-padded frame buffer, written there by its producer
+            hw, Pw = h * wd, wd + 2
+            PP = (h + 2) * Pw                                         # rows per padded image
+            key = (N, h, wd, str(dev), torch.cuda.current_stream(dev).cuda_stream)
+            pads = self._pad_bufs.get(key)
+            if pads is None:
+                if len(self._pad_bufs) > 4:
+                    self._pad_bufs.clear()
+                pads = self._pad_bufs[key] = [torch.zeros(N * PP + 1, dim, device=dev, dtype=dt) for _ in range(3)]
+            inner = dict(out_h=h, out_w=wd, y_img_stride=PP, y_mul_y=Pw, y_off=Pw + 1)      # a producer's rows inside the padding
+            win = dict(out_h=h, out_w=wd, in_h=h + 2, in_w=Pw, a_img_stride=PP, cin=dim, stride=1, dy0=0, dx0=0)
+            ops.embedding(ids, w["cb"], pads[0], relu=True, group=hw, group_stride=PP, off=Pw + 1, inner=wd, inner_stride=Pw)
+            t = torch.empty(N * hw, dim, device=dev, dtype=dt)
+            for i, rp in enumerate(("d0", "d1")):
+                ops.gemm(pads[i], w[rp + ".w3f.bf16"], t, M=N * hw, N=dim, K=9 * dim, lda=dim, ldy=dim, taps_h=3, taps_w=3, bias=w[rp + ".b3f"],
+                         act=ops.ACT_RELU, **win)
+                ops.gemm(t, w[rp + ".w1.bf16"], pads[i + 1], M=N * hw, N=dim, K=dim, lda=dim, ldy=dim, bias=w[rp + ".b1"], scale=w[rp + ".s1"],
+                         shift=w[rp + ".t1"], residual=pads[i], ldr=dim, post_relu=True, **inner)                # decoder[2] ReLU folded
+            up = torch.empty(N * 4 * hw, dim, device=dev, dtype=dt)
+            for py in range(2):
+                for px in range(2):
+                    ops.gemm(pads[2], w[f"d3.w{py}{px}f.bf16"], up, M=N * hw, N=dim, K=4 * dim, lda=dim, ldy=dim, taps_h=2, taps_w=2,
+                             a_off=py * Pw + px, y_img_stride=4 * hw, y_mul_y=4 * wd, y_mul_x=2, y_off=py * 2 * wd + px, bias=w["d3.bf"],
+                             act=ops.ACT_RELU, **win)
+            nt = 16 * self.input_dim
+            taps = torch.empty(N * 4 * hw, nt, device=dev, dtype=torch.float32)
+            ops.gemm(up, w["d6.w16" + s], taps, M=N * 4 * hw, N=nt, K=dim, lda=dim, ldy=nt)
+            ops.convt_fold_tanh(taps, w["d6.b"], out, N=N, IH=2 * h, IW=2 * wd, cout=self.input_dim)
+            return
         if self.down_ratio == 4:
             hw = h * wd
             r = ops.embedding(ids, w["cb"], torch.empty(N * hw, dim, device=dev, dtype=dt), relu=True)

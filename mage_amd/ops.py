@@ -226,7 +226,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
         ntaps = taps_h * taps_w
         table, plain = rowadd is not None and residual is None, rowadd is None and residual is None
         if (d.dtype == BF16 and n_split == 1 and (ntaps > 1 or table) and stride == 1 and dys == 1 and dxs == 1 and dy0 == 0 and dx0 == 0
-                and d.in_h == out_h + taps_h - 1 and d.in_w == out_w + taps_w - 1 and d.cin % 64 == 0 and K % 64 == 0 and scale is None
+                and d.in_h >= out_h + taps_h - 1 and d.in_w >= out_w + taps_w - 1 and d.cin % 64 == 0 and K % 64 == 0 and scale is None
                 and not post_relu and N % 256 == 0 and M % 256 == 0
                 and not os.environ.get("MAGE_GEMM_NO_8PHASE") and not os.environ.get("MAGE_GEMM_NO_TAPS8")):
             if table and act == ACT_NONE:
