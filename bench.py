@@ -295,6 +295,17 @@ def main():
                         "all_gemm_kernels": {"achieved": round(allf / (allms * 1e-3) / 1e12, 2), "frac": round(allf / (allms * 1e-3) / 1e12 / peak, 4),
                                              "ms_per_step": round(allms / all_div, 3),
                                              "measured_in": "timed region" if args.events == "all" else "last warm-up call"}}
+            hv = roofline["hbm_view"]
+            if hv is not None and hv["flop_per_byte"] < hv["machine_balance_flop_per_byte"]:
+                # the dominant kernel's arithmetic intensity is below the machine balance: by the roofline model it is bounded by HBM, so
+                # that is the bound the object is priced against (algorithmic bytes per launch / average launch duration vs 8 TB/s); the
+                # matrix-core view of the same launches (rounds 1-2 reported it as the primary) stays beside it
+                mf = {k: roofline[k] for k in ("achieved", "peak", "unit", "frac")}
+                mf["bound"] = "mfma"
+                roofline.update({"bound": "hbm", "achieved": hv["achieved"], "peak": hv["peak"], "unit": hv["unit"], "frac": hv["frac"],
+                                 "algorithmic_bytes_per_launch": hv["algorithmic_bytes_per_launch"], "flop_per_byte": hv["flop_per_byte"],
+                                 "machine_balance_flop_per_byte": hv["machine_balance_flop_per_byte"], "mfma_view": mf})
+                del roofline["hbm_view"]
         f_call, f_step = call_flops(B, L)
         whole = {"flops_per_call": f_call, "decoder_step_flops": f_step,
                  "achieved": round(f_call / (ms_per_step * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
