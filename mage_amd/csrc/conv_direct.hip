@@ -42,6 +42,56 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     store4(y + pix * cout + co, acc);
 }
 
+// The 1x1 head (the f8 decoder's Conv2d(dim, C, 1) + Tanh at full resolution: 16 M pixels x 512 B per call at cfg4): 16 lanes per pixel,
+// 4 pixels per wave, every lane reads 16-byte chunks (a wave instruction covers four contiguous 256-byte runs), 4 xor-shuffles per
+// output channel.  The wave-per-pixel kernel below spent its time in 6-step reductions: 7.8 ms = 1.06 TB/s on that call.
+template <typename IT>
+__global__ __launch_bounds__(256) void conv_out_1x1_kernel(const IT* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                           float* __restrict__ y, long npix, long plane, int cin, int cout) {
+    constexpr int CPL = 16 / (int)sizeof(IT);                     // channels per 16-byte chunk: 8 (bf16) | 4 (fp32)
+    const int sub = threadIdx.x & 15;
+    const long pix = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const bool live = pix < npix;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const IT* xp = x + pix * cin;
+        for (int c = sub * CPL; c < cin; c += 16 * CPL) {
+            float xv[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL / 4; ++q) {
+                const f32x4 v = load4(xp + c + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[4 * q + e] = v[e];
+            }
+#pragma unroll
+            for (int co = 0; co < 4; ++co) {
+                if (co < cout) {
+                    const float* wp = wt + (long)co * cin + c;
+#pragma unroll
+                    for (int q = 0; q < CPL / 4; ++q) {
+                        const f32x4 wv = *(const f32x4*)(wp + 4 * q);
+                        acc[co] += xv[4 * q] * wv[0] + xv[4 * q + 1] * wv[1] + xv[4 * q + 2] * wv[2] + xv[4 * q + 3] * wv[3];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+        if (co < cout) {
+            float v = acc[co];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            if (live && sub == 0) {
+                const long n = pix / plane, p = pix - n * plane;
+                y[(n * cout + co) * plane + p] = tanhf(v + (bias ? bias[co] : 0.f));
+            }
+        }
+    }
+}
+
 // One wave per output pixel, lanes split the input channels, shuffle reduction, tanh, NCHW fp32 store.
 template <typename IT, bool TRANSPOSED>
 __global__ __launch_bounds__(256) void conv_out_kernel(const IT* __restrict__ x, const float* __restrict__ wt,
@@ -203,6 +253,18 @@ extern "C" int mage_conv_out(const void* x, int32_t x_dtype, const float* weight
     const int OH = transposed ? IH * 2 : IH, OW = transposed ? IW * 2 : IW;
     const dim3 grid((unsigned)(((long)N * OH * OW + 3) / 4)), blk(256);
     hipStream_t s = (hipStream_t)stream;
+    if (!transposed && (x_dtype == MAGE_F32 || x_dtype == MAGE_BF16) && cin % (x_dtype == MAGE_BF16 ? 8 : 4) == 0 &&
+        (((uintptr_t)x | (uintptr_t)weight_t) & 15) == 0) {
+        const long npix = (long)N * IH * IW;
+        const dim3 g1((unsigned)((npix * 16 + 255) / 256));
+        if (x_dtype == MAGE_F32)
+            hipLaunchKernelGGL((conv_out_1x1_kernel<float>), g1, blk, 0, s, (const float*)x, weight_t, bias, y, npix, (long)IH * IW, cin, cout);
+        else
+            hipLaunchKernelGGL((conv_out_1x1_kernel<unsigned short>), g1, blk, 0, s, (const unsigned short*)x, weight_t, bias, y, npix,
+                               (long)IH * IW, cin, cout);
+        MAGE_CHECK_LAUNCH("mage_conv_out");
+        return MAGE_OK;
+    }
 #define CO_LAUNCH(IT, TR) hipLaunchKernelGGL((conv_out_kernel<IT, TR>), grid, blk, 0, s, (const IT*)x, weight_t, bias, y, N, IH, IW, cin, cout, OH, OW)
     if (x_dtype == MAGE_F32) { if (transposed) CO_LAUNCH(float, true); else CO_LAUNCH(float, false); }
     else if (x_dtype == MAGE_BF16) { if (transposed) CO_LAUNCH(unsigned short, true); else CO_LAUNCH(unsigned short, false); }
