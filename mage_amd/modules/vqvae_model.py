@@ -293,20 +293,33 @@ class VectorQuantizedVAE(nn.Module):
                    scale=w[p + ".s1"], shift=w[p + ".t1"], residual=r, ldr=dim, post_relu=post_relu)
         return out
 
-    def _bottleneck(self, w, p, x, dt, n_img, H, W, cin, cout, first_k, last_k, post_relu):
+    def _bottleneck(self, w, p, x, dt, n_img, H, W, cin, cout, first_k, last_k, post_relu, up_first=False):
+        """up_first (decoder blocks behind an nn.Upsample, first_k = 1): x is the LOW-resolution input [n_img, H/2, W/2, cin].  A 1x1
+        convolution and a ReLU act per pixel, so they commute with nearest-neighbour upsampling: the block's first convolution and its
+        identity path run on a quarter of the pixels and only their outputs (cout/4 and cout channels instead of cin, twice) are
+        upsampled -- the same arithmetic per output pixel, bit-identical results."""
         s = "." + ("f32" if dt == torch.float32 else "bf16")
         hid = cout // 4
         dev = x.device
         xr = ops.relu(x, torch.empty_like(x))
+        Hi, Wi = (H // 2, W // 2) if up_first else (H, W)
         if (p + ".wid" + s) in w:
-            idp = torch.empty(n_img * H * W, cout, device=dev, dtype=dt)
-            self._conv(x, w[p + ".wid" + s], idp, n_img=n_img, H=H, W=W, cin=cin, cout=cout, k=1, bias=w[p + ".bid"])
+            idp = torch.empty(n_img * Hi * Wi, cout, device=dev, dtype=dt)
+            self._conv(x, w[p + ".wid" + s], idp, n_img=n_img, H=Hi, W=Wi, cin=cin, cout=cout, k=1, bias=w[p + ".bid"])
         else:
             idp = x
         ks = [first_k, 3, 3, last_k]
         chans = [cin, hid, hid, hid, cout]
         h = xr
-        for j in range(3):
+        j0 = 0
+        if up_first:
+            assert first_k == 1
+            h1 = torch.empty(n_img * Hi * Wi, hid, device=dev, dtype=dt)
+            self._conv(xr, w[f"{p}.w1{s}"], h1, n_img=n_img, H=Hi, W=Wi, cin=cin, cout=hid, k=1, bias=w[f"{p}.b1"], act=ops.ACT_RELU)
+            h = ops.upsample2(h1, torch.empty(n_img * H * W, hid, device=dev, dtype=dt), N=n_img, H=Hi, W=Wi, Cc=hid)
+            idp = ops.upsample2(idp, torch.empty(n_img * H * W, cout, device=dev, dtype=dt), N=n_img, H=Hi, W=Wi, Cc=cout)
+            j0 = 1
+        for j in range(j0, 3):
             nh = torch.empty(n_img * H * W, chans[j + 1], device=dev, dtype=dt)
             self._conv(h, w[f"{p}.w{2 * j + 1}{s}"], nh, n_img=n_img, H=H, W=W, cin=chans[j], cout=chans[j + 1], k=ks[j],
                        bias=w[f"{p}.b{2 * j + 1}"], act=ops.ACT_RELU)
@@ -442,11 +455,10 @@ class VectorQuantizedVAE(nn.Module):
         chans = [(4 * dim, 2 * dim), (2 * dim, dim), (dim, dim), (dim, dim)]
         for bi, (ci, co) in zip((0, 2, 4, 6), chans):
             last = bi == 6
-            x = self._bottleneck(w, f"d{bi}", x, dt, N, H, W, ci, co, 1, 3, post_relu=last)    # decoder[7] ReLU folded
+            # the nn.Upsample in front of blocks 2, 4, 6 is folded into the block (see _bottleneck up_first)
+            x = self._bottleneck(w, f"d{bi}", x, dt, N, H, W, ci, co, 1, 3, post_relu=last, up_first=bi != 0)    # decoder[7] ReLU folded
             if not last:
-                u = torch.empty(N * H * W * 4, co, device=dev, dtype=dt)
-                ops.upsample2(x, u, N=N, H=H, W=W, Cc=co)
-                x, H, W = u, H * 2, W * 2
+                H, W = H * 2, W * 2
         ops.conv_out(x, w["d8.wt"], w["d8.b"], out, N=N, IH=H, IW=W, cin=dim, cout=self.input_dim, transposed=False)
 
     # ------------------------------------------------------------------ forward (values only)
