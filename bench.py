@@ -63,6 +63,50 @@ def hbm_view(key, dom, B, L, d=512):
             "machine_balance_flop_per_byte": round(PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9), 1)}
 
 
+def train_step_probe(args, dev, rank, world, B, L, wl_kw, D):
+    import gc
+    from mage_amd.optim import FlatAdam
+    from mage_amd.utils import synth
+    from mage_amd.utils.util import instantiate_from_config
+    gc.collect()
+    torch.cuda.empty_cache()
+    tm = instantiate_from_config(synth.mnist_model_config(frames_length=L))
+    synth.fill_state_dict(tm, 0)
+    tm = tm.to(dev).set_precision("bf16").train()
+    opt = FlatAdam(tm.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6)          # main_mage.py:121; sharded over the ranks when world > 1
+    tb = {k: v.to(dev) for k, v in synth.synth_batch_mnist(B, L, seed=300 + rank, **wl_kw).items()}
+
+    def one():
+        opt.zero_grad()
+        loss, _ = tm(tb)
+        loss.backward()
+        opt.step()
+        return loss
+    losses = [one().item() for _ in range(2)]                     # warm-up (allocator, derived weight copies, RCCL channels)
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 4
+    for _ in range(n):
+        last = one()
+    D.barrier()
+    torch.cuda.synchronize()
+    dtt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    losses.append(last.item())
+    n_par = sum(p.numel() for p in tm.parameters() if p.requires_grad)
+    out = {"value": round(world * B * L * n / dtt, 1), "unit": "frames/s trained", "ms_per_step": round(dtt / n * 1e3, 2), "steps": n,
+           "batch_per_gpu": B, "frames": L, "dtype": "bf16", "scaling": "weak", "trainable_parameters": n_par,
+           "exchange": (f"reduce_scatter + all_gather of the {n_par * 4 / 2**20:.0f} MiB fp32 arena over RCCL, {world} ranks" if world > 1
+                        else "none (1 rank)"),
+           "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
+           "note": "secondary measurement (the reference's training loop body on the HIP path, synthetic batch resident on the device); "
+                   "not part of `value`"}
+    del tm, opt, tb
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +137,7 @@ def parse():
     ap.add_argument("--no-other-mode", action="store_true", help="skip the second AR mode (clean rocprofv3 runs)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 (parity-gated) pass and the bf16-vs-fp32 token agreement")
     ap.add_argument("--no-decode-roofline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--cpu-clips", type=int, default=4, help="clips of the CPU baseline sample (4 = SURVEY cfg1, the reference's CPU-runnable batch)")
     return ap.parse_args()
 
@@ -259,6 +304,17 @@ def main():
                           "layer-materialised model (sum over the 6 conv layers of input+output activations at the storage dtype); "
                           "the same stack is 1.216 GFLOP/frame, so the MFMA fraction is reported beside it"}
 
+    # one more object, never the metric: the reference's training step (main_mage.py:139-154: forward, loss.backward(), Adam) on the same
+    # model family and batch shape, per rank, with the gradient exchange of the data-parallel path -- reduce-scatter of the flat gradient
+    # arena, Adam on this rank's shard, all-gather of the parameters, over RCCL when there is more than one rank (mage_amd.optim.FlatAdam).
+    # This is the only place of the path with a real exchange step, so it is what an N > 1 run of this script measures RCCL with.
+    train = None
+    if args.precision == "bf16" and not args.no_train_step:
+        try:
+            train = train_step_probe(args, dev, rank, world, B, L, wl_kw, D)
+        except Exception as e:                                   # never lets the secondary measurement take the bench line down
+            train = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * B * L * args.steps / dt
@@ -337,6 +393,7 @@ def main():
                                         else {k: round(v["ms"], 3) for k, v in sorted(warm_prof.items())}),
             "kernel_time_measured_in": "timed region" if args.events == "all" else "last warm-up call (every launch bracketed)",
             "other_ar_mode": other,
+            "train_step": train,
         }
         if cpu_sd is not None:
             res["cpu_baseline"] = cpu_baseline(cpu_sd, L, args.cpu_clips)

@@ -119,3 +119,5 @@ def test_committed_bench_line_keeps_the_driver_contract():
     wc = r["whole_call"]
     assert abs(wc["frac"] - wc["flops_per_call"] / (r["ms_per_step"] * 1e-3) / 1e12 / wc["peak"]) < 1e-3
     assert r["config"]["ranks_seen"] == r["n_gpus"] and "traffic_source" in rf
+    ts = r.get("train_step")                       # secondary: the training step with its gradient exchange (round 2, late)
+    assert ts is None or "error" in ts or (ts["value"] > 0 and ts["scaling"] == "weak" and ts["loss_first_last"][1] < ts["loss_first_last"][0])
