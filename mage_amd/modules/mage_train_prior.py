@@ -20,19 +20,13 @@ from typing import Dict, Optional
 import torch
 
 from .. import ops
+from .mage_train import _split_plan, _wgrad
 from .vqvae_model import VectorQuantizedVAE
 
 F32 = torch.float32
 _conv = VectorQuantizedVAE._conv
 
 __all__ = ["rand_forward", "rand_backward"]
-
-
-def _split_plan(M: int, N: int, K: int):
-    tiles = ((N + 255) // 256) * ((K + 255) // 256)
-    S = max(1, min(64, (512 + tiles - 1) // tiles, M // 512 if M >= 1024 else 1))
-    Mc = ((M + S - 1) // S + 63) // 64 * 64
-    return S, Mc
 
 
 def _flip(d: Dict[str, torch.Tensor], key: str, cin: int, cout: int) -> torch.Tensor:
@@ -207,7 +201,6 @@ def rand_backward(model, tape, dout_ma, kl_coef: torch.Tensor, grads: Dict[str, 
             acc["emb"] = torch.zeros(model.codebook_size, Cc, device=dev, dtype=F32)
         ops.embedding_bwd(tok.reshape(-1).contiguous(), dxa, acc["emb"], group=L * hw, group_stride=ds, off=hw)
     else:                                                   # MAGE+: the embeddings are Linear(latents), written into the same frame slots
-        from .mage_train import _wgrad
         lat = tape["lat_rows"]
         dW, db = _wgrad(dxa, lat, M=B * L * hw, N=Cc, K=lat.shape[1], ld_dy=Cc, ld_x=lat.shape[1],
                         dy_geo=dict(out_w=L * hw, img_stride=ds, a_off=hw))
