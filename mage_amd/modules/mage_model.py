@@ -1075,6 +1075,13 @@ class MAGE(nn.Module):
         video_rows = video_rows.view(B * R * R, 64)
         if extras is not None:
             extras.update(kl_sum=kl_sum, prior=prior)
+        if batch.get("_test_flag"):
+            # forward(test_flag=True) (mage_model.py:604-605): mu / logvar still feed the KL term, the embedding itself is fresh noise
+            # (batch['video_noise'] [B,64,h,w] injects it, as in autoregressive_generate)
+            nz = batch.get("video_noise")
+            if nz is None:
+                nz = torch.randn(B, 64, R, R, device=dev)
+            video_rows = nz.to(dev).float().permute(0, 2, 3, 1).reshape(B * R * R, 64).contiguous()
         return video_rows
 
     @torch.no_grad()
@@ -1116,15 +1123,16 @@ class MAGE(nn.Module):
     def forward(self, batch, test_flag=False):
         """(loss, loss_dict) of the teacher-forced pass (mage_model.py:575-639), incl. the randomness=True terms (KL of the
         reparameterised video prior, the PID-controlled or fixed beta, the speed-embedding l2).  batch['reparam_noise']
-        [B,64,h,w] optionally injects the reparameterisation noise.  Under ``torch.no_grad()``: values only.  In grad mode (any
+        [B,64,h,w] optionally injects the reparameterisation noise; ``test_flag=True`` (values only) replaces the video embedding by noise
+        (batch['video_noise'] injects it) while the KL term still comes from mu / logvar (:604).  Under ``torch.no_grad()``: values only.  In grad mode (any
         parameter requiring grad): the returned loss carries an autograd node backed by the HIP backward kernels
         (modules/mage_train.py, mage_train_prior.py: every config family -- MNIST, CATER with the randomness branch, MAGE+), so
         ``loss.backward(); optimizer.step()`` works."""
-        if test_flag and self.randomness:
-            raise NotImplementedError("forward(test_flag=True) replaces the video embedding by noise AFTER computing it; use "
-                                      "autoregressive_generate for sampling")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if test_flag and self.randomness:
+                raise NotImplementedError("forward(test_flag=True) is an evaluation switch (mage_model.py:604): call it under torch.no_grad()")
             return self._forward_with_graph(batch)
+        batch = dict(batch, _test_flag=bool(test_flag and self.randomness))      # :604: the video embedding is replaced by noise
         extras: dict = {}
         L = self.frames_length
         if self.use_cids:

@@ -340,7 +340,7 @@ def video_prior(sd: SD, x_emb: torch.Tensor) -> torch.Tensor:
 
 
 def mage_forward_loss_random(sd: SD, batch: Dict[str, torch.Tensor], frames_length: int, eps: torch.Tensor, alpha: float,
-                             beta: float, auto_beta: bool = False, v_kl: float = 0.0, pid=None):
+                             beta: float, auto_beta: bool = False, v_kl: float = 0.0, pid=None, test_noise: Optional[torch.Tensor] = None):
     """MAGE.forward (mage_model.py:575-639), use_cids=True, randomness=True.  eps [B,64,h,w] is the reparameterisation noise
     the reference draws with torch.randn_like (:571), injected.  Returns (final_loss, dict of the reference's loss_dict
     values without the train/val prefix, logits, video_emb_prior)."""
@@ -354,6 +354,8 @@ def mage_forward_loss_random(sd: SD, batch: Dict[str, torch.Tensor], frames_leng
     mu = F.conv2d(prior, sd["conv_mu2.weight"], sd["conv_mu2.bias"], padding=1)                  # :570
     logvar = F.conv2d(prior, sd["conv_var2.weight"], sd["conv_var2.bias"], padding=1)
     video_emb = eps * (0.5 * logvar).exp() + mu                                                  # :571-573
+    if test_noise is not None:                                                                   # test_flag=True (:604-605), noise injected
+        video_emb = test_noise
     speed = batch.get("speed")
     first = _frame_features(sd, tok[:, :1])[:, 0].reshape(B, h * w, -1)
     txt = text_encoder(sd, "text_encoder.", batch["text"])

@@ -149,6 +149,29 @@ def test_mage_cater_forward_randomness_golden():
     assert abs(loss.item() - final.item()) < 1e-4 * max(1.0, abs(final.item()))
 
 
+def test_mage_forward_test_flag_replaces_the_video_embedding_by_noise():
+    """MAGE.forward(batch, test_flag=True) (mage_model.py:604-605): the reparameterised embedding is computed (its mu / logvar feed the
+    KL term) and then replaced by noise; against the oracle with the same noise injected."""
+    from oracle import mage_oracle as O
+    from tests.helpers import cpu_sd
+    B, L, seed = 2, 10, 71
+    cfg = synth.cater_model_config(frames_length=L, width=64, layers=3, vq_dim=32, K=64)
+    m = build_mage(cfg, seed, DEV)
+    batch = synth.synth_batch_cater(B, L, seed=seed, text_len=9)
+    g = torch.Generator().manual_seed(seed)
+    eps, noise = torch.randn(B, 64, 16, 16, generator=g), torch.randn(B, 64, 16, 16, generator=g)
+    db = dev_batch(batch)
+    db["reparam_noise"], db["video_noise"] = eps.to(DEV), noise.to(DEV)
+    with torch.no_grad():
+        loss, ld = m(db, test_flag=True)
+        loss_plain, _ = m(db)
+    final, parts, _, _ = O.mage_forward_loss_random(cpu_sd(m), batch, L, eps, alpha=cfg["params"]["alpha"], beta=cfg["params"]["beta"],
+                                                    test_noise=noise)
+    assert abs(loss.item() - final.item()) < 1e-4 * max(1.0, abs(final.item()))
+    assert abs(ld["val/kl_loss"] - parts["kl_loss"]) < 1e-4 * max(1.0, abs(parts["kl_loss"]))
+    assert abs(ld["val/prediction"] - parts["prediction"]) < 1e-4 and abs(loss.item() - loss_plain.item()) > 1e-6
+
+
 def test_mage_plus_forward_latent_golden():
     """MAGE.forward for use_cids=False on the HIP path (Linear embedding written straight into the padded frame buffer of the
     video prior, MSE kernel, PID-controlled beta) against the reference's own loss values and predicted latents."""
