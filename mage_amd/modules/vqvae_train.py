@@ -245,13 +245,16 @@ def vq_train_backward(vq, tape, g_xt, g_ze_rows, g_zq_rows) -> Dict[str, torch.T
     s0 = tape["a0s"]
     da0 = torch.empty_like(dh0)
     grads["encoder.1.weight"], grads["encoder.1.bias"] = ops.bn_backward(s0["x"], dh0, s0["mean"], s0["rstd"], s0["gamma"], da0, mask=tape["h0"])
-    # stem conv (cin = Cin <= 4): the image as channels-last rows is NCHW itself when Cin == 1
-    if Cin != 1:
-        raise NotImplementedError("stage-1 training backward: the stem weight gradient is built for 1-channel images (Moving MNIST)")
+    # stem conv (cin = Cin <= 4): the image as channels-last rows is NCHW itself when Cin == 1; more channels: rows padded to 8 (plumbing)
     M0 = N * H2 * W2
-    dW0, db0 = _wgrad_taps(da0, tape["x"].view(N * H * W, 1), M=M0, N=D, Cin=1, taps=taps16, grid=dict(out_h=H2, out_w=W2, in_h=H, in_w=W, stride=2),
-                           x_ld=1)
-    grads["encoder.0.weight"] = dW0.view(D, 4, 4, 1).permute(0, 3, 1, 2).contiguous()
+    if Cin == 1:
+        xr, Cp = tape["x"].view(N * H * W, 1), 1
+    else:
+        Cp = 8
+        xr = torch.zeros(N * H * W, Cp, device=dev, dtype=F32)
+        xr[:, :Cin] = tape["x"].permute(0, 2, 3, 1).reshape(N * H * W, Cin)
+    dW0, db0 = _wgrad_taps(da0, xr, M=M0, N=D, Cin=Cp, taps=taps16, grid=dict(out_h=H2, out_w=W2, in_h=H, in_w=W, stride=2), x_ld=Cp)
+    grads["encoder.0.weight"] = dW0.view(D, 4, 4, Cp)[..., :Cin].permute(0, 3, 1, 2).contiguous()
     grads["encoder.0.bias"] = db0
     return grads
 

@@ -558,6 +558,32 @@ def test_vqvae8_stage1_training_step_matches_the_reference(tag):
     torch.testing.assert_close(xt2, x_tilde.detach(), atol=1e-5, rtol=0)
 
 
+def test_vqvae_f4_stage1_training_with_rgb_frames_matches_oracle_autograd():
+    """The f4 stack on 3-channel frames (the stem's weight gradient over the image padded to 8 channels, the 48-tap head): every
+    gradient against autograd through the oracle's training-mode forward (the reference's scripts only train f4 on 1-channel MNIST)."""
+    from tests.helpers import build_vqvae
+    m = build_vqvae(3, 4, 32, 64, 23, DEV).train()
+    x = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(23)) * 2 - 1
+    sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in cpu_sd(m).items()}
+    want_loss, _, _ = O.vqvae_train_loss(sd, "", x, beta=2.0)
+    names = [n for n, _ in m.named_parameters()]
+    want = dict(zip(names, torch.autograd.grad(want_loss, [sd[n] for n in names], allow_unused=True)))
+    xt, ze, zq = m(x.to(DEV))
+    loss = F.mse_loss(xt, x.to(DEV)) + F.mse_loss(zq, ze.detach()) + 2.0 * F.mse_loss(ze, zq.detach())
+    assert abs(loss.item() - want_loss.item()) < 1e-5
+    loss.backward()
+    gmax = max(g.abs().max().item() for g in want.values() if g is not None)
+    worst = 0.0
+    for n, p in m.named_parameters():
+        g = want[n] if want[n] is not None else torch.zeros_like(sd[n])
+        if g.abs().max().item() < 1e-4 * gmax:                     # biases in front of a training-mode BatchNorm: zero gradient, noise
+            assert p.grad.abs().max().item() < 1e-4 * gmax, n
+            continue
+        worst = max(worst, rel(p.grad, g))
+    print(f"f4 RGB stage-1 step: worst relative gradient error {worst:.2e}")
+    assert worst < GRAD_TOL
+
+
 def test_pooling_backward_kernels():
     o = ops()
     N, H, W, Cc = 2, 8, 12, 8
