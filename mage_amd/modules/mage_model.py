@@ -970,14 +970,16 @@ class MAGE(nn.Module):
     @torch.no_grad()
     @torch.no_grad()
     def _video_prior(self, tok: Optional[torch.Tensor], lat_rows: Optional[torch.Tensor] = None, B: int = 0, L: int = 0,
-                     tape: Optional[list] = None) -> torch.Tensor:
+                     tape: Optional[list] = None, dt: torch.dtype = F32) -> torch.Tensor:
         """self.conv3d over the token embeddings of ALL frames (mage_model.py:496-501,602-603): tok int64 [B, L, hw] (or, for
         use_cids=False, lat_rows [B*L*hw, 8] fp32 latents whose Linear(E -> C) embedding is taken) -> rows [B*hw, d_model] fp32.  Each Conv3d(3x3x3, temporal stride s, pad 1) is three implicit-GEMM launches, one per temporal tap,
         accumulating in place: the block input lives in a zero-padded frame buffer in which clip b owns frames
         [b*Lp, (b+1)*Lp) (frame 0 = the leading zero pad) with Lp = s * (virtual output frames per clip), so that output image
         i' = b*Lv + t' gathers from frame s*i' + kd: one affine image stride for the whole batch, the clip boundaries and the
         temporal padding are zero frames.  The Lv - Lout virtual frames per clip are never normalised or read.
-        `tape` (a list, training path): receives per block what the backward pass needs (modules/mage_train_prior.py)."""
+        `tape` (a list, training path): receives per block what the backward pass needs (modules/mage_train_prior.py).
+        dt: storage / MFMA dtype of the activations and weights (bf16 in bf16 training: the convolution outputs, the GroupNorm
+        statistics and the block's result stay fp32; the values path and fp32 mode run everything in fp32)."""
         d = self._derived.get(self._build)
         R, Cc = self.image_resolution, self.vision_width
         hw = R * R
@@ -985,10 +987,17 @@ class MAGE(nn.Module):
             B, L = tok.shape[0], tok.shape[1]
         dev = tok.device if tok is not None else lat_rows.device
 
+        def wdt(key):
+            if dt == F32:
+                return d[key]
+            if key + ".bf16" not in d:
+                d[key + ".bf16"] = d[key].to(BF16)
+            return d[key + ".bf16"]
+
         def conv3(xpad, key, Lv, s_t, cin, cout):
             out = torch.empty(B * Lv * hw, cout, device=dev, dtype=F32)
             for kd in range(3):
-                ops.gemm(xpad, d[f"{key}.{kd}"], out, M=B * Lv * hw, N=cout, K=9 * cin, lda=cin, ldy=cout, out_h=R, out_w=R,
+                ops.gemm(xpad, wdt(f"{key}.{kd}"), out, M=B * Lv * hw, N=cout, K=9 * cin, lda=cin, ldy=cout, out_h=R, out_w=R,
                          in_h=R, in_w=R, taps_h=3, taps_w=3, cin=cin, stride=1, dy0=-1, dx0=-1, a_img_stride=s_t * hw,
                          a_off=kd * hw, residual=out if kd else None, ldr=cout)
             return out
@@ -996,7 +1005,7 @@ class MAGE(nn.Module):
         Lin = L
         Lout = (Lin + 1) // 2
         Lp = 2 * (Lout + 1)
-        xa = torch.zeros((B * Lp + 1) * hw, Cc, device=dev, dtype=F32)                        # block 0 input: the embeddings
+        xa = torch.zeros((B * Lp + 1) * hw, Cc, device=dev, dtype=dt)                         # block 0 input: the embeddings
         if tok is not None:
             ops.embedding(tok.reshape(-1).contiguous(), d["emb"], xa, group=L * hw, group_stride=Lp * hw, off=hw)
         else:                                                      # Linear(E -> C) straight into the padded frame buffer (:583)
@@ -1012,7 +1021,7 @@ class MAGE(nn.Module):
             st1, std, st2 = (torch.empty(B, 16, 2, device=dev, dtype=F32) for _ in range(3))
             c1 = conv3(xa, f"p{i}.c1", Lv, 2, cin, cout)
             cd = conv3(xa, f"p{i}.ds", Lv, 2, cin, cout)
-            xb = torch.zeros((B * (Lout + 2) + 2) * hw, cout, device=dev, dtype=F32)           # conv2 input: stride-1 layout
+            xb = torch.zeros((B * (Lout + 2) + 2) * hw, cout, device=dev, dtype=dt)            # conv2 input: stride-1 layout
             ops.groupnorm_act(c1, d[f"p{i}.g1.w"], d[f"p{i}.g1.b"], xb, sample_stride_rows=Lv * hw, row_off=0, eps=blk.bn1.eps,
                               act=1, y_sample_stride_rows=(Lout + 2) * hw, y_row_off=hw, stats=st1, **gn)
             res = ops.groupnorm_act(cd, d[f"p{i}.gd.w"], d[f"p{i}.gd.b"], torch.empty(B * Lout * hw, cout, device=dev, dtype=F32),
@@ -1020,7 +1029,7 @@ class MAGE(nn.Module):
             c2 = conv3(xb, f"p{i}.c2", Lout + 2, 1, cout, cout)
             if i + 1 < len(self.conv3d):                                                       # next block's stride-2 input
                 Lp2 = 2 * ((Lout + 1) // 2 + 1)
-                nxt = torch.zeros((B * Lp2 + 1) * hw, cout, device=dev, dtype=F32)
+                nxt = torch.zeros((B * Lp2 + 1) * hw, cout, device=dev, dtype=dt)
                 ops.groupnorm_act(c2, d[f"p{i}.g2.w"], d[f"p{i}.g2.b"], nxt, sample_stride_rows=(Lout + 2) * hw, row_off=0,
                                   eps=blk.bn2.eps, act=1, residual=res, y_sample_stride_rows=Lp2 * hw, y_row_off=hw, stats=st2, **gn)
                 out_map = (Lp2 * hw, hw)
@@ -1033,7 +1042,7 @@ class MAGE(nn.Module):
                 out_map = (hw, 0)
             if tape is not None:
                 tape.append(dict(xa=xa, c1=c1, cd=cd, xb=xb, c2=c2, res=res, st1=st1, std=std, st2=st2, Lin=Lin, Lout=Lout, Lv=Lv, cin=cin,
-                                 cout=cout, out_map=out_map))
+                                 cout=cout, out_map=out_map, dt=dt))
             xa, cin, Lin = nxt, cout, Lout
         return xa
 

@@ -10,8 +10,10 @@
 Forward = the inference kernels (MAGE._video_prior with a tape, the implicit-GEMM 3x3 convolutions, mage_adain, mage_reparam_kl);
 backward = the same GEMM kernel on flipped / transposed weights for the input gradients (a Conv3d's temporal taps are three
 accumulating launches into the zero-padded frame buffer its forward read from), transposes + one split-K GEMM per weight gradient,
-and mage_groupnorm_bwd / mage_adain_bwd / mage_reparam_kl_bwd (csrc/train.hip).  Everything here is fp32, like the once-per-clip
-prologue of the inference path.
+and mage_groupnorm_bwd / mage_adain_bwd / mage_reparam_kl_bwd (csrc/train.hip).  In bf16 training the Conv3d video prior (the bulk of
+the branch: 36 temporal-tap convolutions over all frames, forward and twice backward) stores its activations and weights in bf16 for
+the matrix cores (convolution outputs, GroupNorm statistics and every gradient stream stay fp32); the per-clip 3x3 heads and ADAIN are
+fp32 in both modes, like the once-per-clip prologue of the inference path.
 """
 from __future__ import annotations
 
@@ -29,12 +31,12 @@ _conv = VectorQuantizedVAE._conv
 __all__ = ["rand_forward", "rand_backward"]
 
 
-def _flip(d: Dict[str, torch.Tensor], key: str, cin: int, cout: int) -> torch.Tensor:
+def _flip(d: Dict[str, torch.Tensor], key: str, cin: int, cout: int, dt=F32) -> torch.Tensor:
     """GEMM weight of the input-gradient convolution of the 3x3 convolution d[key] ([cout, 3, 3, cin] flattened):
-    Wf[ci, (ky, kx), co] = W[co, (2 - ky, 2 - kx), ci]  (a derived copy, cached with the others)."""
-    k = key + ".flip"
+    Wf[ci, (ky, kx), co] = W[co, (2 - ky, 2 - kx), ci]  (a derived copy in dt, cached with the others)."""
+    k = key + (".flip" if dt == F32 else ".flip.bf16")
     if k not in d:
-        d[k] = d[key].reshape(cout, 3, 3, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, 9 * cout).contiguous()
+        d[k] = d[key].reshape(cout, 3, 3, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, 9 * cout).to(dt).contiguous()
     return d[k]
 
 
@@ -43,15 +45,16 @@ def _conv_wgrad(dy, x, *, n_img: int, R: int, cin: int, cout: int, x_img_stride:
     """dW [cout, 9*cin] (tap-major, ci fastest: the GEMM weight layout) = sum over output pixels of dy^T gathered(x), and db.
     dy [n_img*R*R, cout] plain rows; x is read as image i -> rows i*x_img_stride + x_off (a frame of the padded buffer).
     Returns (dW, db, dyT): the transposed dy can be reused for the other temporal taps."""
-    dev = dy.device
+    dev, dt = dy.device, dy.dtype
+    assert x.dtype == dt
     hw = R * R
     M = n_img * hw
     S, Mc = _split_plan(M, cout, 9 * cin)
     Mp = S * Mc
     if dyT is None:
-        dyT = torch.empty(cout, Mp, device=dev, dtype=F32)
+        dyT = torch.empty(cout, Mp, device=dev, dtype=dt)
         ops.transpose(dy, dyT, M=M, Mp=Mp, C=cout, ldx=cout, ldy=Mp)
-    xT = torch.empty(9 * cin, Mp, device=dev, dtype=F32)
+    xT = torch.empty(9 * cin, Mp, device=dev, dtype=dt)
     for t in range(9):
         ops.transpose(x, xT, M=M, Mp=Mp, C=cin, ldx=cin, ldy=Mp, y_row0=t * cin, out_h=R, out_w=R, in_h=R, in_w=R,
                       img_stride=hw if x_img_stride is None else x_img_stride, a_off=x_off, dy=t // 3 - 1, dx=t % 3 - 1)
@@ -88,7 +91,7 @@ def rand_forward(model, batch, tok, ma, B: int, lat_rows=None, L: int = 0):
     R, Cc = model.image_resolution, model.vision_width
     hw, dev = R * R, ma.device
     blocks: list = []
-    prior = model._video_prior(tok, lat_rows, B, L, tape=blocks)                            # [B*hw, Cp]
+    prior = model._video_prior(tok, lat_rows, B, L, tape=blocks, dt=model._dt())           # [B*hw, Cp] fp32
     Cp = prior.shape[1]
     mu = _conv(prior, d["mu2.w"], torch.empty(B * hw, 64, device=dev, dtype=F32), n_img=B, H=R, W=R, cin=Cp, cout=64, k=3, bias=d["mu2.b"])
     logvar = _conv(prior, d["var2.w"], torch.empty_like(mu), n_img=B, H=R, W=R, cin=Cp, cout=64, k=3, bias=d["var2.b"])
@@ -128,7 +131,10 @@ def _prior_backward(model, d, blocks, dprior, grads: Dict[str, torch.Tensor], B:
 
         def conv3_bwd(name, dy, x, n_img, s_t, ci, co, want_dx=True):
             """Conv3d 3x3x3 (temporal stride s_t) as in MAGE._video_prior.conv3: weight gradient [co, ci, 3, 3, 3] and, accumulated
-            over the temporal taps, the gradient of the padded input buffer x."""
+            over the temporal taps, the gradient (fp32) of the padded input buffer x.  The GEMM operands are in the tape's dtype."""
+            dt = t["dt"]
+            if dt != F32:
+                dy = ops.cast(dy, torch.empty(dy.shape, device=dev, dtype=dt))
             dws, dyT = [], None
             for kd in range(3):
                 dW, _, dyT = _conv_wgrad(dy, x, n_img=n_img, R=R, cin=ci, cout=co, x_img_stride=s_t * hw, x_off=kd * hw, dyT=dyT)
@@ -136,9 +142,9 @@ def _prior_backward(model, d, blocks, dprior, grads: Dict[str, torch.Tensor], B:
             del dyT
             dx = None
             if want_dx:
-                dx = torch.zeros_like(x)
+                dx = torch.zeros(x.shape, device=dev, dtype=F32)
                 for kd in range(3):
-                    _conv(dy, _flip(d, f"p{i}.{name}.{kd}", ci, co), dx, n_img=n_img, H=R, W=R, cin=co, cout=ci, k=3, y_img_stride=s_t * hw,
+                    _conv(dy, _flip(d, f"p{i}.{name}.{kd}", ci, co, dt), dx, n_img=n_img, H=R, W=R, cin=co, cout=ci, k=3, y_img_stride=s_t * hw,
                           y_off=kd * hw, residual=dx, ldr=ci)
             return torch.stack(dws, 2), dx
 

@@ -328,8 +328,7 @@ def vq8_train_forward(vq, x: torch.Tensor):
     if H % 8 or W % 8:
         raise ValueError(f"f8 VQ-VAE input {H}x{W} must be a multiple of 8 in both dimensions")
     dim, dev = vq.dim, x.device
-    h = ops.conv_in(x, w["e0.wt"], w["e0.b"], None, None, torch.empty(N * H * W, dim, device=dev, dtype=F32), cin=Cin, H=H, W=W, cout=dim,
-                    kh=7, kw=7, stride=1, pad=3)
+    h = vq._stem7(w, x)
     enc_t, pools = [], []
     hh, ww = H, W
     for bi, ci, co in _F8_ENC:

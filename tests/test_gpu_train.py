@@ -366,6 +366,31 @@ def test_bf16_training_gradients_track_fp32():
     assert min(cos) > 0.98
 
 
+def test_bf16_training_gradients_track_fp32_with_the_randomness_branch():
+    """bf16 training of the CATER family: the Conv3d video prior runs on bf16 operands (fp32 accumulation, statistics and gradient
+    streams); its gradients, and everything downstream of it, track the fp32 mode's."""
+    L, B, seed = 9, 2, 42
+    cfg = synth.cater_model_config(frames_length=L, width=64, layers=3, vq_dim=32, K=64)
+    m = build_mage(cfg, seed, DEV)
+    batch = {k: v.to(DEV) for k, v in synth.synth_batch_cater(B, L, seed=seed, text_len=9).items()}
+    batch["reparam_noise"] = torch.randn(B, 64, 16, 16, generator=torch.Generator().manual_seed(seed)).to(DEV)
+    l32, _ = m(batch)
+    l32.backward()
+    g32 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad(set_to_none=True)
+    m.set_precision("bf16")
+    l16, _ = m(batch)
+    l16.backward()
+    assert abs(l16.item() - l32.item()) < 2e-2 * max(1.0, abs(l32.item()))
+    cos = {}
+    for n, p in m.named_parameters():
+        if p.grad is not None and g32[n].abs().max() > 1e-6 * max(g.abs().max() for g in g32.values()):
+            cos[n] = F.cosine_similarity(p.grad.flatten().double(), g32[n].flatten().double(), dim=0).item()
+    prior = [v for k, v in cos.items() if k.startswith("conv3d.")]
+    print(f"bf16 vs fp32 gradients (randomness branch): prior min cosine {min(prior):.4f}, all min {min(cos.values()):.4f}, mean {np.mean(list(cos.values())):.4f}")
+    assert len(prior) == 36 and min(prior) > 0.98 and np.mean(list(cos.values())) > 0.98
+
+
 def test_dropout_training_mode_is_consistent_between_forward_and_backward():
     """train(): dropout masks are stateless hashes of a per-call seed drawn from torch's RNG.  Same torch seed -> same loss; and
     the directional derivative of that (fixed-mask) loss along a parameter direction agrees with <grad, direction>."""
