@@ -49,15 +49,19 @@ namespace {
 // MT = 16-row MFMA tiles per wave along m: 8 -> 256x256 workgroup tile (bf16 on large problems), 4 -> 128x256 (fp32, whose
 // 8x4 accumulator variant spills, and problems with too few 256-row tiles to fill the chip).
 constexpr int BN = 256;
-constexpr int W_BYTES = BN * 128;
 constexpr int NSTAGE = 2;
-template <int MT> struct Tile {
-    static constexpr int BM = MT * 32;
+// NW = waves side by side along n (each owns 64 columns): 4 -> the 256-column tile; 1 -> the NARROW tile of the lockstep kernel
+// (all 8 waves stacked along m, 64 columns): outputs with N <= 128 (the cout/4 bottleneck convolutions of the f8 VQ-VAE, the 8- and
+// 16-column heads) waste 3/4 of a 256-column tile's matrix-core work; MT = 2 there (256 x 64 tile, 40 KiB per stage).
+template <int MT, int NW = 4> struct Tile {
+    static constexpr int BM = MT * 16 * (8 / NW);
+    static constexpr int BNT = 64 * NW;
     static constexpr int A_BYTES = BM * 128;                   // A part of a stage: BM rows x 128 bytes
-    static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;      // 64 KiB (MT=8) | 48 KiB (MT=4)
+    static constexpr int STAGE_BYTES = A_BYTES + BNT * 128;    // 64 KiB (MT=8) | 48 KiB (MT=4) | 40 KiB (narrow MT=2)
     static constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;    // one workgroup (8 waves, 2 per SIMD) per CU
     static constexpr int LDS_BYTES = RING_BYTES + 8 * 4096;    // + 4 KiB per wave of epilogue staging (epilogue_lean)
-    static constexpr int AU = MT / 2;                          // A units (8 rows x 128 B) per wave per slab
+    static constexpr int AU = BM / 64;                         // A units (8 rows x 128 B) per wave per slab
+    static constexpr int WU = NW;                              // W units per wave per slab
 };
 
 struct GemmArgs {
@@ -424,10 +428,11 @@ __device__ __forceinline__ void ring_barrier() {
 
 // SPLIT: the split-K form (mage_gemm_desc::n_split > 1).  A template parameter so that the kernels of the generation path keep
 // their exact code (the tile decode, two 64-bit strides and the W row stride cost the 8-phase kernel 11 spilled SGPRs otherwise).
-template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE>
+template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE, int NW = 4>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     typedef typename TT<DT>::elem E;
-    constexpr int BM = Tile<MT>::BM, A_BYTES = Tile<MT>::A_BYTES, STAGE_BYTES = Tile<MT>::STAGE_BYTES, AU = Tile<MT>::AU;
+    typedef Tile<MT, NW> TL;
+    constexpr int BM = TL::BM, A_BYTES = TL::A_BYTES, STAGE_BYTES = TL::STAGE_BYTES, AU = TL::AU, WU = TL::WU, BNT = TL::BNT;
     constexpr int CH = TT<DT>::CH;
     constexpr int BK = 8 * CH;
     constexpr int ES = sizeof(E);
@@ -455,8 +460,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     const int lp = lane & 7;             // physical 16-byte chunk
     const char* a_row[AU];               // plain mode: row base pointer (or null)
     int a_img[AU], a_iy[AU], a_ix[AU];   // gather mode
-    const char* w_row[4];
-    int acs[AU], wcs[4];                 // logical chunk this lane fetches for each unit
+    const char* w_row[WU];
+    int acs[AU], wcs[WU];                // logical chunk this lane fetches for each unit
     int ld_tile = chunk0 + li, ld_kt = 0, ld_stage = 0;
 
     auto loader_set_tile = [&](int tile) {
@@ -483,10 +488,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (wave * 4 + i) * 8 + lr;
+        for (int i = 0; i < WU; ++i) {
+            const int r = (wave * WU + i) * 8 + lr;
             wcs[i] = lp ^ ((r >> 1) & 7);
-            const int n = tn * BN + r;
+            const int n = tn * BNT + r;
             w_row[i] = (n < d.N) ? (const char*)d.W + (long)n * (SPLIT ? d.ldw : d.K) * ES + w_sp : nullptr;
         }
     };
@@ -517,12 +522,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
             const int i = u - AU;
             const int kc = ld_kt * BK + wcs[i] * CH;
             const char* wsrc = (live && kc < d.K && w_row[i]) ? w_row[i] + (long)kc * ES : g.zero;
-            glds16(wsrc, sa + A_BYTES + (wave * 4 + i) * 1024);
+            glds16(wsrc, sa + A_BYTES + (wave * WU + i) * 1024);
         }
     };
     auto issue_all = [&]() {
 #pragma unroll
-        for (int u = 0; u < AU + 4; ++u) issue_one(u);
+        for (int u = 0; u < AU + WU; ++u) issue_one(u);
     };
     auto loader_advance = [&]() {
         ld_stage ^= 1;
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     };
 
     // ---- compute state: wave (wm, wn) owns rows [wm*MT*16, +MT*16) x columns [wn*64, +64) of the tile
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / NW, wn = wave % NW;
     const int l15 = lane & 15, grp = lane >> 4;
     const int rsw = (l15 >> 1) & 7;                    // ((row>>1)&7) for every fragment row of this lane
     const int xoff = (wm * MT * 16 + l15) * 128;       // + mt*16*128
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
         const int ts = SPLIT ? c_tile / g.tiles_per_split : 0, trem = SPLIT ? c_tile - ts * g.tiles_per_split : c_tile;
         const int tm = trem / g.ntiles_n, tn = trem - tm * g.ntiles_n;
         const long ysplit = SPLIT ? (long)ts * d.y_split_stride : 0;
-        const int m0 = tm * BM + wm * MT * 16, n0 = tn * BN + wn * 64;
+        const int m0 = tm * BM + wm * MT * 16, n0 = tn * BNT + wn * 64;
         if constexpr (EK == EK_RES_INIT) {
             // y = x + (A W^T + b): start the accumulators from the fp32 residual.  32 independent 16-byte loads per lane,
             // straight into the MFMA layout (row mt*16 + l15, columns nt*16 + grp*4 + {0..3}), no register cost, one
@@ -622,7 +627,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
             // the NEXT phase's fragments (2 ds_read_b128, or the 6 that open the second k-half), issues its share of the
             // next slab's DMAs, then runs 8 MFMAs on fragments requested one phase earlier: LDS latency and DMA issue sit
             // under the matrix pipe instead of in front of it (the compiler's own order was read-all / wait / MFMA-all).
-            constexpr int NG = MT / 2, NU = AU + 4;
+            constexpr int NG = MT / 2, NU = AU + WU;
             const char* xs = st + xoff;
             const char* ws = st + woff;
             const int pcs[2] = {((grp + 0) ^ rsw) * 16, ((grp + 4) ^ rsw) * 16};
@@ -701,7 +706,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
             if (d.y_dtype == MAGE_F32) epilogue_wave<ACT, float, MT, EK>(d, cv, acc, m0, n0, lane, plane, ysplit);
             else epilogue_wave<ACT, unsigned short, MT, EK>(d, cv, acc, m0, n0, lane, plane, ysplit);
         } else {
-            char* stg = smem + Tile<MT>::RING_BYTES + wave * 4096;
+            char* stg = smem + TL::RING_BYTES + wave * 4096;
             if constexpr (LN == LN_CONSUME) {
                 if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit, &lnc);
                 else epilogue_lean<ACT, unsigned short, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit, &lnc);
@@ -1017,23 +1022,24 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     }
 }
 
-template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE>
+template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE, int NW = 4>
 int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
+    typedef Tile<MT, NW> TL;
     // launch attributes are per DEVICE (a process may drive several GPUs, e.g. nn.DataParallel, main_mage.py:106): cached per
     // device index; setting one twice from two threads is harmless
     static bool attr_set[MAGE_MAX_DEVICES] = {false};
     const int dev = mage_device_index();
     MAGE_CHECK_ARG(dev >= 0, "mage_gemm: no current device");
     if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  Tile<MT>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT, LN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  TL::LDS_BYTES);
         attr_set[dev] = true;
     }
     GemmArgs a;
     a.d = *d;
     a.zero = (const char*)mage_zero_page();
-    const int tiles_m = (d->M + Tile<MT>::BM - 1) / Tile<MT>::BM;
-    a.ntiles_n = (d->N + BN - 1) / BN;
+    const int tiles_m = (d->M + TL::BM - 1) / TL::BM;
+    a.ntiles_n = (d->N + TL::BNT - 1) / TL::BNT;
     a.tiles_per_split = tiles_m * a.ntiles_n;
     a.ntiles = a.tiles_per_split * d->n_split;
     const int grid = a.ntiles >= n_cu ? n_cu : ((a.ntiles + 7) & ~7);     // one resident workgroup per CU, multiple of 8
@@ -1060,13 +1066,13 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     if (kind_wants && st_groups > 1 && a.ntiles >= n_cu && tiles_per_wg >= 6) {
         const int es = d->dtype == MAGE_BF16 ? 2 : 4;
         const long nk = ((long)d->K * es + 127) / 128;
-        const long out_b = (long)Tile<MT>::BM * BN * (d->y_dtype == MAGE_BF16 ? 2 : 4);
-        const long res_b = d->residual ? (long)Tile<MT>::BM * BN * (d->res_dtype == MAGE_BF16 ? 2 : 4) : 0;
+        const long out_b = (long)TL::BM * TL::BNT * (d->y_dtype == MAGE_BF16 ? 2 : 4);
+        const long res_b = d->residual ? (long)TL::BM * TL::BNT * (d->res_dtype == MAGE_BF16 ? 2 : 4) : 0;
         const long period = nk * 3400 * MT / 8 + (long)((out_b + res_b) / 10.6);
         a.stagger_groups = st_groups;
         a.stagger_sleeps = (int)(period * st_percent / 100 / st_groups / 1024);
     }
-    if constexpr (DT == MAGE_BF16 && !GATHER && MT == 8 && EK != EK_GENERAL) {
+    if constexpr (DT == MAGE_BF16 && !GATHER && MT == 8 && EK != EK_GENERAL && NW == 4) {
         static int use8 = -1;
         if (use8 < 0) use8 = getenv("MAGE_GEMM_NO_8PHASE") ? 0 : 1;
         const long a_rows = (long)((d->M + d->out_h * d->out_w - 1) / (d->out_h * d->out_w)) * d->a_img_stride + d->a_off + 1;
@@ -1084,7 +1090,7 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
             return MAGE_OK;
         }
     }
-    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT, LN>), dim3(grid), dim3(512), Tile<MT>::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT, LN, NW>), dim3(grid), dim3(512), TL::LDS_BYTES, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
     return MAGE_OK;
 }
@@ -1164,6 +1170,14 @@ int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
     const int n_cu = n_cu_dev[dev];
     // 256-row tiles only where there are enough of them to give every CU at least two (bf16; the fp32 8x4-accumulator
     // variant does not fit the register file)
+    if constexpr (EK != EK_RES_INIT && LN == LN_NONE) {
+        // narrow outputs (N <= 128) on the 256 x 64 tile: a 256-column tile would spend 3/4 (N = 64) or more of its matrix-core work on
+        // columns that do not exist.  Only where a 256-row tile list still fills the chip.
+        static int narrow = -1;
+        if (narrow < 0) narrow = getenv("MAGE_GEMM_NO_NARROW") ? 0 : 1;
+        if (narrow && d->N <= 128 && d->n_split == 1 && (long)((d->M + 255) / 256) * ((d->N + 63) / 64) >= n_cu)
+            return launch_tile<DT, GATHER, ACT, 2, EK, false, LN_NONE, 1>(d, s, n_cu);
+    }
     const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + BN - 1) / BN) * d->n_split;
     if constexpr (!GATHER && ACT == MAGE_ACT_NONE && EK == EK_BIAS) {
         if (d->n_split > 1) {                      // split-K (weight gradients): its own instantiations
