@@ -117,7 +117,10 @@ typedef struct mage_gemm_desc {
      * A = that bf16 copy, W = gamma * W (per input channel), bias = W beta + b, ln_colsum[n] = sum_k W'[n, k]; with ln_stats set the
      * epilogue computes rstd_m (acc - mean_m ln_colsum[n]) + bias[n] before the activation: LN(x) W^T + b without the LayerNorm pass. */
     void* y2;
-    int32_t ldy2, reserved2;
+    int32_t ldy2;
+    int32_t res_half;                  /* general epilogue, out_h > 1: the residual lives at HALF resolution ([img, out_h/2, out_w/2, N] rows):
+                                        * output pixel (oy, ox) adds residual pixel (oy/2, ox/2) -- nn.Upsample(scale_factor=2) of the
+                                        * skip path folded into the convolution that consumes it (vqvae_model.py:147-166,203-209) */
     float* ln_part;
     const float* ln_stats;
     const float* ln_colsum;

@@ -151,14 +151,17 @@ __device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const Col
         const int mq = m0 + mt * 16 + l15;
         const int m = min(mq, d.M - 1);
         int yrow;
+        long rrow;                                      // row of the residual: the output row, or (res_half) its half-resolution pixel
         if (simple_rows) {
             yrow = m * d.y_mul_x + d.y_off;
+            rrow = yrow;
         } else {
             const int img = m / plane;
             const int rem = m - img * plane;
             const int oy = rem / d.out_w;
             const int ox = rem - oy * d.out_w;
             yrow = img * d.y_img_stride + oy * d.y_mul_y + ox * d.y_mul_x + d.y_off;
+            rrow = d.res_half ? (long)img * (plane >> 2) + (long)(oy >> 1) * (d.out_w >> 1) + (ox >> 1) : (long)yrow;
         }
         // everything added after the activation (residual + row table), requested before this row's first store
         f32x4 extra[2][2];
@@ -171,11 +174,11 @@ __device__ __forceinline__ void epilogue_wave(const mage_gemm_desc& d, const Col
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 if (d.res_dtype == MAGE_F32) {
-                    const float* rp = (const float*)d.residual + (long)yrow * d.ldr + nld[k];
+                    const float* rp = (const float*)d.residual + rrow * d.ldr + nld[k];
                     extra[k][0] = *(const f32x4*)rp;
                     extra[k][1] = *(const f32x4*)(rp + 4);
                 } else {
-                    const uint4 r = *(const uint4*)((const unsigned short*)d.residual + (long)yrow * d.ldr + nld[k]);
+                    const uint4 r = *(const uint4*)((const unsigned short*)d.residual + rrow * d.ldr + nld[k]);
                     extra[k][0] = f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
                                         __uint_as_float(r.y & 0xffff0000u)};
                     extra[k][1] = f32x4{__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u), __uint_as_float(r.w << 16),
@@ -1293,6 +1296,8 @@ extern "C" int mage_gemm(const mage_gemm_desc* d_in, void* stream) {
     MAGE_CHECK_ARG(d->n_split == 1 || ((d->a_split_stride | d->w_split_stride) % ch == 0 && d->y_split_stride % 4 == 0 && d->ldw % ch == 0),
                    "mage_gemm: split strides / ldw must keep 16-byte alignment");
     hipStream_t s = (hipStream_t)stream;
+    MAGE_CHECK_ARG(!d->res_half || (d->residual && d->out_h > 1 && d->out_h % 2 == 0 && d->out_w % 2 == 0 && d->n_split == 1),
+                   "mage_gemm: res_half needs a residual and an even out_h x out_w output plane");
     if (const int r = try_taps8(d, s)) return r < 0 ? r : MAGE_OK;
     const bool gather = d->taps_h * d->taps_w > 1 || d->stride != 1 || d->dy0 != 0 || d->dx0 != 0 || d->in_h != d->out_h ||
                         d->in_w != d->out_w;

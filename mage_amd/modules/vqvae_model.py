@@ -299,8 +299,9 @@ class VectorQuantizedVAE(nn.Module):
     def _bottleneck(self, w, p, x, dt, n_img, H, W, cin, cout, first_k, last_k, post_relu, up_first=False):
         """up_first (decoder blocks behind an nn.Upsample, first_k = 1): x is the LOW-resolution input [n_img, H/2, W/2, cin].  A 1x1
         convolution and a ReLU act per pixel, so they commute with nearest-neighbour upsampling: the block's first convolution and its
-        identity path run on a quarter of the pixels and only their outputs (cout/4 and cout channels instead of cin, twice) are
-        upsampled -- the same arithmetic per output pixel, bit-identical results."""
+        identity path run on a quarter of the pixels; only the first convolution's output (cout/4 channels) is upsampled, the
+        identity path is read at low resolution by the block's last convolution (mage_gemm res_half) -- the same arithmetic per
+        output pixel, bit-identical results."""
         s = "." + ("f32" if dt == torch.float32 else "bf16")
         hid = cout // 4
         dev = x.device
@@ -320,8 +321,7 @@ class VectorQuantizedVAE(nn.Module):
             h1 = torch.empty(n_img * Hi * Wi, hid, device=dev, dtype=dt)
             self._conv(xr, w[f"{p}.w1{s}"], h1, n_img=n_img, H=Hi, W=Wi, cin=cin, cout=hid, k=1, bias=w[f"{p}.b1"], act=ops.ACT_RELU)
             h = ops.upsample2(h1, torch.empty(n_img * H * W, hid, device=dev, dtype=dt), N=n_img, H=Hi, W=Wi, Cc=hid)
-            idp = ops.upsample2(idp, torch.empty(n_img * H * W, cout, device=dev, dtype=dt), N=n_img, H=Hi, W=Wi, Cc=cout)
-            j0 = 1
+            j0 = 1                                  # the identity path stays at low resolution: the last convolution reads it there (res_half)
         for j in range(j0, 3):
             nh = torch.empty(n_img * H * W, chans[j + 1], device=dev, dtype=dt)
             self._conv(h, w[f"{p}.w{2 * j + 1}{s}"], nh, n_img=n_img, H=H, W=W, cin=chans[j], cout=chans[j + 1], k=ks[j],
@@ -329,7 +329,7 @@ class VectorQuantizedVAE(nn.Module):
             h = nh
         out = torch.empty(n_img * H * W, cout, device=dev, dtype=dt)
         self._conv(h, w[p + ".w7" + s], out, n_img=n_img, H=H, W=W, cin=hid, cout=cout, k=ks[3], bias=w[p + ".b7"],
-                   residual=idp, ldr=cout, post_relu=post_relu)
+                   residual=idp, ldr=cout, post_relu=post_relu, res_half=up_first)
         return out
 
     # ------------------------------------------------------------------ encoder (always fp32: bit-exact tokens)

@@ -508,3 +508,30 @@ def test_layernorm_folded_around_the_gemms(M):
     # loud on shapes the folded forms do not take
     with pytest.raises(Exception):
         o.gemm(xb[:100], wq.to(DEV), y, M=100, N=4 * C_, K=C_, lda=C_, ldy=4 * C_, bias=c.to(DEV), ln_stats=stats, ln_colsum=s.to(DEV))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_conv_with_half_resolution_residual_and_narrow_outputs(dt):
+    """mage_gemm res_half (the residual of a convolution read at half resolution = nn.Upsample of the skip path folded in) against the
+    same convolution over the explicitly upsampled residual, bit for bit; the shapes cover the narrow 256 x 64 tile (N <= 128 with
+    enough rows) and the 256-column one."""
+    o = ops()
+    from mage_amd.modules.vqvae_model import VectorQuantizedVAE as V
+    for (N, H, W, cin, cout) in ((2, 8, 8, 16, 32), (3, 16, 16, 64, 256), (70, 32, 32, 64, 64), (70, 32, 32, 64, 128)):
+        x = to_dev(rnd(N * H * W, cin, seed=1), dt)
+        w = to_dev(rnd(cout, 9 * cin, seed=2, scale=0.05), dt)
+        b = rnd(cout, seed=3).to(DEV)
+        r_low = to_dev(rnd(N * (H // 2) * (W // 2), cout, seed=4), dt)
+        y = torch.empty(N * H * W, cout, device=DEV, dtype=dt)
+        V._conv(x, w, y, n_img=N, H=H, W=W, cin=cin, cout=cout, k=3, bias=b, residual=r_low, ldr=cout, post_relu=True, res_half=True)
+        r_up = o.upsample2(r_low, torch.empty(N * H * W, cout, device=DEV, dtype=dt), N=N, H=H // 2, W=W // 2, Cc=cout)
+        y2 = torch.empty_like(y)
+        V._conv(x, w, y2, n_img=N, H=H, W=W, cin=cin, cout=cout, k=3, bias=b, residual=r_up, ldr=cout, post_relu=True)
+        assert torch.equal(y, y2)
+        # and against torch (fp32 reference of the same op)
+        xi = x.float().view(N, H, W, cin).permute(0, 3, 1, 2).cpu()
+        wi = w.float().view(cout, 3, 3, cin).permute(0, 3, 1, 2).cpu()
+        want = F.relu(F.conv2d(xi, wi, b.cpu(), padding=1) + r_up.float().view(N, H, W, cout).permute(0, 3, 1, 2).cpu())
+        torch.testing.assert_close(y.float().view(N, H, W, cout).permute(0, 3, 1, 2).cpu(), want, **TOL[dt])
+    with pytest.raises(Exception):
+        o.gemm(x, w, y, M=N * H * W, N=cout, K=9 * cin, lda=cin, ldy=cout, res_half=True)          # no residual
