@@ -535,3 +535,25 @@ def test_conv_with_half_resolution_residual_and_narrow_outputs(dt):
         torch.testing.assert_close(y.float().view(N, H, W, cout).permute(0, 3, 1, 2).cpu(), want, **TOL[dt])
     with pytest.raises(Exception):
         o.gemm(x, w, y, M=N * H * W, N=cout, K=9 * cin, lda=cin, ldy=cout, res_half=True)          # no residual
+
+
+@pytest.mark.parametrize("M,D,K", [(4099, 1024, 512), (20000, 256, 512), (5000, 32, 64), (777, 128, 1000), (33, 64, 300)])
+def test_vq_nearest_on_the_fp64_matrix_cores(M, D, K):
+    """mage_vq_nearest (v_mfma_f64_16x16x4_f64 kernel) against the reference FORMULA evaluated with float64 dot products in torch:
+    fl32(fl32(|c|^2 + |z|^2) - 2 <z, c>), first minimum: indices and the top-2 margin, for ragged M and K (not multiples of the 32-row /
+    64-code blocks), exact codebook hits included."""
+    o = ops()
+    g = torch.Generator().manual_seed(M + D + K)
+    z = torch.randn(M, D, generator=g)
+    cb = torch.randn(K, D, generator=g) * 0.8
+    n_hit = min(K, M) // 2
+    z[:n_hit] = cb[torch.randperm(K, generator=g)[:n_hit]]                 # rows that ARE code vectors
+    zd, cbd = z.to(DEV), cb.to(DEV)
+    cbt, c2 = o.vq_prepare(cbd)
+    ids, mg = o.vq_nearest(zd, cbt, c2, want_margin=True)
+    dots = zd.double() @ cbd.double().t()
+    s32 = c2[None, :] + (zd.double() ** 2).sum(1).float()[:, None]         # fl32(|c|^2 + |z|^2)
+    dist = (s32.double() - 2.0 * dots.float().double()).float()            # fmaf(-2, fl32(dot), s): one rounding
+    srt = dist.sort(dim=1, stable=True)                                    # stable: the first minimum wins, as in the reference
+    assert torch.equal(ids, srt.indices[:, 0])
+    torch.testing.assert_close(mg, srt.values[:, 1] - srt.values[:, 0], atol=0, rtol=0)
