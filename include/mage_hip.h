@@ -338,6 +338,9 @@ int mage_attention_bwd(const mage_attn_desc* desc, const void* dout, void* dq, v
  * calls it again with the same seed (no mask tensor). */
 int mage_dropout(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, int64_t n, float p, uint64_t seed, int32_t accumulate,
                  void* stream);
+/* y = r + dropout(x) with the same mask as mage_dropout(x, ., p, seed): the residual add x + dropout(Linear(.)) of a block
+ * (mage_model.py:48,52) in one pass (r, y fp32; may not alias x). */
+int mage_dropout_add(const void* x, int32_t x_dtype, const float* r, float* y, int64_t n, float p, uint64_t seed, void* stream);
 /* BatchNorm2d in TRAINING mode (stage-1 VQ-VAE training, train_vqvae.py:13-35; vqvae_model.py:112-119,174,186) on channels-last
  * rows [rows, C] fp32: batch statistics are column reductions.  mage_bn_colreduce writes per-workgroup partial column sums
  * partials[n_part][NOUT][C] for mage_sum_partials (fixed order): mode 0: sum x; mode 1: sum (x - mean)^2 (two-pass variance);

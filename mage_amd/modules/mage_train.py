@@ -117,7 +117,7 @@ def _res_linear(run: _Run, a, d, name, x_old, dt, *, M, N, K, seed):
     if run.p == 0:
         return ops.gemm(a, w, torch.empty_like(x_old), M=M, N=N, K=K, lda=K, ldy=N, bias=b, residual=x_old, ldr=N)
     br = ops.gemm(a, w, torch.empty(M, N, device=a.device, dtype=F32), M=M, N=N, K=K, lda=K, ldy=N, bias=b)
-    return ops.dropout(br, x_old.clone(), run.p, seed, accumulate=True)
+    return ops.dropout_add(br, x_old, torch.empty_like(x_old), run.p, seed)
 
 
 # ----------------------------------------------------------------------------------------------------------------- decoder stack

@@ -666,6 +666,14 @@ def dropout(x, y, p: float, seed: int, accumulate: bool = False):
     return y
 
 
+def dropout_add(x, r, y, p: float, seed: int):
+    """y = r + dropout(x) (the mask of dropout(x, ., p, seed)); r, y fp32."""
+    l, s = _dev(x)
+    assert x.is_contiguous() and r.is_contiguous() and y.is_contiguous() and r.dtype == y.dtype == torch.float32 and x.numel() == y.numel() == r.numel()
+    _lib.check(l.mage_dropout_add(x.data_ptr(), code(x), r.data_ptr(), y.data_ptr(), x.numel(), float(p), int(seed) & (2 ** 64 - 1), s), l)
+    return y
+
+
 def adam(p, g, m, v, *, lr: float, beta1: float, beta2: float, eps: float, step: int, grad_scale: float = 1.0):
     l, s = _dev(p)
     for t_ in (p, g, m, v):
