@@ -124,6 +124,10 @@ typedef struct mage_gemm_desc {
     float* ln_part;
     const float* ln_stats;
     const float* ln_colsum;
+    int32_t a_half;                    /* gather form: the input lives at HALF resolution ([img, in_h/2, in_w/2, cin] rows, a_img_stride = that
+                                        * plane): tap pixel (iy, ix) of the in_h x in_w grid reads row (iy/2)*(in_w/2) + ix/2 -- nn.Upsample
+                                        * (scale_factor=2, nearest) in front of a convolution folded into its gather (vqvae_model.py:203-209) */
+    int32_t reserved3;
 } mage_gemm_desc;
 
 int mage_gemm(const mage_gemm_desc* desc, void* stream);

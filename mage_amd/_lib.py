@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
         ("residual", vp), ("ldr", i32), ("res_dtype", i32),
         ("post_relu", i32), ("ldw", i32), ("n_split", i32),
         ("a_split_stride", i64), ("w_split_stride", i64), ("y_split_stride", i64),
-        ("y2", vp), ("ldy2", i32), ("res_half", i32), ("ln_part", vp), ("ln_stats", vp), ("ln_colsum", vp),
+        ("y2", vp), ("ldy2", i32), ("res_half", i32), ("ln_part", vp), ("ln_stats", vp), ("ln_colsum", vp), ("a_half", i32), ("reserved3", i32),
     ]
 
 

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                     const int iy = a_iy[i] + ky * d.dys;
                     const int ix = a_ix[i] + kx * d.dxs;
                     if ((unsigned)iy < (unsigned)d.in_h && (unsigned)ix < (unsigned)d.in_w)
-                        src = (const char*)d.A + ((long)(a_img[i] + iy * d.in_w + ix) * d.lda + ci) * ES;
+                        src = (const char*)d.A + ((long)(a_img[i] + (d.a_half ? (iy >> 1) * (d.in_w >> 1) + (ix >> 1) : iy * d.in_w + ix)) * d.lda + ci) * ES;
                 }
             } else {
                 src = (live && kc < d.K && a_row[i]) ? a_row[i] + (long)kc * ES : g.zero;
@@ -1135,7 +1135,7 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
     // convolutions over a zero-padded input, and (taps 1x1) the Linear layers that add a broadcast row table (in_linear /
     // context_linear + T positions, written into regrouped rows of the decoder stream)
     if (ntaps <= 1 && !table) return 0;
-    if (d->stride != 1 || d->dys != 1 || d->dxs != 1 || d->dy0 != 0 || d->dx0 != 0) return 0;
+    if (d->stride != 1 || d->dys != 1 || d->dxs != 1 || d->dy0 != 0 || d->dx0 != 0 || d->a_half) return 0;
     // zero-padded input only: every tap of every output pixel is a row of the buffer (in_w is the buffer's row pitch: a window that
     // starts inside the padding -- the sub-pixel phases of a transposed convolution -- comes with a_off and a wider pitch)
     if (d->in_h < d->out_h + d->taps_h - 1 || d->in_w < d->out_w + d->taps_w - 1) return 0;
@@ -1296,11 +1296,12 @@ extern "C" int mage_gemm(const mage_gemm_desc* d_in, void* stream) {
     MAGE_CHECK_ARG(d->n_split == 1 || ((d->a_split_stride | d->w_split_stride) % ch == 0 && d->y_split_stride % 4 == 0 && d->ldw % ch == 0),
                    "mage_gemm: split strides / ldw must keep 16-byte alignment");
     hipStream_t s = (hipStream_t)stream;
+    MAGE_CHECK_ARG(!d->a_half || (d->in_h % 2 == 0 && d->in_w % 2 == 0 && d->n_split == 1), "mage_gemm: a_half needs an even in_h x in_w grid");
     MAGE_CHECK_ARG(!d->res_half || (d->residual && d->out_h > 1 && d->out_h % 2 == 0 && d->out_w % 2 == 0 && d->n_split == 1),
                    "mage_gemm: res_half needs a residual and an even out_h x out_w output plane");
     if (const int r = try_taps8(d, s)) return r < 0 ? r : MAGE_OK;
     const bool gather = d->taps_h * d->taps_w > 1 || d->stride != 1 || d->dy0 != 0 || d->dx0 != 0 || d->in_h != d->out_h ||
-                        d->in_w != d->out_w;
+                        d->in_w != d->out_w || d->a_half;
     if (d->dtype == MAGE_BF16) return gather ? launch<MAGE_BF16, true>(d, s) : launch<MAGE_BF16, false>(d, s);
     return gather ? launch<MAGE_F32, true>(d, s) : launch<MAGE_F32, false>(d, s);
 }

@@ -299,9 +299,9 @@ class VectorQuantizedVAE(nn.Module):
     def _bottleneck(self, w, p, x, dt, n_img, H, W, cin, cout, first_k, last_k, post_relu, up_first=False):
         """up_first (decoder blocks behind an nn.Upsample, first_k = 1): x is the LOW-resolution input [n_img, H/2, W/2, cin].  A 1x1
         convolution and a ReLU act per pixel, so they commute with nearest-neighbour upsampling: the block's first convolution and its
-        identity path run on a quarter of the pixels; only the first convolution's output (cout/4 channels) is upsampled, the
-        identity path is read at low resolution by the block's last convolution (mage_gemm res_half) -- the same arithmetic per
-        output pixel, bit-identical results."""
+        identity path run on a quarter of the pixels and nothing is upsampled at all: the second convolution gathers the first one's
+        output at half resolution (mage_gemm a_half), the block's last convolution reads the identity path there (res_half) -- the
+        same arithmetic per output pixel, bit-identical results."""
         s = "." + ("f32" if dt == torch.float32 else "bf16")
         hid = cout // 4
         dev = x.device
@@ -320,12 +320,13 @@ class VectorQuantizedVAE(nn.Module):
             assert first_k == 1
             h1 = torch.empty(n_img * Hi * Wi, hid, device=dev, dtype=dt)
             self._conv(xr, w[f"{p}.w1{s}"], h1, n_img=n_img, H=Hi, W=Wi, cin=cin, cout=hid, k=1, bias=w[f"{p}.b1"], act=ops.ACT_RELU)
-            h = ops.upsample2(h1, torch.empty(n_img * H * W, hid, device=dev, dtype=dt), N=n_img, H=Hi, W=Wi, Cc=hid)
-            j0 = 1                                  # the identity path stays at low resolution: the last convolution reads it there (res_half)
+            h = h1                                  # stays at low resolution too: the next convolution gathers it there (a_half);
+            j0 = 1                                  # the identity path is read there by the last convolution (res_half)
         for j in range(j0, 3):
             nh = torch.empty(n_img * H * W, chans[j + 1], device=dev, dtype=dt)
+            half = dict(a_half=True, a_img_stride=Hi * Wi) if (up_first and j == 1) else {}
             self._conv(h, w[f"{p}.w{2 * j + 1}{s}"], nh, n_img=n_img, H=H, W=W, cin=chans[j], cout=chans[j + 1], k=ks[j],
-                       bias=w[f"{p}.b{2 * j + 1}"], act=ops.ACT_RELU)
+                       bias=w[f"{p}.b{2 * j + 1}"], act=ops.ACT_RELU, **half)
             h = nh
         out = torch.empty(n_img * H * W, cout, device=dev, dtype=dt)
         self._conv(h, w[p + ".w7" + s], out, n_img=n_img, H=H, W=W, cin=hid, cout=cout, k=ks[3], bias=w[p + ".b7"],

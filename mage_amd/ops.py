@@ -175,7 +175,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
          bias=None, scale=None, shift=None, act: int = ACT_NONE, rowadd=None, rowadd_div: int = 1, rowadd_mod: int = 1,
          residual=None, ldr: int = 0, post_relu: bool = False, ldw: int = 0, n_split: int = 1, a_split_stride: int = 0,
          w_split_stride: int = 0, y_split_stride: int = 0, y2=None, ldy2: int = 0, ln_part=None, ln_stats=None,
-         ln_colsum=None, res_half: bool = False) -> torch.Tensor:
+         ln_colsum=None, res_half: bool = False, a_half: bool = False) -> torch.Tensor:
     """Y = epilogue(A (*) W^T); see mage_gemm in include/mage_hip.h for the geometry fields."""
     l, s = _dev(a)
     out_w = M if out_w is None else out_w
@@ -203,11 +203,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     d.a_split_stride, d.w_split_stride, d.y_split_stride = a_split_stride, w_split_stride, y_split_stride
     d.y2, d.ldy2, d.ln_part, d.ln_stats, d.ln_colsum = _p(y2), ldy2, _p(ln_part), _p(ln_stats), _p(ln_colsum)
     d.res_half = int(res_half)
+    d.a_half = int(a_half)
     ln = 2 if ln_stats is not None else (1 if y2 is not None else 0)      # LN_CONSUME / LN_PRODUCE (csrc/gemm.hip)
     if PROFILE.enabled:
         # key = the kernel instantiation mage_gemm dispatches to (mirrors launch_act in csrc/gemm.hip), so that the
         # per-kernel averages line up with rocprofv3's per-symbol statistics
-        gather = taps_h * taps_w > 1 or stride != 1 or dy0 != 0 or dx0 != 0 or d.in_h != d.out_h or d.in_w != d.out_w
+        gather = taps_h * taps_w > 1 or stride != 1 or dy0 != 0 or dx0 != 0 or d.in_h != d.out_h or d.in_w != d.out_w or a_half
         n_cu = torch.cuda.get_device_properties(a.device).multi_processor_count & ~7
         mt = 8 if (d.dtype == BF16 and ((M + 255) // 256) * ((N + 255) // 256) * max(n_split, 1) >= 2 * n_cu) else 4
         if scale is None and rowadd is None and residual is None and not post_relu:

@@ -533,6 +533,13 @@ def test_conv_with_half_resolution_residual_and_narrow_outputs(dt):
         wi = w.float().view(cout, 3, 3, cin).permute(0, 3, 1, 2).cpu()
         want = F.relu(F.conv2d(xi, wi, b.cpu(), padding=1) + r_up.float().view(N, H, W, cout).permute(0, 3, 1, 2).cpu())
         torch.testing.assert_close(y.float().view(N, H, W, cout).permute(0, 3, 1, 2).cpu(), want, **TOL[dt])
+        # a_half: the convolution's INPUT at half resolution (nn.Upsample in front of it folded into the gather)
+        x_low = to_dev(rnd(N * (H // 2) * (W // 2), cin, seed=5), dt)
+        x_up = o.upsample2(x_low, torch.empty(N * H * W, cin, device=DEV, dtype=dt), N=N, H=H // 2, W=W // 2, Cc=cin)
+        ya, yb = torch.empty_like(y), torch.empty_like(y)
+        V._conv(x_low, w, ya, n_img=N, H=H, W=W, cin=cin, cout=cout, k=3, bias=b, act=o.ACT_RELU, a_half=True, a_img_stride=(H // 2) * (W // 2))
+        V._conv(x_up, w, yb, n_img=N, H=H, W=W, cin=cin, cout=cout, k=3, bias=b, act=o.ACT_RELU)
+        assert torch.equal(ya, yb)
     with pytest.raises(Exception):
         o.gemm(x, w, y, M=N * H * W, N=cout, K=9 * cin, lda=cin, ldy=cout, res_half=True)          # no residual
 
