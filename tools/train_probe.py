@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """The reference's training loop (main_mage.py:139-154) on the HIP path: DataLoader with the MovingMnist batch contract ->
-model(batch) -> loss.backward() -> optimizer.step(), timed per step.  usage: train_probe.py [B] [L] [precision] [steps] [mnist|cater]"""
+model(batch) -> loss.backward() -> optimizer.step(), timed per step.  usage: train_probe.py [B] [L] [precision] [steps] [mnist|cater|magep]"""
 import sys
 import time
 
@@ -17,7 +17,8 @@ prec = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 6
 dev = "cuda:0"
 family = sys.argv[5] if len(sys.argv) > 5 else "mnist"              # "cater": config/mage_caterv1.yaml's model (f8 VQ-VAE, randomness branch)
-model = instantiate_from_config(synth.mnist_model_config(frames_length=L) if family == "mnist" else synth.cater_model_config(frames_length=L))
+cfg = {"mnist": synth.mnist_model_config, "cater": synth.cater_model_config, "magep": synth.magep_model_config}[family](frames_length=L)
+model = instantiate_from_config(cfg)                                 # "magep": config/mage+_caterv2.yaml's MAGE side over the stand-in latent first stage
 synth.fill_state_dict(model, 0)
 model = model.to(dev).set_precision(prec).train()
 opt = FlatAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6)
@@ -25,7 +26,7 @@ if family == "mnist":
     ds = glue.SyntheticMovingMnist(B * (steps + 1), frames_length=L)
     loader = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False, collate_fn=ds.collate_fn, num_workers=0)
 else:
-    loader = [synth.synth_batch_cater(B, L, seed=200 + i) for i in range(steps + 1)]
+    loader = [synth.synth_batch_cater(B, L, seed=200 + i, **({"vocab": 50} if family == "magep" else {})) for i in range(steps + 1)]
 times, losses = [], []
 # the synthetic dataset draws its clips on the host (~4 ms per clip, one process): with num_workers=0 the GPU idles ~250 ms between
 # steps, drops its clocks, and the next forward pass measures the ramp (46 vs 133 ms for the same kernels).  A real input pipeline
