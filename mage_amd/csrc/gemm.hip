@@ -1181,6 +1181,14 @@ int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
         if (narrow && d->N <= 128 && d->n_split == 1 && (long)((d->M + 255) / 256) * ((d->N + 63) / 64) >= n_cu)
             return launch_tile<DT, GATHER, ACT, 2, EK, false, LN_NONE, 1>(d, s, n_cu);
     }
+    if constexpr (DT == MAGE_BF16 && !GATHER && ACT == MAGE_ACT_NONE && EK == EK_RES_INIT) {
+        // few rows (the incremental AR loop's x + Linear(.) at 8 k rows x 512 columns: 128 tiles of 128 x 256 on 256 CUs): the narrow tile
+        // cuts the same output into 256 x 64 pieces, one per CU.  Same K order per element: the tokens stay bit-identical to the full loop's.
+        static int few = -1;
+        if (few < 0) few = (getenv("MAGE_GEMM_NO_NARROW") || getenv("MAGE_GEMM_NO_NARROW_FEW")) ? 0 : 1;
+        const long tiles4 = (long)((d->M + 127) / 128) * ((d->N + BN - 1) / BN);
+        if (few && d->n_split == 1 && tiles4 < n_cu && d->N % 64 == 0) return launch_tile<DT, GATHER, ACT, 2, EK, false, LN, 1>(d, s, n_cu);
+    }
     const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + BN - 1) / BN) * d->n_split;
     if constexpr (!GATHER && ACT == MAGE_ACT_NONE && EK == EK_BIAS) {
         if (d->n_split > 1) {                      // split-K (weight gradients): its own instantiations

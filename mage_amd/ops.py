@@ -223,6 +223,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
         if (ek != 1 and ln == 0 and N <= 128 and n_split == 1 and ((M + 255) // 256) * ((N + 63) // 64) >= n_cu
                 and not os.environ.get("MAGE_GEMM_NO_NARROW")):
             mt, nw = 2, 1                                   # the narrow 256 x 64 tile (launch_ek in csrc/gemm.hip)
+        if (ek == 1 and d.dtype == BF16 and not gather and act == ACT_NONE and n_split == 1 and N % 64 == 0
+                and ((M + 127) // 128) * ((N + 255) // 256) < n_cu and not os.environ.get("MAGE_GEMM_NO_NARROW")
+                and not os.environ.get("MAGE_GEMM_NO_NARROW_FEW")):
+            mt, nw = 2, 1                                   # few rows: x + Linear(.) of the incremental loop on the narrow tile
         key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act}, {mt}, {ek}, {sp}, {ln}, {nw}>"
         a_rows = ((M + out_h * out_w - 1) // (out_h * out_w)) * d.a_img_stride + a_off + 1
         if (d.dtype == BF16 and not gather and mt == 8 and ek != 2 and K % 64 == 0 and a_rows * lda * 2 < 2 ** 32
