@@ -30,9 +30,18 @@
 extern "C" {
 #endif
 
-#define MAGE_ABI_VERSION 2
+#define MAGE_ABI_VERSION 3
 
-enum { MAGE_F32 = 0, MAGE_BF16 = 1 };
+/* MAGE_BF16X3 / MAGE_F16X3: SPLIT-PRECISION operands -- the fast parity mode.  A logical fp32 matrix [rows, C] (C % 64 == 0, base
+ * 256-byte aligned) is stored as two 16-bit pieces per element, x ~ hi + lo, per row as 64-column slabs [hi(64) | lo(64)] (so a row
+ * is 2C 16-bit elements and leading dimensions of split tensors are given in 16-bit elements, normally 2C):
+ *     MAGE_BF16X3: hi = bf16(x), lo = bf16(x - hi)           8 + 8 significand bits (relative representation error 2^-18)
+ *     MAGE_F16X3:  hi = f16(x),  lo = f16((x - hi) * 2^11)   11 + 11 bits (2^-22), |x| clamped to 65504
+ * mage_gemm on such operands runs THREE bf16/f16 MFMA products per K slab with fp32 accumulation,
+ *     A W^T ~ A_hi W_lo^T + A_lo W_hi^T (all K slabs; f16: the sum is then scaled by 2^-11)  +  A_hi W_hi^T (all K slabs),
+ * i.e. 3/16 of the exact-fp32 MFMA cost for an fp32-class result (the dropped lo*lo term and the representation error are 2^-18
+ * resp. 2^-22 of a product; fp32's own accumulation error over K terms is of the same order as the f16 form's). */
+enum { MAGE_F32 = 0, MAGE_BF16 = 1, MAGE_BF16X3 = 2, MAGE_F16X3 = 3 };
 enum { MAGE_OK = 0, MAGE_EINVAL = -1, MAGE_EHIP = -2, MAGE_EUNSUPPORTED = -3 };
 enum { MAGE_ACT_NONE = 0, MAGE_ACT_RELU = 1, MAGE_ACT_QUICKGELU = 2, MAGE_ACT_GELU_ERF = 3, MAGE_ACT_TANH = 4 };
 
@@ -77,17 +86,23 @@ int mage_check_device_errors(void* stream);
  * (rowadd set, no bias / residual: the table is loaded into the accumulators before the K loop).  Anything else takes the generic
  * gather kernel.
  *
+ * Split-precision form (dtype MAGE_BF16X3 / MAGE_F16X3): A and W are split tensors (see the dtype enum; lda / ldw in 16-bit elements,
+ * ldw 0 = 2K), K and cin multiples of 64, plain rows or the padded-taps form only (with rowadd: M, N multiples of 256), epilogue
+ * y = act(acc + bias) (act none / QuickGELU) or y = residual + acc + bias (fp32 residual) or y = rowadd[..] + acc; y_dtype MAGE_F32,
+ * or the same split kind (N % 64 == 0, ldy in 16-bit elements, Y 256-byte aligned): the epilogue then writes the pieces of its fp32
+ * result, i.e. the next GEMM's A operand, directly.
+ *
  * Requirements: lda and cin multiples of 8 (bf16) / 4 (f32); N multiple of 8; ldy/ldr multiples of 4 (fp32) / 8 (bf16);
  * A, W, Y 16-byte aligned; W is [N][K] row-major in `dtype`.
  * ------------------------------------------------------------------------------------------- */
 typedef struct mage_gemm_desc {
-    int32_t dtype;                     /* MAGE_F32 | MAGE_BF16: type of A and W and of the MFMA */
+    int32_t dtype;                     /* MAGE_F32 | MAGE_BF16 | MAGE_BF16X3 | MAGE_F16X3: type of A and W and of the MFMA */
     int32_t M, N, K;
     const void* A;
     const void* W;
     void* Y;
     int32_t lda, ldy;                  /* in elements */
-    int32_t y_dtype;                   /* MAGE_F32 | MAGE_BF16 */
+    int32_t y_dtype;                   /* MAGE_F32 | MAGE_BF16 (| the split kind of `dtype`) */
     int32_t out_h, out_w, in_h, in_w;
     int32_t a_img_stride, a_off;
     int32_t taps_h, taps_w, cin, stride;
@@ -135,7 +150,12 @@ int mage_gemm(const mage_gemm_desc* desc, void* stream);
  * var = sum_s part[row][s][1] / C - mean^2, rstd = 1 / sqrt(max(var, 0) + eps); fixed order. */
 int mage_ln_stats(const float* part, int64_t rows, int32_t n_slices, int32_t C, float eps, float* stats, void* stream);
 
-/* LayerNorm over the last dim of fp32 rows; y may be fp32 (may alias x) or bf16.
+/* y = the split-precision form (kind MAGE_BF16X3 | MAGE_F16X3) of fp32 rows x [rows, C] (row stride ldx floats; C % 64 == 0);
+ * y rows have ldy 16-bit elements (>= 2C), y 256-byte aligned.  Weights are split once per state_dict (derived caches); activations
+ * are normally written split by their producers (mage_layernorm, mage_attention, mage_embedding, the GEMM epilogue). */
+int mage_split(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t C, int32_t kind, void* stream);
+
+/* LayerNorm over the last dim of fp32 rows; y may be fp32 (may alias x), bf16, or split (MAGE_BF16X3 / MAGE_F16X3: C % 64 == 0).
  * Replaces nn.LayerNorm at mage_model.py:21,27,84,204,206 and inside nn.TransformerEncoderLayer. */
 int mage_layernorm(const float* x, const float* gamma, const float* beta, void* y, int32_t y_dtype,
                    int64_t rows, int32_t C, float eps, void* stream);
@@ -169,6 +189,8 @@ typedef struct mage_attn_desc {
     const int32_t* kv_len;
     int32_t kv_len_div;
     float scale;
+    int32_t out_split;                 /* 0: out has `dtype`; MAGE_BF16X3 / MAGE_F16X3 (dtype MAGE_F32 only): out is written as split
+                                        * rows (ldo in 16-bit elements = 2 * logical width, 256-byte aligned): out_proj's A operand */
 } mage_attn_desc;
 
 int mage_attention(const mage_attn_desc* desc, void* stream);

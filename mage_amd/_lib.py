@@ -12,9 +12,9 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MAGE_HIP_LIB", os.path.join(_HERE, "lib", "libmage_hip.so"))   # override: kernel-tuning builds only
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X3, F16X3 = 0, 1, 2, 3          # BF16X3 / F16X3: split-precision operands (include/mage_hip.h)
 ACT_NONE, ACT_RELU, ACT_QUICKGELU, ACT_GELU_ERF, ACT_TANH = 0, 1, 2, 3, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -45,7 +45,7 @@ class AttnDesc(C.Structure):
         ("ldq", i32), ("ldk", i32), ("ldv", i32), ("ldo", i32),
         ("n_seq", i32), ("inner", i32), ("nq", i32), ("nk", i32), ("n_head", i32),
         ("q_outer_stride", i32), ("q_axis_stride", i32), ("kv_outer_stride", i32), ("kv_axis_stride", i32),
-        ("causal", i32), ("kv_len", vp), ("kv_len_div", i32), ("scale", f32),
+        ("causal", i32), ("kv_len", vp), ("kv_len_div", i32), ("scale", f32), ("out_split", i32),
     ]
 
 
@@ -65,6 +65,7 @@ SIGNATURES = {
     "mage_maxpool2_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "mage_upsample2_bwd": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "mage_layernorm": (C.c_int, [vp, vp, vp, vp, i32, i64, i32, f32, vp]),
+    "mage_split": (C.c_int, [vp, i64, vp, i64, i64, i32, i32, vp]),
     "mage_attention": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "mage_embedding": (C.c_int, [vp, vp, vp, i32, i64, i32, i32, i32, i64, i64, i64, i64, i64, vp]),
     "mage_vq_nearest": (C.c_int, [vp, vp, vp, i64, i32, i32, vp, vp, vp]),

@@ -96,6 +96,61 @@ __device__ __forceinline__ void store8(unsigned short* p, f32x4 a, f32x4 b) {
 }
 __device__ __forceinline__ void store8(float* p, f32x4 a, f32x4 b) { *(f32x4*)p = a; *(f32x4*)(p + 4) = b; }
 
+// ---- split-precision storage (MAGE_BF16X3 / MAGE_F16X3, include/mage_hip.h) -------------------------------------------------
+// A logical fp32 matrix [rows, C] (C % 64 == 0) kept as TWO 16-bit pieces per element, x ~ hi + lo / LO_SCALE, laid out per row as
+// 64-column slabs  [hi(64) | lo(64)]  (256 bytes per slab: the GEMM's K slab of the hi piece, then of the lo piece).
+//   bf16 pieces: hi = bf16(x), lo = bf16(x - hi)                 (8 + 8 significand bits, fp32 exponent range)
+//   f16  pieces: hi = f16(x),  lo = f16((x - hi) * 2^11)         (11 + 11 significand bits; |x| clamped to 65504)
+// One logical element occupies 4 bytes, so `T* row = base + r * C` is the row start for T = split_bf16 / split_f16 as it is for
+// float, and the slab-relative address of column c follows from the byte address alone when the base is 256-byte aligned:
+// that is what store4 / store8 below use, so every kernel templated on its output type writes split rows unchanged.
+struct split_bf16 { unsigned int pair; };
+struct split_f16 { unsigned int pair; };
+#define MAGE_F16_LO_SCALE 2048.0f
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+// KIND 1 = bf16 pieces, 2 = f16 pieces: two values -> packed hi pair, packed lo pair
+template <int KIND>
+__device__ __forceinline__ void split_pack2(float a, float b, unsigned int& hi, unsigned int& lo) {
+    if constexpr (KIND == 1) {
+        hi = pack_bf16x2(a, b);
+        lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+    } else {
+        a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
+        b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+        const f16x2_t h = {(_Float16)a, (_Float16)b};
+        const f16x2_t l = {(_Float16)((a - (float)h[0]) * MAGE_F16_LO_SCALE), (_Float16)((b - (float)h[1]) * MAGE_F16_LO_SCALE)};
+        hi = __builtin_bit_cast(unsigned int, h);
+        lo = __builtin_bit_cast(unsigned int, l);
+    }
+}
+template <int KIND>
+__device__ __forceinline__ void split_store4(void* p, f32x4 v) {
+    const uintptr_t a = (uintptr_t)p;
+    char* q = (char*)((a & ~(uintptr_t)255) + ((a & 255) >> 1));
+    uint2 h, l;
+    split_pack2<KIND>(v[0], v[1], h.x, l.x);
+    split_pack2<KIND>(v[2], v[3], h.y, l.y);
+    *(uint2*)q = h;
+    *(uint2*)(q + 128) = l;
+}
+__device__ __forceinline__ void store4(split_bf16* p, f32x4 v) { split_store4<1>(p, v); }
+__device__ __forceinline__ void store4(split_f16* p, f32x4 v) { split_store4<2>(p, v); }
+template <int KIND>
+__device__ __forceinline__ void split_store8(void* p, f32x4 v0, f32x4 v1) {
+    const uintptr_t a = (uintptr_t)p;
+    char* q = (char*)((a & ~(uintptr_t)255) + ((a & 255) >> 1));
+    uint4 h, l;
+    split_pack2<KIND>(v0[0], v0[1], h.x, l.x);
+    split_pack2<KIND>(v0[2], v0[3], h.y, l.y);
+    split_pack2<KIND>(v1[0], v1[1], h.z, l.z);
+    split_pack2<KIND>(v1[2], v1[3], h.w, l.w);
+    *(uint4*)q = h;
+    *(uint4*)(q + 128) = l;
+}
+__device__ __forceinline__ void store8(split_bf16* p, f32x4 a, f32x4 b) { split_store8<1>(p, a, b); }
+__device__ __forceinline__ void store8(split_f16* p, f32x4 a, f32x4 b) { split_store8<2>(p, a, b); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

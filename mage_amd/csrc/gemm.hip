@@ -291,7 +291,9 @@ struct LnConsume {
 };
 enum { LN_NONE = 0, LN_PRODUCE = 1, LN_CONSUME = 2 };
 
-template <int ACT, typename OT, int MT, bool AFFINE = false, int LN = LN_NONE>
+// OSPL (1 = bf16 pieces, 2 = f16 pieces; OT = float): the fp32 result leaves as a SPLIT row (common.h): a wave's 64 columns are one
+// K slab of the consumer, [hi(64) | lo(64)] = the same 256 contiguous bytes per row as 64 fp32 values, so only the staging write differs.
+template <int ACT, typename OT, int MT, bool AFFINE = false, int LN = LN_NONE, int OSPL = 0>
 __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32x4 (&bias)[4], f32x4 (&acc)[MT][4], int m0, int n0,
                                               int lane, int plane, char* stg, long ysplit, const LnConsume* lnc = nullptr) {
     constexpr bool F32 = sizeof(OT) == 4;
@@ -305,7 +307,9 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
     int woff[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
-        woff[nt] = F32 ? l15 * RB + (((nt * 4 + grp) ^ l15) << 4) : l15 * RB + (((nt * 2 + (grp >> 1)) ^ ((l15 >> 1) & 7)) << 4) + (grp & 1) * 8;
+        woff[nt] = OSPL ? l15 * RB + (((nt * 2 + (grp >> 1)) ^ l15) << 4) + (grp & 1) * 8     // hi chunk; the lo chunk is this ^ 128
+                 : F32  ? l15 * RB + (((nt * 4 + grp) ^ l15) << 4)
+                        : l15 * RB + (((nt * 2 + (grp >> 1)) ^ ((l15 >> 1) & 7)) << 4) + (grp & 1) * 8;
     // read side: lane -> (row rr + RPI*i, chunk cc)
     const int rr = lane / NCH, cc = lane % NCH;
     int roff[NST];
@@ -320,8 +324,9 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
     const bool interior = (simple_rows || affine_rows) && m0 + MT * 16 <= d.M && n0 + 64 <= d.N;     // wave-uniform
     const bool cv_ok = col < d.N;                                                    // N % 8 == 0: a chunk is all in or all out
     const long row_shift = (AFFINE && !simple_rows && affine_rows) ? (long)(m0 / d.out_w) * (d.y_img_stride - d.out_w) : 0;
-    OT* yp = (OT*)d.Y + ysplit + ((long)((m0 + rr) * d.y_mul_x + d.y_off) + row_shift) * d.ldy + col;      // row m0 + rr, then steps
-    const long step = (long)RPI * d.y_mul_x * d.ldy;
+    const int ldy = OSPL ? d.ldy >> 1 : d.ldy;          // split rows: ldy counts 16-bit elements, a logical element is 4 bytes
+    OT* yp = (OT*)d.Y + ysplit + ((long)((m0 + rr) * d.y_mul_x + d.y_off) + row_shift) * ldy + col;      // row m0 + rr, then steps
+    const long step = (long)RPI * d.y_mul_x * ldy;
     // LN_PRODUCE (fp32 out): the bf16 copy of the same rows (8 bytes per lane: 4 rows x 128 B per instruction)
     [[maybe_unused]] unsigned short* y2p = nullptr;
     [[maybe_unused]] long step2 = 0;
@@ -357,7 +362,13 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_apply<ACT>(v[e]);
             }
-            if constexpr (F32) {
+            if constexpr (OSPL != 0) {
+                uint2 hi, lo;
+                split_pack2<OSPL>(v[0], v[1], hi.x, lo.x);
+                split_pack2<OSPL>(v[2], v[3], hi.y, lo.y);
+                *(uint2*)(stg + woff[nt]) = hi;
+                *(uint2*)(stg + (woff[nt] ^ 128)) = lo;
+            } else if constexpr (F32) {
                 *(f32x4*)(stg + woff[nt]) = v;
             } else {
                 *(uint2*)(stg + woff[nt]) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -406,7 +417,7 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
                         const int ox = rem - oy * d.out_w;
                         yrow = img * d.y_img_stride + oy * d.y_mul_y + ox * d.y_mul_x + d.y_off;
                     }
-                    __builtin_nontemporal_store(o[i], (u32x4*)((OT*)d.Y + ysplit + (long)yrow * d.ldy + col));
+                    __builtin_nontemporal_store(o[i], (u32x4*)((OT*)d.Y + ysplit + (long)yrow * ldy + col));
                 }
             }
         }
@@ -431,8 +442,13 @@ __device__ __forceinline__ void ring_barrier() {
 
 // SPLIT: the split-K form (mage_gemm_desc::n_split > 1).  A template parameter so that the kernels of the generation path keep
 // their exact code (the tile decode, two 64-bit strides and the W row stride cost the 8-phase kernel 11 spilled SGPRs otherwise).
-template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE, int NW = 4>
+// SPL: split-precision operands (1 = bf16 pieces, 2 = f16 pieces; DT = MAGE_BF16 geometry: 128-byte slabs of 64 16-bit elements).  A and W
+// rows are [hi(64) | lo(64)] per 64-column slab of K; the K loop runs 3 * K/64 slabs: first, per logical slab, (A_hi, W_lo) then (A_lo, W_hi)
+// -- the small terms -- then (f16: accumulators * 2^-11, undoing the scale the lo pieces are stored with) the K/64 (A_hi, W_hi) slabs.
+// Only the DMA source offset of a slab, the slab count and the MFMA opcode differ from the bf16 kernel.
+template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE, int NW = 4, int SPL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
+    static_assert(SPL == 0 || (DT == MAGE_BF16 && !GATHER && !SPLIT && LN == LN_NONE && EK != EK_GENERAL), "split-precision form: plain bf16-geometry GEMM, lean epilogues");
     typedef typename TT<DT>::elem E;
     typedef Tile<MT, NW> TL;
     constexpr int BM = TL::BM, A_BYTES = TL::A_BYTES, STAGE_BYTES = TL::STAGE_BYTES, AU = TL::AU, WU = TL::WU, BNT = TL::BNT;
@@ -454,7 +470,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     const int q8 = g.ntiles >> 3, r8 = g.ntiles & 7;
     const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int chunk1 = chunk0 + q8 + (xcd < r8 ? 1 : 0);
-    const int nk = (d.K + BK - 1) / BK;
+    [[maybe_unused]] const int nk2 = SPL ? 2 * (d.K >> 6) : 0;     // SPL: slabs of the two small-term passes (K % 64 == 0, host check)
+    const int nk = SPL ? 3 * (d.K >> 6) : (d.K + BK - 1) / BK;
     __builtin_assume(nk > 0);                          // K > 0 (host check): lets hipcc see that the K loop's vmcnt(0) always runs
     const int plane = d.out_h * d.out_w;
 
@@ -495,16 +512,24 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
             const int r = (wave * WU + i) * 8 + lr;
             wcs[i] = lp ^ ((r >> 1) & 7);
             const int n = tn * BNT + r;
-            w_row[i] = (n < d.N) ? (const char*)d.W + (long)n * (SPLIT ? d.ldw : d.K) * ES + w_sp : nullptr;
+            w_row[i] = (n < d.N) ? (const char*)d.W + (long)n * ((SPLIT || SPL) ? d.ldw : d.K) * ES + w_sp : nullptr;
         }
     };
 
     // DMA of this wave's unit u (A units 0..AU-1, then W units) of slab (ld_tile, ld_kt) into stage ld_stage
     auto issue_one = [&](int u, bool live = true) {
         char* sa = smem + ld_stage * STAGE_BYTES;
+        // SPL: physical 128-byte unit of this slab along the split row: small-term passes walk the row in order for A (hi, lo, hi, lo ..)
+        // and pairwise swapped for W (lo, hi, ..); the main pass takes every hi unit
+        int kta = ld_kt, ktw = ld_kt;
+        if constexpr (SPL != 0) {
+            const bool low = ld_kt < nk2;
+            kta = low ? ld_kt : 2 * (ld_kt - nk2);
+            ktw = low ? (ld_kt ^ 1) : kta;
+        }
         if (u < AU) {
             const int i = u;
-            const int kc = ld_kt * BK + acs[i] * CH;
+            const int kc = kta * BK + acs[i] * CH;
             const char* src = g.zero;
             if (GATHER) {
                 if (live && kc < d.K && a_img[i] >= 0) {
@@ -518,13 +543,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                         src = (const char*)d.A + ((long)(a_img[i] + (d.a_half ? (iy >> 1) * (d.in_w >> 1) + (ix >> 1) : iy * d.in_w + ix)) * d.lda + ci) * ES;
                 }
             } else {
-                src = (live && kc < d.K && a_row[i]) ? a_row[i] + (long)kc * ES : g.zero;
+                src = (live && (SPL || kc < d.K) && a_row[i]) ? a_row[i] + (long)kc * ES : g.zero;
             }
             glds16(src, sa + (wave * AU + i) * 1024);
         } else {
             const int i = u - AU;
-            const int kc = ld_kt * BK + wcs[i] * CH;
-            const char* wsrc = (live && kc < d.K && w_row[i]) ? w_row[i] + (long)kc * ES : g.zero;
+            const int kc = ktw * BK + wcs[i] * CH;
+            const char* wsrc = (live && (SPL || kc < d.K) && w_row[i]) ? w_row[i] + (long)kc * ES : g.zero;
             glds16(wsrc, sa + A_BYTES + (wave * WU + i) * 1024);
         }
     };
@@ -614,12 +639,28 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
             }
         }
         for (int kt = 0; kt < nk; ++kt) {
+            if constexpr (SPL == 2) {
+                if (kt == nk2) {                       // f16 pieces: the small terms (and the residual) carry the lo pieces' 2^11
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[a][b] *= (1.0f / MAGE_F16_LO_SCALE);
+                }
+            }
             // The slab to multiply was issued one whole iteration (or one epilogue) ago; nothing younger is in flight.
             // (the builtin, not inline asm: hipcc's own wait-count pass must SEE this wait, or it guards every later use of
             // the bias vectors fetched above with its own vmcnt(0) — in the epilogue that meant "wait for the previous row's
             // store ack" 16 times per tile)
             __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt/lgkmcnt untouched
             asm volatile("" ::: "memory");
+            if constexpr (SPL == 2 && EK == EK_RES_INIT) {
+                if (kt == 0) {                         // the residual has landed: give it the lo pieces' scale (exact), undone at kt == nk2
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[a][b] *= MAGE_F16_LO_SCALE;
+                }
+            }
             if (kt == 0) MAGE_STAMP(it, 2);
             ring_barrier();                            // everyone's share of the slab is in LDS, and every wave is done
             if (kt == 0) MAGE_STAMP(it, 3);
@@ -674,7 +715,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
                         for (int mm = 0; mm < 2; ++mm) {
                             const int mt = 2 * gq + mm;
-                            if (DT == MAGE_BF16) {
+                            if constexpr (SPL == 2) {
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                    __builtin_bit_cast(f16x8, wf[t][nt]), __builtin_bit_cast(f16x8, xf[t][mt]), acc[mt][nt], 0, 0, 0);
+                            } else if (DT == MAGE_BF16) {
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                     __builtin_bit_cast(bf16x8, wf[t][nt]), __builtin_bit_cast(bf16x8, xf[t][mt]), acc[mt][nt], 0, 0, 0);
                             } else {
@@ -715,6 +759,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                 else epilogue_lean<ACT, unsigned short, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit, &lnc);
             } else if constexpr (LN == LN_PRODUCE) {
                 epilogue_lean<ACT, float, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);       // fp32 stream out (host check)
+            } else if constexpr (SPL != 0) {
+                if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
+                else epilogue_lean<ACT, float, MT, false, LN_NONE, SPL>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);   // split rows out
             } else {
                 if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
                 else epilogue_lean<ACT, unsigned short, MT>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
@@ -752,8 +799,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
 // kt / (cin/64), whose rows sit (ky*in_w + kx) rows further -- kept as three scalar cursors per A piece (no vector instruction in a
 // load section, which is what this kernel's schedule depends on).  The lockstep kernel's generic gather decodes the tap per lane
 // and per slab and re-tests the bounds (frame conv3x3: 773 TFLOP/s, 6.7x its algorithmic bytes fetched: round-1 PMC).
-template <int ACT, int EK, bool SPLIT = false, bool TAPS = false, int LN = LN_NONE>
+// SPL: split-precision operands (see gemm_kernel): 3 * K/64 slabs per tile, the slab -> source offset map in issue(), accumulators scaled
+// once between the small-term passes and the main pass (f16 pieces), the MFMA opcode.  Schedule, hazards and LDS image are unchanged.
+template <int ACT, int EK, bool SPLIT = false, bool TAPS = false, int LN = LN_NONE, int SPL = 0>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
+    static_assert(SPL == 0 || (!SPLIT && LN == LN_NONE), "split-precision form: no split-K, no LayerNorm fold");
     constexpr int MT = 8, BM = 256;
     constexpr int PIECE = 16384, KBUF = 4 * PIECE;
     constexpr int P_A0 = 0, P_A1 = 1, P_W0 = 2, P_W1 = 3;
@@ -767,7 +817,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     const int q8 = g.ntiles >> 3, r8 = g.ntiles & 7;
     const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int chunk1 = chunk0 + q8 + (xcd < r8 ? 1 : 0);
-    const int nk = (d.K + 63) / 64;
+    [[maybe_unused]] const int nk2 = SPL ? 2 * (d.K >> 6) : 0;
+    const int nk = SPL ? 3 * (d.K >> 6) : (d.K + 63) / 64;
     __builtin_assume(nk > 0);
     const int plane = d.out_h * d.out_w;
     int c_tile = chunk0 + li;
@@ -802,7 +853,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
                 voff[P][i] = (unsigned)(arow * d.lda * 2 + (SPLIT ? (long)ts * d.a_split_stride * 2 : 0) + lc[i] * 16);
             } else {
                 const int n = min(tn * BN + (r >> 5) * 64 + (P == P_W1 ? 32 : 0) + (r & 31), d.N - 1);
-                voff[P][i] = (unsigned)((long)n * (SPLIT ? d.ldw : d.K) * 2 + (SPLIT ? (long)ts * d.w_split_stride * 2 : 0) + lc[i] * 16);
+                voff[P][i] = (unsigned)((long)n * ((SPLIT || SPL) ? d.ldw : d.K) * 2 + (SPLIT ? (long)ts * d.w_split_stride * 2 : 0) + lc[i] * 16);
             }
         }
     };
@@ -814,12 +865,22 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
         char* dst = smem + cur_buf[P] * KBUF + P * PIECE + (2 * wave) * 1024;
         const bool isA = P == P_A0 || P == P_A1;
         const char* sbase;
-        if (TAPS && isA) sbase = (const char*)d.A + tap_off[P] + tap_ci[P] * 128;       // P_A0 = 0, P_A1 = 1 index the cursors
-        else sbase = (const char*)(isA ? d.A : d.W) + cur_kt[P] * 128;
+        // SPL: slab kt of the 3 * K/64: kt < nk2 -> logical slab kt/2, pieces (A hi, W lo) for even kt, (A lo, W hi) for odd; else logical slab
+        // kt - nk2, pieces (hi, hi).  The physical 128-byte unit along a split row is 2 * logical + piece.
+        [[maybe_unused]] const int kt_ = cur_kt[P];
+        [[maybe_unused]] const bool low = kt_ < nk2;
+        [[maybe_unused]] const int piece = low ? (isA ? (kt_ & 1) : ((kt_ & 1) ^ 1)) : 0;
+        if constexpr (SPL != 0) {
+            if (TAPS && isA) sbase = (const char*)d.A + tap_off[P] + (tap_ci[P] * 2 + piece) * 128;
+            else sbase = (const char*)(isA ? d.A : d.W) + ((low ? (kt_ & ~1) : 2 * (kt_ - nk2)) + piece) * 128;
+        } else {
+            if (TAPS && isA) sbase = (const char*)d.A + tap_off[P] + tap_ci[P] * 128;       // P_A0 = 0, P_A1 = 1 index the cursors
+            else sbase = (const char*)(isA ? d.A : d.W) + cur_kt[P] * 128;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) glds16(sbase + voff[P][i], dst + i * 1024);
         cur_buf[P] ^= 1;
-        if (TAPS && isA) {
+        if (TAPS && isA && (SPL == 0 || !low || (kt_ & 1))) {         // SPL: the tap cursor follows the LOGICAL slab
             if (++tap_ci[P] == spt) {
                 tap_ci[P] = 0;
                 tap_off[P] += (long)d.lda * 2;
@@ -838,6 +899,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             }
             cur_tile[P] += nwg8;
             set_rows(P);
+        } else if (SPL != 0 && TAPS && isA && cur_kt[P] == nk2) {      // the main pass walks the taps again from the first
+            tap_ci[P] = 0;
+            tap_kx[P] = 0;
+            tap_off[P] = 0;
         }
     };
 #pragma unroll
@@ -906,6 +971,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
         if (wr) ring_barrier();                        // the trailing half drops one barrier behind
         for (int kt = 0; kt < nk; ++kt) {
             [[maybe_unused]] int seg_ph = kt * 4;
+            if constexpr (SPL == 2) {
+                if (kt == nk2) {                       // f16 pieces: the small terms (and the residual) carry the lo pieces' 2^11
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[a][b] *= (1.0f / MAGE_F16_LO_SCALE);
+                }
+            }
             const char* base = smem + c_buf * KBUF;
             u32x4 af[4][2], wf[2][2];                  // [16-row tile of the quadrant][k-half]
             auto read_a = [&](int a) {
@@ -936,9 +1009,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
-                        for (int n = 0; n < 2; ++n)
-                            acc[a * 4 + m][b * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, wf[n][t]), __builtin_bit_cast(bf16x8, af[m][t]), acc[a * 4 + m][b * 2 + n], 0, 0, 0);
+                        for (int n = 0; n < 2; ++n) {
+                            if constexpr (SPL == 2)
+                                acc[a * 4 + m][b * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                    __builtin_bit_cast(f16x8, wf[n][t]), __builtin_bit_cast(f16x8, af[m][t]), acc[a * 4 + m][b * 2 + n], 0, 0, 0);
+                            else
+                                acc[a * 4 + m][b * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(bf16x8, wf[n][t]), __builtin_bit_cast(bf16x8, af[m][t]), acc[a * 4 + m][b * 2 + n], 0, 0, 0);
+                        }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 MAGE_SEG(seg_ph * 4 + 3);
@@ -957,6 +1035,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
                 // order, so "at most 2 outstanding" proves it whatever the previous epilogue's stores are doing
                 __builtin_amdgcn_s_waitcnt(0x0F72);
                 asm volatile("" ::: "memory");
+                if constexpr (SPL == 2) {              // give the residual / row table the lo pieces' scale (exact), undone at kt == nk2
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[a][b] *= MAGE_F16_LO_SCALE;
+                }
             }
             mfma_quadrant(0, 0);
             // phase 2: quadrant (0,1)
@@ -1017,6 +1101,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             else epilogue_lean<ACT, unsigned short, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit, &lnc);
         } else if constexpr (LN == LN_PRODUCE) {
             epilogue_lean<ACT, float, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);          // fp32 stream out (host check)
+        } else if constexpr (SPL != 0) {
+            if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
+            else epilogue_lean<ACT, float, MT, TAPS, LN_NONE, SPL>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);   // split rows out
         } else {
             if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
             else epilogue_lean<ACT, unsigned short, MT, TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
@@ -1025,7 +1112,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     }
 }
 
-template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE, int NW = 4>
+template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE, int NW = 4, int SPL = 0>
 int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     typedef Tile<MT, NW> TL;
     // launch attributes are per DEVICE (a process may drive several GPUs, e.g. nn.DataParallel, main_mage.py:106): cached per
@@ -1034,7 +1121,7 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     const int dev = mage_device_index();
     MAGE_CHECK_ARG(dev >= 0, "mage_gemm: no current device");
     if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT, LN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT, LN, NW, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   TL::LDS_BYTES);
         attr_set[dev] = true;
     }
@@ -1067,8 +1154,8 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     // interleaved A/B with and without it is inside +-0.5 %, so they skip the idle start.  MAGE_GEMM_STAGGER applies to every kind.
     const bool kind_wants = st_env || EK == EK_RES_INIT;
     if (kind_wants && st_groups > 1 && a.ntiles >= n_cu && tiles_per_wg >= 6) {
-        const int es = d->dtype == MAGE_BF16 ? 2 : 4;
-        const long nk = ((long)d->K * es + 127) / 128;
+        const int es = d->dtype == MAGE_F32 ? 4 : 2;
+        const long nk = ((long)d->K * es + 127) / 128 * (SPL ? 3 : 1);
         const long out_b = (long)TL::BM * TL::BNT * (d->y_dtype == MAGE_BF16 ? 2 : 4);
         const long res_b = d->residual ? (long)TL::BM * TL::BNT * (d->res_dtype == MAGE_BF16 ? 2 : 4) : 0;
         const long period = nk * 3400 * MT / 8 + (long)((out_b + res_b) / 10.6);
@@ -1084,16 +1171,16 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
         if (use8 && d->K % 64 == 0 && a_span * 2 < (1L << 32) && w_span * 2 < (1L << 32)) {
             static bool attr8[MAGE_MAX_DEVICES] = {false};
             if (!attr8[dev]) {
-                (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK, SPLIT, false, LN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK, SPLIT, false, LN, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           160 * 1024);
                 attr8[dev] = true;
             }
-            hipLaunchKernelGGL((gemm8_kernel<ACT, EK, SPLIT, false, LN>), dim3(grid), dim3(512), 160 * 1024, s, a);
+            hipLaunchKernelGGL((gemm8_kernel<ACT, EK, SPLIT, false, LN, SPL>), dim3(grid), dim3(512), 160 * 1024, s, a);
             MAGE_CHECK_LAUNCH("mage_gemm");
             return MAGE_OK;
         }
     }
-    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT, LN, NW>), dim3(grid), dim3(512), TL::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT, LN, NW, SPL>), dim3(grid), dim3(512), TL::LDS_BYTES, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
     return MAGE_OK;
 }
@@ -1101,13 +1188,13 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
 
 // Padded-taps convolutions on the 8-phase kernel (gemm8_kernel TAPS): eligible shapes only; returns 1 if launched, 0 if not
 // eligible (the caller falls through to the generic gather kernel), < 0 on error.
-template <int ACT, int EK>
+template <int ACT, int EK, int SPL = 0>
 int launch_taps8(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     const int dev = mage_device_index();
     MAGE_CHECK_ARG(dev >= 0, "mage_gemm: no current device");
     static bool attr[MAGE_MAX_DEVICES] = {false};
     if (!attr[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK, false, true, LN_NONE, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr[dev] = true;
     }
     GemmArgs a;
@@ -1120,15 +1207,16 @@ int launch_taps8(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     a.stagger_groups = 0;
     a.stagger_sleeps = 0;
     const int grid = a.ntiles >= n_cu ? n_cu : ((a.ntiles + 7) & ~7);
-    hipLaunchKernelGGL((gemm8_kernel<ACT, EK, false, true>), dim3(grid), dim3(512), 160 * 1024, s, a);
+    hipLaunchKernelGGL((gemm8_kernel<ACT, EK, false, true, LN_NONE, SPL>), dim3(grid), dim3(512), 160 * 1024, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
     return 1;
 }
 
+template <int SPL = 0>
 int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
     static int use8 = -1;
     if (use8 < 0) use8 = (getenv("MAGE_GEMM_NO_8PHASE") || getenv("MAGE_GEMM_NO_TAPS8")) ? 0 : 1;
-    if (!use8 || d->dtype != MAGE_BF16 || d->n_split != 1) return 0;
+    if ((!use8 && SPL == 0) || d->dtype != (SPL == 0 ? MAGE_BF16 : SPL == 1 ? MAGE_BF16X3 : MAGE_F16X3) || d->n_split != 1) return 0;
     const bool table = d->rowadd && !d->residual;                                                         // y = table[row] + conv (+ bias)
     const bool plain = !d->rowadd && !d->residual;
     const int ntaps = d->taps_h * d->taps_w;
@@ -1152,11 +1240,47 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
     const long n_img = (d->M + (long)d->out_h * d->out_w - 1) / ((long)d->out_h * d->out_w);
     if (d->a_img_stride < (long)(d->out_h + d->taps_h - 2) * d->in_w + d->out_w + d->taps_w - 1) return 0;   // the caller's padded image
     const long a_span = (n_img * d->a_img_stride + d->a_off + (long)d->in_h * d->in_w) * d->lda;
-    if (a_span * 2 >= (1L << 32) || (long)d->N * d->K * 2 >= (1L << 32)) return 0;
-    if (table && d->act == MAGE_ACT_NONE && (((uintptr_t)d->rowadd) & 15) == 0) return launch_taps8<MAGE_ACT_NONE, EK_RES_INIT>(d, s, n_cu);
-    if (plain && d->act == MAGE_ACT_NONE) return launch_taps8<MAGE_ACT_NONE, EK_BIAS>(d, s, n_cu);
-    if (plain && d->act == MAGE_ACT_RELU) return launch_taps8<MAGE_ACT_RELU, EK_BIAS>(d, s, n_cu);
+    if (a_span * 2 >= (1L << 32) || (long)d->N * (SPL ? d->ldw : d->K) * 2 >= (1L << 32)) return 0;
+    if (table && d->act == MAGE_ACT_NONE && (((uintptr_t)d->rowadd) & 15) == 0) return launch_taps8<MAGE_ACT_NONE, EK_RES_INIT, SPL>(d, s, n_cu);
+    if constexpr (SPL == 0) {
+        if (plain && d->act == MAGE_ACT_NONE) return launch_taps8<MAGE_ACT_NONE, EK_BIAS>(d, s, n_cu);
+        if (plain && d->act == MAGE_ACT_RELU) return launch_taps8<MAGE_ACT_RELU, EK_BIAS>(d, s, n_cu);
+    }
     return 0;
+}
+
+// Split-precision GEMMs (dtype MAGE_BF16X3 / MAGE_F16X3): the decoder's Linear layers and frame convolution in the fast parity mode.
+template <int SPL>
+int launch_spl(const mage_gemm_desc* d, hipStream_t s) {
+    static int n_cu_dev[MAGE_MAX_DEVICES] = {0};
+    const int dev = mage_device_index();
+    MAGE_CHECK_ARG(dev >= 0, "mage_gemm: no current device");
+    if (!n_cu_dev[dev]) {
+        hipDeviceProp_t p;
+        int n = 256;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= 8) n = p.multiProcessorCount & ~7;
+        n_cu_dev[dev] = n;
+    }
+    const int n_cu = n_cu_dev[dev];
+    MAGE_CHECK_ARG(!d->scale && !d->post_relu && !d->y2 && !d->ln_stats && d->n_split == 1 && !d->a_half && !d->res_half,
+                   "mage_gemm: split-precision form: epilogue y = act(acc + bias) | residual + acc + bias | rowadd[..] + acc only");
+    MAGE_CHECK_ARG(!d->rowadd && d->out_h == 1 && d->out_w >= d->M && d->y_mul_x == 1 || (d->y_dtype == MAGE_F32 && !d->rowadd),
+                   "mage_gemm: split-precision form: regrouped output rows only with fp32 output; row tables only in the padded-taps form");
+    const bool big = (long)((d->M + 255) / 256) * ((d->N + BN - 1) / BN) >= 2L * n_cu;
+    if (d->residual) {
+        MAGE_CHECK_ARG(d->res_dtype == MAGE_F32 && d->act == MAGE_ACT_NONE && d->out_h == 1 && d->out_w >= d->M && (((uintptr_t)d->residual) & 15) == 0,
+                       "mage_gemm: split-precision form: the residual is the fp32 stream (plain rows, no activation)");
+        return big ? launch_tile<MAGE_BF16, false, MAGE_ACT_NONE, 8, EK_RES_INIT, false, LN_NONE, 4, SPL>(d, s, n_cu)
+                   : launch_tile<MAGE_BF16, false, MAGE_ACT_NONE, 4, EK_RES_INIT, false, LN_NONE, 4, SPL>(d, s, n_cu);
+    }
+    if (d->act == MAGE_ACT_NONE)
+        return big ? launch_tile<MAGE_BF16, false, MAGE_ACT_NONE, 8, EK_BIAS, false, LN_NONE, 4, SPL>(d, s, n_cu)
+                   : launch_tile<MAGE_BF16, false, MAGE_ACT_NONE, 4, EK_BIAS, false, LN_NONE, 4, SPL>(d, s, n_cu);
+    if (d->act == MAGE_ACT_QUICKGELU)
+        return big ? launch_tile<MAGE_BF16, false, MAGE_ACT_QUICKGELU, 8, EK_BIAS, false, LN_NONE, 4, SPL>(d, s, n_cu)
+                   : launch_tile<MAGE_BF16, false, MAGE_ACT_QUICKGELU, 4, EK_BIAS, false, LN_NONE, 4, SPL>(d, s, n_cu);
+    mage_set_error("mage_gemm: split-precision form: activation %d is not available (none / QuickGELU)", d->act);
+    return MAGE_EINVAL;
 }
 
 template <int DT, bool GATHER, int ACT, int EK, int LN = LN_NONE>
@@ -1275,16 +1399,21 @@ extern "C" int mage_debug_read(void* dst, size_t bytes) {
 extern "C" int mage_gemm(const mage_gemm_desc* d_in, void* stream) {
     MAGE_CHECK_ARG(d_in != nullptr, "mage_gemm: null descriptor");
     mage_gemm_desc dn = *d_in;                     // defaults of the optional fields
-    if (dn.ldw == 0) dn.ldw = dn.K;
+    const bool spl = dn.dtype == MAGE_BF16X3 || dn.dtype == MAGE_F16X3;
+    if (dn.ldw == 0) dn.ldw = spl ? 2 * dn.K : dn.K;
     if (dn.n_split <= 0) dn.n_split = 1;
     const mage_gemm_desc* d = &dn;
-    MAGE_CHECK_ARG(d->ldw >= d->K, "mage_gemm: ldw=%d < K=%d", d->ldw, d->K);
+    MAGE_CHECK_ARG(d->ldw >= (spl ? 2 * d->K : d->K), "mage_gemm: ldw=%d < K=%d", d->ldw, d->K);
     MAGE_CHECK_ARG(mage_zero_page() != nullptr, "mage_gemm: mage_init() has not been called");
-    MAGE_CHECK_ARG(d->dtype == MAGE_F32 || d->dtype == MAGE_BF16, "mage_gemm: bad dtype %d", d->dtype);
-    MAGE_CHECK_ARG(d->y_dtype == MAGE_F32 || d->y_dtype == MAGE_BF16, "mage_gemm: bad y_dtype %d", d->y_dtype);
+    MAGE_CHECK_ARG(d->dtype == MAGE_F32 || d->dtype == MAGE_BF16 || spl, "mage_gemm: bad dtype %d", d->dtype);
+    MAGE_CHECK_ARG(d->y_dtype == MAGE_F32 || d->y_dtype == MAGE_BF16 || (spl && d->y_dtype == d->dtype), "mage_gemm: bad y_dtype %d", d->y_dtype);
+    MAGE_CHECK_ARG(!spl || (d->K % 64 == 0 && d->cin % 64 == 0 && d->lda >= 2 * d->cin && d->y_dtype != MAGE_BF16),
+                   "mage_gemm: split-precision operands need K and cin multiples of 64, lda >= 2 cin (16-bit elements), fp32 or split output");
+    MAGE_CHECK_ARG(!spl || d->y_dtype == MAGE_F32 || (d->N % 64 == 0 && d->ldy % 8 == 0 && d->ldy >= 2 * d->N && (((uintptr_t)d->Y) & 255) == 0),
+                   "mage_gemm: split output needs N %% 64 == 0, ldy >= 2N (16-bit elements), Y 256-byte aligned");
     MAGE_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "mage_gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
     MAGE_CHECK_ARG(d->A && d->W && d->Y, "mage_gemm: null operand");
-    const int ch = d->dtype == MAGE_BF16 ? 8 : 4;
+    const int ch = d->dtype == MAGE_F32 ? 4 : 8;
     MAGE_CHECK_ARG(d->N % 8 == 0, "mage_gemm: N=%d must be a multiple of 8", d->N);
     MAGE_CHECK_ARG(d->K % ch == 0 && d->lda % ch == 0 && d->cin % ch == 0,
                    "mage_gemm: K=%d, lda=%d, cin=%d must be multiples of %d", d->K, d->lda, d->cin, ch);
@@ -1307,6 +1436,16 @@ extern "C" int mage_gemm(const mage_gemm_desc* d_in, void* stream) {
     MAGE_CHECK_ARG(!d->a_half || (d->in_h % 2 == 0 && d->in_w % 2 == 0 && d->n_split == 1), "mage_gemm: a_half needs an even in_h x in_w grid");
     MAGE_CHECK_ARG(!d->res_half || (d->residual && d->out_h > 1 && d->out_h % 2 == 0 && d->out_w % 2 == 0 && d->n_split == 1),
                    "mage_gemm: res_half needs a residual and an even out_h x out_w output plane");
+    if (spl) {
+        const bool tapsform = gather_ || d->rowadd;
+        if (tapsform) {
+            const int r = d->dtype == MAGE_BF16X3 ? try_taps8<1>(d, s) : try_taps8<2>(d, s);
+            if (r) return r < 0 ? r : MAGE_OK;
+            mage_set_error("mage_gemm: split-precision form: this convolution / row-table geometry is not eligible for the padded-taps kernel");
+            return MAGE_EUNSUPPORTED;
+        }
+        return d->dtype == MAGE_BF16X3 ? launch_spl<1>(d, s) : launch_spl<2>(d, s);
+    }
     if (const int r = try_taps8(d, s)) return r < 0 ? r : MAGE_OK;
     const bool gather = d->taps_h * d->taps_w > 1 || d->stride != 1 || d->dy0 != 0 || d->dx0 != 0 || d->in_h != d->out_h ||
                         d->in_w != d->out_w || d->a_half;

@@ -1,6 +1,7 @@
 // LayerNorm, short-sequence multi-head attention (axial / text / cross), ADAIN, speed-embedding add.
 // All HBM-bound: one pass over the data, 16-byte vector accesses, fp32 arithmetic.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -73,7 +74,7 @@ __device__ __forceinline__ void copy8(const float* src, float* dst) {
 }
 __device__ __forceinline__ void copy8(const unsigned short* src, unsigned short* dst) { *(uint4*)dst = *(const uint4*)src; }
 
-template <typename T, int NK_MAX>
+template <typename T, int NK_MAX, typename OT = T>   // OT: T, or (T = float) split_bf16 / split_f16: the output leaves as split rows (common.h)
 __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, int hg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* ks = (T*)smem_raw;                            // [nk][hg*32]
@@ -98,7 +99,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, 
     int klen = d.nk;
     if (d.kv_len) klen = min(klen, d.kv_len[s / d.kv_len_div]);
     const T* qp = (const T*)d.q;
-    T* op = (T*)d.out;
+    OT* op = (OT*)d.out;
+    const int ldo = std::is_same<OT, T>::value ? d.ldo : d.ldo >> 1;   // split rows: ldo counts 16-bit elements, a logical element is 4 bytes
     for (int p = threadIdx.x; p < d.nq * hg; p += 256) {
         const int hl = p / d.nq, i = p - hl * d.nq;
         const long row = q_base + (long)i * d.q_axis_stride;
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, 
             }
         }
         const float inv = 1.0f / den;
-        T* orow = op + row * d.ldo + (h0 + hl) * 32;
+        OT* orow = op + row * ldo + (h0 + hl) * 32;
 #pragma unroll
         for (int c = 0; c < 4; ++c) store8(orow + c * 8, o[2 * c] * inv, o[2 * c + 1] * inv);
     }
@@ -373,6 +375,19 @@ int attn_launch(const mage_attn_desc* d, hipStream_t s) {
     const size_t lds = (size_t)d->nk * hg * 32 * 2 * sizeof(T);
     MAGE_CHECK_ARG(lds <= 64 * 1024 && d->n_head % hg == 0, "mage_attention: nk=%d too large for LDS staging", d->nk);
     const dim3 grid(d->n_seq, d->n_head / hg), blk(256);
+    if constexpr (sizeof(T) == 4) {
+        if (d->out_split == MAGE_BF16X3 || d->out_split == MAGE_F16X3) {
+#define ATTN_SPLIT(NK) \
+    do { \
+        if (d->out_split == MAGE_BF16X3) hipLaunchKernelGGL((attention_kernel<float, NK, split_bf16>), grid, blk, lds, s, *d, hg); \
+        else hipLaunchKernelGGL((attention_kernel<float, NK, split_f16>), grid, blk, lds, s, *d, hg); \
+    } while (0)
+            if (d->nk <= 16) ATTN_SPLIT(16); else if (d->nk <= 32) ATTN_SPLIT(32); else ATTN_SPLIT(64);
+#undef ATTN_SPLIT
+            MAGE_CHECK_LAUNCH("mage_attention");
+            return MAGE_OK;
+        }
+    }
     if (d->nk <= 16) hipLaunchKernelGGL((attention_kernel<T, 16>), grid, blk, lds, s, *d, hg);
     else if (d->nk <= 32) hipLaunchKernelGGL((attention_kernel<T, 32>), grid, blk, lds, s, *d, hg);
     else hipLaunchKernelGGL((attention_kernel<T, 64>), grid, blk, lds, s, *d, hg);
@@ -388,8 +403,40 @@ extern "C" int mage_layernorm(const float* x, const float* gamma, const float* b
     MAGE_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, "mage_layernorm: rows=%ld C=%d unsupported", (long)rows, C);
     if (y_dtype == MAGE_F32) return ln_launch<float>(x, gamma, beta, y, rows, C, eps, (hipStream_t)stream);
     if (y_dtype == MAGE_BF16) return ln_launch<unsigned short>(x, gamma, beta, y, rows, C, eps, (hipStream_t)stream);
+    if (y_dtype == MAGE_BF16X3 || y_dtype == MAGE_F16X3) {
+        MAGE_CHECK_ARG(C % 64 == 0 && (((uintptr_t)y) & 255) == 0, "mage_layernorm: split output needs C %% 64 == 0 and y 256-byte aligned");
+        if (y_dtype == MAGE_BF16X3) return ln_launch<split_bf16>(x, gamma, beta, y, rows, C, eps, (hipStream_t)stream);
+        return ln_launch<split_f16>(x, gamma, beta, y, rows, C, eps, (hipStream_t)stream);
+    }
     mage_set_error("mage_layernorm: bad y_dtype %d", y_dtype);
     return MAGE_EINVAL;
+}
+
+// ------------------------------------------------------------------------------------ fp32 rows -> split-precision rows
+namespace {
+template <typename OT>
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, long ldx, OT* __restrict__ y, long ldy, long rows, int C) {
+    const int vpr = C >> 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * vpr) return;
+    const long r = i / vpr;
+    const int c = (int)(i - r * vpr) << 2;
+    store4(y + r * ldy + c, *(const f32x4*)(x + r * ldx + c));
+}
+}  // namespace
+
+extern "C" int mage_split(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t C, int32_t kind, void* stream) {
+    MAGE_CHECK_ARG(x && y && rows > 0 && C > 0 && C % 64 == 0 && ldx % 4 == 0 && ldy % 128 == 0 && ldy >= 2 * (int64_t)C,
+                   "mage_split: C=%d must be a multiple of 64, ldy a multiple of 128 16-bit elements (>= 2C)", C);
+    MAGE_CHECK_ARG(((((uintptr_t)y) & 255) | (((uintptr_t)x) & 15)) == 0, "mage_split: y must be 256-byte aligned, x 16-byte aligned");
+    MAGE_CHECK_ARG(kind == MAGE_BF16X3 || kind == MAGE_F16X3, "mage_split: kind %d is not a split kind", kind);
+    const dim3 grid((unsigned)((rows * (C >> 2) + 255) / 256));
+    if (kind == MAGE_BF16X3)
+        hipLaunchKernelGGL((split_kernel<split_bf16>), grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (split_bf16*)y, (long)(ldy >> 1), (long)rows, C);
+    else
+        hipLaunchKernelGGL((split_kernel<split_f16>), grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (split_f16*)y, (long)(ldy >> 1), (long)rows, C);
+    MAGE_CHECK_LAUNCH("mage_split");
+    return MAGE_OK;
 }
 
 extern "C" int mage_attention(const mage_attn_desc* d, void* stream) {
@@ -398,6 +445,9 @@ extern "C" int mage_attention(const mage_attn_desc* d, void* stream) {
     MAGE_CHECK_ARG(d->nq >= 1 && d->n_seq >= 1 && d->n_head >= 1 && d->inner >= 1, "mage_attention: bad sizes");
     MAGE_CHECK_ARG((d->ldq | d->ldk | d->ldv | d->ldo) % 8 == 0, "mage_attention: leading dims must be multiples of 8");
     MAGE_CHECK_ARG(!d->kv_len || d->kv_len_div >= 1, "mage_attention: kv_len_div must be >= 1");
+    MAGE_CHECK_ARG(d->out_split == 0 || ((d->out_split == MAGE_BF16X3 || d->out_split == MAGE_F16X3) && d->dtype == MAGE_F32 &&
+                                         (d->n_head * 32) % 64 == 0 && d->ldo % 128 == 0 && (((uintptr_t)d->out) & 255) == 0),
+                   "mage_attention: out_split needs fp32 q/k/v, an even head count, ldo a multiple of 128 16-bit elements, out 256-byte aligned");
     if (d->dtype == MAGE_F32) return attn_launch<float>(d, (hipStream_t)stream);
     if (d->dtype == MAGE_BF16) return attn_launch<unsigned short>(d, (hipStream_t)stream);
     mage_set_error("mage_attention: bad dtype %d", d->dtype);

@@ -354,7 +354,15 @@ extern "C" int mage_embedding(const int64_t* ids, const float* table, void* out,
     else if (out_dtype == MAGE_BF16)
         hipLaunchKernelGGL((embedding_kernel<unsigned short>), grid, blk, 0, s, ids, table, (unsigned short*)out, (long)n, C,
                            n_table, relu, (long)group, (long)group_stride, (long)off, (long)inner, (long)inner_stride, err);
-    else {
+    else if (out_dtype == MAGE_BF16X3 || out_dtype == MAGE_F16X3) {     // split rows (common.h): the frame convolution's A operand in the fast parity mode
+        MAGE_CHECK_ARG(C % 64 == 0 && (((uintptr_t)out) & 255) == 0, "mage_embedding: split output needs C %% 64 == 0 and out 256-byte aligned");
+        if (out_dtype == MAGE_BF16X3)
+            hipLaunchKernelGGL((embedding_kernel<split_bf16>), grid, blk, 0, s, ids, table, (split_bf16*)out, (long)n, C, n_table, relu,
+                               (long)group, (long)group_stride, (long)off, (long)inner, (long)inner_stride, err);
+        else
+            hipLaunchKernelGGL((embedding_kernel<split_f16>), grid, blk, 0, s, ids, table, (split_f16*)out, (long)n, C, n_table, relu,
+                               (long)group, (long)group_stride, (long)off, (long)inner, (long)inner_stride, err);
+    } else {
         mage_set_error("mage_embedding: bad out_dtype %d", out_dtype);
         return MAGE_EINVAL;
     }

@@ -7,9 +7,12 @@ libmage_hip.so: channels-last activations ([B, L, H, W, C] is a row-major [token
 attention over strided row sets (no permute/contiguous copies -- the reference spends 19 % of its time
 there), LayerNorm / bias / QuickGELU / residual / positional tables fused around MFMA GEMMs.
 
-Precision: ``set_precision('fp32')`` (default; exact-fp32 MFMA, the parity mode) or ``'bf16'``
+Precision: ``set_precision('fp32')`` (default; exact-fp32 MFMA, the parity mode), ``'bf16'``
 (bf16 MFMA with fp32 accumulation for the decoder stack and VQ-VAE decode; the residual stream,
-LayerNorm, softmax, logits, the once-per-clip prologue and the VQ-VAE encode + quantiser stay fp32).
+LayerNorm, softmax, logits, the once-per-clip prologue and the VQ-VAE encode + quantiser stay fp32), or the
+FAST PARITY modes ``'f16x3'`` / ``'bf16x3'``: everything as in fp32 mode except that the decoder's Linear layers and
+the frame convolution multiply split-precision operands (x ~ hi + lo in two 16-bit pieces; three f16 / bf16 MFMA
+products per K slab, fp32 accumulation -- include/mage_hip.h): fp32-class logits at 3/16 of the exact-fp32 MFMA cost.
 """
 from __future__ import annotations
 
@@ -34,6 +37,18 @@ BF16 = torch.bfloat16
 
 def _sfx(dt: torch.dtype) -> str:
     return ".f32" if dt == F32 else ".bf16"
+
+
+PRECISIONS = {"fp32": (F32, 0), "bf16": (BF16, 0), "bf16x3": (F32, ops.BF16X3), "f16x3": (F32, ops.F16X3)}   # name -> (dtype, split kind)
+
+
+def _wsplit(d: Dict[str, torch.Tensor], name: str, kind: int) -> torch.Tensor:
+    """Split-precision copy of the fp32 weight d[name + '.f32'] ([N, K] -> [N, 2K] 16-bit pieces), built on first use."""
+    key = f"{name}.s{kind}"
+    w = d.get(key)
+    if w is None:
+        w = d[key] = ops.split(d[name + ".f32"].reshape(d[name + ".f32"].shape[0], -1), kind)
+    return w
 
 
 def _need_gpu(t: torch.Tensor, who: str) -> None:
@@ -338,6 +353,7 @@ class FlatAxialDecoder(nn.Module):
                                      zero_module(nn.Conv3d(model_channels, out_channels, 1)))
         self.initialize_parameters()
         self.compute_dtype = F32
+        self.split_kind = 0                    # ops.BF16X3 / ops.F16X3: the fast parity modes (compute_dtype stays fp32)
         self._derived = _Derived(self)
 
     def initialize_parameters(self):
@@ -404,6 +420,8 @@ class FlatAxialDecoder(nn.Module):
     def _run(self, motion: torch.Tensor, imgs: torch.Tensor, *, B: int, hh: int, ww: int) -> torch.Tensor:
         """motion [B*hw, Cc], imgs [B*(L-1)*hw, Ci] in the compute dtype -> logits [B*(L-1)*hw, K] fp32
         (use_cids=False: predicted latents [B*(L-1)*hw, 8] fp32 whose first out_channels columns are valid)."""
+        if self._split_on():
+            return self._run_split(motion, imgs, B=B, hh=hh, ww=ww)
         d = self._derived.get(self._build)
         dt, Cc, L, dev = self.compute_dtype, self.model_channels, self.frames_length, motion.device
         hw = hh * ww
@@ -489,6 +507,8 @@ class FlatAxialDecoder(nn.Module):
     def _inc_step(self, st: dict, motion: Optional[torch.Tensor], imgs: torch.Tensor) -> torch.Tensor:
         """Append position(s): the first call takes the motion anchor (slot 0) and frame 0's features (slot 1); later calls
         take the features of the newest frame only.  Returns the logits of the last appended slot, [B*hw, K] fp32."""
+        if self._split_on():
+            return self._inc_step_split(st, motion, imgs)
         d = self._derived.get(self._build)
         dt, Cc, L, dev = self.compute_dtype, self.model_channels, self.frames_length, imgs.device
         B, hh, ww = st["B"], st["hh"], st["ww"]
@@ -563,6 +583,141 @@ class FlatAxialDecoder(nn.Module):
         xa = x if dt == F32 else xn
         logits = torch.empty(B * hw, self.out_channels, device=dev, dtype=F32)
         _linear(xa, d, "out", logits, dt, M=B * hw, N=self.out_channels, K=Cc, out_w=hw, a_img_stride=P * hw, a_off=(P - 1) * hw)
+        st["p"] = p0 + P
+        return logits
+
+
+    # ------------------------------------------------------------------ the fast parity modes ('f16x3' / 'bf16x3')
+    # The stack of _run / _inc_step with fp32 everywhere EXCEPT the operands of the Linear layers: those are split-precision
+    # tensors (two 16-bit pieces per element, ops.split_empty) written directly by their producers -- LayerNorm, the attention
+    # kernel, the c_fc epilogue (QuickGELU), the last c_proj epilogue -- and multiplied as three f16 / bf16 MFMA products per K
+    # slab (include/mage_hip.h, MAGE_F16X3).  Residual stream, q / k / v, softmax and logits are fp32 as in 'fp32' mode.
+    def _split_on(self) -> bool:
+        return bool(self.split_kind) and self.compute_dtype == F32 and self.model_channels % 64 == 0
+
+    def _taps_ok(self, rows: int) -> bool:
+        """in_linear / context_linear (+ T positions) and the frame convolution run as the padded-taps form of the split GEMM."""
+        return self.model_channels % 256 == 0 and rows % 256 == 0 and self.in_channels % 64 == 0 and self.context_channels % 64 == 0
+
+    def _lin_s(self, a, d, name, y, *, M, N, K, lo=0, hi=None, **kw):
+        sk = self.split_kind
+        w, b = _wsplit(d, name, sk), d.get(name + ".b")
+        if hi is not None or lo:
+            w, b = w[lo:hi], (None if b is None else b[lo:hi])
+        y_split = kw.pop("y_split", False)
+        return ops.gemm(a, w, y, M=M, N=N, K=K, lda=kw.pop("lda", 2 * K), ldy=kw.pop("ldy", 2 * N if y_split else N), bias=b,
+                        split_kind=sk, y_split=y_split, **kw)
+
+    def _embed_inputs_split(self, d, x, motion, imgs, *, B, hw, P, tp, n_img_rows):
+        """context_linear -> slot 0 (if motion), in_linear -> the other slot(s), + T positions: rows of x [B*P*hw, C] fp32.
+        motion fp32 rows; imgs split rows (from _frame_features in split mode) or fp32 rows."""
+        sk, Cc = self.split_kind, self.model_channels
+        img_split = imgs.dtype != F32
+        if motion is not None:
+            if self._taps_ok(B * hw):
+                self._lin_s(ops.split(motion, sk), d, "context_linear", x, M=B * hw, N=Cc, K=self.context_channels, out_w=hw,
+                            y_img_stride=P * hw, rowadd=tp, rowadd_div=hw, rowadd_mod=P)
+            else:
+                _linear(motion, d, "context_linear", x, F32, M=B * hw, N=Cc, K=self.context_channels, out_w=hw, y_img_stride=P * hw,
+                        rowadd=tp, rowadd_div=hw, rowadd_mod=P)
+        off = hw if motion is not None else 0
+        if img_split:
+            self._lin_s(imgs, d, "in_linear", x, M=n_img_rows, N=Cc, K=self.in_channels, out_w=n_img_rows // B, y_img_stride=P * hw,
+                        y_off=off, rowadd=tp, rowadd_div=hw, rowadd_mod=P)
+        else:
+            _linear(imgs, d, "in_linear", x, F32, M=n_img_rows, N=Cc, K=self.in_channels, out_w=n_img_rows // B, y_img_stride=P * hw,
+                    y_off=off, rowadd=tp, rowadd_div=hw, rowadd_mod=P)
+
+    @torch.no_grad()
+    def _run_split(self, motion: torch.Tensor, imgs: torch.Tensor, *, B: int, hh: int, ww: int) -> torch.Tensor:
+        d = self._derived.get(self._build)
+        sk, Cc, L, dev = self.split_kind, self.model_channels, self.frames_length, motion.device
+        hw = hh * ww
+        M = B * L * hw
+        H = Cc // 32
+        x = torch.empty(M, Cc, device=dev, dtype=F32)
+        self._embed_inputs_split(d, x, motion, imgs, B=B, hw=hw, P=L, tp=d["tpos"], n_img_rows=B * (L - 1) * hw)
+        xn = ops.split_empty(M, Cc, sk, dev)
+        qkv = torch.empty(M, 3 * Cc, device=dev, dtype=F32)
+        ao = ops.split_empty(M, Cc, sk, dev)
+        hdn = ops.split_empty(M, 4 * Cc, sk, dev)
+        for i in range(self.layers):
+            p = f"b{i}"
+            axis = i % 3
+            if axis == 0:
+                geo = dict(n_seq=B * hw, inner=hw, nq=L, nk=L, q_outer_stride=L * hw, q_axis_stride=hw, causal=True)
+            elif axis == 1:
+                geo = dict(n_seq=B * L * ww, inner=ww, nq=hh, nk=hh, q_outer_stride=hw, q_axis_stride=ww, causal=False)
+            else:
+                geo = dict(n_seq=B * L * hh, inner=1, nq=ww, nk=ww, q_outer_stride=ww, q_axis_stride=1, causal=False)
+            ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], xn, 1e-5, split_kind=sk)
+            self._lin_s(xn, d, p + ".in_proj", qkv, M=M, N=3 * Cc, K=Cc)
+            ops.attention(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], ao, ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=2 * Cc, n_head=H,
+                          kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], out_split=sk, **geo)
+            self._lin_s(ao, d, p + ".out_proj", x, M=M, N=Cc, K=Cc, residual=x, ldr=Cc)
+            ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5, split_kind=sk)
+            self._lin_s(xn, d, p + ".c_fc", hdn, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU, y_split=True)
+            if i == self.layers - 1 and self.use_cids:       # only the head reads the last x: it leaves the epilogue as split rows
+                self._lin_s(hdn, d, p + ".c_proj", xn, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc, y_split=True)
+            else:
+                self._lin_s(hdn, d, p + ".c_proj", x, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
+        if not self.use_cids:                                 # MAGE+ head (N = 8 columns): GroupNorm + SiLU, fp32 GEMM
+            y = ops.groupnorm_silu(x, d["gn.w"], d["gn.b"], torch.empty(B * (L - 1) * hw, Cc, device=dev, dtype=F32), n_samples=B,
+                                   rows_per_sample=(L - 1) * hw, sample_stride_rows=L * hw, row_off=hw, groups=32,
+                                   eps=self.out[0].eps)
+            n8 = d["out.f32"].shape[0]
+            pred = torch.empty(B * (L - 1) * hw, n8, device=dev, dtype=F32)
+            return _linear(y, d, "out", pred, F32, M=B * (L - 1) * hw, N=n8, K=Cc)
+        logits = torch.empty(B * (L - 1) * hw, self.out_channels, device=dev, dtype=F32)
+        self._lin_s(xn, d, "out", logits, M=B * (L - 1) * hw, N=self.out_channels, K=Cc, out_w=(L - 1) * hw, a_img_stride=L * hw,
+                    a_off=hw)
+        return logits
+
+    @torch.no_grad()
+    def _inc_step_split(self, st: dict, motion: Optional[torch.Tensor], imgs: torch.Tensor) -> torch.Tensor:
+        d = self._derived.get(self._build)
+        sk, Cc, L, dev = self.split_kind, self.model_channels, self.frames_length, imgs.device
+        B, hh, ww = st["B"], st["hh"], st["ww"]
+        hw, H = hh * ww, Cc // 32
+        p0 = st["p"]
+        P = 2 if motion is not None else 1
+        assert (p0 == 0) == (motion is not None) and p0 + P <= L
+        M = B * P * hw
+        x = torch.empty(M, Cc, device=dev, dtype=F32)
+        self._embed_inputs_split(d, x, motion, imgs, B=B, hw=hw, P=P, tp=d["tpos"][p0:], n_img_rows=B * hw)
+        xn = ops.split_empty(M, Cc, sk, dev)
+        qkv = torch.empty(M, 3 * Cc, device=dev, dtype=F32)
+        ao = ops.split_empty(M, Cc, sk, dev)
+        hdn = ops.split_empty(M, 4 * Cc, sk, dev)
+        for i in range(self.layers):
+            p = f"b{i}"
+            axis = i % 3
+            ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], xn, 1e-5, split_kind=sk)
+            if axis == 0:
+                kv = st["kv"][i]                                             # [B, L, hw, K|V] fp32
+                self._lin_s(xn, d, p + ".in_proj", qkv, M=M, N=Cc, K=Cc, lo=0, hi=Cc, ldy=Cc)
+                self._lin_s(xn, d, p + ".in_proj", kv, M=M, N=2 * Cc, K=Cc, lo=Cc, hi=3 * Cc, ldy=2 * Cc, out_w=P * hw,
+                            y_img_stride=L * hw, y_off=p0 * hw)
+                ops.attention(qkv, kv, kv[:, Cc:], ao, ldq=Cc, ldk=2 * Cc, ldv=2 * Cc, ldo=2 * Cc, n_seq=B * hw, inner=hw, nq=P,
+                              nk=p0 + P, n_head=H, q_outer_stride=P * hw, q_axis_stride=hw, kv_outer_stride=L * hw,
+                              kv_axis_stride=hw, causal=True, out_split=sk)
+            else:
+                self._lin_s(xn, d, p + ".in_proj", qkv, M=M, N=3 * Cc, K=Cc)
+                if axis == 1:
+                    geo = dict(n_seq=B * P * ww, inner=ww, nq=hh, nk=hh, q_outer_stride=hw, q_axis_stride=ww)
+                else:
+                    geo = dict(n_seq=B * P * hh, inner=1, nq=ww, nk=ww, q_outer_stride=ww, q_axis_stride=1)
+                ops.attention(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], ao, ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=2 * Cc, n_head=H,
+                              kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], out_split=sk, **geo)
+            self._lin_s(ao, d, p + ".out_proj", x, M=M, N=Cc, K=Cc, residual=x, ldr=Cc)
+            ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5, split_kind=sk)
+            self._lin_s(xn, d, p + ".c_fc", hdn, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU, y_split=True)
+            if i == self.layers - 1:
+                self._lin_s(hdn, d, p + ".c_proj", xn, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc, y_split=True)
+            else:
+                self._lin_s(hdn, d, p + ".c_proj", x, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc)
+        logits = torch.empty(B * hw, self.out_channels, device=dev, dtype=F32)
+        self._lin_s(xn, d, "out", logits, M=B * hw, N=self.out_channels, K=Cc, out_w=hw, a_img_stride=P * hw, a_off=(P - 1) * hw)
         st["p"] = p0 + P
         return logits
 
@@ -669,16 +824,21 @@ class MAGE(nn.Module):
         nn.init.normal_(self.visual_token_embedding.weight, std=0.02)            # mage_model.py:524
 
     def set_precision(self, precision: str) -> "MAGE":
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         self.precision = precision
-        self.generate_model.compute_dtype = F32 if precision == "fp32" else BF16
+        self.generate_model.compute_dtype, self.generate_model.split_kind = PRECISIONS[precision]
         if hasattr(self.first_stage_model, "set_precision"):     # an external latent first stage (MAGE+) has no such switch
-            self.first_stage_model.set_precision(precision)
+            self.first_stage_model.set_precision("bf16" if precision == "bf16" else "fp32")
         return self
 
     def _dt(self) -> torch.dtype:
-        return F32 if self.precision == "fp32" else BF16
+        return PRECISIONS[self.precision][0]
+
+    def _sk(self) -> int:
+        """Split kind of the fast parity modes (0 otherwise, and for a decoder width the split GEMM does not take)."""
+        gm = self.generate_model
+        return gm.split_kind if getattr(gm, "_split_on", None) and gm._split_on() else 0
 
     def _build(self):
         d: Dict[str, torch.Tensor] = {}
@@ -728,7 +888,7 @@ class MAGE(nn.Module):
         return out.view(*x.shape[:2], *out.shape[1:]).contiguous()
 
     # ------------------------------------------------------------------ shared pieces
-    def _frame_features(self, tokens: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+    def _frame_features(self, tokens: torch.Tensor, dt: torch.dtype, split: bool = False) -> torch.Tensor:
         """ids [n, hw] -> conv3x3(embedding) + (H_pos + W_pos) as rows [n*hw, C] (mage_model.py:581,586-588,674-676).
 
         bf16 mode: the embedding rows are written into the interior of a zero-padded (R+2) x (R+2) frame buffer, so that the
@@ -738,6 +898,22 @@ class MAGE(nn.Module):
         d = self._derived.get(self._build)
         R, Cc = self.image_resolution, self.vision_width
         n = tokens.numel() // (R * R)
+        sk = self._sk() if split else 0
+        if sk and Cc % 256 == 0 and (n * R * R) % 256 == 0 and self.generate_model._taps_ok(n * R * R):
+            # fast parity modes: the same padded-taps convolution on split-precision operands; the features leave as split rows
+            # (in_linear's A operand)
+            P = R + 2
+            key = (n, str(tokens.device), torch.cuda.current_stream(tokens.device).cuda_stream, sk)
+            pad = self._pad_frames.get(key)
+            if pad is None:
+                if len(self._pad_frames) > 8:
+                    self._pad_frames.clear()
+                pad = self._pad_frames[key] = ops.split_empty(n * P * P + 1, Cc, sk, tokens.device, zero=True)
+            ops.embedding(tokens.reshape(-1), d["emb"], pad, group=R * R, group_stride=P * P, off=P + 1, inner=R, inner_stride=P, split_kind=sk)
+            out = ops.split_empty(n * R * R, Cc, sk, tokens.device)
+            return ops.gemm(pad, _wsplit(d, "conv", sk), out, M=n * R * R, N=Cc, K=9 * Cc, lda=2 * Cc, ldy=2 * Cc, out_h=R, out_w=R, in_h=P,
+                            in_w=P, a_img_stride=P * P, taps_h=3, taps_w=3, cin=Cc, rowadd=d["hwpos"], rowadd_div=1, rowadd_mod=R * R,
+                            split_kind=sk, y_split=True)
         if dt == F32 or Cc % 64:
             emb = ops.embedding(tokens.reshape(-1), d["emb"], torch.empty(n * R * R, Cc, device=tokens.device, dtype=dt))
             return VectorQuantizedVAE._conv(emb, d["conv" + _sfx(dt)], torch.empty_like(emb), n_img=n, H=R, W=R, cin=Cc, cout=Cc,
@@ -945,7 +1121,7 @@ class MAGE(nn.Module):
             st = self.generate_model._inc_begin(B, R, R, images.device)
             prev = tok0.contiguous()
             for i in range(Lm1):
-                feats = self._frame_features(prev, dt)                                        # newest frame only
+                feats = self._frame_features(prev, dt, split=True)                            # newest frame only
                 step_logits = self.generate_model._inc_step(st, ma_dt if i == 0 else None, feats)
                 prev = torch.empty(B, hw, device=images.device, dtype=torch.int64)
                 ops.argmax(step_logits, prev, rows=B * hw, K=K)
@@ -956,7 +1132,7 @@ class MAGE(nn.Module):
         cur = tok0[:, None, :].repeat(1, Lm1, 1).contiguous()                                 # :670 future slots hold frame 0
         logits = None
         for i in range(Lm1):                                                                  # :673-684
-            feats = self._frame_features(cur, dt)
+            feats = self._frame_features(cur, dt, split=True)
             logits = self.generate_model._run(ma_dt, feats, B=B, hh=R, ww=R)                  # [B*(L-1)*hw, K]
             if i != Lm1 - 1:                                                                  # argmax of frame i -> slot i+1
                 ops.argmax(logits, cur, rows=B * hw, K=K, group=hw, in_group_stride=Lm1 * hw, in_off=i * hw,
@@ -967,7 +1143,6 @@ class MAGE(nn.Module):
         return torch.cat([images[:, 0:1].to(video.dtype), video], 1)                         # :691
 
     # ------------------------------------------------------------------ teacher-forced pass (mage_model.py:575-639)
-    @torch.no_grad()
     @torch.no_grad()
     def _video_prior(self, tok: Optional[torch.Tensor], lat_rows: Optional[torch.Tensor] = None, B: int = 0, L: int = 0,
                      tape: Optional[list] = None, dt: torch.dtype = F32) -> torch.Tensor:
@@ -1035,7 +1210,8 @@ class MAGE(nn.Module):
                 out_map = (Lp2 * hw, hw)
             else:
                 if Lout != 1:
-                    raise ValueError(f"the Conv3d video prior needs 9 <= frames <= 16 to collapse to one frame (got {L})")
+                    raise ValueError(f"the Conv3d video prior's four stride-2 blocks must collapse the clip to ONE frame "
+                                     f"(frames_length <= 16); got {L} frames -> {Lout}")
                 nxt = ops.groupnorm_act(c2, d[f"p{i}.g2.w"], d[f"p{i}.g2.b"], torch.empty(B * hw, cout, device=dev, dtype=F32),
                                         sample_stride_rows=(Lout + 2) * hw, row_off=0, eps=blk.bn2.eps, act=1, residual=res, stats=st2,
                                         **gn)
@@ -1060,7 +1236,7 @@ class MAGE(nn.Module):
         tok = self.first_stage_encode(images).reshape(B, -1, R * R)                          # :579
         video_rows = self._reparam_video_rows(batch, B, extras, tok=tok) if self.randomness else None
         ma = self._motion_anchor(tok[:, 0].contiguous(), batch, None, video_rows=video_rows)
-        feats = self._frame_features(tok[:, :L - 1].contiguous(), dt)
+        feats = self._frame_features(tok[:, :L - 1].contiguous(), dt, split=True)
         logits = self.generate_model._run(ma if dt == F32 else ma.to(dt), feats, B=B, hh=R, ww=R)
         return tok.view(B, -1, R, R), logits.view(B, L - 1, R, R, self.codebook_size)
 

@@ -13,11 +13,11 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc
+from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, BF16X3, F16X3, F32, AttnDesc, GemmDesc
 
 __all__ = ["gemm", "layernorm", "attention", "embedding", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
            "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mse", "check_device_errors", "graph_events_supported", "transpose", "row_sum", "sum_partials", "layernorm_bwd", "act", "act_bwd", "cross_entropy_bwd", "embedding_bwd", "group_rowsum", "attention_bwd", "dropout", "adam", "bn_train_stats", "bn_apply", "bn_backward", "convt_unfold_tanh_bwd", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
-           "PROFILE", "F32", "BF16", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
+           "split", "split_empty", "split_dtype", "PROFILE", "F32", "BF16", "BF16X3", "F16X3", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
 
 
 def code(t: torch.Tensor) -> int:
@@ -30,6 +30,31 @@ def code(t: torch.Tensor) -> int:
 
 def tdtype(c: int) -> torch.dtype:
     return torch.float32 if c == F32 else torch.bfloat16
+
+
+# ---- split-precision tensors (MAGE_BF16X3 / MAGE_F16X3, include/mage_hip.h): a logical fp32 [rows, C] matrix kept as two 16-bit pieces
+# per element, per row as 64-column slabs [hi(64) | lo(64)].  To torch it is a [rows, 2C] tensor of bfloat16 / float16 (plumbing:
+# the pieces are only ever read by mage_gemm); the kind travels beside it.
+def split_dtype(kind: int) -> torch.dtype:
+    return torch.bfloat16 if kind == BF16X3 else torch.float16
+
+
+def split_empty(rows: int, C_: int, kind: int, device, zero: bool = False) -> torch.Tensor:
+    assert C_ % 64 == 0 and kind in (BF16X3, F16X3)
+    f = torch.zeros if zero else torch.empty
+    return f(rows, 2 * C_, device=device, dtype=split_dtype(kind))
+
+
+def split(x: torch.Tensor, kind: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 rows [rows, C] (row stride x.stride(0)) -> split rows [rows, 2C] (mage_split)."""
+    l, s = _dev(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    rows, C_ = x.shape
+    if out is None:
+        out = split_empty(rows, C_, kind, x.device)
+    assert out.dtype == split_dtype(kind) and out.is_contiguous() and out.shape[-1] == 2 * C_
+    _lib.check(l.mage_split(x.data_ptr(), x.stride(0), out.data_ptr(), 2 * C_, rows, C_, kind, s), l)
+    return out
 
 
 def _dev(t: torch.Tensor):
@@ -175,9 +200,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
          bias=None, scale=None, shift=None, act: int = ACT_NONE, rowadd=None, rowadd_div: int = 1, rowadd_mod: int = 1,
          residual=None, ldr: int = 0, post_relu: bool = False, ldw: int = 0, n_split: int = 1, a_split_stride: int = 0,
          w_split_stride: int = 0, y_split_stride: int = 0, y2=None, ldy2: int = 0, ln_part=None, ln_stats=None,
-         ln_colsum=None, res_half: bool = False, a_half: bool = False) -> torch.Tensor:
-    """Y = epilogue(A (*) W^T); see mage_gemm in include/mage_hip.h for the geometry fields."""
+         ln_colsum=None, res_half: bool = False, a_half: bool = False, split_kind: int = 0, y_split: bool = False) -> torch.Tensor:
+    """Y = epilogue(A (*) W^T); see mage_gemm in include/mage_hip.h for the geometry fields.
+    split_kind BF16X3 / F16X3: a and w are split-precision tensors (lda / ldw in 16-bit elements); y_split: so is y (ldy likewise)."""
     l, s = _dev(a)
+    if split_kind:
+        return _gemm_split(l, s, a, w, y, M=M, N=N, K=K, lda=lda, ldy=ldy, out_h=out_h, out_w=out_w, in_h=in_h, in_w=in_w,
+                           a_img_stride=a_img_stride, a_off=a_off, taps_h=taps_h, taps_w=taps_w, cin=cin, y_img_stride=y_img_stride,
+                           y_mul_y=y_mul_y, y_mul_x=y_mul_x, y_off=y_off, bias=bias, act=act, rowadd=rowadd, rowadd_div=rowadd_div,
+                           rowadd_mod=rowadd_mod, residual=residual, ldr=ldr, ldw=ldw, split_kind=split_kind, y_split=y_split)
     out_w = M if out_w is None else out_w
     in_h = out_h if in_h is None else in_h
     in_w = out_w if in_w is None else in_w
@@ -252,6 +283,41 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     return y
 
 
+def _gemm_split(l, s, a, w, y, *, M, N, K, lda, ldy, out_h, out_w, in_h, in_w, a_img_stride, a_off, taps_h, taps_w, cin, y_img_stride, y_mul_y,
+                y_mul_x, y_off, bias, act, rowadd, rowadd_div, rowadd_mod, residual, ldr, ldw, split_kind, y_split):
+    """The split-precision form of mage_gemm (3 MFMA products per K slab, fp32-class result): plain rows or the padded-taps form."""
+    sd = split_dtype(split_kind)
+    assert a.dtype == sd and w.dtype == sd and (y.dtype == sd if y_split else y.dtype == torch.float32), (a.dtype, w.dtype, y.dtype)
+    out_w = M if out_w is None else out_w
+    in_h = out_h if in_h is None else in_h
+    in_w = out_w if in_w is None else in_w
+    d = GemmDesc()
+    d.dtype, d.M, d.N, d.K = split_kind, M, N, K
+    d.A, d.W, d.Y = a.data_ptr(), w.data_ptr(), y.data_ptr()
+    d.lda, d.ldy, d.y_dtype = lda, ldy, (split_kind if y_split else F32)
+    d.out_h, d.out_w, d.in_h, d.in_w = out_h, out_w, in_h, in_w
+    d.a_img_stride = in_h * in_w if a_img_stride is None else a_img_stride
+    d.a_off = a_off
+    d.taps_h, d.taps_w, d.cin, d.stride = taps_h, taps_w, (K // (taps_h * taps_w) if cin is None else cin), 1
+    d.dy0, d.dx0, d.dys, d.dxs = 0, 0, 1, 1
+    d.y_img_stride = out_h * out_w if y_img_stride is None else y_img_stride
+    d.y_mul_y = out_w if y_mul_y is None else y_mul_y
+    d.y_mul_x, d.y_off = y_mul_x, y_off
+    d.bias, d.act = _p(bias), act
+    d.rowadd, d.rowadd_div, d.rowadd_mod = _p(rowadd), rowadd_div, rowadd_mod
+    d.residual, d.ldr, d.res_dtype = _p(residual), ldr, F32
+    d.ldw, d.n_split = ldw, 1
+    if PROFILE.enabled:
+        key = f"gemm_split<{split_kind}, {act}, {1 if residual is not None else 0}, {taps_h * taps_w}>"
+        if PROFILE.wants(key):
+            ev = PROFILE.begin()
+            _lib.check(l.mage_gemm(C.byref(d), s), l)
+            PROFILE.end(key, ev, 2.0 * M * N * K)
+            return y
+    _lib.check(l.mage_gemm(C.byref(d), s), l)
+    return y
+
+
 def ln_stats(part: torch.Tensor, C_: int, eps: float, stats: torch.Tensor) -> torch.Tensor:
     """(mean, rstd) per row from a producer GEMM's partial sums ``part[rows, n_slices, 2]`` (mage_ln_stats)."""
     l, s = _dev(part)
@@ -266,12 +332,14 @@ def ln_stats(part: torch.Tensor, C_: int, eps: float, stats: torch.Tensor) -> to
     return stats
 
 
-def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch.Tensor, eps: float) -> torch.Tensor:
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch.Tensor, eps: float, split_kind: int = 0) -> torch.Tensor:
+    """y = LayerNorm(x); split_kind BF16X3 / F16X3: y is a split-precision tensor [rows, 2C]."""
     l, s = _dev(x)
     assert x.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous()
     Cc = x.shape[-1]
+    assert not split_kind or (y.dtype == split_dtype(split_kind) and y.numel() == 2 * x.numel())
     ev = PROFILE.begin() if PROFILE.wants("layernorm") else None
-    _lib.check(l.mage_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), code(y),
+    _lib.check(l.mage_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), split_kind or code(y),
                                 x.numel() // Cc, Cc, float(eps), s), l)
     if ev is not None:
         PROFILE.end("layernorm", ev, 0.0, float(x.numel()) * (4 + y.element_size()))
@@ -279,7 +347,8 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch
 
 
 def attention(q, k, v, out, *, ldq, ldk, ldv, ldo, n_seq, inner, nq, nk, n_head, q_outer_stride, q_axis_stride,
-              kv_outer_stride, kv_axis_stride, causal=False, kv_len=None, kv_len_div=1, scale=None):
+              kv_outer_stride, kv_axis_stride, causal=False, kv_len=None, kv_len_div=1, scale=None, out_split: int = 0):
+    """out_split BF16X3 / F16X3 (fp32 q, k, v): out is a split-precision tensor, ldo in 16-bit elements (2 * logical width)."""
     l, s = _dev(q)
     d = AttnDesc()
     d.dtype = code(q)
@@ -291,6 +360,7 @@ def attention(q, k, v, out, *, ldq, ldk, ldv, ldo, n_seq, inner, nq, nk, n_head,
     d.causal = int(causal)
     d.kv_len, d.kv_len_div = _p(kv_len), kv_len_div
     d.scale = float(32 ** -0.5 if scale is None else scale)
+    d.out_split = out_split
     ev = PROFILE.begin() if PROFILE.wants("attention") else None
     _lib.check(l.mage_attention(C.byref(d), s), l)
     if ev is not None:
@@ -300,13 +370,13 @@ def attention(q, k, v, out, *, ldq, ldk, ldv, ldo, n_seq, inner, nq, nk, n_head,
 
 
 def embedding(ids: torch.Tensor, table: torch.Tensor, out: torch.Tensor, *, relu: bool = False, group: Optional[int] = None,
-              group_stride: Optional[int] = None, off: int = 0, inner: int = 0, inner_stride: int = 0) -> torch.Tensor:
+              group_stride: Optional[int] = None, off: int = 0, inner: int = 0, inner_stride: int = 0, split_kind: int = 0) -> torch.Tensor:
     l, s = _dev(table)
     assert ids.dtype == torch.int64 and ids.is_contiguous() and table.dtype == torch.float32 and table.is_contiguous()
     n = ids.numel()
     group = n if group is None else group
     group_stride = group if group_stride is None else group_stride
-    _lib.check(l.mage_embedding(ids.data_ptr(), table.data_ptr(), out.data_ptr(), code(out), n, table.shape[1],
+    _lib.check(l.mage_embedding(ids.data_ptr(), table.data_ptr(), out.data_ptr(), split_kind or code(out), n, table.shape[1],
                                 table.shape[0], int(relu), group, group_stride, off, inner, inner_stride, s), l)
     return out
 

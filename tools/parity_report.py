@@ -2,7 +2,7 @@
 """Measured parity of the HIP path against every committed golden (GPU box): max |error| per stage, so that the gates in
 tests/test_gpu_parity.py are chosen from numbers, and committed under profiles/ as evidence.
 
-    python tools/parity_report.py > gpurun_out/parity_report.txt
+    python tools/parity_report.py [fp32|f16x3|bf16x3] > gpurun_out/parity_report.txt
 """
 import os
 import sys
@@ -13,9 +13,14 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mage_amd.utils import synth  # noqa: E402
-from tests.helpers import build_mage, golden, t  # noqa: E402
+from tests.helpers import build_mage as _build_mage, golden, t  # noqa: E402
 
 DEV = "cuda:0"
+PREC = sys.argv[1] if len(sys.argv) > 1 else "fp32"        # fp32 | f16x3 | bf16x3 (| bf16: free-running tokens will differ)
+
+
+def build_mage(cfg, seed, device):
+    return _build_mage(cfg, seed, device).set_precision(PREC)
 
 
 def dev(b):
@@ -39,6 +44,7 @@ def tok_report(got, want, margin):
 
 def main():
     torch.manual_seed(0)
+    print(f"precision mode: {PREC}", flush=True)
     for tag in ("mage_mnist_L4", "mage_mnist_L6_ragged"):
         g = golden(tag)
         B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
