@@ -277,7 +277,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
         if PROFILE.wants(key):
             ev = PROFILE.begin()
             _lib.check(l.mage_gemm(C.byref(d), s), l)
-            PROFILE.end(key, ev, 2.0 * M * N * K)
+            # algorithmic HBM bytes of this launch (SURVEY 8d's convention: every operand once): A + W + Y (+ fp32 residual, + the bf16
+            # copy and the LayerNorm partial sums of the producer form)
+            es, ys = a.element_size(), y.element_size()
+            nb = float(M) * K * es + float(N) * K * es + float(M) * N * ys
+            if residual is not None:
+                nb += float(M) * N * residual.element_size()
+            if y2 is not None:
+                nb += float(M) * N * 2 + float(M) * (N // 64) * 8
+            PROFILE.end(key, ev, 2.0 * M * N * K, nb)
             return y
     _lib.check(l.mage_gemm(C.byref(d), s), l)
     return y
@@ -312,7 +320,8 @@ def _gemm_split(l, s, a, w, y, *, M, N, K, lda, ldy, out_h, out_w, in_h, in_w, a
         if PROFILE.wants(key):
             ev = PROFILE.begin()
             _lib.check(l.mage_gemm(C.byref(d), s), l)
-            PROFILE.end(key, ev, 2.0 * M * N * K)
+            nb = 4.0 * M * K + 4.0 * N * K + float(M) * N * 4 * (2 if residual is not None else 1)
+            PROFILE.end(key, ev, 2.0 * M * N * K, nb)
             return y
     _lib.check(l.mage_gemm(C.byref(d), s), l)
     return y
