@@ -191,6 +191,12 @@ typedef struct mage_attn_desc {
     float scale;
     int32_t out_split;                 /* 0: out has `dtype`; MAGE_BF16X3 / MAGE_F16X3 (dtype MAGE_F32 only): out is written as split
                                         * rows (ldo in 16-bit elements = 2 * logical width, 256-byte aligned): out_proj's A operand */
+    /* Dropout on the attention PROBABILITIES (nn.MultiheadAttention(dropout=p) in train(): the text encoder's
+     * nn.TransformerEncoderLayer, mage_model.py:193-199): out = (softmax(.) * keep / (1 - p)) v with the stateless mask
+     * keep(s, h, i, j) = hash(drop_seed, ((s * n_head + h) * nq + i) * nk + j) >= p * 2^32, recomputed by mage_attention_bwd.
+     * fp32 thread-per-query kernels only (drop_p = 0: off). */
+    float drop_p;
+    uint64_t drop_seed;
 } mage_attn_desc;
 
 int mage_attention(const mage_attn_desc* desc, void* stream);

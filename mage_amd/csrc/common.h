@@ -151,6 +151,16 @@ __device__ __forceinline__ void split_store8(void* p, f32x4 v0, f32x4 v1) {
 __device__ __forceinline__ void store8(split_bf16* p, f32x4 a, f32x4 b) { split_store8<1>(p, a, b); }
 __device__ __forceinline__ void store8(split_f16* p, f32x4 a, f32x4 b) { split_store8<2>(p, a, b); }
 
+// stateless dropout masks: keep(i) = hash32(seed * 0x9e3779b97f4a7c15 + i) >= p * 2^32 (mage_dropout, mage_attention's drop_p)
+__device__ __forceinline__ unsigned hash32(unsigned long long v) {
+    v ^= v >> 33;
+    v *= 0xff51afd7ed558ccdULL;
+    v ^= v >> 33;
+    v *= 0xc4ceb9fe1a85ec53ULL;
+    v ^= v >> 33;
+    return (unsigned)v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

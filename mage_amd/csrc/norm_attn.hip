@@ -98,6 +98,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, 
     __syncthreads();
     int klen = d.nk;
     if (d.kv_len) klen = min(klen, d.kv_len[s / d.kv_len_div]);
+    const unsigned drop_thresh = d.drop_p > 0.f ? (unsigned)((double)d.drop_p * 4294967296.0) : 0u;
+    const float inv_keep = 1.0f / (1.0f - d.drop_p);
     const T* qp = (const T*)d.q;
     OT* op = (OT*)d.out;
     const int ldo = std::is_same<OT, T>::value ? d.ldo : d.ldo >> 1;   // split rows: ldo counts 16-bit elements, a logical element is 4 bytes
@@ -139,8 +141,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, 
 #pragma unroll
         for (int j = 0; j < NK_MAX; ++j) {
             if (j < jmax) {
-                const float pj = expf(sc[j] - mx);
+                float pj = expf(sc[j] - mx);
                 den += pj;
+                if (drop_thresh) {                   // dropout on the probabilities (train() of the text encoder): the sum stays unmasked
+                    const unsigned long long idx = (((unsigned long long)s * d.n_head + (h0 + hl)) * d.nq + i) * d.nk + j;
+                    pj = hash32(d.drop_seed * 0x9e3779b97f4a7c15ULL + idx) >= drop_thresh ? pj * inv_keep : 0.f;
+                }
                 const T* vr = vs + j * rowf + hl * 32;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -445,6 +451,8 @@ extern "C" int mage_attention(const mage_attn_desc* d, void* stream) {
     MAGE_CHECK_ARG(d->nq >= 1 && d->n_seq >= 1 && d->n_head >= 1 && d->inner >= 1, "mage_attention: bad sizes");
     MAGE_CHECK_ARG((d->ldq | d->ldk | d->ldv | d->ldo) % 8 == 0, "mage_attention: leading dims must be multiples of 8");
     MAGE_CHECK_ARG(!d->kv_len || d->kv_len_div >= 1, "mage_attention: kv_len_div must be >= 1");
+    MAGE_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f && (d->drop_p == 0.f || (d->dtype == MAGE_F32 && d->out_split == 0)),
+                   "mage_attention: drop_p=%g needs fp32 q/k/v (the thread-per-query kernel) and 0 <= p < 1", (double)d->drop_p);
     MAGE_CHECK_ARG(d->out_split == 0 || ((d->out_split == MAGE_BF16X3 || d->out_split == MAGE_F16X3) && d->dtype == MAGE_F32 &&
                                          (d->n_head * 32) % 64 == 0 && d->ldo % 128 == 0 && (((uintptr_t)d->out) & 255) == 0),
                    "mage_attention: out_split needs fp32 q/k/v, an even head count, ldo a multiple of 128 16-bit elements, out 256-byte aligned");

@@ -417,6 +417,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const mage_attn_desc
     float* ps = gs + qb * 33;
     float* ds = ps + qb * nkp;
     if (h >= d.n_head) return;                       // whole wave; no workgroup barriers below (waves are independent)
+    const unsigned drop_thresh = d.drop_p > 0.f ? (unsigned)((double)d.drop_p * 4294967296.0) : 0u;
+    const float inv_keep = 1.0f / (1.0f - d.drop_p);
     const int outer = s / d.inner, in = s - outer * d.inner;
     const long q_base = (long)outer * d.q_outer_stride + in;
     const long kv_base = (long)outer * d.kv_outer_stride + in;
@@ -481,6 +483,10 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const mage_attn_desc
                 float dp = 0.f;
 #pragma unroll
                 for (int c = 0; c < 32; ++c) dp += g[c] * vs[j * 32 + c];
+                if (drop_thresh) {                   // P' = P keep / (1 - p): dP = dP' keep / (1 - p); dv below uses P'
+                    const unsigned long long idx = (((unsigned long long)s * d.n_head + h) * d.nq + i) * d.nk + j;
+                    dp = hash32(d.drop_seed * 0x9e3779b97f4a7c15ULL + idx) >= drop_thresh ? dp * inv_keep : 0.f;
+                }
                 ps[lane * nkp + j] = p;
                 ds[lane * nkp + j] = dp;
                 dsum += p * dp;
@@ -502,7 +508,12 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const mage_attn_desc
         __builtin_amdgcn_s_waitcnt(0xC07F);
         if (lane < d.nk) {
             for (int i = 0; i < nb; ++i) {
-                const float t = ds[i * nkp + lane], p = ps[i * nkp + lane];
+                const float t = ds[i * nkp + lane];
+                float p = ps[i * nkp + lane];
+                if (drop_thresh) {
+                    const unsigned long long idx = (((unsigned long long)s * d.n_head + h) * d.nq + (i0 + i)) * d.nk + lane;
+                    p = hash32(d.drop_seed * 0x9e3779b97f4a7c15ULL + idx) >= drop_thresh ? p * inv_keep : 0.f;
+                }
 #pragma unroll
                 for (int c = 0; c < 32; ++c) {
                     dka[c] += t * qs[i * 33 + c];
@@ -526,14 +537,6 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const mage_attn_desc
 
 // ------------------------------------------------------------------------------------------------ dropout
 // Stateless mask: keep(i) = hash(seed, i) >= p * 2^32, recomputed identically in the backward pass (no mask tensor).
-__device__ __forceinline__ unsigned hash32(unsigned long long v) {
-    v ^= v >> 33;
-    v *= 0xff51afd7ed558ccdULL;
-    v ^= v >> 33;
-    v *= 0xc4ceb9fe1a85ec53ULL;
-    v ^= v >> 33;
-    return (unsigned)v;
-}
 // y = (accumulate ? y : 0) + x * keep / (1 - p)      x: T, y: YT
 template <typename T, typename YT>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, YT* __restrict__ y, long n, unsigned thresh, float inv_keep,
@@ -1151,6 +1154,8 @@ extern "C" int mage_attention_bwd(const mage_attn_desc* d, const void* dout, voi
     MAGE_CHECK_ARG(d->nk >= 1 && d->nk <= 64 && d->nq >= 1 && d->n_seq >= 1 && d->n_head >= 1 && d->inner >= 1,
                    "mage_attention_bwd: nk=%d nq=%d unsupported", d->nk, d->nq);
     hipStream_t s = (hipStream_t)stream;
+    MAGE_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f && (d->drop_p == 0.f || d->dtype == MAGE_F32),
+                   "mage_attention_bwd: drop_p=%g needs the fp32 kernels and 0 <= p < 1", (double)d->drop_p);
     if (d->dtype == MAGE_BF16 && d->nq <= 32 && d->nk <= 32 && !getenv("MAGE_ATTN_NO_MFMA") && d->ldq % 8 == 0 && d->ldk % 8 == 0 &&
         d->ldv % 8 == 0 && d->ldo % 8 == 0 && ld_dq % 8 == 0 && ld_dk % 8 == 0 && ld_dv % 8 == 0 &&
         ((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0)) {

@@ -53,6 +53,8 @@ class _Run:
         self.dt = dt
         self.p = float(p) if training else 0.0
         self.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.p > 0 else 0
+        if self.p > 0 and torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.seed += 1000003 * torch.distributed.get_rank()       # identically seeded data-parallel ranks draw different masks
         self.site = 0
 
     def next_seed(self) -> int:
@@ -393,7 +395,9 @@ def _text_forward(te, run: _Run, text):
         qkv = ops.gemm(x, d[p + ".in_proj.f32"], torch.empty(B * S, 3 * Wd, device=dev, dtype=F32), M=B * S, N=3 * Wd, K=Wd, lda=Wd,
                        ldy=3 * Wd, bias=d[p + ".in_proj.b"])
         ao = torch.empty(B * S, Wd, device=dev, dtype=F32)
-        ops.attention(qkv, qkv[:, Wd:], qkv[:, 2 * Wd:], ao, ldq=3 * Wd, ldk=3 * Wd, ldv=3 * Wd, ldo=Wd, **geo)
+        # nn.TransformerEncoderLayer(dropout=p) also drops attention PROBABILITIES in train() (mage_model.py:193-199)
+        sa_seed = run.next_seed()
+        ops.attention(qkv, qkv[:, Wd:], qkv[:, 2 * Wd:], ao, ldq=3 * Wd, ldk=3 * Wd, ldv=3 * Wd, ldo=Wd, drop_p=run.p, drop_seed=sa_seed, **geo)
         s1_seed, sh_seed, s2_seed = run.next_seed(), run.next_seed(), run.next_seed()
         s1 = _res_linear(run, ao, d, p + ".out_proj", x, F32, M=B * S, N=Wd, K=Wd, seed=s1_seed)
         x1 = ops.layernorm(s1, d[p + ".norm1.w"], d[p + ".norm1.b"], torch.empty_like(s1), d[p + ".norm1.eps"])
@@ -404,7 +408,7 @@ def _text_forward(te, run: _Run, text):
             hdn = ops.dropout(hdn, torch.empty_like(hdn), run.p, sh_seed)
         s2 = _res_linear(run, hdn, d, p + ".fc2", x1, F32, M=B * S, N=Wd, K=4 * Wd, seed=s2_seed)
         x2 = ops.layernorm(s2, d[p + ".norm2.w"], d[p + ".norm2.b"], torch.empty_like(s2), d[p + ".norm2.eps"])
-        layers.append(dict(x_in=x, qkv=qkv, ao=ao, s1=s1, x1=x1, hpre=hpre, s2=s2, seeds=(s1_seed, sh_seed, s2_seed)))
+        layers.append(dict(x_in=x, qkv=qkv, ao=ao, s1=s1, x1=x1, hpre=hpre, s2=s2, seeds=(s1_seed, sh_seed, s2_seed), sa_seed=sa_seed))
         x = x2
     xf = ops.layernorm(x, d["ln_text_final.w"], d["ln_text_final.b"], torch.empty_like(x), te.ln_text_final.eps)
     out = ops.gemm(xf, d["proj.f32"], torch.empty(B * S, te.output_dim, device=dev, dtype=F32), M=B * S, N=te.output_dim, K=Wd, lda=Wd,
@@ -449,7 +453,7 @@ def _text_backward(te, run32: _Run, tape, dout, grads, pre: str = "text_encoder"
         qkv = t["qkv"]
         dqkv = torch.empty(R, 3 * Wd, device=dev, dtype=F32)
         ops.attention_bwd(qkv, qkv[:, Wd:], qkv[:, 2 * Wd:], dao, dqkv, dqkv[:, Wd:], dqkv[:, 2 * Wd:], ldq=3 * Wd, ldk=3 * Wd, ldv=3 * Wd,
-                          ldo=Wd, ld_dq=3 * Wd, ld_dk=3 * Wd, ld_dv=3 * Wd, **tape["geo"])
+                          ldo=Wd, ld_dq=3 * Wd, ld_dk=3 * Wd, ld_dv=3 * Wd, drop_p=run32.p, drop_seed=t["sa_seed"], **tape["geo"])
         grads[lp + ".self_attn.in_proj_weight"], grads[lp + ".self_attn.in_proj_bias"] = _wgrad(dqkv, t["x_in"], M=R, N=3 * Wd, K=Wd,
                                                                                                ld_dy=3 * Wd, ld_x=Wd)
         dx = _gemm_x(dqkv, _wt(d, p + ".in_proj", F32), torch.empty(R, Wd, device=dev, dtype=F32), M=R, N=Wd, K=3 * Wd, residual=ds1, ldr=Wd)
@@ -479,6 +483,7 @@ def train_forward(model, batch):
     run = _Run(dt, model.dropout, model.training)
     run32 = _Run(F32, model.dropout, model.training)
     run32.seed, run32.p = run.seed, run.p
+    run32.site = 1 << 20            # its own stream of dropout sites: the decoder's and the encoders' layers never share a seed
     d = model._derived.get(model._build)
     dev = images.device
     tok = tok_in = tok0 = lat_all = lat_in = lat0 = None

@@ -496,6 +496,12 @@ class VectorQuantizedVAE(nn.Module):
                     x_tilde, z_e, zq, t = vqvae_train.vq_train_forward(self, x)
                 N, hh, ww, D = t["N"], t["h"], t["wd"], self.dim
                 return x_tilde, z_e.view(N, hh, ww, D).permute(0, 3, 1, 2), zq.view(N, hh, ww, D).permute(0, 3, 1, 2)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and not getattr(self, "_warned_eval_grad", False):
+            import warnings
+            self._warned_eval_grad = True
+            warnings.warn("VectorQuantizedVAE.forward in eval() returns VALUES from the inference kernels (no autograd graph): a "
+                          "loss.backward() on them fails.  Call model.train() for the training graph (train_vqvae.py:13-35), or wrap "
+                          "evaluation in torch.no_grad() as the reference's test loop does (train_vqvae.py:38-55).", stacklevel=2)
         with torch.no_grad():
             return self._forward_eval(x)
 

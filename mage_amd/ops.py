@@ -356,7 +356,8 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch
 
 
 def attention(q, k, v, out, *, ldq, ldk, ldv, ldo, n_seq, inner, nq, nk, n_head, q_outer_stride, q_axis_stride,
-              kv_outer_stride, kv_axis_stride, causal=False, kv_len=None, kv_len_div=1, scale=None, out_split: int = 0):
+              kv_outer_stride, kv_axis_stride, causal=False, kv_len=None, kv_len_div=1, scale=None, out_split: int = 0,
+              drop_p: float = 0.0, drop_seed: int = 0):
     """out_split BF16X3 / F16X3 (fp32 q, k, v): out is a split-precision tensor, ldo in 16-bit elements (2 * logical width)."""
     l, s = _dev(q)
     d = AttnDesc()
@@ -370,6 +371,7 @@ def attention(q, k, v, out, *, ldq, ldk, ldv, ldo, n_seq, inner, nq, nk, n_head,
     d.kv_len, d.kv_len_div = _p(kv_len), kv_len_div
     d.scale = float(32 ** -0.5 if scale is None else scale)
     d.out_split = out_split
+    d.drop_p, d.drop_seed = float(drop_p), int(drop_seed) & (2 ** 64 - 1)       # dropout on the probabilities (fp32 kernels; mage_hip.h)
     ev = PROFILE.begin() if PROFILE.wants("attention") else None
     _lib.check(l.mage_attention(C.byref(d), s), l)
     if ev is not None:
@@ -728,7 +730,8 @@ def group_rowsum(x, out, *, rows: int, C: int, div: int, mod: int, row_scale=Non
 
 
 def attention_bwd(q, k, v, dout, dq, dk, dv, *, ldq, ldk, ldv, ldo, ld_dq, ld_dk, ld_dv, n_seq, inner, nq, nk, n_head, q_outer_stride,
-                  q_axis_stride, kv_outer_stride, kv_axis_stride, causal=False, kv_len=None, kv_len_div=1, scale=None):
+                  q_axis_stride, kv_outer_stride, kv_axis_stride, causal=False, kv_len=None, kv_len_div=1, scale=None,
+                  drop_p: float = 0.0, drop_seed: int = 0):
     l, s = _dev(q)
     d = AttnDesc()
     d.dtype = code(q)
@@ -740,6 +743,7 @@ def attention_bwd(q, k, v, dout, dq, dk, dv, *, ldq, ldk, ldv, ldo, ld_dq, ld_dk
     d.causal = int(causal)
     d.kv_len, d.kv_len_div = _p(kv_len), kv_len_div
     d.scale = float(32 ** -0.5 if scale is None else scale)
+    d.drop_p, d.drop_seed = float(drop_p), int(drop_seed) & (2 ** 64 - 1)
     _lib.check(l.mage_attention_bwd(C.byref(d), dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ld_dq, ld_dk, ld_dv, s), l)
 
 

@@ -67,6 +67,11 @@ class FlatAdam(torch.optim.Optimizer):
         self.v = torch.zeros(self.shard_n, device=dev, dtype=torch.float32)
         self.shard_g = torch.empty(self.shard_n, device=dev, dtype=torch.float32) if self.sharded else None
         self.steps = 0
+        if self.world > 1:
+            # DistributedDataParallel broadcasts rank 0's parameters when it wraps a model (main_mage.py:95); a bare model + FlatAdam
+            # gets the same guarantee here: replicas that were initialised differently start from rank 0's weights
+            dist.broadcast(self.flat_p, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+            _vq.bump_weights_epoch()
 
     # ------------------------------------------------------------------ gradients
     def zero_grad(self, set_to_none: bool = False):
@@ -115,17 +120,50 @@ class FlatAdam(torch.optim.Optimizer):
         return loss
 
     # ------------------------------------------------------------------ checkpoints (main_mage.py:189-199)
+    def _full_moments(self):
+        """exp_avg / exp_avg_sq over the WHOLE arena on every rank (the shards all-gathered): the reference saves its checkpoint from
+        rank 0 only (main_mage.py:186-193), so a sharded state would lose (W-1)/W of the moments."""
+        if not self.sharded or self.world == 1:
+            return self.m[:self.n].clone(), self.v[:self.n].clone()
+        m = torch.empty(self.n_pad, device=self.m.device, dtype=torch.float32)
+        v = torch.empty(self.n_pad, device=self.m.device, dtype=torch.float32)
+        dist.all_gather_into_tensor(m, self.m, group=self.pg)
+        dist.all_gather_into_tensor(v, self.v, group=self.pg)
+        return m[:self.n], v[:self.n]
+
     def state_dict(self):
-        return {"state": {"step": self.steps, "exp_avg": self.m.clone(), "exp_avg_sq": self.v.clone(), "shard_off": self.shard_off,
-                          "shard_n": self.shard_n, "world": self.world if self.sharded else 1},
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        """torch.optim.Adam's layout: state[i] = {step, exp_avg, exp_avg_sq} per parameter (in parameter order) + param_groups, so the
+        'optimizer' entry of a checkpoint is interchangeable with the reference's optim.Adam (main_mage.py:121,189-199,210-228) and
+        independent of the world size it was written with.  A collective call when sharded: every rank must make it."""
+        m, v = self._full_moments()
+        state = {}
+        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
+            k = p.numel()
+            state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": m[off:off + k].view(p.shape).clone(),
+                        "exp_avg_sq": v[off:off + k].view(p.shape).clone()}
+        groups = [dict({k: v_ for k, v_ in g.items() if k != "params"}, params=list(range(len(self.params)))) for g in self.param_groups]
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
+        """Accepts torch.optim.Adam's per-parameter layout (written by this class at ANY world size, or by the reference's optim.Adam)."""
         st = sd["state"]
-        if st["shard_n"] != self.shard_n or st["shard_off"] != self.shard_off:
-            raise ValueError("FlatAdam.load_state_dict: the checkpoint was written with a different sharding")
-        self.steps = int(st["step"])
-        self.m.copy_(st["exp_avg"])
-        self.v.copy_(st["exp_avg_sq"])
+        if len(st) not in (0, len(self.params)):
+            raise ValueError(f"FlatAdam.load_state_dict: {len(st)} parameter states for {len(self.params)} parameters")
+        m = torch.zeros(self.n_pad, device=self.m.device, dtype=torch.float32)
+        v = torch.zeros(self.n_pad, device=self.m.device, dtype=torch.float32)
+        steps = 0
+        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
+            e = st.get(i, st.get(str(i)))
+            if e is None:
+                continue
+            if tuple(e["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"FlatAdam.load_state_dict: state {i} has shape {tuple(e['exp_avg'].shape)}, parameter {tuple(p.shape)}")
+            k = p.numel()
+            m[off:off + k].copy_(e["exp_avg"].reshape(-1))
+            v[off:off + k].copy_(e["exp_avg_sq"].reshape(-1))
+            steps = max(steps, int(float(e["step"])))
+        self.steps = steps
+        self.m.copy_(m[self.shard_off:self.shard_off + self.shard_n])
+        self.v.copy_(v[self.shard_off:self.shard_off + self.shard_n])
         for g, sg in zip(self.param_groups, sd["param_groups"]):
-            g.update(sg)
+            g.update({k: v_ for k, v_ in sg.items() if k != "params"})

@@ -22,7 +22,7 @@ import torch
 
 from . import synth
 
-__all__ = ["MNIST_VOCAB", "CATER_V1_VOCAB", "CATER_V2_VOCAB", "encode_caption", "decode_caption", "sample_clip", "collate",
+__all__ = ["MNIST_VOCAB", "CATER_V1_VOCAB", "CATER_V2_VOCAB", "encode_caption", "decode_caption", "sample_indices", "sample_clip", "collate",
            "SyntheticMovingMnist", "make_checkpoint", "save_checkpoint", "load_checkpoint_into", "save_gifs"]
 
 # word tables (data, dataload.py:199-203, 300-312): ids are part of the checkpoint contract (text_encoder.token_embedding rows)
@@ -49,13 +49,17 @@ def decode_caption(tokens, vocab: Dict[str, int] = MNIST_VOCAB) -> str:
     return "".join(" " + rev[int(t)] for t in tokens)                      # leading space, like dataload.py:228-236
 
 
-def sample_clip(images_raw: np.ndarray, frames_length: int, sample_speed: Sequence[float], speed: float) -> torch.Tensor:
-    """uint8 [T, C, H, W] -> float32 [frames_length, C, H, W] in [-0.5, 0.5] (dataload.py:243-259): keep
-    round(T / interval) evenly spaced frames with interval = max(1, speed * (s_max - s_min) + s_min), truncate to frames_length,
-    normalise, pad by repeating the last frame."""
-    T = images_raw.shape[0]
-    interval = max(1.0, speed * (sample_speed[-1] - sample_speed[0]) + sample_speed[0])
-    idx = np.floor(np.linspace(0, T - 1, round(T / interval), endpoint=True)).astype(np.int32)
+def sample_indices(n_raw: int, sample_speed: Sequence[float], speed: float, min_interval: float = 1.0) -> np.ndarray:
+    """The `speed` frame sub-sampling rule (dataload.py:245-248 MovingMnist, min interval 1.0; :361-363 CATER, min interval 3.0): keep
+    round(T / interval) evenly spaced frames with interval = max(min_interval, speed * (s_max - s_min) + s_min)."""
+    interval = max(float(min_interval), speed * (sample_speed[-1] - sample_speed[0]) + sample_speed[0])
+    return np.floor(np.linspace(0, n_raw - 1, round(n_raw / interval), endpoint=True)).astype(np.int32)
+
+
+def sample_clip(images_raw: np.ndarray, frames_length: int, sample_speed: Sequence[float], speed: float, min_interval: float = 1.0) -> torch.Tensor:
+    """uint8 [T, C, H, W] -> float32 [frames_length, C, H, W] in [-0.5, 0.5] (dataload.py:243-259): the sample_indices frames,
+    truncated to frames_length, normalised, padded by repeating the last frame."""
+    idx = sample_indices(images_raw.shape[0], sample_speed, speed, min_interval)
     clip = torch.tensor(images_raw[idx][:frames_length] / 255.0 - 0.5, dtype=torch.float)
     if clip.shape[0] < frames_length:
         clip = torch.cat([clip, clip[-1].unsqueeze(0).repeat(frames_length - clip.shape[0], 1, 1, 1)], 0)

@@ -1,4 +1,7 @@
-"""Caller-side glue: batch contract producer, checkpoint format, gif writer."""
+"""Caller-side glue: batch contract producer, checkpoint format, gif writer.  The caption tables, the encode /
+decode rules, the `speed` frame sub-sampling and collate are pinned by tests/golden/glue_dataload.json: outputs of the REFERENCE's
+dataload.py classes (MovingMnistLMDB, CATER) run by tools/gen_golden_glue.py on in-memory readers."""
+import json
 import os
 
 import numpy as np
@@ -70,3 +73,51 @@ def test_gif_writer(tmp_path):
     assert im.n_frames == 6 and im.size == (64, 64) and im.info["duration"] in (330, 333)          # GIF delays are stored in 1/100 s
     rgb = glue.save_gifs(torch.rand(3, 3, 32, 32) * 2 - 1, "rgb", str(tmp_path / "ckpt" / "model_best.pth"))
     assert Image.open(rgb).n_frames == 3
+
+
+def _fixture():
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glue_dataload.json")))
+
+
+def test_caption_tables_equal_the_reference_dataload_tables():
+    fx = _fixture()
+    assert glue.MNIST_VOCAB == fx["mnist_vocab"] and glue.CATER_V1_VOCAB == fx["caterv1_vocab"] and glue.CATER_V2_VOCAB == fx["caterv2_vocab"]
+    assert fx["mnist_padding_idx"] == glue.MNIST_VOCAB["[PAD]"] == 0
+
+
+def test_mnist_items_and_collate_equal_the_reference_dataset_outputs():
+    """MovingMnistLMDB.__getitem__ / collate_fn (dataload.py:240-271) on a reader whose raw frame t is the constant t: captions, the
+    sampled + truncated + padded frame sequence for the reference's own random speed, and the padded caption matrix."""
+    fx = _fixture()
+    for key in ("mnist_L16", "mnist_L8", "mnist_L24"):
+        f = fx[key]
+        L, ss, T = f["frames_length"], f["sample_speed"], f["raw_frames"]
+        raw = (np.arange(T, dtype=np.uint8)[:, None, None, None] * np.ones((T, 1, 2, 2), np.uint8))
+        items = []
+        for it in f["items"]:
+            tok = glue.encode_caption(it["caption"])
+            assert tok.tolist() == it["text"] and glue.decode_caption(tok) == it["decoded"]
+            clip = glue.sample_clip(raw, L, ss, it["speed"])
+            assert list(clip.shape) == it["images_shape"] and str(clip.dtype) == it["images_dtype"]
+            assert [int(round((v + 0.5) * 255)) for v in clip[:, 0, 0, 0].tolist()] == it["frame_values_x255"]
+            items.append({"images": clip, "text": tok, "speed": torch.tensor(it["speed"], dtype=torch.float)})
+        b = glue.collate(items)
+        assert sorted(b.keys()) == f["collate_keys"] and b["text"].tolist() == f["collate_text"]
+        assert list(b["images"].shape) == f["collate_images_shape"] and list(b["speed"].shape) == f["collate_speed_shape"]
+
+
+def test_cater_captions_and_sampling_equal_the_reference_dataset_outputs():
+    """CATER.__getitem__ (dataload.py:349-372): both CATER word tables through encode / decode, and the sub-sampling rule with its
+    minimum interval of 3 frames (301-frame videos, frames_length 32)."""
+    fx = _fixture()
+    for dset, vocab in (("caterv1", glue.CATER_V1_VOCAB), ("caterv2", glue.CATER_V2_VOCAB)):
+        f = fx[dset]
+        toks = []
+        for it in f["items"]:
+            tok = glue.encode_caption(it["caption"], vocab)
+            assert tok.tolist() == it["text"] and glue.decode_caption(tok, vocab) == it["decoded"]
+            idx = glue.sample_indices(f["raw_frames"], f["sample_speed"], it["speed"], min_interval=f["min_interval"])[:f["frames_length"]]
+            idx = list(idx) + [idx[-1]] * (f["frames_length"] - len(idx))
+            assert [int(i) for i in idx] == it["frame_index"]
+            toks.append(tok)
+        assert torch.nn.utils.rnn.pad_sequence(toks, batch_first=True, padding_value=0).tolist() == f["collate_text"]

@@ -403,6 +403,67 @@ def test_bf16_mode_against_reference_goldens(tag, sub):
     assert bad_first == 0, "a clip's first divergence from the reference is at a position the reference decides by more than the bf16 error"
 
 
+def test_full_size_properties_cfg3_double_mnist_per_gpu_share():
+    """BASELINE cfg3 at its PER-GPU size (256 clips over 8 GPUs = 32 clips, L = 16, two moving digits, captions of 16 / 18 / 20 tokens
+    right-padded to 20: the padded-text quirk of SURVEY 8a9/a10) through the size-independent properties: determinism,
+    shard == slice of the whole batch, incremental == full loop, first frame passed through, range."""
+    B, L = 32, 16
+    m = build_mage(synth.mnist_model_config(frames_length=L), 0, DEV).set_precision("bf16")
+    cb = synth.synth_batch_mnist(B, L, seed=11, digits=2, caption_lengths=(16, 18, 20))
+    assert cb["text"].shape[1] == 20 and len({int(n) for n in (cb["text"] != 0).sum(1)}) > 1          # ragged, right-padded
+    batch = dev_batch(cb)
+    v1 = m.autoregressive_generate(batch)
+    tok1 = m.last_tokens.clone()
+    assert tuple(v1.shape) == (B, L, 1, 64, 64) and v1.abs().max().item() <= 1.0
+    assert torch.equal(v1[:, 0], batch["images"][:, 0])
+    v2 = m.autoregressive_generate(batch)
+    assert torch.equal(tok1, m.last_tokens) and torch.equal(v1, v2)
+    q = {k: v[8:16] for k, v in batch.items()}                                       # an interior shard: 8 clips
+    vq = m.autoregressive_generate(q)
+    assert torch.equal(m.last_tokens, tok1[8:16]) and torch.equal(vq, v1[8:16])
+    m.ar_mode = "incremental"
+    vi = m.autoregressive_generate(batch)
+    assert torch.equal(m.last_tokens, tok1) and torch.equal(vi, v1)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_batch_without_speed_key_against_the_oracle(precision):
+    """The 'speed' key is optional (mage_model.py:611,666 guard it with `'speed' in batch`): sampling and the teacher-forced loss on
+    a batch WITHOUT it, against the CPU oracle on the same weights -- and the result differs from the with-speed one."""
+    L, B, seed = 4, 2, 31
+    m = build_mage(synth.mnist_model_config(frames_length=L), seed, DEV).set_precision(precision)
+    full = synth.synth_batch_mnist(B, L, seed=seed)
+    batch = {k: v for k, v in full.items() if k != "speed"}
+    video = m.autoregressive_generate(dev_batch(batch))
+    want, want_tok, _, trace = O.mage_generate(cpu_sd(m), batch, L, return_trace=True)
+    top2 = trace.topk(2, dim=-1)[0]
+    margin = (top2[..., 0] - top2[..., 1]).abs()
+    assert assert_tokens(m.last_tokens.cpu(), want_tok, margin, TOK_TOL, "AR tokens, no speed key") == 0
+    torch.testing.assert_close(video.cpu(), want, atol=LOGIT_TOL, rtol=0)
+    loss, _ = m(dev_batch(batch))
+    want_loss = O.mage_forward_loss(cpu_sd(m), batch, L)[0]
+    assert abs(loss.item() - float(want_loss)) < 1e-4
+    loss_speed, _ = m(dev_batch(full))
+    assert abs(loss_speed.item() - loss.item()) > 1e-6                              # the speed embedding is really applied when given
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16x3"])
+@pytest.mark.parametrize("ar_mode", ["full", "incremental"])
+def test_single_clip_equals_row_of_a_batch(precision, ar_mode):
+    """The reference samples ONE clip per call (main_mage.py:205,239-241: DataLoader(batch_size=1)).  B = 1 takes other tile shapes
+    than B = 4 (one 128-row tile list vs the 8-phase kernel); the result must be the same clip, bitwise."""
+    L = 16
+    m = build_mage(synth.mnist_model_config(frames_length=L), 3, DEV).set_precision(precision)
+    m.ar_mode = ar_mode
+    batch = dev_batch(synth.synth_batch_mnist(4, L, seed=9))
+    v4 = m.autoregressive_generate(batch)
+    t4 = m.last_tokens.clone()
+    for r in (0, 3):
+        one = {k: v[r:r + 1] for k, v in batch.items()}
+        v1 = m.autoregressive_generate(one)
+        assert torch.equal(m.last_tokens, t4[r:r + 1]) and torch.equal(v1, v4[r:r + 1])
+
+
 # ------------------------------------------------------------------------------------------------ CATER configs at FULL size
 def test_full_size_properties_cfg4_caterv1():
     """BASELINE cfg4 (config/mage_caterv1.yaml, frames_length 32, 128x128, B=32, bf16) at its stated size, through

@@ -429,6 +429,52 @@ def test_dropout_training_mode_is_consistent_between_forward_and_backward():
     assert abs(fd - an) < 0.05 * max(abs(an), 1e-3) + 2e-4
 
 
+def test_attention_probability_dropout_forward_backward_consistent():
+    """nn.TransformerEncoderLayer(dropout=p) drops attention PROBABILITIES in train() (mage_model.py:193-199): mage_attention's drop_p /
+    drop_seed.  The mask is a stateless hash, so (a) it can be read back by sending v = identity rows, (b) the forward equals
+    softmax * mask / (1 - p) @ v, (c) the backward's gradients equal autograd's through that expression with the same mask."""
+    from mage_amd import ops as o
+    g = torch.Generator().manual_seed(4)
+    B, S, Wd, H, p, seed = 3, 32, 64, 2, 0.25, 777
+    qkv = torch.randn(B * S, 3 * Wd, generator=g).to(DEV)
+    kv_len = torch.tensor([32, 20, 27], dtype=torch.int32, device=DEV)
+    geo = dict(n_seq=B, inner=1, nq=S, nk=S, n_head=H, q_outer_stride=S, q_axis_stride=1, kv_outer_stride=S, kv_axis_stride=1, kv_len=kv_len,
+               kv_len_div=1)
+    ld = dict(ldq=3 * Wd, ldk=3 * Wd, ldv=3 * Wd, ldo=Wd)
+    out = o.attention(qkv, qkv[:, Wd:], qkv[:, 2 * Wd:], torch.empty(B * S, Wd, device=DEV), drop_p=p, drop_seed=seed, **ld, **geo)
+    out2 = o.attention(qkv, qkv[:, Wd:], qkv[:, 2 * Wd:], torch.empty(B * S, Wd, device=DEV), drop_p=p, drop_seed=seed, **ld, **geo)
+    out0 = o.attention(qkv, qkv[:, Wd:], qkv[:, 2 * Wd:], torch.empty(B * S, Wd, device=DEV), **ld, **geo)
+    assert torch.equal(out, out2) and not torch.equal(out, out0)
+    # read the mask back: v = one-hot rows (key j -> e_j) turns out[i, :] into the dropped probabilities of query i
+    eye = torch.zeros(B * S, 3 * Wd, device=DEV)
+    eye[:, :2 * Wd] = qkv[:, :2 * Wd]
+    for h in range(H):
+        eye[:, 2 * Wd + h * 32:2 * Wd + (h + 1) * 32] = torch.eye(32, device=DEV).repeat(B, 1)
+    pd = o.attention(eye, eye[:, Wd:], eye[:, 2 * Wd:], torch.empty(B * S, Wd, device=DEV), drop_p=p, drop_seed=seed, **ld, **geo)
+    p0 = o.attention(eye, eye[:, Wd:], eye[:, 2 * Wd:], torch.empty(B * S, Wd, device=DEV), **ld, **geo)
+    pd, p0 = pd.view(B, S, H, 32).permute(0, 2, 1, 3), p0.view(B, S, H, 32).permute(0, 2, 1, 3)        # [B, H, i, j]
+    valid = p0 > 0
+    mask = (pd > 0) | ~valid
+    keep_rate = mask[valid].float().mean().item()
+    assert abs(keep_rate - (1 - p)) < 0.03, keep_rate
+    torch.testing.assert_close(pd[mask & valid], p0[mask & valid] / (1 - p), rtol=1e-5, atol=1e-7)
+    # autograd through the written-out expression with that mask
+    x = qkv.clone().double().requires_grad_(True)
+    q, k, v = (x[:, i * Wd:(i + 1) * Wd].view(B, S, H, 32).permute(0, 2, 1, 3) for i in range(3))
+    sc = q @ k.transpose(-1, -2) * 32 ** -0.5
+    jj = torch.arange(S, device=DEV)
+    sc = sc.masked_fill(jj[None, None, None, :] >= kv_len.long()[:, None, None, None], float("-inf"))
+    pr = torch.softmax(sc, -1) * mask.double() / (1 - p)
+    want = (pr @ v).permute(0, 2, 1, 3).reshape(B * S, Wd)
+    torch.testing.assert_close(out.double(), want.detach(), rtol=1e-5, atol=1e-5)
+    dout = torch.randn(B * S, Wd, generator=g).to(DEV)
+    want.backward(dout.double())
+    dqkv = torch.zeros(B * S, 3 * Wd, device=DEV)
+    o.attention_bwd(qkv, qkv[:, Wd:], qkv[:, 2 * Wd:], dout, dqkv, dqkv[:, Wd:], dqkv[:, 2 * Wd:], ld_dq=3 * Wd, ld_dk=3 * Wd, ld_dv=3 * Wd,
+                    drop_p=p, drop_seed=seed, **ld, **geo)
+    torch.testing.assert_close(dqkv.double(), x.grad, rtol=1e-4, atol=1e-5)
+
+
 def test_flat_adam_training_steps_track_torch_adam_on_the_oracle():
     """Three optimizer steps: HIP forward/backward + FlatAdam (one fused launch over the flat arena) against the oracle's autograd +
     torch.optim.Adam with the reference's hyper-parameters (main_mage.py:121)."""

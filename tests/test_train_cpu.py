@@ -60,6 +60,17 @@ def test_flat_adam_matches_torch_adam_single_process(monkeypatch):
     opt2 = FlatAdam(_net(1).parameters(), lr=1e-2, betas=(0.9, 0.98), eps=1e-6)
     opt2.load_state_dict(sd)
     assert opt2.steps == 4 and torch.equal(opt2.m, opt.m) and opt2.param_groups[0]["lr"] == 1e-2
+    # the checkpoint entry has torch.optim.Adam's layout: interchangeable with the reference's optimizer in both directions
+    rsd = ref.state_dict()
+    assert set(sd["state"]) == set(rsd["state"]) and sd["param_groups"][0]["params"] == rsd["param_groups"][0]["params"]
+    for i in rsd["state"]:
+        assert torch.allclose(sd["state"][i]["exp_avg"], rsd["state"][i]["exp_avg"], atol=1e-7)
+        assert torch.allclose(sd["state"][i]["exp_avg_sq"], rsd["state"][i]["exp_avg_sq"], atol=1e-9)
+        assert float(sd["state"][i]["step"]) == float(rsd["state"][i]["step"])
+    opt3 = FlatAdam(_net(1).parameters(), lr=1e-2, betas=(0.9, 0.98), eps=1e-6)
+    opt3.load_state_dict(rsd)                               # a reference checkpoint's 'optimizer' entry
+    assert opt3.steps == 4 and torch.allclose(opt3.m, opt.m, atol=1e-7)
+    torch.optim.Adam(_net(1).parameters(), lr=1e-2).load_state_dict(sd)     # and the other way round
 
 
 def _free_port():
@@ -79,9 +90,10 @@ def _worker(rank, world, port, q):
     from mage_amd.utils import dist as D
     FlatAdam._adam = _adam_double
     D.init_from_env("gloo")
-    net = _net(2)
+    net = _net(2 + 10 * rank)                                # replicas initialised DIFFERENTLY: FlatAdam broadcasts rank 0's (as DDP does)
     opt = FlatAdam(net.parameters(), lr=1e-2, betas=(0.9, 0.98), eps=1e-6)
     assert opt.sharded and opt.shard_n * world == opt.n_pad and opt.m.numel() == opt.shard_n      # optimizer state is divided by W
+    assert all(torch.equal(a, b) for a, b in zip(net.parameters(), _net(2).parameters()))
     data = torch.randn(8, 7, generator=torch.Generator().manual_seed(5))
     mine = data[rank * 4:(rank + 1) * 4]                     # each rank sees its half of the global batch
     for _ in range(3):
@@ -91,7 +103,10 @@ def _worker(rank, world, port, q):
     flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
-    q.put((rank, flat.tolist(), bool(torch.equal(gathered[0], gathered[1]))))    # plain lists: no shared-memory handles outlive the worker
+    # checkpoint: the full moments on EVERY rank (the reference saves from rank 0 only), loadable at another world size
+    sd = opt.state_dict()
+    mom = torch.cat([sd["state"][i]["exp_avg"].reshape(-1) for i in range(len(opt.params))])
+    q.put((rank, flat.tolist(), bool(torch.equal(gathered[0], gathered[1])), mom.tolist()))    # plain lists: no shared-memory handles outlive the worker
     D.barrier()
     dist.destroy_process_group()
 
@@ -118,3 +133,5 @@ def test_sharded_step_over_two_ranks_equals_the_global_batch_step():
         ref.step()
     want = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     assert torch.allclose(torch.tensor(res[0][1]), want, atol=2e-6)
+    want_m = torch.cat([ref.state_dict()["state"][i]["exp_avg"].reshape(-1) for i in range(len(list(net.parameters())))])
+    assert res[0][3] == res[1][3] and torch.allclose(torch.tensor(res[0][3]), want_m, atol=2e-6)     # sharded moments, gathered
