@@ -103,6 +103,63 @@ def train_step_probe(args, dev, rank, world, B, L, wl_kw, D):
     return out
 
 
+def latency_b1(model2, dev, L):
+    """The reference's own sampling shape (main_mage.py:205,239-241: DataLoader(batch_size=1), one autoregressive_generate call per
+    clip): wall milliseconds per clip at B = 1, HIP-graph replay on (the call is launch-bound at this size), for the cfg2 model
+    (MNIST f4, L frames of 64x64) and the cfg4 model (config/mage_caterv1.yaml, 32 frames of 128x128, randomness branch with the
+    noise injected), both AR modes, the bf16 mode and the fast parity mode f16x3.  Median of 7 replays after warm-up + capture."""
+    import gc
+    from mage_amd.utils import synth
+    from mage_amd.utils.util import instantiate_from_config
+
+    def measure(model, batch):
+        out = {}
+        saved = (model.precision, model.ar_mode, model.use_graph, model.streams)
+        model.streams = 1
+        for prec in ("bf16", "f16x3"):
+            model.set_precision(prec)
+            for mode in ("full", "incremental"):
+                model.ar_mode = mode
+                row = {}
+                for graph in (True, False):
+                    model.use_graph = graph
+                    for _ in range(3):                       # eager warm-up, capture, first replay
+                        model.autoregressive_generate(batch)
+                    torch.cuda.synchronize()
+                    ts = []
+                    for _ in range(7):
+                        t0 = time.perf_counter()
+                        model.autoregressive_generate(batch)
+                        torch.cuda.synchronize()
+                        ts.append((time.perf_counter() - t0) * 1e3)
+                    row["graph" if graph else "eager"] = round(sorted(ts)[3], 3)
+                    row["replayed"] = row.get("replayed", False) or (graph and getattr(model, "last_call_mode", "eager") == "graph")
+                out[f"{prec}/{mode}"] = {"ms_per_clip": row["graph"] if row["replayed"] else row["eager"], "ms_per_clip_eager": row["eager"],
+                                         "graph_replayed": row["replayed"]}
+        model.set_precision(saved[0])
+        model.ar_mode, model.use_graph, model.streams = saved[1], saved[2], saved[3]
+        model._graphs = {}
+        return out
+    res = {"unit": "ms per clip (B = 1), wall, median of 7",
+           "note": "the reference samples one clip per call (main_mage.py:205,239-241); B = 1 equals row 0 of a larger batch bitwise "
+                   "(tests/test_gpu_parity.py::test_single_clip_equals_row_of_a_batch)"}
+    b2 = {k: v.to(dev) for k, v in synth.synth_batch_mnist(1, L, seed=77).items()}
+    res["cfg2_model"] = dict(measure(model2, b2), clip=f"{L} frames of 64x64")
+    gc.collect()
+    torch.cuda.empty_cache()
+    L4 = 32
+    m4 = instantiate_from_config(synth.cater_model_config(frames_length=L4)).eval()
+    synth.fill_state_dict(m4, 0)
+    m4 = m4.to(dev)
+    b4 = {k: v.to(dev) for k, v in synth.synth_batch_cater(1, L4, seed=78).items()}
+    b4["video_noise"] = torch.randn(1, 64, 16, 16, generator=torch.Generator().manual_seed(9)).to(dev)
+    res["cfg4_model"] = dict(measure(m4, b4), clip=f"{L4} frames of 128x128 (config/mage_caterv1.yaml, f8 VQ-VAE)")
+    del m4, b4
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +191,7 @@ def parse():
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 (parity-gated) pass and the bf16-vs-fp32 token agreement")
     ap.add_argument("--no-decode-roofline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--no-latency-b1", action="store_true", help="skip the B = 1 latency table (rank 0 at N = 1 only)")
     ap.add_argument("--cpu-clips", type=int, default=4, help="clips of the CPU baseline sample (4 = SURVEY cfg1, the reference's CPU-runnable batch)")
     return ap.parse_args()
 
@@ -336,6 +394,13 @@ def main():
         except Exception as e:                                   # never lets the secondary measurement take the bench line down
             train = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    lat = None
+    if rank == 0 and world == 1 and args.precision == "bf16" and not args.no_latency_b1:
+        try:
+            lat = latency_b1(model, dev, L)
+        except Exception as e:
+            lat = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * B * L * args.steps / dt
@@ -401,6 +466,7 @@ def main():
             "kernel_time_measured_in": "timed region" if args.events == "all" else "last warm-up call (every launch bracketed)",
             "other_ar_mode": other,
             "train_step": train,
+            "latency_b1": lat,
         }
         if replayed:
             res["config"]["graph_replay_note"] = ("the timed calls replay ONE captured HIP graph of the whole autoregressive_generate call "

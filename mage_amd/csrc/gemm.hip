@@ -1311,6 +1311,7 @@ int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
         static int few = -1;
         if (few < 0) few = (getenv("MAGE_GEMM_NO_NARROW") || getenv("MAGE_GEMM_NO_NARROW_FEW")) ? 0 : 1;
         const long tiles4 = (long)((d->M + 127) / 128) * ((d->N + BN - 1) / BN);
+        // (tiles4 == n_cu, the B = 64 incremental step, measured on the narrow tile: 31.5 vs 28.2 ms per call -- the 128 x 256 tile stays)
         if (few && d->n_split == 1 && tiles4 < n_cu && d->N % 64 == 0) return launch_tile<DT, GATHER, ACT, 2, EK, false, LN, 1>(d, s, n_cu);
     }
     const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + BN - 1) / BN) * d->n_split;

@@ -335,6 +335,93 @@ extern "C" int mage_vq_nearest(const float* z, const float* codebook_t, const fl
     return MAGE_OK;
 }
 
+// ------------------------------------------------------------------------------------ convolution of an embedding as a table sum
+// A k x k convolution (stride 1, zero padding (k-1)/2) over nn.Embedding rows has only n_codes distinct input vectors, so it is
+//     y[img, p, :] = pos[p, :] + sum over taps (ky, kx) of T[tap][ids[img, p + (ky, kx) - centre], :]      (taps outside the image: nothing)
+// with T[tap][code] = W_tap emb[code] precomputed once per weights (and any Linear applied to the result folded into T and pos).
+// One wave per output pixel: taps_h*taps_w rows of C floats gathered from a table that lives in L2 / Infinity Cache (9 x 512 x 512
+// fp32 = 9.4 MB at the MNIST config), summed in a fixed order in fp32, + a broadcast row table (the T positions), written to row
+// yrow = (m / group) * y_group_stride + m % group + y_off of y (m = img*H*W + p): the frame slots of the decoder's residual stream.
+namespace {
+template <typename TT_, int VPL>
+__global__ __launch_bounds__(256) void table_conv_kernel(const int64_t* __restrict__ ids, const TT_* __restrict__ table, const float* __restrict__ pos,
+                                                         const float* __restrict__ rowadd, float* __restrict__ y, long n_pix, int H, int W,
+                                                         int th, int tw, int n_codes, int C, long group, long y_group_stride, long y_off,
+                                                         long rowadd_div, int rowadd_mod, long ldy, int* __restrict__ err) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= n_pix) return;
+    const int lane = threadIdx.x & 63;
+    const int plane = H * W;
+    const long img = m / plane;
+    const int p = (int)(m - img * plane);
+    const int py = p / W, px = p - py * W;
+    f32x4 acc[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int c = j * 256 + lane * 4;
+        acc[j] = (pos && c < C) ? *(const f32x4*)(pos + (long)p * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t* img_ids = ids + img * plane;
+    for (int ky = 0; ky < th; ++ky) {
+        const int iy = py + ky - (th >> 1);
+        if ((unsigned)iy >= (unsigned)H) continue;
+        for (int kx = 0; kx < tw; ++kx) {
+            const int ix = px + kx - (tw >> 1);
+            if ((unsigned)ix >= (unsigned)W) continue;
+            long id = img_ids[iy * W + ix];
+            if (id < 0 || id >= n_codes) {      // the reference's nn.Embedding raises IndexError: reported by mage_check_device_errors
+                if (lane == 0) mage_raise(err, MAGE_DEVERR_EMBEDDING_ID, id, n_codes);
+                id = id < 0 ? 0 : n_codes - 1;
+            }
+            const TT_* row = table + ((long)(ky * tw + kx) * n_codes + id) * C;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const int c = j * 256 + lane * 4;
+                if (c < C) acc[j] += load4(row + c);
+            }
+        }
+    }
+    const long yrow = (m / group) * y_group_stride + m % group + y_off;
+    if (rowadd) {
+        const float* rp = rowadd + ((yrow / rowadd_div) % rowadd_mod) * (long)C;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const int c = j * 256 + lane * 4;
+            if (c < C) acc[j] += *(const f32x4*)(rp + c);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int c = j * 256 + lane * 4;
+        if (c < C) *(f32x4*)(y + yrow * ldy + c) = acc[j];
+    }
+}
+}  // namespace
+
+extern "C" int mage_table_conv(const int64_t* ids, int64_t n_img, int32_t H, int32_t W, int32_t taps_h, int32_t taps_w, const void* table,
+                               int32_t table_dtype, int32_t n_codes, int32_t C, const float* pos, const float* rowadd, int64_t rowadd_div,
+                               int32_t rowadd_mod, float* y, int64_t ldy, int64_t group, int64_t y_group_stride, int64_t y_off, void* stream) {
+    MAGE_CHECK_ARG(ids && table && y, "mage_table_conv: null pointer");
+    MAGE_CHECK_ARG(n_img > 0 && H > 0 && W > 0 && taps_h >= 1 && taps_w >= 1 && (taps_h & 1) && (taps_w & 1) && n_codes > 0 && C > 0 && C % 4 == 0 &&
+                       C <= 2048 && ldy >= C && ldy % 4 == 0 && group > 0,
+                   "mage_table_conv: bad sizes (odd taps, C %% 4 == 0, C <= 2048)");
+    MAGE_CHECK_ARG(!rowadd || (rowadd_div >= 1 && rowadd_mod >= 1), "mage_table_conv: bad rowadd div/mod");
+    MAGE_CHECK_ARG(table_dtype == MAGE_F32 || table_dtype == MAGE_BF16, "mage_table_conv: bad table dtype %d", table_dtype);
+    int* err = mage_error_word();
+    MAGE_CHECK_ARG(err != nullptr, "mage_table_conv: mage_init() has not been called");
+    const long n_pix = (long)n_img * H * W;
+    const dim3 grid((unsigned)((n_pix + 3) / 4)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+#define TC(T_, V) hipLaunchKernelGGL((table_conv_kernel<T_, V>), grid, blk, 0, s, ids, (const T_*)table, pos, rowadd, y, n_pix, H, W, taps_h, taps_w, n_codes, C, \
+                                     (long)group, (long)y_group_stride, (long)y_off, (long)rowadd_div, rowadd_mod, (long)ldy, err)
+    const int vpl = (C + 255) / 256;
+    if (table_dtype == MAGE_F32) { if (vpl <= 1) TC(float, 1); else if (vpl <= 2) TC(float, 2); else if (vpl <= 4) TC(float, 4); else TC(float, 8); }
+    else { if (vpl <= 1) TC(unsigned short, 1); else if (vpl <= 2) TC(unsigned short, 2); else if (vpl <= 4) TC(unsigned short, 4); else TC(unsigned short, 8); }
+#undef TC
+    MAGE_CHECK_LAUNCH("mage_table_conv");
+    return MAGE_OK;
+}
+
 extern "C" int mage_embedding(const int64_t* ids, const float* table, void* out, int32_t out_dtype, int64_t n, int32_t C,
                               int32_t n_table, int32_t relu, int64_t group, int64_t group_stride, int64_t off, int64_t inner,
                               int64_t inner_stride, void* stream) {

@@ -42,6 +42,20 @@ def _sfx(dt: torch.dtype) -> str:
 PRECISIONS = {"fp32": (F32, 0), "bf16": (BF16, 0), "bf16x3": (F32, ops.BF16X3), "f16x3": (F32, ops.F16X3)}   # name -> (dtype, split kind)
 
 
+class FrameTokens:
+    """Frames handed to the decoder as TOKEN IDS [n_img, hw] instead of features: conv3x3(embedding(ids)) + positions and the
+    decoder's in_linear are one table sum straight into the residual stream (MAGE._frame_tables, mage_table_conv)."""
+
+    def __init__(self, tokens: torch.Tensor, T2: torch.Tensor, P2: torch.Tensor, R: int):
+        self.tokens, self.T2, self.P2, self.R = tokens.contiguous(), T2, P2, R
+
+    def fill(self, x: torch.Tensor, *, n_img: int, per_clip: int, P: int, y_off: int, tp: torch.Tensor) -> None:
+        """Rows (clip b, slot y_off/hw + l) of x [B*P*hw, C] fp32 <- in_linear(conv(emb(ids[b, l])) + H/W positions) + T positions."""
+        hw = self.R * self.R
+        ops.table_conv(self.tokens, self.T2, x, n_img=n_img, H=self.R, W=self.R, pos=self.P2, rowadd=tp, rowadd_div=hw, rowadd_mod=P,
+                       ldy=x.shape[1], group=per_clip * hw, y_group_stride=P * hw, y_off=y_off)
+
+
 def _wsplit(d: Dict[str, torch.Tensor], name: str, kind: int) -> torch.Tensor:
     """Split-precision copy of the fp32 weight d[name + '.f32'] ([N, K] -> [N, 2K] 16-bit pieces), built on first use."""
     key = f"{name}.s{kind}"
@@ -431,8 +445,11 @@ class FlatAxialDecoder(nn.Module):
         # context_linear -> slot 0, in_linear -> slots 1..L-1, + T_positional_embedding, no concat copy (:375-378)
         _linear(motion, d, "context_linear", x, dt, M=B * hw, N=Cc, K=self.context_channels, out_w=hw, y_img_stride=L * hw,
                 rowadd=d["tpos"], rowadd_div=hw, rowadd_mod=L)
-        _linear(imgs, d, "in_linear", x, dt, M=B * (L - 1) * hw, N=Cc, K=self.in_channels, out_w=(L - 1) * hw,
-                y_img_stride=L * hw, y_off=hw, rowadd=d["tpos"], rowadd_div=hw, rowadd_mod=L)
+        if isinstance(imgs, FrameTokens):
+            imgs.fill(x, n_img=B * (L - 1), per_clip=L - 1, P=L, y_off=hw, tp=d["tpos"])
+        else:
+            _linear(imgs, d, "in_linear", x, dt, M=B * (L - 1) * hw, N=Cc, K=self.in_channels, out_w=(L - 1) * hw,
+                    y_img_stride=L * hw, y_off=hw, rowadd=d["tpos"], rowadd_div=hw, rowadd_mod=L)
         xn = torch.empty(M, Cc, device=dev, dtype=dt)
         qkv = torch.empty(M, 3 * Cc, device=dev, dtype=dt)
         ao = torch.empty(M, Cc, device=dev, dtype=dt)
@@ -510,7 +527,8 @@ class FlatAxialDecoder(nn.Module):
         if self._split_on():
             return self._inc_step_split(st, motion, imgs)
         d = self._derived.get(self._build)
-        dt, Cc, L, dev = self.compute_dtype, self.model_channels, self.frames_length, imgs.device
+        dt, Cc, L = self.compute_dtype, self.model_channels, self.frames_length
+        dev = imgs.tokens.device if isinstance(imgs, FrameTokens) else imgs.device
         B, hh, ww = st["B"], st["hh"], st["ww"]
         hw, H = hh * ww, Cc // 32
         p0 = st["p"]
@@ -522,8 +540,11 @@ class FlatAxialDecoder(nn.Module):
         if motion is not None:
             _linear(motion, d, "context_linear", x, dt, M=B * hw, N=Cc, K=self.context_channels, out_w=hw, y_img_stride=P * hw,
                     rowadd=tp, rowadd_div=hw, rowadd_mod=P)
-        _linear(imgs, d, "in_linear", x, dt, M=B * hw, N=Cc, K=self.in_channels, out_w=hw, y_img_stride=P * hw,
-                y_off=(P - 1) * hw, rowadd=tp, rowadd_div=hw, rowadd_mod=P)
+        if isinstance(imgs, FrameTokens):
+            imgs.fill(x, n_img=B, per_clip=1, P=P, y_off=(P - 1) * hw, tp=tp)
+        else:
+            _linear(imgs, d, "in_linear", x, dt, M=B * hw, N=Cc, K=self.in_channels, out_w=hw, y_img_stride=P * hw,
+                    y_off=(P - 1) * hw, rowadd=tp, rowadd_div=hw, rowadd_mod=P)
         xn = torch.empty(M, Cc, device=dev, dtype=dt)
         qkv = torch.empty(M, 3 * Cc, device=dev, dtype=dt)
         ao = torch.empty(M, Cc, device=dev, dtype=dt)
@@ -612,7 +633,8 @@ class FlatAxialDecoder(nn.Module):
         """context_linear -> slot 0 (if motion), in_linear -> the other slot(s), + T positions: rows of x [B*P*hw, C] fp32.
         motion fp32 rows; imgs split rows (from _frame_features in split mode) or fp32 rows."""
         sk, Cc = self.split_kind, self.model_channels
-        img_split = imgs.dtype != F32
+        img_tok = isinstance(imgs, FrameTokens)
+        img_split = (not img_tok) and imgs.dtype != F32
         if motion is not None:
             if self._taps_ok(B * hw):
                 self._lin_s(ops.split(motion, sk), d, "context_linear", x, M=B * hw, N=Cc, K=self.context_channels, out_w=hw,
@@ -621,7 +643,9 @@ class FlatAxialDecoder(nn.Module):
                 _linear(motion, d, "context_linear", x, F32, M=B * hw, N=Cc, K=self.context_channels, out_w=hw, y_img_stride=P * hw,
                         rowadd=tp, rowadd_div=hw, rowadd_mod=P)
         off = hw if motion is not None else 0
-        if img_split:
+        if img_tok:
+            imgs.fill(x, n_img=n_img_rows // hw, per_clip=n_img_rows // hw // B, P=P, y_off=off, tp=tp)
+        elif img_split:
             self._lin_s(imgs, d, "in_linear", x, M=n_img_rows, N=Cc, K=self.in_channels, out_w=n_img_rows // B, y_img_stride=P * hw,
                         y_off=off, rowadd=tp, rowadd_div=hw, rowadd_mod=P)
         else:
@@ -676,7 +700,8 @@ class FlatAxialDecoder(nn.Module):
     @torch.no_grad()
     def _inc_step_split(self, st: dict, motion: Optional[torch.Tensor], imgs: torch.Tensor) -> torch.Tensor:
         d = self._derived.get(self._build)
-        sk, Cc, L, dev = self.split_kind, self.model_channels, self.frames_length, imgs.device
+        sk, Cc, L = self.split_kind, self.model_channels, self.frames_length
+        dev = imgs.tokens.device if isinstance(imgs, FrameTokens) else imgs.device
         B, hh, ww = st["B"], st["hh"], st["ww"]
         hw, H = hh * ww, Cc // 32
         p0 = st["p"]
@@ -807,6 +832,7 @@ class MAGE(nn.Module):
         self.last_call_mode = "eager"
         self._pad_frames: dict = {}    # zero-padded frame buffers of _frame_features (bf16 mode), by (images, device, stream)
         self.use_graph = False         # True: autoregressive_generate replays a captured HIP graph of the whole call (see there)
+        self.frame_table = True        # conv3x3(token embedding) (+ in_linear) as a table sum (_frame_tables); False: the convolution GEMM
         self._graphs: dict = {}
         self._derived = _Derived(self)
         self.last_tokens: Optional[torch.Tensor] = None
@@ -888,6 +914,48 @@ class MAGE(nn.Module):
         return out.view(*x.shape[:2], *out.shape[1:]).contiguous()
 
     # ------------------------------------------------------------------ shared pieces
+    def _frame_tables(self):
+        """conv3x3 over token EMBEDDINGS has only codebook_size distinct input vectors (mage_model.py:581,586-588): by linearity
+            conv(emb(ids))[p] = sum_taps T[tap][ids[p + tap]],   T[tap][code] = W_tap emb[code]        [9, K, C] fp32
+        and the decoder's in_linear applied to it (+ H/W positions, + bias) folds in as well:
+            T2[tap][code] = W_in T[tap][code],   P2[p] = W_in (H_pos + W_pos)[p] + b_in               (mage_model.py:375-376)
+        Built once per weights on the fp32 MFMA kernels (a derived cache like the folded BatchNorm vectors); 9.4 MB each at the MNIST
+        config: resident in L2 / Infinity Cache.  The per-call work becomes a gather-sum (mage_table_conv): 0 matrix-core FLOPs for
+        the 2*9*C^2 + 2*C^2 per pixel the reference spends (11 % of a decoder iteration), fp32-exact sums in every precision mode.
+        Returns the cache dict with 'ft.T', 'ft.T2', 'ft.P2' (None when not applicable: use_cids=False, MAGE_NO_FRAME_TABLE=1); `self.frame_table = False`
+        switches the callers back to the convolution GEMM + in_linear (the reference's operation order) at any time."""
+        d = self._derived.get(self._build)
+        if "ft.T" in d:
+            return d
+        R, Cc, Kc = self.image_resolution, self.vision_width, self.codebook_size
+        gm = self.generate_model
+        ok = (self.use_cids and not os.environ.get("MAGE_NO_FRAME_TABLE") and Cc % 4 == 0
+              and 9 * Kc * max(Cc, getattr(gm, "model_channels", Cc)) * 4 <= (256 << 20) and "emb" in d and d["emb"].is_cuda
+              and getattr(gm, "in_channels", None) == Cc and hasattr(gm, "_build"))
+        if not ok:
+            d["ft.T"] = d["ft.T2"] = d["ft.P2"] = None
+            return d
+        gd = gm._derived.get(gm._build)
+        Cd = gm.model_channels
+        emb, dev = d["emb"], d["emb"].device
+        cw = d["conv.f32"].view(Cc, 9, Cc)
+        T = torch.empty(9, Kc, Cc, device=dev, dtype=F32)
+        T2 = torch.empty(9, Kc, Cd, device=dev, dtype=F32)
+        w_in = gd["in_linear.f32"]
+        for tap in range(9):
+            ops.gemm(emb, cw[:, tap].contiguous(), T[tap], M=Kc, N=Cc, K=Cc, lda=Cc, ldy=Cc)
+            ops.gemm(T[tap], w_in, T2[tap], M=Kc, N=Cd, K=Cc, lda=Cc, ldy=Cd)
+        P2 = ops.gemm(d["hwpos"], w_in, torch.empty(R * R, Cd, device=dev, dtype=F32), M=R * R, N=Cd, K=Cc, lda=Cc, ldy=Cd, bias=gd.get("in_linear.b"))
+        d["ft.T"], d["ft.T2"], d["ft.P2"] = T, T2, P2
+        return d
+
+    def _frame_source(self, tokens: torch.Tensor, dt: torch.dtype):
+        """What the decoder gets for its frame slots: FrameTokens (table sum, in_linear folded) or the convolved features."""
+        ft = self._frame_tables()
+        if ft["ft.T2"] is not None and getattr(self, "frame_table", True):
+            return FrameTokens(tokens.reshape(-1, self.image_resolution ** 2), ft["ft.T2"], ft["ft.P2"], self.image_resolution)
+        return self._frame_features(tokens, dt, split=True)
+
     def _frame_features(self, tokens: torch.Tensor, dt: torch.dtype, split: bool = False) -> torch.Tensor:
         """ids [n, hw] -> conv3x3(embedding) + (H_pos + W_pos) as rows [n*hw, C] (mage_model.py:581,586-588,674-676).
 
@@ -898,6 +966,11 @@ class MAGE(nn.Module):
         d = self._derived.get(self._build)
         R, Cc = self.image_resolution, self.vision_width
         n = tokens.numel() // (R * R)
+        if dt == F32 and not split:
+            ft = self._frame_tables()
+            if ft["ft.T"] is not None and getattr(self, "frame_table", True):                  # the once-per-clip prologue: fp32 features
+                return ops.table_conv(tokens.reshape(-1).contiguous(), ft["ft.T"], torch.empty(n * R * R, Cc, device=tokens.device, dtype=F32),
+                                      n_img=n, H=R, W=R, pos=d["hwpos"])
         sk = self._sk() if split else 0
         if sk and Cc % 256 == 0 and (n * R * R) % 256 == 0 and self.generate_model._taps_ok(n * R * R):
             # fast parity modes: the same padded-taps convolution on split-precision operands; the features leave as split rows
@@ -1015,7 +1088,7 @@ class MAGE(nn.Module):
         if prof != "off" and not ops.graph_events_supported(batch["images"].device):
             return self._generate_eager(batch)              # per-launch events wanted, but they cannot be captured here
         key = (tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items())), self.precision, self.ar_mode, gens, prof,
-               str(batch["images"].device))
+               str(batch["images"].device), bool(getattr(self, "frame_table", True)))
         ent = self._graphs.get(key)
         if ent is None:
             self._graphs = {k: v for k, v in self._graphs.items() if k[3] == gens}       # graphs of replaced weights are dead
@@ -1053,6 +1126,7 @@ class MAGE(nn.Module):
         for mod in (self.generate_model, self.ma_encoder, self.text_encoder, getattr(self, "adain", None), self.first_stage_model):
             if mod is not None and hasattr(mod, "_derived") and hasattr(mod, "_build"):
                 mod._derived.get(mod._build)
+        self._frame_tables()
 
     def _generate_multistream(self, batch, n):
         B = batch["images"].shape[0]
@@ -1121,7 +1195,7 @@ class MAGE(nn.Module):
             st = self.generate_model._inc_begin(B, R, R, images.device)
             prev = tok0.contiguous()
             for i in range(Lm1):
-                feats = self._frame_features(prev, dt, split=True)                            # newest frame only
+                feats = self._frame_source(prev, dt)                                          # newest frame only
                 step_logits = self.generate_model._inc_step(st, ma_dt if i == 0 else None, feats)
                 prev = torch.empty(B, hw, device=images.device, dtype=torch.int64)
                 ops.argmax(step_logits, prev, rows=B * hw, K=K)
@@ -1132,7 +1206,7 @@ class MAGE(nn.Module):
         cur = tok0[:, None, :].repeat(1, Lm1, 1).contiguous()                                 # :670 future slots hold frame 0
         logits = None
         for i in range(Lm1):                                                                  # :673-684
-            feats = self._frame_features(cur, dt, split=True)
+            feats = self._frame_source(cur, dt)
             logits = self.generate_model._run(ma_dt, feats, B=B, hh=R, ww=R)                  # [B*(L-1)*hw, K]
             if i != Lm1 - 1:                                                                  # argmax of frame i -> slot i+1
                 ops.argmax(logits, cur, rows=B * hw, K=K, group=hw, in_group_stride=Lm1 * hw, in_off=i * hw,
@@ -1236,7 +1310,7 @@ class MAGE(nn.Module):
         tok = self.first_stage_encode(images).reshape(B, -1, R * R)                          # :579
         video_rows = self._reparam_video_rows(batch, B, extras, tok=tok) if self.randomness else None
         ma = self._motion_anchor(tok[:, 0].contiguous(), batch, None, video_rows=video_rows)
-        feats = self._frame_features(tok[:, :L - 1].contiguous(), dt, split=True)
+        feats = self._frame_source(tok[:, :L - 1].contiguous(), dt)
         logits = self.generate_model._run(ma if dt == F32 else ma.to(dt), feats, B=B, hh=R, ww=R)
         return tok.view(B, -1, R, R), logits.view(B, L - 1, R, R, self.codebook_size)
 

@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, BF16X3, F16X3, F32, AttnDesc, GemmDesc
 
-__all__ = ["gemm", "layernorm", "attention", "embedding", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
+__all__ = ["gemm", "layernorm", "attention", "embedding", "table_conv", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
            "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mse", "check_device_errors", "graph_events_supported", "transpose", "row_sum", "sum_partials", "layernorm_bwd", "act", "act_bwd", "cross_entropy_bwd", "embedding_bwd", "group_rowsum", "attention_bwd", "dropout", "adam", "bn_train_stats", "bn_apply", "bn_backward", "convt_unfold_tanh_bwd", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
            "split", "split_empty", "split_dtype", "PROFILE", "F32", "BF16", "BF16X3", "F16X3", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
 
@@ -390,6 +390,24 @@ def embedding(ids: torch.Tensor, table: torch.Tensor, out: torch.Tensor, *, relu
     _lib.check(l.mage_embedding(ids.data_ptr(), table.data_ptr(), out.data_ptr(), split_kind or code(out), n, table.shape[1],
                                 table.shape[0], int(relu), group, group_stride, off, inner, inner_stride, s), l)
     return out
+
+
+def table_conv(ids: torch.Tensor, table: torch.Tensor, y: torch.Tensor, *, n_img: int, H: int, W: int, taps: int = 3, pos=None, rowadd=None,
+               rowadd_div: int = 1, rowadd_mod: int = 1, ldy: Optional[int] = None, group: Optional[int] = None,
+               y_group_stride: Optional[int] = None, y_off: int = 0) -> torch.Tensor:
+    """y rows = pos + sum of table[tap][ids[neighbour]] + rowadd: a k x k convolution of embedding rows as a table sum (mage_table_conv)."""
+    l, s = _dev(table)
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == n_img * H * W and y.dtype == torch.float32
+    assert table.dim() == 3 and table.shape[0] == taps * taps and table.is_contiguous()
+    Cc = table.shape[2]
+    group = n_img * H * W if group is None else group
+    y_group_stride = group if y_group_stride is None else y_group_stride
+    ev = PROFILE.begin() if PROFILE.wants("table_conv") else None
+    _lib.check(l.mage_table_conv(ids.data_ptr(), n_img, H, W, taps, taps, table.data_ptr(), code(table), table.shape[1], Cc, _p(pos), _p(rowadd),
+                                 rowadd_div, rowadd_mod, y.data_ptr(), Cc if ldy is None else ldy, group, y_group_stride, y_off, s), l)
+    if ev is not None:
+        PROFILE.end("table_conv", ev, 0.0, float(n_img) * H * W * Cc * (taps * taps * table.element_size() + 4))
+    return y
 
 
 def vq_prepare(codebook: torch.Tensor):

@@ -564,3 +564,38 @@ def test_vq_nearest_on_the_fp64_matrix_cores(M, D, K):
     srt = dist.sort(dim=1, stable=True)                                    # stable: the first minimum wins, as in the reference
     assert torch.equal(ids, srt.indices[:, 0])
     torch.testing.assert_close(mg, srt.values[:, 1] - srt.values[:, 0], atol=0, rtol=0)
+
+
+def test_table_conv_equals_convolution_of_embeddings_and_folded_linear():
+    """mage_table_conv: conv3x3(embedding(ids)) + positions (+ a Linear folded into the table) as a gather-sum, against torch's conv2d
+    on the embedded image (fp64), incl. border pixels, regrouped output rows and the broadcast row table."""
+    from mage_amd import ops as o
+    g = torch.Generator().manual_seed(8)
+    Kc, C, Cd, R, B, Lm1, L = 48, 64, 128, 6, 2, 3, 4
+    emb = torch.randn(Kc, C, generator=g).to(DEV)
+    cw = (torch.randn(C, C, 3, 3, generator=g) * 0.1).to(DEV)                      # [Cout, Cin, kh, kw]
+    w_in = (torch.randn(Cd, C, generator=g) * 0.1).to(DEV)
+    b_in = torch.randn(Cd, generator=g).to(DEV)
+    pos = torch.randn(R * R, C, generator=g).to(DEV)
+    tpos = torch.randn(L, Cd, generator=g).to(DEV)
+    ids = torch.randint(0, Kc, (B * Lm1, R * R), generator=g).to(DEV)
+    T = torch.stack([emb.double() @ cw[:, :, ky, kx].double().t() for ky in range(3) for kx in range(3)]).float().contiguous()     # [9, Kc, C]
+    y = o.table_conv(ids, T, torch.empty(B * Lm1 * R * R, C, device=DEV), n_img=B * Lm1, H=R, W=R, pos=pos)
+    img = emb[ids].view(B * Lm1, R, R, C).permute(0, 3, 1, 2).double()
+    want = torch.nn.functional.conv2d(img, cw.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, C) + pos.double().repeat(B * Lm1, 1)
+    torch.testing.assert_close(y.double(), want, rtol=1e-5, atol=1e-5)
+    # the decoder form: in_linear folded, frames written into slots 1.. of [B, L, hw, Cd] with the T positions
+    T2 = (T.double() @ w_in.double().t()).float().contiguous()
+    P2 = (pos.double() @ w_in.double().t() + b_in.double()).float().contiguous()
+    x = torch.full((B * L * R * R, Cd), 7.0, device=DEV)
+    o.table_conv(ids, T2, x, n_img=B * Lm1, H=R, W=R, pos=P2, rowadd=tpos, rowadd_div=R * R, rowadd_mod=L, group=Lm1 * R * R,
+                 y_group_stride=L * R * R, y_off=R * R)
+    xw = x.view(B, L, R * R, Cd)
+    assert (xw[:, 0] == 7.0).all()                                                  # slot 0 (the motion anchor's) untouched
+    want2 = (want @ w_in.double().t() + b_in.double()).view(B, Lm1, R * R, Cd) + tpos.double()[1:].view(1, Lm1, 1, Cd)
+    torch.testing.assert_close(xw[:, 1:].double(), want2, rtol=1e-5, atol=2e-5)
+    bad = ids.clone()
+    bad[0, 0] = Kc
+    o.table_conv(bad, T, torch.empty(B * Lm1 * R * R, C, device=DEV), n_img=B * Lm1, H=R, W=R)
+    with pytest.raises(ValueError, match="out of range"):
+        o.check_device_errors(DEV)

@@ -566,3 +566,27 @@ def test_graph_replay_carries_per_kernel_events():
         assert set(s) == {"layernorm"} and s["layernorm"]["calls"] == 2 * per_call and 0.0 < s["layernorm"]["ms"] < 1e3
     finally:
         ops.PROFILE.reset()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "f16x3"])
+def test_frame_table_path_against_the_convolution_path(precision):
+    """conv3x3(token embedding) + in_linear as a table sum (MAGE._frame_tables, the default) against the reference's operation order
+    (embedding -> convolution GEMM -> in_linear GEMM; model.frame_table = False): same tokens on the golden batch in the parity
+    modes, logits within fp32 rounding (fp32 / f16x3) resp. the bf16 error (bf16: the table path is the more exact of the two)."""
+    g = golden("mage_mnist_L6_ragged")
+    B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
+    m = build_mage(synth.mnist_model_config(frames_length=L), seed, DEV).set_precision(precision)
+    batch = dev_batch(synth.synth_batch_mnist(B, L, seed=seed, digits=int(g["digits"]), text_len=int(g["text_len"]), ragged_text=True))
+    assert m._frame_tables()["ft.T2"] is not None
+    tok_t, lg_t = m.teacher_forced_logits(batch)
+    m.frame_table = False
+    tok_c, lg_c = m.teacher_forced_logits(batch)
+    assert torch.equal(tok_t, tok_c)
+    err = (lg_t - lg_c).abs().max().item()
+    print(f"{precision}: teacher-forced logits, table path vs convolution path: {err:.2e}")
+    assert err < (2e-5 if precision != "bf16" else 0.06)
+    if precision != "bf16":
+        for ft in (False, True):
+            m.frame_table = ft
+            m.autoregressive_generate(batch)
+            assert assert_tokens(m.last_tokens.cpu(), g["gen_tokens"], g["margin"], TOK_TOL, f"AR tokens, frame_table={ft}") == 0

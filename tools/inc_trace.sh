@@ -20,6 +20,17 @@ for r in last:
     a = agg.setdefault(k, [0, 0])
     a[0] += 1
     a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+# one AR iteration in launch order (the 60 launches that end the second-to-last decoder iteration of the last call)
+import re
+seq = [r for r in last if "Cijk" not in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(seq) if "argmax" in r["Kernel_Name"]]
+if len(idx) >= 3:
+    a, b = idx[-3], idx[-2]
+    t0 = int(seq[a]["End_Timestamp"])
+    print(f"--- one AR iteration ({b - a} launches, {(int(seq[b]['End_Timestamp']) - t0) / 1e3:.1f} us):")
+    for r in seq[a + 1:b + 1]:
+        nm = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])[:70]
+        print(f"   +{(int(r['Start_Timestamp']) - t0) / 1e3:8.1f}  {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:7.1f} us  {nm}  grid={r['Grid_Size_X']}")
 for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"{t/1e3:9.1f} us  {c:4d} x {t/c/1e3:7.1f} us  {k}")
 PY
