@@ -216,14 +216,16 @@ int mage_embedding(const int64_t* ids, const float* table, void* out, int32_t ou
 /* k x k convolution (stride 1, zero padding (k-1)/2, no bias) of nn.Embedding rows as a TABLE SUM -- the frame convolution
  * `conv(visual_token_embedding(ids))` of mage_model.py:581,586-588,674-676 (and, folded in by linearity, the `in_linear` that consumes it
  * :375-376 and its bias): the input has only n_codes distinct vectors, so
- *     y[yrow(m), :] = pos[p, :] + sum_{taps inside the image} table[tap][ids[img, neighbour], :] + rowadd[(yrow / rowadd_div) % rowadd_mod, :]
+ *     y[yrow(m), :] = act(pos[p, :] + bias[:] + sum_{taps inside the image} table[tap][ids[img, neighbour], :] + rowadd[(yrow / rowadd_div) % rowadd_mod, :])
  * m = img*H*W + p, yrow(m) = (m / group)*y_group_stride + m % group + y_off; table [taps_h*taps_w][n_codes][C] (fp32 or bf16) = W_tap emb[code]
- * precomputed once per weights by the caller (derived cache; 9.4 MB at the MNIST config: resident in L2 / Infinity Cache), pos [H*W][C] and
- * rowadd optional fp32 tables; fp32 sums in a fixed order; y fp32.  0 FLOP on the matrix cores instead of 2*9*C*C per pixel.
+ * precomputed once per weights by the caller (derived cache; 9.4 MB at the MNIST config: resident in L2 / Infinity Cache), pos [H*W][C], bias [C]
+ * and rowadd optional fp32 tables; act = ReLU if relu; fp32 sums in a fixed order; y fp32 or bf16.  0 FLOP on the matrix cores instead of
+ * 2*9*C*C per pixel.  Also the first 3x3 convolution of the f4 VQ-VAE decoder (vqvae_model.py:111-124,180: conv(relu(codebook[ids]))).
  * An id outside [0, n_codes) is recorded for mage_check_device_errors like mage_embedding's. */
 int mage_table_conv(const int64_t* ids, int64_t n_img, int32_t H, int32_t W, int32_t taps_h, int32_t taps_w, const void* table,
-                    int32_t table_dtype, int32_t n_codes, int32_t C, const float* pos, const float* rowadd, int64_t rowadd_div,
-                    int32_t rowadd_mod, float* y, int64_t ldy, int64_t group, int64_t y_group_stride, int64_t y_off, void* stream);
+                    int32_t table_dtype, int32_t n_codes, int32_t C, const float* pos, const float* bias, int32_t relu, const float* rowadd,
+                    int64_t rowadd_div, int32_t rowadd_mod, void* y, int32_t y_dtype, int64_t ldy, int64_t group, int64_t y_group_stride,
+                    int64_t y_off, void* stream);
 
 /* Nearest codebook entry, reference formula and tie-break (vqvae_model.py:8-25):
  *   dist[m,k] = (|c_k|^2 + |z_m|^2) - 2 * <z_m, c_k>,  idx[m] = first k attaining the minimum.

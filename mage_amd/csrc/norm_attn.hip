@@ -294,6 +294,134 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const mage_attn_des
     }
 }
 
+// Few queries, many sequences (the incremental AR step's temporal attention: nq = 1 or 2 new positions against a K,V cache of up to
+// 32, 16384 sequences at cfg2): one WAVE per sequence, no LDS, no barrier.  Per (sequence, head) the SAME instruction sequence on the
+// same operand values as attention_mfma_kernel (S^T = K Q^T by one 16x16x32 MFMA, in-lane softmax + two xor-shuffles, P = hi + lo,
+// O^T = V^T P^T by 16x16x16 MFMAs) -- the incremental loop's tokens stay bit-identical to the full pass's -- with the V rows in a
+// wave-private LDS tile (rows beyond nk are clamped copies: their probabilities are exactly 0) and four heads' loads in flight before
+// the first MFMA.  The workgroup-per-sequence kernel
+// spends its time in per-workgroup latency at this shape (V staging + barrier for ONE query): 107 us per launch at cfg2 against
+// ~55 us of K,V cache bytes.
+template <int NKB>
+__global__ __launch_bounds__(256) void attention_mfma_fewq_kernel(const mage_attn_desc d) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= d.n_seq) return;
+    const int outer = s / d.inner, in = s - outer * d.inner;
+    const long q_base = (long)outer * d.q_outer_stride + in;
+    const long kv_base = (long)outer * d.kv_outer_stride + in;
+    const unsigned short* qp = (const unsigned short*)d.q;
+    const unsigned short* kp = (const unsigned short*)d.k;
+    const unsigned short* vp = (const unsigned short*)d.v;
+    unsigned short* op = (unsigned short*)d.out;
+    int klen = d.nk;
+    if (d.kv_len) klen = min(klen, d.kv_len[s / d.kv_len_div]);
+    const int r = lane & 15, g = lane >> 4;
+    const int qi = r;                                                         // nq <= 16: one query block
+    const long qrow = q_base + (long)min(qi, d.nq - 1) * d.q_axis_stride;
+    const int jmax = d.causal ? min(klen, qi + 1 + (d.nk - d.nq)) : klen;
+    long krow[NKB], krow_v[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        krow[kb] = (kv_base + (long)min(kb * 16 + r, d.nk - 1) * d.kv_axis_stride) * d.ldk;
+        krow_v[kb] = (kv_base + (long)min(kb * 16 + r, d.nk - 1) * d.kv_axis_stride) * d.ldv;
+    }
+    // chunks of CH heads: their loads are all in flight before the first MFMA.  (Measured: a software-pipelined variant -- chunk c+1's
+    // loads under chunk c's arithmetic -- needs 168 VGPRs, 2 waves per SIMD, and is SLOWER: 105 us at nk = 2 against 74; this kernel
+    // lives off occupancy.)
+    // V^T fragments (lane (n, g) needs V[4g+e][n], e = 0..3: a column walk): each lane loads 16 bytes of a V row like a K fragment,
+    // parks them in a WAVE-PRIVATE LDS tile (no barrier: one wave's DS operations execute in order) and reads its four 2-byte values
+    // back.  (Fetched as 2-byte global loads the kernel was bound by the texture addresser: 75 us at nk = 2.)
+    constexpr int CH = 4, VP = 40;                                           // 80-byte LDS rows
+    __shared__ unsigned short vsm[4][CH][NKB * 16][VP];
+    const int wv = threadIdx.x >> 6;
+    uint4 kf[1][CH][NKB], qf[1][CH];
+    ashort4 vt[1][CH][2][NKB];
+    auto load_chunk = [&](int buf, int h0) {
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+            const int h = min(h0 + t, d.n_head - 1);
+            qf[buf][t] = *(const uint4*)(qp + qrow * d.ldq + h * 32 + g * 8);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                kf[buf][t][kb] = *(const uint4*)(kp + krow[kb] + h * 32 + g * 8);
+                *(uint4*)&vsm[wv][t][kb * 16 + r][g * 8] = *(const uint4*)(vp + krow_v[kb] + h * 32 + g * 8);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < CH; ++t)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vt[buf][t][b][kb][e] = (short)vsm[wv][t][kb * 16 + 4 * g + e][b * 16 + r];
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto compute_chunk = [&](int buf, int h0) {
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+            const int h = h0 + t;
+            if (h >= d.n_head) break;
+            f32x4 st[NKB];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(abf16x8, kf[buf][t][kb]), __builtin_bit_cast(abf16x8, qf[buf][t]),
+                                                                 f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    st[kb][e] = (kb * 16 + 4 * g + e < jmax) ? st[kb][e] * d.scale : -INFINITY;
+                    mx = fmaxf(mx, st[kb][e]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float den = 0.f;
+            ashort4 phi[NKB], plo[NKB];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = (kb * 16 + 4 * g + e < jmax) ? expf(st[kb][e] - mx) : 0.f;
+                    den += p;
+                    const unsigned hb = __float_as_uint(p) & 0xffff0000u;
+                    phi[kb][e] = (short)(hb >> 16);
+                    plo[kb][e] = (short)(__float_as_uint(p - __uint_as_float(hb)) >> 16);
+                }
+            den += __shfl_xor(den, 16);
+            den += __shfl_xor(den, 32);
+            f32x4 o[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                o[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt[buf][t][b][kb], phi[kb], o[b], 0, 0, 0);
+                    o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt[buf][t][b][kb], plo[kb], o[b], 0, 0, 0);
+                }
+            }
+            const float inv = 1.0f / den;
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[0][e]), __float_as_uint(o[1][e]), false, false);
+                v0[e] = __uint_as_float(sw[0]) * inv;
+                v1[e] = __uint_as_float(sw[1]) * inv;
+            }
+            if (qi < d.nq) {
+                const int col = h * 32 + 16 * (g & 1) + 8 * (g >> 1);
+                store8(op + (q_base + (long)qi * d.q_axis_stride) * d.ldo + col, v0, v1);
+            }
+        }
+    };
+    for (int h0 = 0; h0 < d.n_head; h0 += CH) {
+        load_chunk(0, h0);
+        compute_chunk(0, h0);
+    }
+}
+
 // ------------------------------------------------------------------------------------ ADAIN
 // grid = (B, C/64); block 256 = 64 channels x 4 position phases.
 __global__ __launch_bounds__(256) void adain_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -365,6 +493,13 @@ int attn_launch(const mage_attn_desc* d, hipStream_t s) {
         if (d->nq <= 32 && d->nk <= 32 && d->n_head <= 32 && !getenv("MAGE_ATTN_NO_MFMA") &&
             ((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->out) & 15) == 0)) {
             const int nkb = d->nk <= 16 ? 1 : 2;
+            if (d->nq <= 2 && d->n_seq >= 1024 && !getenv("MAGE_ATTN_NO_FEWQ")) {      // the incremental step's temporal attention
+                const dim3 grid((unsigned)((d->n_seq + 3) / 4));
+                if (nkb == 1) hipLaunchKernelGGL((attention_mfma_fewq_kernel<1>), grid, dim3(256), 0, s, *d);
+                else hipLaunchKernelGGL((attention_mfma_fewq_kernel<2>), grid, dim3(256), 0, s, *d);
+                MAGE_CHECK_LAUNCH("mage_attention");
+                return MAGE_OK;
+            }
             const size_t lds = (size_t)16 * nkb * (d->n_head * 32 + 16) * 2;
             const int hpw = (d->n_head + 3) / 4;
 #define ATTN_MFMA(NKB, MH) hipLaunchKernelGGL((attention_mfma_kernel<NKB, MH>), dim3(d->n_seq), dim3(256), lds, s, *d)

@@ -343,9 +343,10 @@ extern "C" int mage_vq_nearest(const float* z, const float* codebook_t, const fl
 // fp32 = 9.4 MB at the MNIST config), summed in a fixed order in fp32, + a broadcast row table (the T positions), written to row
 // yrow = (m / group) * y_group_stride + m % group + y_off of y (m = img*H*W + p): the frame slots of the decoder's residual stream.
 namespace {
-template <typename TT_, int VPL>
+template <typename TT_, typename OT, int VPL>
 __global__ __launch_bounds__(256) void table_conv_kernel(const int64_t* __restrict__ ids, const TT_* __restrict__ table, const float* __restrict__ pos,
-                                                         const float* __restrict__ rowadd, float* __restrict__ y, long n_pix, int H, int W,
+                                                         const float* __restrict__ bias, int relu,
+                                                         const float* __restrict__ rowadd, OT* __restrict__ y, long n_pix, int H, int W,
                                                          int th, int tw, int n_codes, int C, long group, long y_group_stride, long y_off,
                                                          long rowadd_div, int rowadd_mod, long ldy, int* __restrict__ err) {
     const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -360,6 +361,7 @@ __global__ __launch_bounds__(256) void table_conv_kernel(const int64_t* __restri
     for (int j = 0; j < VPL; ++j) {
         const int c = j * 256 + lane * 4;
         acc[j] = (pos && c < C) ? *(const f32x4*)(pos + (long)p * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias && c < C) acc[j] += *(const f32x4*)(bias + c);
     }
     const int64_t* img_ids = ids + img * plane;
     for (int ky = 0; ky < th; ++ky) {
@@ -393,30 +395,42 @@ __global__ __launch_bounds__(256) void table_conv_kernel(const int64_t* __restri
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
         const int c = j * 256 + lane * 4;
-        if (c < C) *(f32x4*)(y + yrow * ldy + c) = acc[j];
+        if (c < C) {
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][e] = fmaxf(acc[j][e], 0.f);
+            }
+            store4(y + yrow * ldy + c, acc[j]);
+        }
     }
 }
 }  // namespace
 
 extern "C" int mage_table_conv(const int64_t* ids, int64_t n_img, int32_t H, int32_t W, int32_t taps_h, int32_t taps_w, const void* table,
-                               int32_t table_dtype, int32_t n_codes, int32_t C, const float* pos, const float* rowadd, int64_t rowadd_div,
-                               int32_t rowadd_mod, float* y, int64_t ldy, int64_t group, int64_t y_group_stride, int64_t y_off, void* stream) {
+                               int32_t table_dtype, int32_t n_codes, int32_t C, const float* pos, const float* bias, int32_t relu,
+                               const float* rowadd, int64_t rowadd_div, int32_t rowadd_mod, void* y, int32_t y_dtype, int64_t ldy, int64_t group,
+                               int64_t y_group_stride, int64_t y_off, void* stream) {
     MAGE_CHECK_ARG(ids && table && y, "mage_table_conv: null pointer");
     MAGE_CHECK_ARG(n_img > 0 && H > 0 && W > 0 && taps_h >= 1 && taps_w >= 1 && (taps_h & 1) && (taps_w & 1) && n_codes > 0 && C > 0 && C % 4 == 0 &&
                        C <= 2048 && ldy >= C && ldy % 4 == 0 && group > 0,
                    "mage_table_conv: bad sizes (odd taps, C %% 4 == 0, C <= 2048)");
     MAGE_CHECK_ARG(!rowadd || (rowadd_div >= 1 && rowadd_mod >= 1), "mage_table_conv: bad rowadd div/mod");
-    MAGE_CHECK_ARG(table_dtype == MAGE_F32 || table_dtype == MAGE_BF16, "mage_table_conv: bad table dtype %d", table_dtype);
+    MAGE_CHECK_ARG((table_dtype == MAGE_F32 || table_dtype == MAGE_BF16) && (y_dtype == MAGE_F32 || y_dtype == MAGE_BF16),
+                   "mage_table_conv: bad table / y dtype %d %d", table_dtype, y_dtype);
     int* err = mage_error_word();
     MAGE_CHECK_ARG(err != nullptr, "mage_table_conv: mage_init() has not been called");
     const long n_pix = (long)n_img * H * W;
     const dim3 grid((unsigned)((n_pix + 3) / 4)), blk(256);
     hipStream_t s = (hipStream_t)stream;
-#define TC(T_, V) hipLaunchKernelGGL((table_conv_kernel<T_, V>), grid, blk, 0, s, ids, (const T_*)table, pos, rowadd, y, n_pix, H, W, taps_h, taps_w, n_codes, C, \
-                                     (long)group, (long)y_group_stride, (long)y_off, (long)rowadd_div, rowadd_mod, (long)ldy, err)
+#define TC(T_, O_, V) hipLaunchKernelGGL((table_conv_kernel<T_, O_, V>), grid, blk, 0, s, ids, (const T_*)table, pos, bias, relu, rowadd, (O_*)y, n_pix, H, W, \
+                                         taps_h, taps_w, n_codes, C, (long)group, (long)y_group_stride, (long)y_off, (long)rowadd_div, rowadd_mod, (long)ldy, err)
+#define TCV(T_, O_) do { if (vpl <= 1) TC(T_, O_, 1); else if (vpl <= 2) TC(T_, O_, 2); else if (vpl <= 4) TC(T_, O_, 4); else TC(T_, O_, 8); } while (0)
     const int vpl = (C + 255) / 256;
-    if (table_dtype == MAGE_F32) { if (vpl <= 1) TC(float, 1); else if (vpl <= 2) TC(float, 2); else if (vpl <= 4) TC(float, 4); else TC(float, 8); }
-    else { if (vpl <= 1) TC(unsigned short, 1); else if (vpl <= 2) TC(unsigned short, 2); else if (vpl <= 4) TC(unsigned short, 4); else TC(unsigned short, 8); }
+    if (table_dtype == MAGE_F32 && y_dtype == MAGE_F32) TCV(float, float);
+    else if (table_dtype == MAGE_F32) TCV(float, unsigned short);
+    else if (y_dtype == MAGE_F32) TCV(unsigned short, float);
+    else TCV(unsigned short, unsigned short);
+#undef TCV
 #undef TC
     MAGE_CHECK_LAUNCH("mage_table_conv");
     return MAGE_OK;

@@ -953,7 +953,14 @@ class MAGE(nn.Module):
         """What the decoder gets for its frame slots: FrameTokens (table sum, in_linear folded) or the convolved features."""
         ft = self._frame_tables()
         if ft["ft.T2"] is not None and getattr(self, "frame_table", True):
-            return FrameTokens(tokens.reshape(-1, self.image_resolution ** 2), ft["ft.T2"], ft["ft.P2"], self.image_resolution)
+            T2 = ft["ft.T2"]
+            if dt == BF16 and self._sk() == 0:
+                # bf16 mode: the table itself in bf16 (half the L2 / Infinity-Cache bytes per gathered row; entries rounded once, sums
+                # and positions stay fp32 -- the same class of error as the bf16 operands of the convolution it replaces)
+                if "ft.T2.bf16" not in ft:
+                    ft["ft.T2.bf16"] = T2.to(BF16)
+                T2 = ft["ft.T2.bf16"]
+            return FrameTokens(tokens.reshape(-1, self.image_resolution ** 2), T2, ft["ft.P2"], self.image_resolution)
         return self._frame_features(tokens, dt, split=True)
 
     def _frame_features(self, tokens: torch.Tensor, dt: torch.dtype, split: bool = False) -> torch.Tensor:

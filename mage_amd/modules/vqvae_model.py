@@ -410,6 +410,22 @@ class VectorQuantizedVAE(nn.Module):
             self._decode_chunk(ids[s:e], out[s:e])
         return out
 
+    def _d0_table(self, w):
+        """T[tap][code] = (BatchNorm-folded) W3_tap relu(codebook[code]) of the decoder's first ResBlock (vqvae_model.py:111-124,180),
+        bf16 [9, K, dim]; built once per weights on the fp32 MFMA kernel.  None when switched off (MAGE_NO_DECODE_TABLE=1)."""
+        if "d0.tab" not in w:
+            if os.environ.get("MAGE_NO_DECODE_TABLE") or 9 * self.K * self.dim * 2 > (64 << 20):
+                w["d0.tab"] = None
+            else:
+                dim, Kc, dev = self.dim, self.K, w["cb"].device
+                rcb = torch.relu(w["cb"]).contiguous()                                              # [K, dim] fp32 (derived-cache bookkeeping)
+                w3 = (w["d0.w3.f32"] * w["d0.s3"][:, None]).view(dim, 9, dim)
+                T = torch.empty(9, Kc, dim, device=dev, dtype=torch.float32)
+                for tap in range(9):
+                    ops.gemm(rcb, w3[:, tap].contiguous(), T[tap], M=Kc, N=dim, K=dim, lda=dim, ldy=dim)
+                w["d0.tab"] = T.to(torch.bfloat16)
+        return w["d0.tab"]
+
     def _decode_chunk(self, ids: torch.Tensor, out: torch.Tensor) -> None:
         w = self._weights()
         dt = self.decode_dtype
@@ -432,8 +448,13 @@ class VectorQuantizedVAE(nn.Module):
             ops.embedding(ids, w["cb"], pads[0], relu=True, group=hw, group_stride=PP, off=Pw + 1, inner=wd, inner_stride=Pw)
             t = torch.empty(N * hw, dim, device=dev, dtype=dt)
             for i, rp in enumerate(("d0", "d1")):
-                ops.gemm(pads[i], w[rp + ".w3f.bf16"], t, M=N * hw, N=dim, K=9 * dim, lda=dim, ldy=dim, taps_h=3, taps_w=3, bias=w[rp + ".b3f"],
-                         act=ops.ACT_RELU, **win)
+                if i == 0 and self._d0_table(w) is not None:
+                    # the first 3x3 convolution reads relu(codebook[ids]): K distinct input vectors -> a table sum (mage_table_conv;
+                    # 9 x K x dim bf16 = 2.4 MB: resident in every XCD's L2), a quarter of the stack's matrix-core FLOPs not spent
+                    ops.table_conv(ids.reshape(-1), w["d0.tab"], t, n_img=N, H=h, W=wd, bias=w["d0.b3f"], relu=True)
+                else:
+                    ops.gemm(pads[i], w[rp + ".w3f.bf16"], t, M=N * hw, N=dim, K=9 * dim, lda=dim, ldy=dim, taps_h=3, taps_w=3, bias=w[rp + ".b3f"],
+                             act=ops.ACT_RELU, **win)
                 ops.gemm(t, w[rp + ".w1.bf16"], pads[i + 1], M=N * hw, N=dim, K=dim, lda=dim, ldy=dim, bias=w[rp + ".b1"], scale=w[rp + ".s1"],
                          shift=w[rp + ".t1"], residual=pads[i], ldr=dim, post_relu=True, **inner)                # decoder[2] ReLU folded
             up = torch.empty(N * 4 * hw, dim, device=dev, dtype=dt)

@@ -392,19 +392,21 @@ def embedding(ids: torch.Tensor, table: torch.Tensor, out: torch.Tensor, *, relu
     return out
 
 
-def table_conv(ids: torch.Tensor, table: torch.Tensor, y: torch.Tensor, *, n_img: int, H: int, W: int, taps: int = 3, pos=None, rowadd=None,
+def table_conv(ids: torch.Tensor, table: torch.Tensor, y: torch.Tensor, *, n_img: int, H: int, W: int, taps: int = 3, pos=None, bias=None,
+               relu: bool = False, rowadd=None,
                rowadd_div: int = 1, rowadd_mod: int = 1, ldy: Optional[int] = None, group: Optional[int] = None,
                y_group_stride: Optional[int] = None, y_off: int = 0) -> torch.Tensor:
     """y rows = pos + sum of table[tap][ids[neighbour]] + rowadd: a k x k convolution of embedding rows as a table sum (mage_table_conv)."""
     l, s = _dev(table)
-    assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == n_img * H * W and y.dtype == torch.float32
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == n_img * H * W
     assert table.dim() == 3 and table.shape[0] == taps * taps and table.is_contiguous()
     Cc = table.shape[2]
     group = n_img * H * W if group is None else group
     y_group_stride = group if y_group_stride is None else y_group_stride
     ev = PROFILE.begin() if PROFILE.wants("table_conv") else None
-    _lib.check(l.mage_table_conv(ids.data_ptr(), n_img, H, W, taps, taps, table.data_ptr(), code(table), table.shape[1], Cc, _p(pos), _p(rowadd),
-                                 rowadd_div, rowadd_mod, y.data_ptr(), Cc if ldy is None else ldy, group, y_group_stride, y_off, s), l)
+    _lib.check(l.mage_table_conv(ids.data_ptr(), n_img, H, W, taps, taps, table.data_ptr(), code(table), table.shape[1], Cc, _p(pos), _p(bias),
+                                 int(relu), _p(rowadd), rowadd_div, rowadd_mod, y.data_ptr(), code(y), Cc if ldy is None else ldy, group,
+                                 y_group_stride, y_off, s), l)
     if ev is not None:
         PROFILE.end("table_conv", ev, 0.0, float(n_img) * H * W * Cc * (taps * taps * table.element_size() + 4))
     return y

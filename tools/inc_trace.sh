@@ -35,3 +35,11 @@ for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"{t/1e3:9.1f} us  {c:4d} x {t/c/1e3:7.1f} us  {k}")
 PY
 cat $OUT/inc_profile.txt
+python - <<PY
+import csv
+rows = list(csv.DictReader(open("/tmp/ki/k_kernel_trace.csv")))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+n = len(rows) // 5
+last = [r for r in rows[-n:] if "fewq" in r["Kernel_Name"] or ("attention_mfma_kernel" in r["Kernel_Name"] and int(r["Grid_Size_X"]) > 2000000)]
+print("temporal attention launches of the last call (us):", " ".join(f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.0f}" for r in last))
+PY
