@@ -155,6 +155,13 @@ int mage_ln_stats(const float* part, int64_t rows, int32_t n_slices, int32_t C, 
  * are normally written split by their producers (mage_layernorm, mage_attention, mage_embedding, the GEMM epilogue). */
 int mage_split(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t C, int32_t kind, void* stream);
 
+/* mage_split with a row map and an optional ReLU: y row  (i / group)*group_stride + ((i % group) / inner)*inner_stride + (i % group) % inner + off
+ * (mage_embedding's map: the interior of a zero-padded frame buffer) <- split(relu ? max(x row i, 0) : x row i); x_relu (optional, may be x):
+ * the same rows written back as fp32 -- a ResBlock's in-place ReLU (vqvae_model.py:111-124): its skip path and its 3x3 convolution's
+ * padded split input in one pass. */
+int mage_split_rows(const float* x, int64_t ldx, void* y, int64_t rows, int32_t C, int32_t kind, int32_t relu, int64_t group,
+                    int64_t group_stride, int64_t off, int64_t inner, int64_t inner_stride, float* x_relu, void* stream);
+
 /* LayerNorm over the last dim of fp32 rows; y may be fp32 (may alias x), bf16, or split (MAGE_BF16X3 / MAGE_F16X3: C % 64 == 0).
  * Replaces nn.LayerNorm at mage_model.py:21,27,84,204,206 and inside nn.TransformerEncoderLayer. */
 int mage_layernorm(const float* x, const float* gamma, const float* beta, void* y, int32_t y_dtype,
@@ -255,14 +262,17 @@ int mage_cross_entropy(const float* logits, const int64_t* target, int64_t rows,
  * mage_conv_in:  NCHW fp32 image [N, cin<=4, H, W] -> channels-last [N, OH, OW, cout] (y_dtype),
  *   y = act((conv(x) + bias) * scale + shift).  f4 stem Conv2d(1,dim,4,2,1)+BN+ReLU (vqvae_model.py:173-175),
  *   f8 stem Conv2d(3,dim,7,padding=3) (:193).  weight_t is the transposed copy [cin, kh, kw, cout] fp32
- *   (lanes = output channels read it coalesced).
+ *   (lanes = output channels read it coalesced).  y_dtype may be a split kind (MAGE_F16X3 / MAGE_BF16X3).  s2d = 1: the output is written
+ *   as OFFSET SPACE-TO-DEPTH rows [N, OH/2+1, OW/2+1, 4*cout] (block (R, C) = pixels (2R-1..2R, 2C-1..2C); the caller zeroes the buffer
+ *   once: border sub-blocks are never written), so that a following Conv2d(., ., 4, 2, 1) (vqvae_model.py:176) is a 2x2 / stride-1
+ *   window over blocks = the padded-taps form of mage_gemm with cin = 4*cout.
  * mage_conv_out: channels-last [N, IH, IW, cin] (x_dtype) -> NCHW fp32 [N, cout<=4, OH, OW], y = tanh(.):
  *   transposed=1: ConvTranspose2d(dim, cout, 4, 2, 1) (vqvae_model.py:187-188), weight_t [4, 4, cout, cin]
  *   (= torch weight [cin, cout, ky, kx] permuted to ky, kx, cout, cin);
  *   transposed=0: Conv2d(dim, cout, 1) (:212-213), weight_t [cout, cin]. */
 int mage_conv_in(const float* x, const float* weight_t, const float* bias, const float* scale, const float* shift,
                  void* y, int32_t y_dtype, int32_t N, int32_t cin, int32_t H, int32_t W, int32_t cout,
-                 int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t act, void* stream);
+                 int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t act, int32_t s2d, void* stream);
 int mage_conv_out(const void* x, int32_t x_dtype, const float* weight_t, const float* bias, float* y,
                   int32_t N, int32_t IH, int32_t IW, int32_t cin, int32_t cout, int32_t transposed, void* stream);
 /* The same ConvTranspose2d(dim, cout, 4, 2, 1) + Tanh head (vqvae_model.py:187-189) as GEMM + fold, which reads the

@@ -73,7 +73,8 @@ SIGNATURES = {
     "mage_vq_prepare": (C.c_int, [vp, i32, i32, vp, vp, vp]),
     "mage_argmax": (C.c_int, [vp, i64, i32, i64, i64, i64, i64, vp, i64, i64, vp, vp]),
     "mage_cross_entropy": (C.c_int, [vp, vp, i64, i32, vp, vp, vp]),
-    "mage_conv_in": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "mage_conv_in": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "mage_split_rows": (C.c_int, [vp, i64, vp, i64, i32, i32, i32, i64, i64, i64, i64, i64, vp, vp]),
     "mage_conv_out": (C.c_int, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mage_convt_fold_tanh": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "mage_maxpool2": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),

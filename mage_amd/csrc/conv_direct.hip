@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
                                                       const float* __restrict__ bias, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, OT* __restrict__ y, int N, int cin,
                                                       int H, int W, int cout, int kh, int kw, int stride, int pad, int OH,
-                                                      int OW, int act) {
+                                                      int OW, int act, int s2d) {
     const int cq = cout / 4;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)N * OH * OW * cq;
@@ -39,7 +39,17 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
     }
-    store4(y + pix * cout + co, acc);
+    if (s2d) {
+        // offset space-to-depth rows for a following 4x4 / stride-2 / pad-1 convolution: block (R, C) = ((oy+1)/2, (ox+1)/2) of a
+        // (OH/2+1) x (OW/2+1) grid holds the 2x2 pixels (2R-1..2R, 2C-1..2C) as 4*cout channels, so that convolution is a 2x2 /
+        // stride-1 window over blocks (the padded-taps form of mage_gemm); border sub-blocks are never written: they stay zero
+        const int BW = OW / 2 + 1, BH = OH / 2 + 1;
+        const long row = (long)n * (BH * BW) + (long)((oy + 1) >> 1) * BW + ((ox + 1) >> 1);
+        const int q = ((oy + 1) & 1) * 2 + ((ox + 1) & 1);
+        store4(y + row * (4 * cout) + q * cout + co, acc);
+    } else {
+        store4(y + pix * cout + co, acc);
+    }
 }
 
 // The 1x1 head (the f8 decoder's Conv2d(dim, C, 1) + Tanh at full resolution: 16 M pixels x 512 B per call at cfg4): 16 lanes per pixel,
@@ -224,7 +234,7 @@ inline dim3 grid1(long items) { return dim3((unsigned)((items + 255) / 256)); }
 
 extern "C" int mage_conv_in(const float* x, const float* weight_t, const float* bias, const float* scale, const float* shift,
                             void* y, int32_t y_dtype, int32_t N, int32_t cin, int32_t H, int32_t W, int32_t cout, int32_t kh,
-                            int32_t kw, int32_t stride, int32_t pad, int32_t act, void* stream) {
+                            int32_t kw, int32_t stride, int32_t pad, int32_t act, int32_t s2d, void* stream) {
     MAGE_CHECK_ARG(x && weight_t && y, "mage_conv_in: null pointer");
     MAGE_CHECK_ARG(N > 0 && cin > 0 && cin <= 4 && cout % 4 == 0 && stride >= 1, "mage_conv_in: cin=%d cout=%d unsupported", cin, cout);
     MAGE_CHECK_ARG(!scale == !shift, "mage_conv_in: scale and shift must be given together");
@@ -232,13 +242,22 @@ extern "C" int mage_conv_in(const float* x, const float* weight_t, const float* 
     const int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1;
     const long items = (long)N * OH * OW * (cout / 4);
     hipStream_t s = (hipStream_t)stream;
+    MAGE_CHECK_ARG(!s2d || (OH % 2 == 0 && OW % 2 == 0), "mage_conv_in: the space-to-depth output needs an even output plane");
     if (y_dtype == MAGE_F32)
         hipLaunchKernelGGL((conv_in_kernel<float>), grid1(items), dim3(256), 0, s, x, weight_t, bias, scale, shift, (float*)y, N,
-                           cin, H, W, cout, kh, kw, stride, pad, OH, OW, act);
+                           cin, H, W, cout, kh, kw, stride, pad, OH, OW, act, s2d);
     else if (y_dtype == MAGE_BF16)
         hipLaunchKernelGGL((conv_in_kernel<unsigned short>), grid1(items), dim3(256), 0, s, x, weight_t, bias, scale, shift,
-                           (unsigned short*)y, N, cin, H, W, cout, kh, kw, stride, pad, OH, OW, act);
-    else {
+                           (unsigned short*)y, N, cin, H, W, cout, kh, kw, stride, pad, OH, OW, act, s2d);
+    else if (y_dtype == MAGE_BF16X3 || y_dtype == MAGE_F16X3) {
+        MAGE_CHECK_ARG(cout % 64 == 0 && (((uintptr_t)y) & 255) == 0, "mage_conv_in: split output needs cout %% 64 == 0 and y 256-byte aligned");
+        if (y_dtype == MAGE_BF16X3)
+            hipLaunchKernelGGL((conv_in_kernel<split_bf16>), grid1(items), dim3(256), 0, s, x, weight_t, bias, scale, shift, (split_bf16*)y, N,
+                               cin, H, W, cout, kh, kw, stride, pad, OH, OW, act, s2d);
+        else
+            hipLaunchKernelGGL((conv_in_kernel<split_f16>), grid1(items), dim3(256), 0, s, x, weight_t, bias, scale, shift, (split_f16*)y, N,
+                               cin, H, W, cout, kh, kw, stride, pad, OH, OW, act, s2d);
+    } else {
         mage_set_error("mage_conv_in: bad y_dtype %d", y_dtype);
         return MAGE_EINVAL;
     }

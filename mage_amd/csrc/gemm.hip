@@ -1246,6 +1246,10 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
         if (plain && d->act == MAGE_ACT_NONE) return launch_taps8<MAGE_ACT_NONE, EK_BIAS>(d, s, n_cu);
         if (plain && d->act == MAGE_ACT_RELU) return launch_taps8<MAGE_ACT_RELU, EK_BIAS>(d, s, n_cu);
     }
+    if constexpr (SPL == 2) {      // f16 pieces: the VQ-VAE encoder's convolutions (bias with BatchNorm folded in, ReLU)
+        if (plain && d->act == MAGE_ACT_NONE) return launch_taps8<MAGE_ACT_NONE, EK_BIAS, 2>(d, s, n_cu);
+        if (plain && d->act == MAGE_ACT_RELU) return launch_taps8<MAGE_ACT_RELU, EK_BIAS, 2>(d, s, n_cu);
+    }
     return 0;
 }
 

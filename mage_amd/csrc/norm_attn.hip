@@ -566,6 +566,48 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
 }
 }  // namespace
 
+namespace {
+template <typename OT>
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, long ldx, OT* __restrict__ y, long rows, int C, int relu,
+                                                         long group, long group_stride, long off, long inner, long inner_stride,
+                                                         float* __restrict__ x_relu) {
+    const int vpr = C >> 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * vpr) return;
+    const long r = i / vpr;
+    const int c = (int)(i - r * vpr) << 2;
+    f32x4 v = *(const f32x4*)(x + r * ldx + c);
+    if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (x_relu) *(f32x4*)(x_relu + r * ldx + c) = v;
+    const long ig = r % group;
+    const long orow = (r / group) * group_stride + (ig / inner) * inner_stride + (ig % inner) + off;
+    store4(y + orow * C + c, v);
+}
+}  // namespace
+
+extern "C" int mage_split_rows(const float* x, int64_t ldx, void* y, int64_t rows, int32_t C, int32_t kind, int32_t relu, int64_t group,
+                               int64_t group_stride, int64_t off, int64_t inner, int64_t inner_stride, float* x_relu, void* stream) {
+    MAGE_CHECK_ARG(x && y && rows > 0 && C > 0 && C % 64 == 0 && ldx % 4 == 0 && group > 0, "mage_split_rows: C=%d must be a multiple of 64", C);
+    MAGE_CHECK_ARG(((((uintptr_t)y) & 255) | (((uintptr_t)x) & 15)) == 0, "mage_split_rows: y must be 256-byte aligned, x 16-byte aligned");
+    MAGE_CHECK_ARG(kind == MAGE_BF16X3 || kind == MAGE_F16X3, "mage_split_rows: kind %d is not a split kind", kind);
+    if (inner <= 0) {
+        inner = group;
+        inner_stride = group;
+    }
+    const dim3 grid((unsigned)((rows * (C >> 2) + 255) / 256));
+    if (kind == MAGE_BF16X3)
+        hipLaunchKernelGGL((split_rows_kernel<split_bf16>), grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (split_bf16*)y, (long)rows, C, relu,
+                           (long)group, (long)group_stride, (long)off, (long)inner, (long)inner_stride, x_relu);
+    else
+        hipLaunchKernelGGL((split_rows_kernel<split_f16>), grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (split_f16*)y, (long)rows, C, relu,
+                           (long)group, (long)group_stride, (long)off, (long)inner, (long)inner_stride, x_relu);
+    MAGE_CHECK_LAUNCH("mage_split_rows");
+    return MAGE_OK;
+}
+
 extern "C" int mage_split(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t C, int32_t kind, void* stream) {
     MAGE_CHECK_ARG(x && y && rows > 0 && C > 0 && C % 64 == 0 && ldx % 4 == 0 && ldy % 128 == 0 && ldy >= 2 * (int64_t)C,
                    "mage_split: C=%d must be a multiple of 64, ldy a multiple of 128 16-bit elements (>= 2C)", C);

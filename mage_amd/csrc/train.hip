@@ -178,6 +178,38 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
     out[i] = s;
 }
 
+// The same sum for 16-byte aligned operands: a workgroup owns 64 float4 columns, its four waves take the partials p = w, w+4, w+8, ..
+// (independent 16-byte loads, 4 in flight per lane) and their four sums are added in a fixed order through LDS:
+//     out = ((s_0 + s_1) + (s_2 + s_3)) [+ out],  s_w = part[w] + part[w+4] + ...      -- deterministic, like the scalar kernel's order.
+// The scalar kernel walked 64 dependent 4-byte loads per thread: 6.9 ms per training step at B = 64 for ~2.7 GB of split-K partials.
+__global__ __launch_bounds__(256) void sum_partials4_kernel(const float* __restrict__ part, long stride, int n_part, long n4,
+                                                            float* __restrict__ out, int accumulate) {
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long i4 = (long)blockIdx.x * 64 + lane;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i4 < n4) {
+        const float* p0 = part + i4 * 4;
+        int p = w;
+        for (; p + 12 < n_part; p += 16) {
+            const f32x4 a = *(const f32x4*)(p0 + (long)p * stride), b = *(const f32x4*)(p0 + (long)(p + 4) * stride);
+            const f32x4 c = *(const f32x4*)(p0 + (long)(p + 8) * stride), e = *(const f32x4*)(p0 + (long)(p + 12) * stride);
+            s += a;
+            s += b;
+            s += c;
+            s += e;
+        }
+        for (; p < n_part; p += 4) s += *(const f32x4*)(p0 + (long)p * stride);
+    }
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && i4 < n4) {
+        f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (accumulate) t += *(const f32x4*)(out + i4 * 4);
+        *(f32x4*)(out + i4 * 4) = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNorm backward
 // One wave per row (statistics recomputed from the saved LN input, two-pass as in the forward kernel):
 //   xhat = (x - mean) rstd;  g = dy * gamma;  dx = rstd (g - mean_c(g) - xhat mean_c(g xhat))       [+= if accumulate]
@@ -821,6 +853,12 @@ extern "C" int mage_row_sum(const void* x, int32_t dtype, int64_t ld, int64_t n,
 
 extern "C" int mage_sum_partials(const float* part, int64_t stride, int32_t n_part, int64_t n, float* out, int32_t accumulate, void* stream) {
     MAGE_CHECK_ARG(part && out && n_part > 0 && n > 0, "mage_sum_partials: bad arguments");
+    if (n % 4 == 0 && stride % 4 == 0 && n_part >= 4 && ((((uintptr_t)part | (uintptr_t)out) & 15) == 0)) {
+        hipLaunchKernelGGL(sum_partials4_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream, part, (long)stride, n_part,
+                           (long)(n / 4), out, accumulate);
+        MAGE_CHECK_LAUNCH("mage_sum_partials");
+        return MAGE_OK;
+    }
     hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, (long)stride, n_part,
                        (long)n, out, accumulate);
     MAGE_CHECK_LAUNCH("mage_sum_partials");

@@ -343,6 +343,9 @@ class VectorQuantizedVAE(nn.Module):
         N, dev, dim, f = x.shape[0], x.device, self.dim, torch.float32
         if self.down_ratio == 4:
             H, W = x.shape[2], x.shape[3]
+            if (dim % 256 == 0 and H % 4 == 0 and W % 4 == 0 and (N * (H // 4) * (W // 4)) % 256 == 0 and self.input_dim <= 4
+                    and not os.environ.get("MAGE_ENCODE_FP32") and getattr(self, "encode_split", True)):
+                return self._encode_f4_split(w, x, N, H, W)
             h0 = torch.empty(N * (H // 2) * (W // 2), dim, device=dev, dtype=f)
             ops.conv_in(x, w["e0.wt"], w["e0.b"], w["e0.s"], w["e0.t"], h0, cin=self.input_dim, H=H, W=W, cout=dim, kh=4,
                         kw=4, stride=2, pad=1, act=ops.ACT_RELU)
@@ -365,6 +368,59 @@ class VectorQuantizedVAE(nn.Module):
                 ops.maxpool2(h, p, N=N, H=H, W=W, Cc=co)
                 h, H, W = p, H // 2, W // 2
         return h
+
+    def _enc_split_weights(self, w):
+        """f16x3 operands of the f4 encoder's GEMM-shaped convolutions (built once per weights): the 4x4 / stride-2 convolution as a
+        2x2 window over offset space-to-depth blocks (w2[co, by, bx, dy, dx, ci] = W[co, ci, 2by+dy, 2bx+dx]), the ResBlocks' 3x3 and 1x1
+        convolutions with their eval BatchNorm folded in (W' = alpha W, b' = alpha b + beta)."""
+        if "e3.ws" not in w:
+            sk, dim = ops.F16X3, self.dim
+            W4 = self.encoder[3].weight.float()                                            # [cout, cin, 4, 4]
+            w2 = W4.view(dim, dim, 2, 2, 2, 2).permute(0, 2, 4, 3, 5, 1).reshape(dim, 16 * dim).contiguous()   # [co, by, bx, dy, dx, ci]
+            w["e3.ws"] = ops.split(w2, sk)
+            for p in ("e4", "e5"):
+                w[p + ".w3s"] = ops.split((w[p + ".w3.f32"] * w[p + ".s3"][:, None]).contiguous(), sk)
+                w[p + ".b3f"] = (w[p + ".b3"] * w[p + ".s3"] + w[p + ".t3"]).contiguous()
+                w[p + ".w1s"] = ops.split((w[p + ".w1.f32"] * w[p + ".s1"][:, None]).contiguous(), sk)
+                w[p + ".b1f"] = (w[p + ".b1"] * w[p + ".s1"] + w[p + ".t1"]).contiguous()
+        return w
+
+    def _encode_f4_split(self, w, x: torch.Tensor, N: int, H: int, W: int) -> torch.Tensor:
+        """The f4 encoder (vqvae_model.py:172-179) with its four GEMM-shaped convolutions on split-precision operands (MAGE_F16X3:
+        three f16 MFMA products per K slab, fp32 accumulation -- fp32-class results, measured 5e-6 per GEMM against the exact-fp32
+        chain's 1e-5) in the padded-taps form of the 8-phase kernel, 2.5x the exact-fp32 MFMA rate:
+          stem (direct kernel) -> split rows in the offset space-to-depth layout -> Conv 4x4/s2 as a 2x2 window over 4*dim channels
+          -> ReLU (the ResBlock's in-place one) -> per ResBlock: rows into a zero-padded split frame buffer, 3x3 (+BN, ReLU) -> split
+          rows, 1x1 (+BN) + the fp32 skip.
+        The quantiser that follows stays on the fp64 matrix cores; the golden token gates are unchanged."""
+        sk, dim, dev = ops.F16X3, self.dim, x.device
+        self._enc_split_weights(w)
+        h, wd = H // 4, W // 4
+        hw, BH, BW = h * wd, H // 4 + 1, W // 4 + 1
+        PPb, Pw = BH * BW, wd + 2
+        PP = (h + 2) * Pw
+        key = ("enc", N, H, W, str(dev), torch.cuda.current_stream(dev).cuda_stream)
+        bufs = self._pad_bufs.get(key)
+        if bufs is None:
+            if len(self._pad_bufs) > 4:
+                self._pad_bufs.clear()
+            bufs = self._pad_bufs[key] = (ops.split_empty(N * PPb + 1, 4 * dim, sk, dev, zero=True), ops.split_empty(N * PP + 1, dim, sk, dev, zero=True))
+        y1, pad = bufs
+        ops.conv_in(x, w["e0.wt"], w["e0.b"], w["e0.s"], w["e0.t"], y1, cin=self.input_dim, H=H, W=W, cout=dim, kh=4, kw=4, stride=2, pad=1,
+                    act=ops.ACT_RELU, split_kind=sk, s2d=True)
+        r = torch.empty(N * hw, dim, device=dev, dtype=torch.float32)
+        ops.gemm(y1, w["e3.ws"], r, M=N * hw, N=dim, K=16 * dim, lda=8 * dim, ldy=dim, out_h=h, out_w=wd, in_h=BH, in_w=BW, a_img_stride=PPb,
+                 taps_h=2, taps_w=2, cin=4 * dim, bias=w["e3.b"], act=ops.ACT_RELU, split_kind=sk)
+        t = ops.split_empty(N * hw, dim, sk, dev)
+        for i, p in enumerate(("e4", "e5")):
+            # r = relu(block input): the skip path (fp32) and, split into the padded frame buffer, the 3x3 convolution's input
+            ops.split_rows(r, pad, sk, relu=i > 0, relu_writeback=i > 0, group=hw, group_stride=PP, off=Pw + 1, inner=wd, inner_stride=Pw)
+            ops.gemm(pad, w[p + ".w3s"], t, M=N * hw, N=dim, K=9 * dim, lda=2 * dim, ldy=2 * dim, out_h=h, out_w=wd, in_h=h + 2, in_w=Pw,
+                     a_img_stride=PP, taps_h=3, taps_w=3, cin=dim, bias=w[p + ".b3f"], act=ops.ACT_RELU, split_kind=sk, y_split=True)
+            z = torch.empty(N * hw, dim, device=dev, dtype=torch.float32)
+            ops.gemm(t, w[p + ".w1s"], z, M=N * hw, N=dim, K=dim, lda=2 * dim, ldy=dim, bias=w[p + ".b1f"], residual=r, ldr=dim, split_kind=sk)
+            r = z
+        return r
 
     def _stem7(self, w, x: torch.Tensor) -> torch.Tensor:
         """The f8 stem Conv2d(C, dim, 7, padding=3) on full-resolution frames as an implicit GEMM over the image laid out as

@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, BF16X3, F16X3, F32, AttnDesc, GemmDesc
 
-__all__ = ["gemm", "layernorm", "attention", "embedding", "table_conv", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
+__all__ = ["gemm", "layernorm", "attention", "embedding", "table_conv", "split_rows", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
            "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mse", "check_device_errors", "graph_events_supported", "transpose", "row_sum", "sum_partials", "layernorm_bwd", "act", "act_bwd", "cross_entropy_bwd", "embedding_bwd", "group_rowsum", "attention_bwd", "dropout", "adam", "bn_train_stats", "bn_apply", "bn_backward", "convt_unfold_tanh_bwd", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
            "split", "split_empty", "split_dtype", "PROFILE", "F32", "BF16", "BF16X3", "F16X3", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
 
@@ -457,11 +457,25 @@ def cross_entropy(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     return loss[0]
 
 
-def conv_in(x, weight_t, bias, scale, shift, y, *, cin, H, W, cout, kh, kw, stride, pad, act=ACT_NONE):
+def conv_in(x, weight_t, bias, scale, shift, y, *, cin, H, W, cout, kh, kw, stride, pad, act=ACT_NONE, split_kind: int = 0, s2d: bool = False):
+    """split_kind: y is a split-precision tensor; s2d: offset space-to-depth rows [N, OH/2+1, OW/2+1, 4*cout] (mage_hip.h)."""
     l, s = _dev(x)
     assert x.dtype == torch.float32 and x.is_contiguous()
-    _lib.check(l.mage_conv_in(x.data_ptr(), weight_t.data_ptr(), _p(bias), _p(scale), _p(shift), y.data_ptr(), code(y),
-                              x.shape[0], cin, H, W, cout, kh, kw, stride, pad, act, s), l)
+    _lib.check(l.mage_conv_in(x.data_ptr(), weight_t.data_ptr(), _p(bias), _p(scale), _p(shift), y.data_ptr(), split_kind or code(y),
+                              x.shape[0], cin, H, W, cout, kh, kw, stride, pad, act, int(s2d), s), l)
+    return y
+
+
+def split_rows(x: torch.Tensor, y: torch.Tensor, kind: int, *, relu: bool = False, group: Optional[int] = None,
+               group_stride: Optional[int] = None, off: int = 0, inner: int = 0, inner_stride: int = 0, relu_writeback: bool = False):
+    """fp32 rows x [rows, C] -> split rows of y under mage_embedding's row map (+ ReLU; relu_writeback: x itself becomes relu(x))."""
+    l, s = _dev(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and y.dtype == split_dtype(kind)
+    rows, C_ = x.shape
+    group = rows if group is None else group
+    group_stride = group if group_stride is None else group_stride
+    _lib.check(l.mage_split_rows(x.data_ptr(), x.stride(0), y.data_ptr(), rows, C_, kind, int(relu), group, group_stride, off, inner, inner_stride,
+                                 x.data_ptr() if relu_writeback else None, s), l)
     return y
 
 

@@ -590,3 +590,24 @@ def test_frame_table_path_against_the_convolution_path(precision):
             m.frame_table = ft
             m.autoregressive_generate(batch)
             assert assert_tokens(m.last_tokens.cpu(), g["gen_tokens"], g["margin"], TOK_TOL, f"AR tokens, frame_table={ft}") == 0
+
+
+def test_f4_encoder_split_precision_path_against_exact_fp32_path():
+    """The f4 encoder's convolutions on f16x3 operands (VectorQuantizedVAE._encode_f4_split, the default) against the exact-fp32 MFMA
+    gather path (encode_split = False) on 64 synthetic frames: features within fp32 rounding of each other, identical tokens wherever
+    the quantiser's own top-2 margin exceeds that noise -- and the reference's golden tokens with BOTH (test_vqvae_f4_golden...)."""
+    m = build_vqvae(1, 4, 256, 512, 17, DEV)
+    x = synth.synth_batch_mnist(4, 16, seed=23)["images"].reshape(64, 1, 64, 64).to(DEV)
+    z_s = m._encode_features(x).clone()
+    ids_s = m.encode(x)
+    m.encode_split = False
+    z_f = m._encode_features(x)
+    ids_f = m.encode(x)
+    err = (z_s - z_f).abs().max().item()
+    w = m._weights()
+    from mage_amd import ops as o
+    _, margin = o.vq_nearest(z_f, w["cbt"], w["c2"], want_margin=True)
+    bad = (ids_s.reshape(-1) != ids_f.reshape(-1))
+    print(f"f16x3 encoder vs exact fp32: max |d z_e| {err:.2e} (|z_e| max {z_f.abs().max().item():.2f}), token mismatches {int(bad.sum())} of {bad.numel()}")
+    assert err < 3e-5
+    assert not (bad & (margin > TOK_TOL)).any()

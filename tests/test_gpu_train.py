@@ -429,6 +429,23 @@ def test_dropout_training_mode_is_consistent_between_forward_and_backward():
     assert abs(fd - an) < 0.05 * max(abs(an), 1e-3) + 2e-4
 
 
+def test_sum_partials_fixed_order_vector_and_scalar_kernels():
+    """mage_sum_partials (split-K partial products, LayerNorm gamma / beta partials): the 16-byte kernel (four waves over the partials,
+    fixed-order LDS sum) and the scalar fallback against an fp64 sum; bitwise repeatable; `accumulate` adds to the output."""
+    from mage_amd import ops as o
+    g = torch.Generator().manual_seed(12)
+    for n_part, n, stride in ((1, 256, 256), (3, 1024, 1024), (4, 4096, 4096), (37, 3 * 512, 2048), (64, 262144, 262144), (7, 250, 252)):
+        part = torch.randn(n_part, stride, generator=g).to(DEV)
+        want = part[:, :n].double().sum(0)
+        out = o.sum_partials(part, torch.empty(n, device=DEV), stride=stride, n_part=n_part, n=n)
+        assert (out.double() - want).abs().max().item() < 1e-5 * max(1.0, n_part ** 0.5) * 4
+        out2 = o.sum_partials(part, torch.empty(n, device=DEV), stride=stride, n_part=n_part, n=n)
+        assert torch.equal(out, out2)
+        base = torch.randn(n, generator=g).to(DEV)
+        acc = o.sum_partials(part, base.clone(), stride=stride, n_part=n_part, n=n, accumulate=True)
+        assert (acc.double() - (want + base.double())).abs().max().item() < 1e-5 * max(1.0, n_part ** 0.5) * 4
+
+
 def test_attention_probability_dropout_forward_backward_consistent():
     """nn.TransformerEncoderLayer(dropout=p) drops attention PROBABILITIES in train() (mage_model.py:193-199): mage_attention's drop_p /
     drop_seed.  The mask is a stateless hash, so (a) it can be read back by sending v = identity rows, (b) the forward equals
