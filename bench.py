@@ -414,7 +414,7 @@ def main():
         # only rocprofv3 can read: tools/pmc_bench.sh collects them on this same command in two separate --pmc passes
         # and the summary is committed under profiles/; bench.py reports it only for the matching workload and says where from.
         traffic, traffic_source = None, None
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             pmc_path = os.path.join(ROOT, "profiles", name)
             if dom_key and os.path.exists(pmc_path) and (B, L, args.precision, args.ar_mode, args.workload) == (64, 16, "bf16", "full", "cfg2"):
                 traffic = json.load(open(pmc_path)).get(dom_key, {}).get("hbm_bytes_per_launch")
@@ -425,8 +425,8 @@ def main():
             dom = gemms[dom_key]
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             allf, allms = sum(v["flops"] for v in all_src.values()), sum(v["ms"] for v in all_src.values())
-            roofline = {"bound": "mfma", "kernel": dom_key + "  [gemm8_kernel<act, epilogue kind, split-K, padded taps, LayerNorm fold>: the 8-phase ping-pong bf16 256x256 GEMM; "
-                                                             "gemm_kernel<dtype, gather, act, m-tiles/wave, epilogue kind, split-K, LayerNorm fold>: the "
+            roofline = {"bound": "mfma", "kernel": dom_key + "  [gemm8_kernel<act, epilogue kind, split-K, padded taps, LayerNorm fold, split precision>: the 8-phase ping-pong bf16 256x256 GEMM; "
+                                                             "gemm_kernel<dtype, gather, act, m-tiles/wave, epilogue kind, split-K, LayerNorm fold, n-waves, split precision>: the "
                                                              "lockstep one.  Epilogue kind 1 = x + Linear(.) with the fp32 residual: attention out_proj "
                                                              "and MLP c_proj of the decoder stack; LayerNorm fold 1 = it also writes the bf16 copy of x "
                                                              "and the row partial sums the next Linear normalises with (2 = that consumer)]",

@@ -258,11 +258,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
                 and ((M + 127) // 128) * ((N + 255) // 256) < n_cu and not os.environ.get("MAGE_GEMM_NO_NARROW")
                 and not os.environ.get("MAGE_GEMM_NO_NARROW_FEW")):
             mt, nw = 2, 1                                   # few rows: x + Linear(.) of the incremental loop on the narrow tile
-        key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act}, {mt}, {ek}, {sp}, {ln}, {nw}>"
+        key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act}, {mt}, {ek}, {sp}, {ln}, {nw}, 0>"
         a_rows = ((M + out_h * out_w - 1) // (out_h * out_w)) * d.a_img_stride + a_off + 1
         if (d.dtype == BF16 and not gather and mt == 8 and ek != 2 and K % 64 == 0 and a_rows * lda * 2 < 2 ** 32
                 and N * K * 2 < 2 ** 32 and not os.environ.get("MAGE_GEMM_NO_8PHASE")):
-            key = f"gemm8_kernel<{act}, {ek}, {sp}, false, {ln}>"    # the 8-phase ping-pong variant (launch_tile in csrc/gemm.hip)
+            key = f"gemm8_kernel<{act}, {ek}, {sp}, false, {ln}, 0>"    # the 8-phase ping-pong variant (launch_tile in csrc/gemm.hip)
         # padded-taps convolutions and row-table Linears on the 8-phase kernel (try_taps8 in csrc/gemm.hip)
         ntaps = taps_h * taps_w
         table, plain = rowadd is not None and residual is None, rowadd is None and residual is None
@@ -271,9 +271,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
                 and not post_relu and N % 256 == 0 and M % 256 == 0
                 and not os.environ.get("MAGE_GEMM_NO_8PHASE") and not os.environ.get("MAGE_GEMM_NO_TAPS8")):
             if table and act == ACT_NONE:
-                key = "gemm8_kernel<0, 1, false, true, 0>"
+                key = "gemm8_kernel<0, 1, false, true, 0, 0>"
             elif plain and act in (ACT_NONE, ACT_RELU):
-                key = f"gemm8_kernel<{act}, 0, false, true, 0>"
+                key = f"gemm8_kernel<{act}, 0, false, true, 0, 0>"
         if PROFILE.wants(key):
             ev = PROFILE.begin()
             _lib.check(l.mage_gemm(C.byref(d), s), l)
