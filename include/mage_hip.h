@@ -182,7 +182,9 @@ int mage_layernorm(const float* x, const float* gamma, const float* beta, void* 
  * kv_len (optional, int32 [ceil(n_seq / kv_len_div)]): only keys j < kv_len[s / kv_len_div] are visible.
  * ------------------------------------------------------------------------------------------- */
 typedef struct mage_attn_desc {
-    int32_t dtype;                     /* element type of q, k, v and out */
+    int32_t dtype;                     /* element type of q, k, v and out; MAGE_F16X3: q, k, v are SPLIT rows (ld* in 16-bit elements; head h's
+                                        * columns through the slab map) and out_split must be MAGE_F16X3: the fast parity mode's axial attention
+                                        * on the matrix cores (three f16 MFMA passes per product, nq, nk <= 32) */
     const void* q;
     const void* k;
     const void* v;

@@ -1268,8 +1268,7 @@ int launch_spl(const mage_gemm_desc* d, hipStream_t s) {
     const int n_cu = n_cu_dev[dev];
     MAGE_CHECK_ARG(!d->scale && !d->post_relu && !d->y2 && !d->ln_stats && d->n_split == 1 && !d->a_half && !d->res_half,
                    "mage_gemm: split-precision form: epilogue y = act(acc + bias) | residual + acc + bias | rowadd[..] + acc only");
-    MAGE_CHECK_ARG(!d->rowadd && d->out_h == 1 && d->out_w >= d->M && d->y_mul_x == 1 || (d->y_dtype == MAGE_F32 && !d->rowadd),
-                   "mage_gemm: split-precision form: regrouped output rows only with fp32 output; row tables only in the padded-taps form");
+    MAGE_CHECK_ARG(!d->rowadd, "mage_gemm: split-precision form: row tables only in the padded-taps form");
     const bool big = (long)((d->M + 255) / 256) * ((d->N + BN - 1) / BN) >= 2L * n_cu;
     if (d->residual) {
         MAGE_CHECK_ARG(d->res_dtype == MAGE_F32 && d->act == MAGE_ACT_NONE && d->out_h == 1 && d->out_w >= d->M && (((uintptr_t)d->residual) & 15) == 0,

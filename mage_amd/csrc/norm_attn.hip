@@ -422,6 +422,145 @@ __global__ __launch_bounds__(256) void attention_mfma_fewq_kernel(const mage_att
     }
 }
 
+// The fast parity mode's axial attention (q, k, v and out are SPLIT rows of f16 pieces, common.h): attention_mfma_kernel's structure
+// with every product as three f16 MFMA passes -- S^T = (K_hi Q_lo^T + K_lo Q_hi^T) 2^-11 + K_hi Q_hi^T by v_mfma_f32_16x16x32_f16,
+// softmax in fp32, P = hi + lo 2^-11 in f16 pieces, O^T = (V_hi^T P_lo^T + V_lo^T P_hi^T) 2^-11 + V_hi^T P_hi^T by 16x16x16 --
+// 22-bit operands, fp32 accumulation: fp32-class like the split GEMMs, in place of the thread-per-(query, head) fp32 kernel (540 vs
+// ~200 us per launch at cfg2).  Logical column c of a split row sits at 16-bit index (c / 64) * 128 + piece * 64 + c % 64.
+typedef __attribute__((ext_vector_type(4))) _Float16 ahalf4;
+__device__ __forceinline__ int split_col(int c, int piece) { return ((c >> 6) << 7) + (piece << 6) + (c & 63); }
+
+template <int NKB, int MAXH>
+__global__ __launch_bounds__(256) void attention_mfma_split_kernel(const mage_attn_desc d) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned short* vs = (unsigned short*)smem_raw;     // [16*NKB][2*n_head*32 + 16]: physical (split) V rows; rows >= nk are zero
+    const int prow = d.n_head * 64, vpitch = prow + 16;
+    const int s = blockIdx.x;
+    const int outer = s / d.inner, in = s - outer * d.inner;
+    const long q_base = (long)outer * d.q_outer_stride + in;
+    const long kv_base = (long)outer * d.kv_outer_stride + in;
+    const unsigned short* qp = (const unsigned short*)d.q;
+    const unsigned short* kp = (const unsigned short*)d.k;
+    const unsigned short* vp = (const unsigned short*)d.v;
+    split_f16* op = (split_f16*)d.out;
+    const int ldo = d.ldo >> 1;
+    const int vec_per_row = prow / 8;
+    for (int e = threadIdx.x; e < 16 * NKB * vec_per_row; e += 256) {
+        const int j = e / vec_per_row, c = (e - j * vec_per_row) * 8;
+        uint4 val = uint4{0u, 0u, 0u, 0u};
+        if (j < d.nk) val = *(const uint4*)(vp + (kv_base + (long)j * d.kv_axis_stride) * d.ldv + c);
+        *(uint4*)(vs + j * vpitch + c) = val;
+    }
+    int klen = d.nk;
+    if (d.kv_len) klen = min(klen, d.kv_len[s / d.kv_len_div]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    constexpr float LO = 1.0f / MAGE_F16_LO_SCALE;
+    uint4 kf[MAXH][NKB][2];
+#pragma unroll
+    for (int t = 0; t < MAXH; ++t) {
+        const int h = wave + 4 * t;
+        if (h < d.n_head) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const long krow = (kv_base + (long)min(kb * 16 + r, d.nk - 1) * d.kv_axis_stride) * d.ldk;
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) kf[t][kb][pc] = *(const uint4*)(kp + krow + split_col(h * 32 + g * 8, pc));
+            }
+        }
+    }
+    __syncthreads();
+    const int nqb = (d.nq + 15) >> 4;
+    for (int qb = 0; qb < nqb; ++qb) {
+        const int qi = qb * 16 + r;
+        const long qrow = (q_base + (long)min(qi, d.nq - 1) * d.q_axis_stride) * d.ldq;
+        const int jmax = d.causal ? min(klen, qi + 1 + (d.nk - d.nq)) : klen;
+        uint4 qf[MAXH][2];
+#pragma unroll
+        for (int t = 0; t < MAXH; ++t) {
+            const int h = wave + 4 * t;
+            if (h < d.n_head) {
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) qf[t][pc] = *(const uint4*)(qp + qrow + split_col(h * 32 + g * 8, pc));
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MAXH; ++t) {
+            const int h = wave + 4 * t;
+            if (h >= d.n_head) break;
+            f32x4 st[NKB];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[t][kb][0]), __builtin_bit_cast(f16x8, qf[t][1]),
+                                                                 f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[t][kb][1]), __builtin_bit_cast(f16x8, qf[t][0]), a, 0, 0, 0);
+                a *= LO;
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[t][kb][0]), __builtin_bit_cast(f16x8, qf[t][0]), a, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = (kb * 16 + 4 * g + e < jmax) ? a[e] * d.scale : -INFINITY;
+                    mx = fmaxf(mx, a[e]);
+                }
+                st[kb] = a;
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float den = 0.f;
+            ahalf4 phi[NKB], plo[NKB];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = (kb * 16 + 4 * g + e < jmax) ? expf(st[kb][e] - mx) : 0.f;
+                    den += p;
+                    const _Float16 ph = (_Float16)p;
+                    phi[kb][e] = ph;
+                    plo[kb][e] = (_Float16)((p - (float)ph) * MAGE_F16_LO_SCALE);
+                }
+            den += __shfl_xor(den, 16);
+            den += __shfl_xor(den, 32);
+            f32x4 o[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                ahalf4 vth[NKB], vtl[NKB];
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    const unsigned short* vr = vs + (kb * 16 + 4 * g) * vpitch;
+                    const int ch = split_col(h * 32 + b * 16 + r, 0), cl = split_col(h * 32 + b * 16 + r, 1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vth[kb][e] = __builtin_bit_cast(_Float16, vr[e * vpitch + ch]);
+                        vtl[kb][e] = __builtin_bit_cast(_Float16, vr[e * vpitch + cl]);
+                    }
+                }
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    a = __builtin_amdgcn_mfma_f32_16x16x16f16(vth[kb], plo[kb], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x16f16(vtl[kb], phi[kb], a, 0, 0, 0);
+                }
+                a *= LO;
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) a = __builtin_amdgcn_mfma_f32_16x16x16f16(vth[kb], phi[kb], a, 0, 0, 0);
+                o[b] = a;
+            }
+            const float inv = 1.0f / den;
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[0][e]), __float_as_uint(o[1][e]), false, false);
+                v0[e] = __uint_as_float(sw[0]) * inv;
+                v1[e] = __uint_as_float(sw[1]) * inv;
+            }
+            if (qi < d.nq) {
+                const int col = h * 32 + 16 * (g & 1) + 8 * (g >> 1);
+                store8(op + (q_base + (long)qi * d.q_axis_stride) * ldo + col, v0, v1);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ ADAIN
 // grid = (B, C/64); block 256 = 64 channels x 4 position phases.
 __global__ __launch_bounds__(256) void adain_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -622,6 +761,28 @@ extern "C" int mage_split(const float* x, int64_t ldx, void* y, int64_t ldy, int
     return MAGE_OK;
 }
 
+namespace {
+int attn_split_launch(const mage_attn_desc* d, hipStream_t s) {
+    MAGE_CHECK_ARG(d->nq <= 32 && d->nk <= 32 && d->n_head <= 32 && d->n_head % 2 == 0 && d->out_split == MAGE_F16X3 && d->drop_p == 0.f,
+                   "mage_attention: split (f16x3) q/k/v: nq, nk <= 32, an even head count, split output");
+    MAGE_CHECK_ARG((d->ldq | d->ldk | d->ldv | d->ldo) % 128 == 0 && ((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->out) & 255) == 0),
+                   "mage_attention: split operands need leading dimensions that are multiples of 128 16-bit elements and 256-byte aligned bases");
+    const int nkb = d->nk <= 16 ? 1 : 2;
+    const size_t lds = (size_t)16 * nkb * (d->n_head * 64 + 16) * 2;
+    const int hpw = (d->n_head + 3) / 4;
+#define ATTN_S(NKB, MH) \
+    do { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attention_mfma_split_kernel<NKB, MH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((attention_mfma_split_kernel<NKB, MH>), dim3(d->n_seq), dim3(256), lds, s, *d); \
+    } while (0)
+    if (nkb == 1) { if (hpw <= 2) ATTN_S(1, 2); else if (hpw <= 4) ATTN_S(1, 4); else ATTN_S(1, 8); }
+    else { if (hpw <= 2) ATTN_S(2, 2); else if (hpw <= 4) ATTN_S(2, 4); else ATTN_S(2, 8); }
+#undef ATTN_S
+    MAGE_CHECK_LAUNCH("mage_attention");
+    return MAGE_OK;
+}
+}  // namespace
+
 extern "C" int mage_attention(const mage_attn_desc* d, void* stream) {
     MAGE_CHECK_ARG(d && d->q && d->k && d->v && d->out, "mage_attention: null pointer");
     MAGE_CHECK_ARG(d->nk >= 1 && d->nk <= 64, "mage_attention: nk=%d outside [1, 64]", d->nk);
@@ -630,11 +791,12 @@ extern "C" int mage_attention(const mage_attn_desc* d, void* stream) {
     MAGE_CHECK_ARG(!d->kv_len || d->kv_len_div >= 1, "mage_attention: kv_len_div must be >= 1");
     MAGE_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f && (d->drop_p == 0.f || (d->dtype == MAGE_F32 && d->out_split == 0)),
                    "mage_attention: drop_p=%g needs fp32 q/k/v (the thread-per-query kernel) and 0 <= p < 1", (double)d->drop_p);
-    MAGE_CHECK_ARG(d->out_split == 0 || ((d->out_split == MAGE_BF16X3 || d->out_split == MAGE_F16X3) && d->dtype == MAGE_F32 &&
+    MAGE_CHECK_ARG(d->out_split == 0 || ((d->out_split == MAGE_BF16X3 || d->out_split == MAGE_F16X3) && (d->dtype == MAGE_F32 || d->dtype == MAGE_F16X3) &&
                                          (d->n_head * 32) % 64 == 0 && d->ldo % 128 == 0 && (((uintptr_t)d->out) & 255) == 0),
                    "mage_attention: out_split needs fp32 q/k/v, an even head count, ldo a multiple of 128 16-bit elements, out 256-byte aligned");
     if (d->dtype == MAGE_F32) return attn_launch<float>(d, (hipStream_t)stream);
     if (d->dtype == MAGE_BF16) return attn_launch<unsigned short>(d, (hipStream_t)stream);
+    if (d->dtype == MAGE_F16X3) return attn_split_launch(d, (hipStream_t)stream);
     mage_set_error("mage_attention: bad dtype %d", d->dtype);
     return MAGE_EINVAL;
 }

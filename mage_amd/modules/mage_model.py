@@ -517,6 +517,9 @@ class FlatAxialDecoder(nn.Module):
     @torch.no_grad()
     def _inc_begin(self, B: int, hh: int, ww: int, device) -> dict:
         dt, Cc, L = self.compute_dtype, self.model_channels, self.frames_length
+        if self._split_on() and self._attn_split():        # f16x3: K, V cached as split rows (what the attention kernel reads)
+            caches = {i: ops.split_empty(B * L * hh * ww, 2 * Cc, self.split_kind, device) for i in range(self.layers) if i % 3 == 0}
+            return {"B": B, "hh": hh, "ww": ww, "kv": caches, "p": 0}
         caches = {i: torch.empty(B * L * hh * ww, 2 * Cc, device=device, dtype=dt) for i in range(self.layers) if i % 3 == 0}
         return {"B": B, "hh": hh, "ww": ww, "kv": caches, "p": 0}
 
@@ -616,6 +619,11 @@ class FlatAxialDecoder(nn.Module):
     def _split_on(self) -> bool:
         return bool(self.split_kind) and self.compute_dtype == F32 and self.model_channels % 64 == 0
 
+    def _attn_split(self) -> bool:
+        """f16x3: the axial attentions read split q, k, v on the matrix cores (attention_mfma_split_kernel); sequences up to 32."""
+        return (self.split_kind == ops.F16X3 and self.frames_length <= 32 and (self.model_channels // 32) % 2 == 0
+                and not os.environ.get("MAGE_ATTN_SPLIT_FP32"))
+
     def _taps_ok(self, rows: int) -> bool:
         """in_linear / context_linear (+ T positions) and the frame convolution run as the padded-taps form of the split GEMM."""
         return self.model_channels % 256 == 0 and rows % 256 == 0 and self.in_channels % 64 == 0 and self.context_channels % 64 == 0
@@ -662,7 +670,8 @@ class FlatAxialDecoder(nn.Module):
         x = torch.empty(M, Cc, device=dev, dtype=F32)
         self._embed_inputs_split(d, x, motion, imgs, B=B, hw=hw, P=L, tp=d["tpos"], n_img_rows=B * (L - 1) * hw)
         xn = ops.split_empty(M, Cc, sk, dev)
-        qkv = torch.empty(M, 3 * Cc, device=dev, dtype=F32)
+        qs = self._attn_split()                # f16x3: q, k, v leave the QKV epilogue as split rows, attention on the matrix cores
+        qkv = ops.split_empty(M, 3 * Cc, sk, dev) if qs else torch.empty(M, 3 * Cc, device=dev, dtype=F32)
         ao = ops.split_empty(M, Cc, sk, dev)
         hdn = ops.split_empty(M, 4 * Cc, sk, dev)
         for i in range(self.layers):
@@ -675,9 +684,11 @@ class FlatAxialDecoder(nn.Module):
             else:
                 geo = dict(n_seq=B * L * hh, inner=1, nq=ww, nk=ww, q_outer_stride=ww, q_axis_stride=1, causal=False)
             ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], xn, 1e-5, split_kind=sk)
-            self._lin_s(xn, d, p + ".in_proj", qkv, M=M, N=3 * Cc, K=Cc)
-            ops.attention(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], ao, ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=2 * Cc, n_head=H,
-                          kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], out_split=sk, **geo)
+            self._lin_s(xn, d, p + ".in_proj", qkv, M=M, N=3 * Cc, K=Cc, y_split=qs)
+            m_ = 2 if qs else 1                                                      # split rows: 2 16-bit elements per logical column
+            ops.attention(qkv, qkv[:, m_ * Cc:], qkv[:, m_ * 2 * Cc:], ao, ldq=m_ * 3 * Cc, ldk=m_ * 3 * Cc, ldv=m_ * 3 * Cc, ldo=2 * Cc, n_head=H,
+                          kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], out_split=sk, split_kind=sk if qs else 0,
+                          **geo)
             self._lin_s(ao, d, p + ".out_proj", x, M=M, N=Cc, K=Cc, residual=x, ldr=Cc)
             ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5, split_kind=sk)
             self._lin_s(xn, d, p + ".c_fc", hdn, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU, y_split=True)
@@ -711,7 +722,10 @@ class FlatAxialDecoder(nn.Module):
         x = torch.empty(M, Cc, device=dev, dtype=F32)
         self._embed_inputs_split(d, x, motion, imgs, B=B, hw=hw, P=P, tp=d["tpos"][p0:], n_img_rows=B * hw)
         xn = ops.split_empty(M, Cc, sk, dev)
-        qkv = torch.empty(M, 3 * Cc, device=dev, dtype=F32)
+        qs = self._attn_split()
+        m_ = 2 if qs else 1                                                  # split rows: 2 16-bit elements per logical column
+        ask = sk if qs else 0
+        qkv = ops.split_empty(M, 3 * Cc, sk, dev) if qs else torch.empty(M, 3 * Cc, device=dev, dtype=F32)
         ao = ops.split_empty(M, Cc, sk, dev)
         hdn = ops.split_empty(M, 4 * Cc, sk, dev)
         for i in range(self.layers):
@@ -719,21 +733,22 @@ class FlatAxialDecoder(nn.Module):
             axis = i % 3
             ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], xn, 1e-5, split_kind=sk)
             if axis == 0:
-                kv = st["kv"][i]                                             # [B, L, hw, K|V] fp32
-                self._lin_s(xn, d, p + ".in_proj", qkv, M=M, N=Cc, K=Cc, lo=0, hi=Cc, ldy=Cc)
-                self._lin_s(xn, d, p + ".in_proj", kv, M=M, N=2 * Cc, K=Cc, lo=Cc, hi=3 * Cc, ldy=2 * Cc, out_w=P * hw,
-                            y_img_stride=L * hw, y_off=p0 * hw)
-                ops.attention(qkv, kv, kv[:, Cc:], ao, ldq=Cc, ldk=2 * Cc, ldv=2 * Cc, ldo=2 * Cc, n_seq=B * hw, inner=hw, nq=P,
+                kv = st["kv"][i]                                             # [B, L, hw, K|V] fp32 (f16x3: split rows)
+                qv = qkv.view(-1)[:M * m_ * Cc].view(M, m_ * Cc)             # q of the new positions, packed [M, C]
+                self._lin_s(xn, d, p + ".in_proj", qv, M=M, N=Cc, K=Cc, lo=0, hi=Cc, ldy=m_ * Cc, y_split=qs)
+                self._lin_s(xn, d, p + ".in_proj", kv, M=M, N=2 * Cc, K=Cc, lo=Cc, hi=3 * Cc, ldy=m_ * 2 * Cc, out_w=P * hw,
+                            y_img_stride=L * hw, y_off=p0 * hw, y_split=qs)
+                ops.attention(qv, kv, kv[:, m_ * Cc:], ao, ldq=m_ * Cc, ldk=m_ * 2 * Cc, ldv=m_ * 2 * Cc, ldo=2 * Cc, n_seq=B * hw, inner=hw, nq=P,
                               nk=p0 + P, n_head=H, q_outer_stride=P * hw, q_axis_stride=hw, kv_outer_stride=L * hw,
-                              kv_axis_stride=hw, causal=True, out_split=sk)
+                              kv_axis_stride=hw, causal=True, out_split=sk, split_kind=ask)
             else:
-                self._lin_s(xn, d, p + ".in_proj", qkv, M=M, N=3 * Cc, K=Cc)
+                self._lin_s(xn, d, p + ".in_proj", qkv, M=M, N=3 * Cc, K=Cc, y_split=qs)
                 if axis == 1:
                     geo = dict(n_seq=B * P * ww, inner=ww, nq=hh, nk=hh, q_outer_stride=hw, q_axis_stride=ww)
                 else:
                     geo = dict(n_seq=B * P * hh, inner=1, nq=ww, nk=ww, q_outer_stride=ww, q_axis_stride=1)
-                ops.attention(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], ao, ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=2 * Cc, n_head=H,
-                              kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], out_split=sk, **geo)
+                ops.attention(qkv, qkv[:, m_ * Cc:], qkv[:, m_ * 2 * Cc:], ao, ldq=m_ * 3 * Cc, ldk=m_ * 3 * Cc, ldv=m_ * 3 * Cc, ldo=2 * Cc, n_head=H,
+                              kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], out_split=sk, split_kind=ask, **geo)
             self._lin_s(ao, d, p + ".out_proj", x, M=M, N=Cc, K=Cc, residual=x, ldr=Cc)
             ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5, split_kind=sk)
             self._lin_s(xn, d, p + ".c_fc", hdn, M=M, N=4 * Cc, K=Cc, act=ops.ACT_QUICKGELU, y_split=True)

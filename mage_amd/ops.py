@@ -357,11 +357,12 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch
 
 def attention(q, k, v, out, *, ldq, ldk, ldv, ldo, n_seq, inner, nq, nk, n_head, q_outer_stride, q_axis_stride,
               kv_outer_stride, kv_axis_stride, causal=False, kv_len=None, kv_len_div=1, scale=None, out_split: int = 0,
-              drop_p: float = 0.0, drop_seed: int = 0):
-    """out_split BF16X3 / F16X3 (fp32 q, k, v): out is a split-precision tensor, ldo in 16-bit elements (2 * logical width)."""
+              drop_p: float = 0.0, drop_seed: int = 0, split_kind: int = 0):
+    """out_split BF16X3 / F16X3 (fp32 q, k, v): out is a split-precision tensor, ldo in 16-bit elements (2 * logical width).
+    split_kind F16X3: q, k, v are split-precision tensors too (ld* in 16-bit elements; views start at 2 * the logical column)."""
     l, s = _dev(q)
     d = AttnDesc()
-    d.dtype = code(q)
+    d.dtype = split_kind or code(q)
     d.q, d.k, d.v, d.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
     d.ldq, d.ldk, d.ldv, d.ldo = ldq, ldk, ldv, ldo
     d.n_seq, d.inner, d.nq, d.nk, d.n_head = n_seq, inner, nq, nk, n_head
