@@ -342,8 +342,9 @@ def main():
                   "note": "f16x3 = the fast parity mode: fp32 everywhere except that the decoder's Linear layers and the frame convolution multiply "
                           "split-precision operands (x = hi + lo/2^11 in two f16 pieces; A_hi W_lo + A_lo W_hi, scaled, + A_hi W_hi on "
                           "v_mfma_f32_16x16x32_f16, fp32 accumulation).  It passes every fp32-mode golden gate (reference token sequences "
-                          "bit-exact incl. the 7680-decision L=16 clip, logits within 1e-4: tests/test_gpu_split.py; measured 3.7e-6 vs the "
-                          "exact-fp32 mode's 7.0e-6, profiles/r03_parity_report_f16x3.txt)",
+                          "bit-exact incl. the 7680-decision L=16 clip, logits within 1e-4: tests/test_gpu_split.py; measured 4.1e-6 vs the "
+                          "exact-fp32 mode's 7.5e-6, profiles/r03_parity_report_{f16x3,fp32}.txt); its axial attention also runs as three f16 MFMA "
+                          "passes per product on split q / k / v rows",
                   "other_ar_mode": {"ar_mode": other_mode, "value": round(world * B * L * n3 / dt3o, 2), "ms_per_step": round(dt3o / n3 * 1e3, 3),
                                     "tokens_identical": same3},
                   "exact_fp32": {"dtype": "fp32", "value": round(world * B * L / dt32, 2), "ms_per_step": round(dt32 * 1e3, 3), "steps": 1,
