@@ -483,7 +483,30 @@ def main():
             res["config"]["graph_replay_note"] = ("the timed calls replay ONE captured HIP graph of the whole autoregressive_generate call "
                                                   "(same kernels, same order, bit-identical results; tests/test_gpu_parity.py)")
         if cpu_sd is not None:
-            res["cpu_baseline"] = cpu_baseline(cpu_sd, L, args.cpu_clips)
+            res["cpu_baseline"], oracle_tok, oracle_margin = cpu_baseline(cpu_sd, L, args.cpu_clips)
+            # the same clips through the HIP path: do the GPU token sequences equal the CPU oracle's (= the reference's algorithm, pinned
+            # by the goldens)?  north_star: "reference-matching VQ token sequences on Single Moving MNIST"
+            try:
+                cb = {k: v.to(dev) for k, v in synth.synth_batch_mnist(args.cpu_clips, L, seed=100).items()}
+                agree = {}
+                saved = (model.precision, model.ar_mode)
+                model.ar_mode = "full"
+                for prec in ("f16x3", "fp32", "bf16"):
+                    model.set_precision(prec)
+                    model.autoregressive_generate(cb)
+                    got = model.last_tokens.cpu()
+                    eq = got == oracle_tok
+                    bad = ~eq
+                    agree[prec] = {"all_positions": round(eq.float().mean().item(), 5), "clips_identical": round(eq.flatten(1).all(1).float().mean().item(), 5),
+                                   "mismatches_where_oracle_margin_above_2e-5": int((bad & (oracle_margin > 2e-5)).sum())}
+                model.set_precision(saved[0])
+                model.ar_mode = saved[1]
+                res["cpu_baseline"]["gpu_tokens_vs_oracle"] = dict(agree, clips=args.cpu_clips, positions=int(oracle_tok.numel()),
+                                                                   oracle_min_top2_margin=float(oracle_margin.min()),
+                                                                   note="free-running AR token sequences of the HIP path against the CPU oracle's on the "
+                                                                        "baseline sample's clips (same weights, same inputs)")
+            except Exception as e:
+                res["cpu_baseline"]["gpu_tokens_vs_oracle"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(res))
     if world > 1:
         D.barrier()
@@ -524,8 +547,10 @@ def cpu_baseline(sd, L, clips):
             best = min(best, (time.perf_counter() - t0, th))
         torch.set_num_threads(best[1])
         t0 = time.perf_counter()
-        O.mage_generate(sd, batch, L)
+        _, o_tok, _, o_trace = O.mage_generate(sd, batch, L, return_trace=True)
         dt = time.perf_counter() - t0
+        top2 = o_trace.topk(2, dim=-1)[0]
+        o_margin = (top2[..., 0] - top2[..., 1]).abs()
         # one thread, one clip: first a SHORT clip (6 frames); if that predicts < 40 s for the full clip length (the loop's
         # cost grows ~L^2), the full-length clip is timed too and reported instead.  The sample is stated, never extrapolated.
         torch.set_num_threads(1)
@@ -543,7 +568,7 @@ def cpu_baseline(sd, L, clips):
             L1 = L
             dt1 = one_thread(L1)
         torch.set_num_threads(best[1])
-    return {"value": round(clips * L / dt, 3), "unit": "frames/s", "cores": best[1], "kind": "port", "cpu": _cpu_model_name(),
+    return ({"value": round(clips * L / dt, 3), "unit": "frames/s", "cores": best[1], "kind": "port", "cpu": _cpu_model_name(),
             "host_threads": ncpu,
             "sample": f"{clips} clips x {L} frames (same model, fp32, oracle/mage_oracle.py mage_generate = the reference's "
                       f"full-recompute AR loop, torch {torch.__version__} CPU ops, {best[1]} of {ncpu} host threads "
@@ -551,7 +576,7 @@ def cpu_baseline(sd, L, clips):
             "one_thread": {"value": round(L1 / dt1, 3), "unit": "frames/s", "cores": 1,
                            "sample": f"1 clip x {L1} frames on 1 thread (same model and loop" +
                                      ("" if L1 == L else "; shorter clip so that the sample stays bounded: the loop's cost grows ~L^2") +
-                                     f"), {dt1:.1f} s"}}
+                                     f"), {dt1:.1f} s"}}, o_tok, o_margin)
 
 
 if __name__ == "__main__":

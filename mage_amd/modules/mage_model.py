@@ -413,7 +413,8 @@ class FlatAxialDecoder(nn.Module):
                 wq = (w * g[None, :]).to(BF16)
                 d[f"b{i}.{lin}.lnw"] = wq
                 d[f"b{i}.{lin}.lns"] = wq.float().sum(dim=1).contiguous()
-                d[f"b{i}.{lin}.lnc"] = (w.double() @ bt.double() + d[f"b{i}.{lin}.b"].double()).float().contiguous()
+                # c_n = sum_k W_nk beta_k + b_n in fp64 (a row-wise reduction: derived-cache bookkeeping, no BLAS call)
+                d[f"b{i}.{lin}.lnc"] = ((w.double() * bt.double()[None, :]).sum(1) + d[f"b{i}.{lin}.b"].double()).float().contiguous()
         return d
 
     def _fold(self, dt, B: int, hw: int) -> bool:
