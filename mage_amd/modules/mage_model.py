@@ -620,6 +620,17 @@ class FlatAxialDecoder(nn.Module):
     def _split_on(self) -> bool:
         return bool(self.split_kind) and self.compute_dtype == F32 and self.model_channels % 64 == 0
 
+    def _warm_split(self) -> None:
+        """Build every split-precision weight copy now (MAGE._warm_derived: on the caller's stream, before side streams fork)."""
+        if not self._split_on():
+            return
+        d = self._derived.get(self._build)
+        names = ["in_linear", "context_linear"] + (["out"] if self.use_cids else [])
+        for i in range(self.layers):
+            names += [f"b{i}.in_proj", f"b{i}.out_proj", f"b{i}.c_fc", f"b{i}.c_proj"]
+        for n in names:
+            _wsplit(d, n, self.split_kind)
+
     def _attn_split(self) -> bool:
         """f16x3: the axial attentions read split q, k, v on the matrix cores (attention_mfma_split_kernel); sequences up to 32."""
         return (self.split_kind == ops.F16X3 and self.frames_length <= 32 and (self.model_channels // 32) % 2 == 0
@@ -1150,6 +1161,10 @@ class MAGE(nn.Module):
             if mod is not None and hasattr(mod, "_derived") and hasattr(mod, "_build"):
                 mod._derived.get(mod._build)
         self._frame_tables()
+        if hasattr(self.generate_model, "_warm_split"):
+            self.generate_model._warm_split()
+            if self._sk():
+                _wsplit(self._derived.get(self._build), "conv", self._sk())
 
     def _generate_multistream(self, batch, n):
         B = batch["images"].shape[0]

@@ -275,6 +275,14 @@ def test_multistream_clip_groups_are_bit_identical():
     m.streams, m.ar_mode = 4, "incremental"
     v3 = m.autoregressive_generate(batch)
     assert torch.equal(m.last_tokens, t1) and torch.equal(v1, v3)
+    # the fast parity mode on side streams: its split-precision weight copies are built on the caller's stream first (_warm_derived)
+    m2 = build_mage(synth.mnist_model_config(frames_length=6), 5, DEV).set_precision("f16x3")
+    m2.streams = 2
+    v4 = m2.autoregressive_generate(batch)
+    t4 = m2.last_tokens.clone()
+    m2.streams = 1
+    v5 = m2.autoregressive_generate(batch)
+    assert torch.equal(m2.last_tokens, t4) and torch.equal(v4, v5)
 
 
 def test_mage_plus_latent_path_golden():
@@ -507,7 +515,7 @@ def test_full_size_properties_cfg5_mage_plus():
 
 
 # ------------------------------------------------------------------------------------------------ HIP-graph replay of the call
-@pytest.mark.parametrize("precision,ar_mode", [("fp32", "full"), ("bf16", "full"), ("bf16", "incremental")])
+@pytest.mark.parametrize("precision,ar_mode", [("fp32", "full"), ("bf16", "full"), ("bf16", "incremental"), ("f16x3", "incremental")])
 def test_graph_replay_is_bit_identical_to_eager(precision, ar_mode):
     """MAGE.use_graph: the whole autoregressive_generate call replayed from one captured HIP graph (no allocation, no host
     decision inside) gives bitwise the eager result, also on NEW inputs of the same shape, and the golden tokens in fp32."""
@@ -528,7 +536,7 @@ def test_graph_replay_is_bit_identical_to_eager(precision, ar_mode):
             v = m.autoregressive_generate(b)
             assert torch.equal(v, wv) and torch.equal(m.last_tokens, wt), (rnd_, m.last_call_mode)
     assert m.last_call_mode == "graph"
-    if precision == "fp32":
+    if precision in ("fp32", "f16x3"):
         m.autoregressive_generate(b1)
         assert assert_tokens(m.last_tokens.cpu(), g["gen_tokens"], g["margin"], TOK_TOL, "graph-replayed AR tokens") == 0
     # replaced weights invalidate the captured graph (its kernels point at the old derived copies)

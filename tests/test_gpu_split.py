@@ -117,6 +117,24 @@ def test_split_row_producers_match_fp32_twins(kind):
     assert (unsplit(ps, kind) - p32.double()).abs().max().item() < tol * table.abs().max().item()
 
 
+@pytest.mark.parametrize("nq,nk,causal", [(16, 16, False), (16, 16, True), (24, 24, True), (32, 32, False), (2, 20, True), (1, 9, True)])
+def test_split_attention_on_the_matrix_cores_against_fp32_attention(nq, nk, causal):
+    """attention_mfma_split_kernel (q, k, v, out as f16x3 split rows; one and two key blocks; the incremental step's query-block-appended-
+    to-a-cache shape) against the fp32 thread-per-query kernel on the same values."""
+    kind = ops.F16X3
+    g = torch.Generator().manual_seed(nq * 100 + nk)
+    Cc, H, n_seq = 512, 16, 48
+    q = torch.randn(n_seq * nq, Cc, generator=g).to(DEV)
+    kv = torch.randn(n_seq * nk, 2 * Cc, generator=g).to(DEV)
+    geo = dict(n_seq=n_seq, inner=1, nq=nq, nk=nk, n_head=H, q_outer_stride=nq, q_axis_stride=1, kv_outer_stride=nk, kv_axis_stride=1, causal=causal)
+    want = ops.attention(q, kv, kv[:, Cc:], torch.empty(n_seq * nq, Cc, device=DEV), ldq=Cc, ldk=2 * Cc, ldv=2 * Cc, ldo=Cc, **geo)
+    qs, kvs = ops.split(q, kind), ops.split(kv, kind)
+    got = ops.attention(qs, kvs, kvs[:, 2 * Cc:], ops.split_empty(n_seq * nq, Cc, kind, DEV), ldq=2 * Cc, ldk=4 * Cc, ldv=4 * Cc, ldo=2 * Cc,
+                        out_split=kind, split_kind=kind, **geo)
+    err = (unsplit(got, kind) - want.double()).abs().max().item()
+    assert err < 2e-5, err
+
+
 @pytest.mark.parametrize("kind", KINDS)
 def test_frame_features_and_decoder_pass_track_fp32_mode(kind):
     """Teacher-forced on the reference's own L = 16 tokens: frame convolution + decoder stack in the split mode against the
