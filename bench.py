@@ -507,6 +507,13 @@ def main():
                                                                         "baseline sample's clips (same weights, same inputs)")
             except Exception as e:
                 res["cpu_baseline"]["gpu_tokens_vs_oracle"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        # the headline secondary numbers once more as flat scalars (tools that keep only top-level scalars of this line still see them)
+        res["parity_mode_frames_per_s"] = parity["value"] if parity else None
+        res["parity_mode_dtype"] = parity["dtype"] if parity else None
+        res["incremental_mode_frames_per_s"] = (other["value"] if other and other["ar_mode"] == "incremental" else
+                                                (round(value, 2) if args.ar_mode == "incremental" else None))
+        gto = res.get("cpu_baseline", {}).get("gpu_tokens_vs_oracle", {}) if cpu_sd is not None else {}
+        res["parity_mode_tokens_equal_cpu_oracle"] = (gto.get("f16x3", {}).get("all_positions") == 1.0) if "f16x3" in gto else None
         print(json.dumps(res))
     if world > 1:
         D.barrier()
