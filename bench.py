@@ -264,7 +264,7 @@ def main():
     sync_all()
     # timed region: HIP events on the launch stream around the dominant symbol's launches (--events all: around all).  With
     # graph replay the event pairs are event-record nodes of the captured graph (same stream, same positions).
-    ops.PROFILE.reset(enabled=True, only=None if (args.events == "all" or dom_warm is None) else [dom_warm])
+    ops.PROFILE.reset(enabled=True, only=None if (args.events == "all" or dom_warm is None) else [dom_warm, "decoder_step"])
     prime()
     ops.PROFILE.clear()
     sync_all()
@@ -454,6 +454,17 @@ def main():
                          "convolution + in_linear (11 % of the reference's FLOPs) are a gather-sum over precomputed tables "
                          "(mage_table_conv): they leave the numerator, the call gets faster, the fraction falls"
                  } if args.ar_mode == "full" else None
+        tstep = None
+        if args.ar_mode == "full" and prof.get("decoder_step", {}).get("calls"):
+            ds = prof["decoder_step"]
+            f_dec = f_step - (B * (L - 1) * 256 * 2 * 512 * 512 if tables_on else 0)       # in_linear leaves with the table sum
+            t_dec = ds["ms"] / ds["calls"]
+            tstep = {"ms": round(t_dec, 3), "calls": ds["calls"] // args.steps, "flops": f_dec, "achieved": round(f_dec / (t_dec * 1e-3) / 1e12, 1),
+                     "peak": peak, "unit": "TFLOP/s", "frac": round(f_dec / (t_dec * 1e-3) / 1e12 / peak, 4),
+                     "note": "north_star's 'transformer step': one FlatAxialDecoder pass (frame slots via the table sum, context_linear, 6 axial "
+                             "blocks incl. LayerNorm / attention, head) over all L slots = one of the L-1 recomputes of the reference loop; HIP events "
+                             "around each pass inside the timed region; executed FLOPs (SURVEY 8d F_step, minus in_linear when it is folded into "
+                             "the table)"}
         wl_name = ("cfg2: Single Moving MNIST" if args.workload == "cfg2" else "cfg3: Double Moving MNIST (two digits, captions 16/18/20 tokens padded to 20)")
         res = {
             "metric": "generated frames/sec (64x64, 16-frame clips)", "value": round(value, 2), "unit": "frames/s",
@@ -470,6 +481,7 @@ def main():
                        "generated_only_value": round(value * (L - 1) / L, 2)},
             "roofline": roofline,
             "whole_call": whole,
+            "transformer_step": tstep,
             "roofline_decode": decode,
             "parity_mode": parity,
             "kernel_time_ms_per_step": ({k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items())} if args.events == "all"

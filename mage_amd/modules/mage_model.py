@@ -1245,7 +1245,10 @@ class MAGE(nn.Module):
         logits = None
         for i in range(Lm1):                                                                  # :673-684
             feats = self._frame_source(cur, dt)
+            ev = ops.PROFILE.begin() if ops.PROFILE.wants("decoder_step") else None          # bench.py: the transformer step on its own
             logits = self.generate_model._run(ma_dt, feats, B=B, hh=R, ww=R)                  # [B*(L-1)*hw, K]
+            if ev is not None:
+                ops.PROFILE.end("decoder_step", ev, 0.0)
             if i != Lm1 - 1:                                                                  # argmax of frame i -> slot i+1
                 ops.argmax(logits, cur, rows=B * hw, K=K, group=hw, in_group_stride=Lm1 * hw, in_off=i * hw,
                            out_group_stride=Lm1 * hw, out_off=(i + 1) * hw)
