@@ -358,6 +358,16 @@ int mage_transpose(const void* x, int32_t dtype, int64_t ldx, void* y, int64_t l
  * that its weight gradient needs. */
 int mage_transpose_colsum(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int64_t Mp, int32_t C, int32_t out_w,
                           int64_t img_stride, int64_t a_off, float* colsum, int32_t n_part, void* stream);
+/* Weight gradient WITHOUT transposed copies: partials[s][n][k] = sum over tokens t in [s*tokens_per_split, (s+1)*tokens_per_split) ∩ [0, T)
+ * of dY[t*lda + n] * X[t*ldb + k]  (bf16 operands, row-major over the token index; fp32 accumulation and output; N and K multiples of
+ * 256, tokens_per_split a multiple of 64, n_split * tokens_per_split >= T); the caller adds the n_split partials (mage_sum_partials).
+ * dW = dY^T X of every nn.Linear of the decoder stack (loss.backward(), main_mage.py:152): tiles go to LDS as stored and the MFMA
+ * fragments are read with the transposing LDS load (ds_read_b64_tr_b16).  db_partials (optional, [n_split][N]): the bias gradient's
+ * column sums of dY per slice, added up from the fragments the kernel holds anyway.  mage_colsum: the same column sums on their own,
+ * partials[p][c] over the p-th of n_part row chunks (fp32; finished by mage_sum_partials). */
+int mage_gemm_tn(const void* dY, int64_t lda, const void* X, int64_t ldb, int64_t T, int32_t N, int32_t K, int32_t n_split,
+                 int64_t tokens_per_split, float* partials, float* db_partials, void* stream);
+int mage_colsum(const void* x, int64_t ld, int64_t T, int32_t C, float* partials, int32_t n_part, void* stream);
 /* Row sums (fp32, fixed order): bias gradients db = column sums of dY, taken from the transposed dY.  The n columns are cut into
  * n_chunk chunks: out[chunk*rows + r] = sum over chunk of x[r*ld + c]; n_chunk > 1 is finished by mage_sum_partials. */
 int mage_row_sum(const void* x, int32_t dtype, int64_t ld, int64_t n, int32_t rows, float* out, int32_t n_chunk, void* stream);

@@ -94,6 +94,8 @@ SIGNATURES = {
     "mage_bn_apply": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
     "mage_bn_bwd_apply": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
     "mage_convt_unfold_tanh_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mage_gemm_tn": (C.c_int, [vp, i64, vp, i64, i64, i32, i32, i32, i64, vp, vp, vp]),
+    "mage_colsum": (C.c_int, [vp, i64, i64, i32, vp, i32, vp]),
     "mage_row_sum": (C.c_int, [vp, i32, i64, i64, i32, vp, i32, vp]),
     "mage_sum_partials": (C.c_int, [vp, i64, i32, i64, vp, i32, vp]),
     "mage_layernorm_bwd": (C.c_int, [vp, vp, vp, i32, vp, vp, i32, i64, i32, f32, i32, vp]),

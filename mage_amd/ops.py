@@ -684,6 +684,38 @@ def transpose(x, y, *, M: int, Mp: int, C: int, ldx: int, ldy: int, y_row0: int 
     return y
 
 
+def gemm_tn(dy, x, *, T: int, N: int, K: int, ld_dy: int, ld_x: int, want_bias: bool = True):
+    """dW [N, K] = dy[:T, :N]^T x[:T, :K] (fp32) and db [N] = column sums of dy, from ROW-MAJOR bf16 dy / x (no transposed copies):
+    mage_gemm_tn over token slices + mage_sum_partials (+ mage_colsum)."""
+    l, s = _dev(dy)
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and N % 256 == 0 and K % 256 == 0
+    n_cu = torch.cuda.get_device_properties(dy.device).multi_processor_count & ~7
+    tiles = (N // 256) * (K // 256)
+    S = int(max(1, min(256, (2 * n_cu) // tiles, (T + 511) // 512)))      # two rounds of workgroups per CU, never a third (a 4-workgroup tail
+    tps = ((T + S - 1) // S + 63) // 64 * 64                              # cost in_proj a third of its time), >= 512 tokens per slice
+    S = (T + tps - 1) // tps
+    part = torch.empty(S, N, K, device=dy.device, dtype=torch.float32)
+    dbp = torch.empty(S, N, device=dy.device, dtype=torch.float32) if want_bias else None
+    ev = PROFILE.begin() if PROFILE.wants("gemm_tn") else None
+    _lib.check(l.mage_gemm_tn(dy.data_ptr(), ld_dy, x.data_ptr(), ld_x, T, N, K, S, tps, part.data_ptr(), _p(dbp), s), l)
+    if ev is not None:
+        PROFILE.end("gemm_tn", ev, 2.0 * T * N * K)
+    dW = part[0] if S == 1 else sum_partials(part, torch.empty(N, K, device=dy.device, dtype=torch.float32), stride=N * K, n_part=S, n=N * K)
+    db = None
+    if want_bias:           # the kernel's per-slice column sums of dy (from the fragments it holds anyway), added in a fixed order
+        db = dbp[0] if S == 1 else sum_partials(dbp, torch.empty(N, device=dy.device, dtype=torch.float32), stride=N, n_part=S, n=N)
+    return dW, db
+
+
+def colsum(x: torch.Tensor, *, T: int, C_: int, ld: int) -> torch.Tensor:
+    """Column sums (fp32 [C]) of bf16 rows x[:T, :C] (mage_colsum + mage_sum_partials): a bias gradient on its own."""
+    l, s = _dev(x)
+    n_part = int(max(1, min(1024, T // 128)))
+    cp = torch.empty(n_part, C_, device=x.device, dtype=torch.float32)
+    _lib.check(l.mage_colsum(x.data_ptr(), ld, T, C_, cp.data_ptr(), n_part, s), l)
+    return cp[0] if n_part == 1 else sum_partials(cp, torch.empty(C_, device=x.device, dtype=torch.float32), stride=C_, n_part=n_part, n=C_)
+
+
 def row_sum(x, out, *, ld: int, n: int, rows: int):
     l, s = _dev(x)
     n_chunk = int(max(1, min(64, n // 2048, 16384 // max(rows, 1))))      # enough waves to fill the chip, >= 2048 columns each

@@ -429,6 +429,29 @@ def test_dropout_training_mode_is_consistent_between_forward_and_backward():
     assert abs(fd - an) < 0.05 * max(abs(an), 1e-3) + 2e-4
 
 
+@pytest.mark.parametrize("T,N,K,ld_dy,ld_x", [(4096, 256, 256, 256, 256), (5000, 512, 256, 512, 256), (16384, 512, 2048, 1536, 2048), (70000, 1536, 512, 1536, 512)])
+def test_gemm_tn_weight_gradient_against_fp64(T, N, K, ld_dy, ld_x):
+    """mage_gemm_tn: dW = dY^T X from row-major bf16 operands through the transposing LDS load (no transposed copies), token slices +
+    fixed-order partial sums, and the column sums of dY (bias gradient); ragged token counts, strided operands (a column slice of a wider
+    matrix), bitwise repeatable."""
+    from mage_amd import ops as o
+    g = torch.Generator().manual_seed(T + N)
+    dy_full = (torch.randn(T, ld_dy, generator=g) * 0.5).to(DEV).bfloat16()
+    x_full = torch.randn(T, ld_x, generator=g).to(DEV).bfloat16()
+    c0 = ld_dy - N                                          # the LAST N columns of a wider matrix (the k|v part of dqkv)
+    dy = dy_full[:, c0:]
+    dW, db = o.gemm_tn(dy, x_full, T=T, N=N, K=K, ld_dy=ld_dy, ld_x=ld_x)
+    want = dy.double().t() @ x_full[:, :K].double()
+    scale = want.abs().max().item()
+    assert (dW.double() - want).abs().max().item() < 2e-5 * scale + 1e-3
+    want_b = dy.double().sum(0)
+    assert (db.double() - want_b).abs().max().item() < 1e-4 * want_b.abs().max().item() + 1e-3
+    dW2, db2 = o.gemm_tn(dy, x_full, T=T, N=N, K=K, ld_dy=ld_dy, ld_x=ld_x)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    cs = o.colsum(dy, T=T, C_=N, ld=ld_dy)
+    assert (cs.double() - want_b).abs().max().item() < 1e-4 * want_b.abs().max().item() + 1e-3
+
+
 def test_sum_partials_fixed_order_vector_and_scalar_kernels():
     """mage_sum_partials (split-K partial products, LayerNorm gamma / beta partials): the 16-byte kernel (four waves over the partials,
     fixed-order LDS sum) and the scalar fallback against an fp64 sum; bitwise repeatable; `accumulate` adds to the output."""
