@@ -36,7 +36,11 @@ __device__ __forceinline__ void glds16_tn(const void* src, char* lds_wave_base) 
                                      0);
 }
 __device__ __forceinline__ tr4 lds_tr(const char* p) {
+#ifdef MAGE_TN_NOTR      // tuning build: a plain 8-byte LDS read at the same address (wrong values, same traffic): is the transposing read the limiter?
+    return *(const tr4*)p;
+#else
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)p);
+#endif
 }
 
 __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnArgs g) {

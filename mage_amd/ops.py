@@ -691,8 +691,11 @@ def gemm_tn(dy, x, *, T: int, N: int, K: int, ld_dy: int, ld_x: int, want_bias: 
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and N % 256 == 0 and K % 256 == 0
     n_cu = torch.cuda.get_device_properties(dy.device).multi_processor_count & ~7
     tiles = (N // 256) * (K // 256)
-    S = int(max(1, min(256, (2 * n_cu) // tiles, (T + 511) // 512)))      # two rounds of workgroups per CU, never a third (a 4-workgroup tail
-    tps = ((T + S - 1) // S + 63) // 64 * 64                              # cost in_proj a third of its time), >= 512 tokens per slice
+    # ONE workgroup per CU, never a partial second round (measured at cfg2, TFLOP/s for in_proj / out_proj / c_fc / c_proj: one round
+    # 596 / 631 / 734 / 719, two 574 / 535 / 689 / 675, four 502 / 418 / 648 / 629: long K loops amortise the ring start-up and the 256 KB
+    # of fp32 partials each workgroup writes); >= 512 tokens per slice
+    S = int(max(1, min(256, n_cu // tiles, (T + 511) // 512)))
+    tps = ((T + S - 1) // S + 63) // 64 * 64
     S = (T + tps - 1) // tps
     part = torch.empty(S, N, K, device=dy.device, dtype=torch.float32)
     dbp = torch.empty(S, N, device=dy.device, dtype=torch.float32) if want_bias else None
