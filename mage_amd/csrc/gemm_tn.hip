@@ -60,19 +60,31 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnArgs g) {
     // 8-bank slots, and the two groups of a 32-lane LDS pass (token blocks g, g+1: 1 KB apart, the same banks) in complementary slots
     const int strip = wave >> 1, tb0 = (wave & 1) * 4;
     const uintptr_t zero = (uintptr_t)g.zero;
-    auto issue = [&](int slab, int stage) {
+    // per-lane source addresses of this wave's four units of slab 0, advanced by one slab (64 rows) per issue: no 64-bit multiplies in
+    // the loop (the two waves of a SIMD share its VALU with each other's MFMA issue)
+    uintptr_t pa[4], pb[4];
+    long tl[4];                                        // tokens left from this lane's row to the slice's end (<= 0: past the end)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col_in_strip = (((pc >> 1) ^ (rr & 3) ^ (j & 1)) << 4) + ((pc & 1) << 3);
+        const long t = t_begin + (tb0 + j) * 8 + rr;
+        pa[j] = (uintptr_t)(g.A + t * g.lda + (long)tm * 256 + strip * 64 + col_in_strip);
+        pb[j] = (uintptr_t)(g.B + t * g.ldb + (long)tk * 256 + strip * 64 + col_in_strip);
+        tl[j] = t_end - t;
+    }
+    const uintptr_t da = (uintptr_t)(64 * g.lda * 2), db_ = (uintptr_t)(64 * g.ldb * 2);
+    auto issue = [&](int stage) {
         char* base = smem + stage * STAGE + (wave * 4) * 1024;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int col_in_strip = (((pc >> 1) ^ (rr & 3) ^ (j & 1)) << 4) + ((pc & 1) << 3);
-            const long t = t_begin + (long)slab * 64 + (tb0 + j) * 8 + rr;
-            const bool live = t < t_end;
             // integer select: one v_cndmask pair per address (a pointer select between an SGPR-based and a VGPR-based address made hipcc
             // emit two differently addressed loads under exec-mask branches)
-            const uintptr_t pa = live ? (uintptr_t)(g.A + t * g.lda + (long)tm * 256 + strip * 64 + col_in_strip) : zero;
-            const uintptr_t pb = live ? (uintptr_t)(g.B + t * g.ldb + (long)tk * 256 + strip * 64 + col_in_strip) : zero;
-            glds16_tn((const void*)pa, base + j * 1024);
-            glds16_tn((const void*)pb, base + PART + j * 1024);
+            const bool live = tl[j] > 0;
+            glds16_tn((const void*)(live ? pa[j] : zero), base + j * 1024);
+            glds16_tn((const void*)(live ? pb[j] : zero), base + PART + j * 1024);
+            pa[j] += da;
+            pb[j] += db_;
+            tl[j] -= 64;
         }
     };
 
@@ -94,13 +106,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnArgs g) {
     const bf16x2v ones2 = {(__bf16)1.0f, (__bf16)1.0f};
     float dbs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    if (nslab > 0) issue(0, 0);
+    if (nslab > 0) issue(0);
     for (int kt = 0; kt < nslab; ++kt) {
         __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's share of slab kt has landed
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();                  // everyone's share is in LDS; everyone is done with the other stage
         asm volatile("" ::: "memory");
-        if (kt + 1 < nslab) issue(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < nslab) issue((kt + 1) & 1);
         const char* st = smem + (kt & 1) * STAGE;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
