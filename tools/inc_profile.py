@@ -16,6 +16,7 @@ m = m.to("cuda:0").set_precision("bf16")
 m.ar_mode = mode
 import os
 m.use_graph = bool(os.environ.get("INC_GRAPH"))
+m.streams = int(os.environ.get("INC_STREAMS", "1"))
 m.autoregressive_generate({k: v.to("cuda:0") for k, v in synth.synth_batch_mnist(64, 16, seed=100).items()})
 batch = {k: v.to("cuda:0") for k, v in synth.synth_batch_mnist(64, 16, seed=100).items()}
 m.autoregressive_generate(batch)
