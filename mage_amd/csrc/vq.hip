@@ -415,8 +415,11 @@ extern "C" int mage_table_conv(const int64_t* ids, int64_t n_img, int32_t H, int
                        C <= 2048 && ldy >= C && ldy % 4 == 0 && group > 0,
                    "mage_table_conv: bad sizes (odd taps, C %% 4 == 0, C <= 2048)");
     MAGE_CHECK_ARG(!rowadd || (rowadd_div >= 1 && rowadd_mod >= 1), "mage_table_conv: bad rowadd div/mod");
-    MAGE_CHECK_ARG((table_dtype == MAGE_F32 || table_dtype == MAGE_BF16) && (y_dtype == MAGE_F32 || y_dtype == MAGE_BF16),
+    const bool ysplit = y_dtype == MAGE_BF16X3 || y_dtype == MAGE_F16X3;
+    MAGE_CHECK_ARG((table_dtype == MAGE_F32 || table_dtype == MAGE_BF16) && (y_dtype == MAGE_F32 || y_dtype == MAGE_BF16 || ysplit),
                    "mage_table_conv: bad table / y dtype %d %d", table_dtype, y_dtype);
+    MAGE_CHECK_ARG(!ysplit || (C % 64 == 0 && ldy == C && (((uintptr_t)y) & 255) == 0 && table_dtype == MAGE_F32),
+                   "mage_table_conv: split output needs an fp32 table, C %% 64 == 0, packed rows, y 256-byte aligned");
     int* err = mage_error_word();
     MAGE_CHECK_ARG(err != nullptr, "mage_table_conv: mage_init() has not been called");
     const long n_pix = (long)n_img * H * W;
@@ -426,7 +429,9 @@ extern "C" int mage_table_conv(const int64_t* ids, int64_t n_img, int32_t H, int
                                          taps_h, taps_w, n_codes, C, (long)group, (long)y_group_stride, (long)y_off, (long)rowadd_div, rowadd_mod, (long)ldy, err)
 #define TCV(T_, O_) do { if (vpl <= 1) TC(T_, O_, 1); else if (vpl <= 2) TC(T_, O_, 2); else if (vpl <= 4) TC(T_, O_, 4); else TC(T_, O_, 8); } while (0)
     const int vpl = (C + 255) / 256;
-    if (table_dtype == MAGE_F32 && y_dtype == MAGE_F32) TCV(float, float);
+    if (y_dtype == MAGE_F16X3) TCV(float, split_f16);
+    else if (y_dtype == MAGE_BF16X3) TCV(float, split_bf16);
+    else if (table_dtype == MAGE_F32 && y_dtype == MAGE_F32) TCV(float, float);
     else if (table_dtype == MAGE_F32) TCV(float, unsigned short);
     else if (y_dtype == MAGE_F32) TCV(unsigned short, float);
     else TCV(unsigned short, unsigned short);

@@ -882,7 +882,7 @@ class MAGE(nn.Module):
         self.precision = precision
         self.generate_model.compute_dtype, self.generate_model.split_kind = PRECISIONS[precision]
         if hasattr(self.first_stage_model, "set_precision"):     # an external latent first stage (MAGE+) has no such switch
-            self.first_stage_model.set_precision("bf16" if precision == "bf16" else "fp32")
+            self.first_stage_model.set_precision(precision)
         return self
 
     def _dt(self) -> torch.dtype:

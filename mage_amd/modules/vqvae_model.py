@@ -162,6 +162,7 @@ class VectorQuantizedVAE(nn.Module):
             raise ValueError(f"down_ratio must be 4 or 8, got {down_ratio}")
         self.apply(weights_init)
         self.decode_dtype = torch.float32          # torch.bfloat16 = MFMA-bf16 performance mode for decode
+        self.decode_split = 0                      # ops.F16X3: the f4 decode stack on split-precision operands (set_precision('f16x3'))
         self.decode_chunk = 1024                   # frames per decode launch group (bounds workspace: 0.8 GB at dim 256)
         self._pad_bufs = {}                        # zero-padded frame buffers of the bf16 decode, keyed by (frames, grid, device, stream)
         self._derived = _Derived(self)
@@ -179,9 +180,10 @@ class VectorQuantizedVAE(nn.Module):
         print(f"Restored from {path}")
 
     def set_precision(self, precision: str) -> "VectorQuantizedVAE":
-        """'fp32' (parity: exact-fp32 MFMA) or 'bf16' (decode stack on bf16 MFMA; encode + VQ stay fp32
-        so token indices stay bit-exact)."""
-        self.decode_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[precision]
+        """'fp32' (parity: exact-fp32 MFMA), 'bf16' (decode stack on bf16 MFMA; encode + VQ stay fp32-class so token indices stay
+        bit-exact), or 'f16x3' / 'bf16x3' (the fast parity modes: the f4 decode stack on split-precision operands, fp32-class frames)."""
+        self.decode_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16, "f16x3": torch.float32, "bf16x3": torch.float32}[precision]
+        self.decode_split = ops.F16X3 if precision in ("f16x3", "bf16x3") else 0     # f16 pieces for both: the encoder's kind
         return self
 
     # ------------------------------------------------------------------ derived weights
@@ -482,9 +484,73 @@ class VectorQuantizedVAE(nn.Module):
                 w["d0.tab"] = T.to(torch.bfloat16)
         return w["d0.tab"]
 
+    def _dec_split_weights(self, w):
+        """f16x3 operands of the f4 decoder (built once per weights): the first ResBlock's 3x3 convolution as an fp32 table over
+        relu(codebook) (_d0_table's fp32 twin), the second one's 3x3 and both 1x1 convolutions with their BatchNorm folded in, the four
+        sub-pixel 2x2 convolutions of ConvTranspose2d(dim, dim, 4, 2, 1) + BatchNorm in forward window order."""
+        if "d0.tab32" not in w:
+            sk, dim, Kc = ops.F16X3, self.dim, self.K
+            rcb = torch.relu(w["cb"]).contiguous()
+            w3 = (w["d0.w3.f32"] * w["d0.s3"][:, None]).view(dim, 9, dim)
+            T = torch.empty(9, Kc, dim, device=rcb.device, dtype=torch.float32)
+            for tap in range(9):
+                ops.gemm(rcb, w3[:, tap].contiguous(), T[tap], M=Kc, N=dim, K=dim, lda=dim, ldy=dim)
+            w["d0.tab32"] = T
+            w["d1.w3s"] = ops.split((w["d1.w3.f32"] * w["d1.s3"][:, None]).contiguous(), sk)
+            for p in ("d0", "d1"):
+                w[p + ".w1s"] = ops.split((w[p + ".w1.f32"] * w[p + ".s1"][:, None]).contiguous(), sk)
+                w[p + ".b1f"] = (w[p + ".b1"] * w[p + ".s1"] + w[p + ".t1"]).contiguous()
+            for py in range(2):
+                for px in range(2):
+                    wsub = w[f"d3.w{py}{px}.f32"].view(dim, 2, 2, -1).flip(1, 2).reshape(dim, -1)
+                    w[f"d3.w{py}{px}s"] = ops.split((wsub * w["d3.s"][:, None]).contiguous(), sk)
+        return w
+
+    def _decode_chunk_split(self, w, ids: torch.Tensor, out: torch.Tensor) -> None:
+        """The f4 decoder (vqvae_model.py:180-189) in the fast parity modes: every 256-channel convolution on f16x3 operands (fp32-class
+        frames at ~2.5x the exact-fp32 gather kernels' speed), the C-channel head on the fp32 narrow-tile GEMM as before."""
+        sk, dim, dev = ops.F16X3, self.dim, ids.device
+        self._dec_split_weights(w)
+        N, h, wd = ids.shape
+        hw, Pw = h * wd, wd + 2
+        PP = (h + 2) * Pw
+        key = ("dec_s", N, h, wd, str(dev), torch.cuda.current_stream(dev).cuda_stream)
+        pad = self._pad_bufs.get(key)
+        if pad is None:
+            if len(self._pad_bufs) > 6:
+                self._pad_bufs.clear()
+            pad = self._pad_bufs[key] = ops.split_empty(N * PP + 1, dim, sk, dev, zero=True)
+        inner = dict(group=hw, group_stride=PP, off=Pw + 1, inner=wd, inner_stride=Pw)
+        flat = ids.reshape(-1)
+        r = ops.embedding(flat, w["cb"], torch.empty(N * hw, dim, device=dev, dtype=torch.float32), relu=True)        # the skip path of d0
+        t = ops.split_empty(N * hw, dim, sk, dev)
+        ops.table_conv(flat, w["d0.tab32"], t, n_img=N, H=h, W=wd, bias=w["d0.b3f"], relu=True, split_kind=sk)       # conv3x3 + BN + ReLU of d0
+        z = torch.empty(N * hw, dim, device=dev, dtype=torch.float32)
+        ops.gemm(t, w["d0.w1s"], z, M=N * hw, N=dim, K=dim, lda=2 * dim, ldy=dim, bias=w["d0.b1f"], residual=r, ldr=dim, split_kind=sk)
+        ops.split_rows(z, pad, sk, relu=True, relu_writeback=True, **inner)                                           # d1's in-place ReLU
+        win = dict(out_h=h, out_w=wd, in_h=h + 2, in_w=Pw, a_img_stride=PP, cin=dim)
+        ops.gemm(pad, w["d1.w3s"], t, M=N * hw, N=dim, K=9 * dim, lda=2 * dim, ldy=2 * dim, taps_h=3, taps_w=3, bias=w["d1.b3f"],
+                 act=ops.ACT_RELU, split_kind=sk, y_split=True, **win)
+        z2 = torch.empty(N * hw, dim, device=dev, dtype=torch.float32)
+        ops.gemm(t, w["d1.w1s"], z2, M=N * hw, N=dim, K=dim, lda=2 * dim, ldy=dim, bias=w["d1.b1f"], residual=z, ldr=dim, split_kind=sk)
+        ops.split_rows(z2, pad, sk, relu=True, **inner)                                                               # decoder[2] ReLU
+        up = torch.empty(N * 4 * hw, dim, device=dev, dtype=torch.float32)
+        for py in range(2):
+            for px in range(2):
+                ops.gemm(pad, w[f"d3.w{py}{px}s"], up, M=N * hw, N=dim, K=4 * dim, lda=2 * dim, ldy=dim, taps_h=2, taps_w=2,
+                         a_off=py * Pw + px, y_img_stride=4 * hw, y_mul_y=4 * wd, y_mul_x=2, y_off=py * 2 * wd + px, bias=w["d3.bf"],
+                         act=ops.ACT_RELU, split_kind=sk, **win)
+        nt = 16 * self.input_dim
+        taps = torch.empty(N * 4 * hw, nt, device=dev, dtype=torch.float32)
+        ops.gemm(up, w["d6.w16.f32"], taps, M=N * 4 * hw, N=nt, K=dim, lda=dim, ldy=nt)
+        ops.convt_fold_tanh(taps, w["d6.b"], out, N=N, IH=2 * h, IW=2 * wd, cout=self.input_dim)
+
     def _decode_chunk(self, ids: torch.Tensor, out: torch.Tensor) -> None:
         w = self._weights()
         dt = self.decode_dtype
+        if (self.down_ratio == 4 and getattr(self, "decode_split", 0) and self.dim % 256 == 0 and (ids.shape[0] * ids.shape[1] * ids.shape[2]) % 256 == 0
+                and not os.environ.get("MAGE_DECODE_FP32")):
+            return self._decode_chunk_split(w, ids, out)
         s = "." + ("f32" if dt == torch.float32 else "bf16")
         N, dev, dim = ids.shape[0], ids.device, self.dim
         h, wd = ids.shape[1], ids.shape[2]

@@ -394,7 +394,7 @@ def embedding(ids: torch.Tensor, table: torch.Tensor, out: torch.Tensor, *, relu
 
 
 def table_conv(ids: torch.Tensor, table: torch.Tensor, y: torch.Tensor, *, n_img: int, H: int, W: int, taps: int = 3, pos=None, bias=None,
-               relu: bool = False, rowadd=None,
+               relu: bool = False, rowadd=None, split_kind: int = 0,
                rowadd_div: int = 1, rowadd_mod: int = 1, ldy: Optional[int] = None, group: Optional[int] = None,
                y_group_stride: Optional[int] = None, y_off: int = 0) -> torch.Tensor:
     """y rows = pos + sum of table[tap][ids[neighbour]] + rowadd: a k x k convolution of embedding rows as a table sum (mage_table_conv)."""
@@ -406,7 +406,7 @@ def table_conv(ids: torch.Tensor, table: torch.Tensor, y: torch.Tensor, *, n_img
     y_group_stride = group if y_group_stride is None else y_group_stride
     ev = PROFILE.begin() if PROFILE.wants("table_conv") else None
     _lib.check(l.mage_table_conv(ids.data_ptr(), n_img, H, W, taps, taps, table.data_ptr(), code(table), table.shape[1], Cc, _p(pos), _p(bias),
-                                 int(relu), _p(rowadd), rowadd_div, rowadd_mod, y.data_ptr(), code(y), Cc if ldy is None else ldy, group,
+                                 int(relu), _p(rowadd), rowadd_div, rowadd_mod, y.data_ptr(), split_kind or code(y), Cc if ldy is None else ldy, group,
                                  y_group_stride, y_off, s), l)
     if ev is not None:
         PROFILE.end("table_conv", ev, 0.0, float(n_img) * H * W * Cc * (taps * taps * table.element_size() + 4))

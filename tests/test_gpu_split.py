@@ -252,3 +252,20 @@ def test_f16x3_full_size_cfg2_properties():
     clips = (m.last_tokens == tok1).flatten(1).all(1).float().mean().item()
     print(f"f16x3 vs fp32 mode, free-running at cfg2: token agreement {agree:.4f}, identical clips {clips:.3f}")
     assert agree > 0.9
+
+
+def test_f16x3_decoder_against_the_exact_fp32_decoder_and_the_golden():
+    """The f4 decoder on f16x3 operands (VectorQuantizedVAE.set_precision('f16x3'): table sum for the first 3x3 convolution, split GEMMs for
+    the other 256-channel convolutions) against the exact-fp32 gather path on 64 frames and against the reference's golden frames."""
+    from tests.helpers import build_vqvae
+    g = golden("vqvae_f4")
+    m = build_vqvae(1, 4, 256, 512, int(g["seed"]), DEV)
+    ids = torch.randint(0, 512, (64, 16, 16), generator=torch.Generator().manual_seed(2)).to(DEV)
+    want = m.decode(ids)
+    m.set_precision("f16x3")
+    got = m.decode(ids)
+    err = (got - want).abs().max().item()
+    print(f"f16x3 decode vs exact fp32 decode: max |d| {err:.2e}")
+    assert err < 2e-5
+    rec = m.decode(t(g["ids"]).long().to(DEV))
+    torch.testing.assert_close(rec.cpu(), t(g["rec"]), atol=LOGIT_TOL, rtol=0)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
 """A few incremental-mode calls, eager, for rocprofv3 --kernel-trace --stats: GPU-busy time per call vs wall."""
+import os
 import sys
 import time
 
@@ -12,7 +13,7 @@ from mage_amd.utils.util import instantiate_from_config  # noqa: E402
 mode = sys.argv[1] if len(sys.argv) > 1 else "incremental"
 m = instantiate_from_config(synth.mnist_model_config(frames_length=16)).eval()
 synth.fill_state_dict(m, 0)
-m = m.to("cuda:0").set_precision("bf16")
+m = m.to("cuda:0").set_precision(os.environ.get("INC_PRECISION", "bf16"))
 m.ar_mode = mode
 import os
 m.use_graph = bool(os.environ.get("INC_GRAPH"))
