@@ -561,6 +561,129 @@ __global__ __launch_bounds__(256) void attention_mfma_split_kernel(const mage_at
     }
 }
 
+// The few-query form of attention_mfma_split_kernel (the incremental step's temporal attention in f16x3 mode): wave per sequence, the V
+// pieces in a wave-private LDS tile, per (sequence, head) the same instruction sequence as the workgroup-per-sequence kernel (the
+// incremental loop's tokens stay bit-identical to the full pass's).
+template <int NKB>
+__global__ __launch_bounds__(256) void attention_mfma_split_fewq_kernel(const mage_attn_desc d) {
+    constexpr int CH = 2, VP = 40;
+    __shared__ unsigned short vsm[4][CH][2][NKB * 16][VP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int s = blockIdx.x * 4 + wv;
+    if (s >= d.n_seq) return;
+    const int outer = s / d.inner, in = s - outer * d.inner;
+    const long q_base = (long)outer * d.q_outer_stride + in;
+    const long kv_base = (long)outer * d.kv_outer_stride + in;
+    const unsigned short* qp = (const unsigned short*)d.q;
+    const unsigned short* kp = (const unsigned short*)d.k;
+    const unsigned short* vp = (const unsigned short*)d.v;
+    split_f16* op = (split_f16*)d.out;
+    const int ldo = d.ldo >> 1;
+    int klen = d.nk;
+    if (d.kv_len) klen = min(klen, d.kv_len[s / d.kv_len_div]);
+    const int r = lane & 15, g = lane >> 4;
+    const int qi = r;
+    const long qrow = (q_base + (long)min(qi, d.nq - 1) * d.q_axis_stride) * d.ldq;
+    const int jmax = d.causal ? min(klen, qi + 1 + (d.nk - d.nq)) : klen;
+    constexpr float LO = 1.0f / MAGE_F16_LO_SCALE;
+    long krow[NKB], vrow[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        krow[kb] = (kv_base + (long)min(kb * 16 + r, d.nk - 1) * d.kv_axis_stride) * d.ldk;
+        vrow[kb] = (kv_base + (long)min(kb * 16 + r, d.nk - 1) * d.kv_axis_stride) * d.ldv;
+    }
+    for (int h0 = 0; h0 < d.n_head; h0 += CH) {
+        uint4 kf[CH][NKB][2], qf[CH][2];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+            const int h = min(h0 + t, d.n_head - 1);
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                const int c = split_col(h * 32 + g * 8, pc);
+                qf[t][pc] = *(const uint4*)(qp + qrow + c);
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    kf[t][kb][pc] = *(const uint4*)(kp + krow[kb] + c);
+                    *(uint4*)&vsm[wv][t][pc][kb * 16 + r][g * 8] = *(const uint4*)(vp + vrow[kb] + c);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+            const int h = h0 + t;
+            if (h >= d.n_head) break;
+            f32x4 st[NKB];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[t][kb][0]), __builtin_bit_cast(f16x8, qf[t][1]),
+                                                                 f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[t][kb][1]), __builtin_bit_cast(f16x8, qf[t][0]), a, 0, 0, 0);
+                a *= LO;
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[t][kb][0]), __builtin_bit_cast(f16x8, qf[t][0]), a, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = (kb * 16 + 4 * g + e < jmax) ? a[e] * d.scale : -INFINITY;
+                    mx = fmaxf(mx, a[e]);
+                }
+                st[kb] = a;
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float den = 0.f;
+            ahalf4 phi[NKB], plo[NKB];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = (kb * 16 + 4 * g + e < jmax) ? expf(st[kb][e] - mx) : 0.f;
+                    den += p;
+                    const _Float16 ph = (_Float16)p;
+                    phi[kb][e] = ph;
+                    plo[kb][e] = (_Float16)((p - (float)ph) * MAGE_F16_LO_SCALE);
+                }
+            den += __shfl_xor(den, 16);
+            den += __shfl_xor(den, 32);
+            f32x4 o[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                ahalf4 vth[NKB], vtl[NKB];
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vth[kb][e] = __builtin_bit_cast(_Float16, vsm[wv][t][0][kb * 16 + 4 * g + e][b * 16 + r]);
+                        vtl[kb][e] = __builtin_bit_cast(_Float16, vsm[wv][t][1][kb * 16 + 4 * g + e][b * 16 + r]);
+                    }
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    a = __builtin_amdgcn_mfma_f32_16x16x16f16(vth[kb], plo[kb], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x16f16(vtl[kb], phi[kb], a, 0, 0, 0);
+                }
+                a *= LO;
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) a = __builtin_amdgcn_mfma_f32_16x16x16f16(vth[kb], phi[kb], a, 0, 0, 0);
+                o[b] = a;
+            }
+            const float inv = 1.0f / den;
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[0][e]), __float_as_uint(o[1][e]), false, false);
+                v0[e] = __uint_as_float(sw[0]) * inv;
+                v1[e] = __uint_as_float(sw[1]) * inv;
+            }
+            if (qi < d.nq) {
+                const int col = h * 32 + 16 * (g & 1) + 8 * (g >> 1);
+                store8(op + (q_base + (long)qi * d.q_axis_stride) * ldo + col, v0, v1);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ------------------------------------------------------------------------------------ ADAIN
 // grid = (B, C/64); block 256 = 64 channels x 4 position phases.
 __global__ __launch_bounds__(256) void adain_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -768,6 +891,13 @@ int attn_split_launch(const mage_attn_desc* d, hipStream_t s) {
     MAGE_CHECK_ARG((d->ldq | d->ldk | d->ldv | d->ldo) % 128 == 0 && ((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->out) & 255) == 0),
                    "mage_attention: split operands need leading dimensions that are multiples of 128 16-bit elements and 256-byte aligned bases");
     const int nkb = d->nk <= 16 ? 1 : 2;
+    if (d->nq <= 2 && d->n_seq >= 1024 && !getenv("MAGE_ATTN_NO_FEWQ")) {      // the incremental step's temporal attention
+        const dim3 grid((unsigned)((d->n_seq + 3) / 4));
+        if (nkb == 1) hipLaunchKernelGGL((attention_mfma_split_fewq_kernel<1>), grid, dim3(256), 0, s, *d);
+        else hipLaunchKernelGGL((attention_mfma_split_fewq_kernel<2>), grid, dim3(256), 0, s, *d);
+        MAGE_CHECK_LAUNCH("mage_attention");
+        return MAGE_OK;
+    }
     const size_t lds = (size_t)16 * nkb * (d->n_head * 64 + 16) * 2;
     const int hpw = (d->n_head + 3) / 4;
 #define ATTN_S(NKB, MH) \
