@@ -49,17 +49,27 @@ namespace {
 // MT = 16-row MFMA tiles per wave along m: 8 -> 256x256 workgroup tile (bf16 on large problems), 4 -> 128x256 (fp32, whose
 // 8x4 accumulator variant spills, and problems with too few 256-row tiles to fill the chip).
 constexpr int BN = 256;
-constexpr int NSTAGE = 2;
+template <int DT, bool GATHER, int MT, int EK, bool SPLIT, int NW> constexpr int ring_stages() {
+#ifdef MAGE_GEMM_RING2
+    return 2;
+#else
+    return (DT == MAGE_BF16 && !GATHER && MT == 4 && NW == 4 && !SPLIT) ? 3 : 2;
+#endif
+}
 // NW = waves side by side along n (each owns 64 columns): 4 -> the 256-column tile; 1 -> the NARROW tile of the lockstep kernel
 // (all 8 waves stacked along m, 64 columns): outputs with N <= 128 (the cout/4 bottleneck convolutions of the f8 VQ-VAE, the 8- and
 // 16-column heads) waste 3/4 of a 256-column tile's matrix-core work; MT = 2 there (256 x 64 tile, 40 KiB per stage).
-template <int MT, int NW = 4> struct Tile {
+// NST = stages of the lockstep kernel's slab ring.  3 for the bf16 128x256 tile (small problems: one to three tiles per CU): its slab
+// (0.43 µs of matrix-core work per CU) is shorter than the L2/HBM -> LDS round trip, so with ONE slab in flight the K loop ran at the
+// memory latency (1.25 µs per slab measured); with two in flight (counted vmcnt) it does not.  The epilogue's staging windows then
+// live in the stage the tile's last slab was read from (free until the next tile's third slab is requested): 144 KiB in all.
+template <int MT, int NW = 4, int NST = 2> struct Tile {
     static constexpr int BM = MT * 16 * (8 / NW);
     static constexpr int BNT = 64 * NW;
     static constexpr int A_BYTES = BM * 128;                   // A part of a stage: BM rows x 128 bytes
     static constexpr int STAGE_BYTES = A_BYTES + BNT * 128;    // 64 KiB (MT=8) | 48 KiB (MT=4) | 40 KiB (narrow MT=2)
-    static constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;    // one workgroup (8 waves, 2 per SIMD) per CU
-    static constexpr int LDS_BYTES = RING_BYTES + 8 * 4096;    // + 4 KiB per wave of epilogue staging (epilogue_lean)
+    static constexpr int RING_BYTES = NST * STAGE_BYTES;       // one workgroup (8 waves, 2 per SIMD) per CU
+    static constexpr int LDS_BYTES = RING_BYTES + (NST == 2 ? 8 * 4096 : 0);    // + 4 KiB per wave of epilogue staging (epilogue_lean)
     static constexpr int AU = BM / 64;                         // A units (8 rows x 128 B) per wave per slab
     static constexpr int WU = NW;                              // W units per wave per slab
 };
@@ -450,7 +460,8 @@ template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int 
 __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     static_assert(SPL == 0 || (DT == MAGE_BF16 && !GATHER && !SPLIT && LN == LN_NONE && EK != EK_GENERAL), "split-precision form: plain bf16-geometry GEMM, lean epilogues");
     typedef typename TT<DT>::elem E;
-    typedef Tile<MT, NW> TL;
+    constexpr int NST = ring_stages<DT, GATHER, MT, EK, SPLIT, NW>();
+    typedef Tile<MT, NW, NST> TL;
     constexpr int BM = TL::BM, A_BYTES = TL::A_BYTES, STAGE_BYTES = TL::STAGE_BYTES, AU = TL::AU, WU = TL::WU, BNT = TL::BNT;
     constexpr int CH = TT<DT>::CH;
     constexpr int BK = 8 * CH;
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
         for (int u = 0; u < AU + WU; ++u) issue_one(u);
     };
     auto loader_advance = [&]() {
-        ld_stage ^= 1;
+        ld_stage = ld_stage + 1 == NST ? 0 : ld_stage + 1;
         if (++ld_kt == nk) {
             ld_kt = 0;
             ld_tile += nwg8;
@@ -586,6 +597,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     }
     issue_all();
     loader_advance();
+    if constexpr (NST == 3) {                          // two slabs in flight from here on
+        const bool more = ld_tile < chunk1;
+#pragma unroll
+        for (int u = 0; u < AU + WU; ++u) issue_one(u, more);
+        if (more) loader_advance();
+    }
     int c_stage = 0;
 
     for (int it = 0; c_tile < chunk1; c_tile += nwg8, ++it) {
@@ -638,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                 lnc.s[b] = *(const f32x4*)(d.ln_colsum + (n < d.N ? n : 0));
             }
         }
-        for (int kt = 0; kt < nk; ++kt) {
+        auto lo_scale = [&](int kt) __attribute__((always_inline)) {
             if constexpr (SPL == 2) {
                 if (kt == nk2) {                       // f16 pieces: the small terms (and the residual) carry the lo pieces' 2^11
 #pragma unroll
@@ -647,11 +664,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                         for (int b = 0; b < 4; ++b) acc[a][b] *= (1.0f / MAGE_F16_LO_SCALE);
                 }
             }
-            // The slab to multiply was issued one whole iteration (or one epilogue) ago; nothing younger is in flight.
-            // (the builtin, not inline asm: hipcc's own wait-count pass must SEE this wait, or it guards every later use of
-            // the bias vectors fetched above with its own vmcnt(0) — in the epilogue that meant "wait for the previous row's
-            // store ack" 16 times per tile)
-            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt/lgkmcnt untouched
+        };
+        // one slab, after the wait for its DMAs
+        auto slab = [&](int kt) __attribute__((always_inline)) {
             asm volatile("" ::: "memory");
             if constexpr (SPL == 2 && EK == EK_RES_INIT) {
                 if (kt == 0) {                         // the residual has landed: give it the lo pieces' scale (exact), undone at kt == nk2
@@ -733,7 +748,28 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                 }
             }
             if (more) loader_advance();
-            c_stage ^= 1;
+            c_stage = c_stage + 1 == NST ? 0 : c_stage + 1;
+        };
+        // The slab to multiply was issued one whole iteration (or one epilogue) ago; with the 2-stage ring nothing younger is in
+        // flight: vmcnt(0).  (the builtin, not inline asm: hipcc's own wait-count pass must SEE this wait, or it guards every later
+        // use of the bias vectors fetched above with its own vmcnt(0) — in the epilogue that meant "wait for the previous row's
+        // store ack" 16 times per tile.)  3-stage ring: the tile's first slab still waits for everything (residual tile, bias, the
+        // previous tile's store acks; the second slab was requested long ago), the later ones leave the AU + WU DMAs of the slab
+        // after them in flight -- peeled so that the vmcnt(0) dominates every later use of the tile-start loads.
+        if constexpr (NST == 2) {
+            for (int kt = 0; kt < nk; ++kt) {
+                lo_scale(kt);
+                __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0), expcnt/lgkmcnt untouched
+                slab(kt);
+            }
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            slab(0);
+            for (int kt = 1; kt < nk; ++kt) {
+                lo_scale(kt);
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (AU + WU));      // vmcnt(AU + WU <= 15)
+                slab(kt);
+            }
         }
 #if MAGE_ABL == 1 || MAGE_ABL == 5 || MAGE_ABL == 6
         {   // tuning build: main loop only (keep the accumulators alive, store nothing)
@@ -754,6 +790,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
             else epilogue_wave<ACT, unsigned short, MT, EK>(d, cv, acc, m0, n0, lane, plane, ysplit);
         } else {
             char* stg = smem + TL::RING_BYTES + wave * 4096;
+            if constexpr (NST == 3) {                  // staging in the stage of the tile's last slab, once every wave has read it
+                ring_barrier();
+                stg = smem + (c_stage == 0 ? NST - 1 : c_stage - 1) * STAGE_BYTES + wave * 4096;
+            }
             if constexpr (LN == LN_CONSUME) {
                 if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit, &lnc);
                 else epilogue_lean<ACT, unsigned short, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit, &lnc);
@@ -1114,7 +1154,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
 
 template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE, int NW = 4, int SPL = 0>
 int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
-    typedef Tile<MT, NW> TL;
+    typedef Tile<MT, NW, ring_stages<DT, GATHER, MT, EK, SPLIT, NW>()> TL;
     // launch attributes are per DEVICE (a process may drive several GPUs, e.g. nn.DataParallel, main_mage.py:106): cached per
     // device index; setting one twice from two threads is harmless
     static bool attr_set[MAGE_MAX_DEVICES] = {false};
