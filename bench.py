@@ -426,16 +426,28 @@ def main():
             dom = gemms[dom_key]
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             allf, allms = sum(v["flops"] for v in all_src.values()), sum(v["ms"] for v in all_src.values())
-            roofline = {"bound": "mfma", "kernel": dom_key + "  [gemm8_kernel<act, epilogue kind, split-K, padded taps, LayerNorm fold, split precision>: the 8-phase ping-pong bf16 256x256 GEMM; "
-                                                             "gemm_kernel<dtype, gather, act, m-tiles/wave, epilogue kind, split-K, LayerNorm fold, n-waves, split precision>: the "
-                                                             "lockstep one.  Epilogue kind 1 = x + Linear(.) with the fp32 residual: attention out_proj "
-                                                             "and MLP c_proj of the decoder stack; LayerNorm fold 1 = it also writes the bf16 copy of x "
-                                                             "and the row partial sums the next Linear normalises with (2 = that consumer)]",
+            legend = ("  [gemm8_kernel<act, epilogue kind, split-K, padded taps, LayerNorm fold, split precision(, bf16 residual stream)>: the 8-phase "
+                      "ping-pong bf16 256x256 GEMM; gemm_kernel<dtype, gather, act, m-tiles/wave, epilogue kind, split-K, LayerNorm fold, n-waves, "
+                      "split precision(, bf16 residual stream)>: the lockstep one.  act 2 = QuickGELU (c_fc).  Epilogue kind 1 = x + Linear(.): "
+                      "attention out_proj and MLP c_proj of the decoder stack, the residual x loaded into the accumulators (bf16 rows when the "
+                      "last argument is true: the bf16 mode keeps x in bf16 between the blocks); LayerNorm fold 1 = it also writes the row partial "
+                      "sums the next Linear normalises with (2 = that consumer: QKV, c_fc)]")
+            # the GEMM symbol with the second-largest time, same accounting (the x + Linear(.) producers when c_fc leads, or the reverse)
+            second = None
+            rest = sorted((k for k in gemms if k != dom_key), key=lambda k: -gemms[k]["ms"])
+            if rest:
+                g2 = gemms[rest[0]]
+                a2 = g2["flops"] / (g2["ms"] * 1e-3) / 1e12
+                second = {"kernel": rest[0], "achieved": round(a2, 2), "frac": round(a2 / peak, 4), "launches_per_step": g2["calls"] // args.steps,
+                          "avg_launch_us": round(g2["ms"] * 1e3 / g2["calls"], 2), "flops_per_launch": g2["flops"] / g2["calls"],
+                          "hbm_view": hbm_view(rest[0], g2)}
+            roofline = {"bound": "mfma", "kernel": dom_key + legend,
                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": dom["calls"] // args.steps,
                         "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
                         "flops_per_launch": dom["flops"] / dom["calls"],
                         "hbm_view": hbm_view(dom_key, dom),
+                        "second_kernel": second,
                         "all_gemm_kernels": {"achieved": round(allf / (allms * 1e-3) / 1e12, 2), "frac": round(allf / (allms * 1e-3) / 1e12 / peak, 4),
                                              "ms_per_step": round(allms / all_div, 3),
                                              "measured_in": "timed region" if args.events == "all" else "last warm-up call"}}
@@ -475,6 +487,9 @@ def main():
                        "global_batch": world * B, "frames": L, "parallelism": f"clip-sharded x{world} (no data-path collective)",
                        "ranks_seen": seen, "ar_mode": model.ar_mode, "streams_per_gpu": args.streams,
                        "frame_table": bool(getattr(model, "frame_table", False)),
+                       "residual_stream": ("bf16 (x kept in bf16 between the blocks; LayerNorm sums from the fp32 values before rounding; "
+                                           "MAGE_STREAM_FP32=1 restores the fp32 stream + bf16 copy)"
+                                           if args.precision == "bf16" and model.generate_model._stream_bf16() else "fp32"),
                        "graph_replay": replayed,
                        "frame_count_convention": "B*L frames per call: the output clip [B,L,C,H,W] incl. the passed-through first frame "
                                                  "(SURVEY 8d, reference mage_model.py:691); generated-only = value * (L-1)/L",

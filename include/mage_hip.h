@@ -130,7 +130,10 @@ typedef struct mage_gemm_desc {
      * set it also writes a bf16 copy of the new rows (ldy2 elements per row) and ln_part[row][N/64][2] = (sum, sum of squares) of each
      * 64-column slice; mage_ln_stats reduces those to ln_stats[row][2] = (mean, rstd).  Consumer -- the Linear that follows the norm:
      * A = that bf16 copy, W = gamma * W (per input channel), bias = W beta + b, ln_colsum[n] = sum_k W'[n, k]; with ln_stats set the
-     * epilogue computes rstd_m (acc - mean_m ln_colsum[n]) + bias[n] before the activation: LN(x) W^T + b without the LayerNorm pass. */
+     * epilogue computes rstd_m (acc - mean_m ln_colsum[n]) + bias[n] before the activation: LN(x) W^T + b without the LayerNorm pass.
+     * bf16 stream: with ln_part set, y2 null and y_dtype MAGE_BF16 the producer writes the bf16 rows as its only output (the residual
+     * may itself be that bf16 stream, res_dtype MAGE_BF16: x stays in bf16 between the blocks; a bf16 residual is also accepted by the
+     * plain x + Linear(.) form without ln_part).  The partial sums are always those of the fp32 values before rounding. */
     void* y2;
     int32_t ldy2;
     int32_t res_half;                  /* general epilogue, out_h > 1: the residual lives at HALF resolution ([img, out_h/2, out_w/2, N] rows):

@@ -442,6 +442,19 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
     }
 }
 
+// RB (template parameter of both kernels): the residual of EK_RES_INIT is a BF16 stream (the decoder's bf16 mode keeps x in bf16 between
+// its blocks: half the residual bytes in, and LN_PRODUCE then writes the bf16 rows as its ONLY output).  The 8 bytes of a lane's 4 columns
+// land in the first two registers of the accumulator they seed and are widened in place once the tile's first wait has passed: no staging
+// registers, all 32 loads of a tile in flight at once, as in the fp32 form.
+__device__ __forceinline__ void res_bf16_request(f32x4& a, const unsigned short* p) {
+    const uint2 t = *(const uint2*)p;
+    a = f32x4{__uint_as_float(t.x), __uint_as_float(t.y), 0.f, 0.f};
+}
+__device__ __forceinline__ void res_bf16_widen(f32x4& a) {
+    const unsigned lo = __float_as_uint(a[0]), hi = __float_as_uint(a[1]);
+    a = f32x4{__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+}
+
 // raw barrier that LDS-DMA may stay in flight across (a __syncthreads() would drain vmcnt to 0); the empty asm
 // statements keep the compiler from moving LDS accesses over it
 __device__ __forceinline__ void ring_barrier() {
@@ -456,8 +469,9 @@ __device__ __forceinline__ void ring_barrier() {
 // rows are [hi(64) | lo(64)] per 64-column slab of K; the K loop runs 3 * K/64 slabs: first, per logical slab, (A_hi, W_lo) then (A_lo, W_hi)
 // -- the small terms -- then (f16: accumulators * 2^-11, undoing the scale the lo pieces are stored with) the K/64 (A_hi, W_hi) slabs.
 // Only the DMA source offset of a slab, the slab count and the MFMA opcode differ from the bf16 kernel.
-template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE, int NW = 4, int SPL = 0>
+template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE, int NW = 4, int SPL = 0, bool RB = false>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
+    static_assert(!RB || (DT == MAGE_BF16 && EK == EK_RES_INIT && SPL == 0), "bf16 residual stream: the bf16 x + Linear(.) kinds");
     static_assert(SPL == 0 || (DT == MAGE_BF16 && !GATHER && !SPLIT && LN == LN_NONE && EK != EK_GENERAL), "split-precision form: plain bf16-geometry GEMM, lean epilogues");
     typedef typename TT<DT>::elem E;
     constexpr int NST = ring_stages<DT, GATHER, MT, EK, SPLIT, NW>();
@@ -618,10 +632,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
             for (int a = 0; a < MT; ++a) {
                 const int m = min(m0 + a * 16 + l15, d.M - 1);
                 const float* rp = (const float*)d.residual + (long)(m * d.y_mul_x + d.y_off) * d.ldr;
+                [[maybe_unused]] const unsigned short* rpb = (const unsigned short*)d.residual + (long)(m * d.y_mul_x + d.y_off) * d.ldr;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int n = n0 + b * 16 + grp * 4;
-                    acc[a][b] = *(const f32x4*)(rp + (n < d.N ? n : 0));
+                    if constexpr (RB) res_bf16_request(acc[a][b], rpb + (n < d.N ? n : 0));
+                    else acc[a][b] = *(const f32x4*)(rp + (n < d.N ? n : 0));
                 }
             }
         } else {
@@ -668,6 +684,14 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
         // one slab, after the wait for its DMAs
         auto slab = [&](int kt) __attribute__((always_inline)) {
             asm volatile("" ::: "memory");
+            if constexpr (RB) {
+                if (kt == 0) {                         // the residual rows have landed: widen them in place
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) res_bf16_widen(acc[a][b]);
+                }
+            }
             if constexpr (SPL == 2 && EK == EK_RES_INIT) {
                 if (kt == 0) {                         // the residual has landed: give it the lo pieces' scale (exact), undone at kt == nk2
 #pragma unroll
@@ -798,7 +822,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                 if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit, &lnc);
                 else epilogue_lean<ACT, unsigned short, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit, &lnc);
             } else if constexpr (LN == LN_PRODUCE) {
-                epilogue_lean<ACT, float, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);       // fp32 stream out (host check)
+                // fp32 stream + bf16 copy, or (y_dtype bf16) the bf16 stream alone
+                if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
+                else epilogue_lean<ACT, unsigned short, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
             } else if constexpr (SPL != 0) {
                 if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
                 else epilogue_lean<ACT, float, MT, false, LN_NONE, SPL>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);   // split rows out
@@ -841,7 +867,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
 // and per slab and re-tests the bounds (frame conv3x3: 773 TFLOP/s, 6.7x its algorithmic bytes fetched: round-1 PMC).
 // SPL: split-precision operands (see gemm_kernel): 3 * K/64 slabs per tile, the slab -> source offset map in issue(), accumulators scaled
 // once between the small-term passes and the main pass (f16 pieces), the MFMA opcode.  Schedule, hazards and LDS image are unchanged.
-template <int ACT, int EK, bool SPLIT = false, bool TAPS = false, int LN = LN_NONE, int SPL = 0>
+template <int ACT, int EK, bool SPLIT = false, bool TAPS = false, int LN = LN_NONE, int SPL = 0, bool RB = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     static_assert(SPL == 0 || (!SPLIT && LN == LN_NONE), "split-precision form: no split-K, no LayerNorm fold");
     constexpr int MT = 8, BM = 256;
@@ -993,10 +1019,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
                 } else {
                     rp = (const float*)d.residual + (long)(m * d.y_mul_x + d.y_off) * d.ldr;
                 }
+                [[maybe_unused]] const unsigned short* rpb = (const unsigned short*)d.residual + (long)(m * d.y_mul_x + d.y_off) * d.ldr;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int n = n0 + b * 16 + grp * 4;
-                    acc[a][b] = *(const f32x4*)(rp + (n < d.N ? n : 0));
+                    if constexpr (RB) res_bf16_request(acc[a][b], rpb + (n < d.N ? n : 0));
+                    else acc[a][b] = *(const f32x4*)(rp + (n < d.N ? n : 0));
                 }
             }
         } else {
@@ -1081,6 +1109,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
 #pragma unroll
                         for (int b = 0; b < 4; ++b) acc[a][b] *= MAGE_F16_LO_SCALE;
                 }
+                if constexpr (RB) {                    // bf16 residual rows: widen in place
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) res_bf16_widen(acc[a][b]);
+                }
             }
             mfma_quadrant(0, 0);
             // phase 2: quadrant (0,1)
@@ -1140,7 +1174,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit, &lnc);
             else epilogue_lean<ACT, unsigned short, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit, &lnc);
         } else if constexpr (LN == LN_PRODUCE) {
-            epilogue_lean<ACT, float, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);          // fp32 stream out (host check)
+            // fp32 stream + bf16 copy, or (y_dtype bf16; always with RB: host check) the bf16 stream alone
+            if (RB || d.y_dtype != MAGE_F32) epilogue_lean<ACT, unsigned short, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
+            else epilogue_lean<ACT, float, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
         } else if constexpr (SPL != 0) {
             if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
             else epilogue_lean<ACT, float, MT, TAPS, LN_NONE, SPL>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);   // split rows out
@@ -1152,7 +1188,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     }
 }
 
-template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE, int NW = 4, int SPL = 0>
+template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE, int NW = 4, int SPL = 0, bool RB = false>
 int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     typedef Tile<MT, NW, ring_stages<DT, GATHER, MT, EK, SPLIT, NW>()> TL;
     // launch attributes are per DEVICE (a process may drive several GPUs, e.g. nn.DataParallel, main_mage.py:106): cached per
@@ -1161,7 +1197,7 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     const int dev = mage_device_index();
     MAGE_CHECK_ARG(dev >= 0, "mage_gemm: no current device");
     if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT, LN, NW, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT, LN, NW, SPL, RB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   TL::LDS_BYTES);
         attr_set[dev] = true;
     }
@@ -1211,16 +1247,16 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
         if (use8 && d->K % 64 == 0 && a_span * 2 < (1L << 32) && w_span * 2 < (1L << 32)) {
             static bool attr8[MAGE_MAX_DEVICES] = {false};
             if (!attr8[dev]) {
-                (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK, SPLIT, false, LN, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK, SPLIT, false, LN, SPL, RB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           160 * 1024);
                 attr8[dev] = true;
             }
-            hipLaunchKernelGGL((gemm8_kernel<ACT, EK, SPLIT, false, LN, SPL>), dim3(grid), dim3(512), 160 * 1024, s, a);
+            hipLaunchKernelGGL((gemm8_kernel<ACT, EK, SPLIT, false, LN, SPL, RB>), dim3(grid), dim3(512), 160 * 1024, s, a);
             MAGE_CHECK_LAUNCH("mage_gemm");
             return MAGE_OK;
         }
     }
-    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT, LN, NW, SPL>), dim3(grid), dim3(512), TL::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_kernel<DT, GATHER, ACT, MT, EK, SPLIT, LN, NW, SPL, RB>), dim3(grid), dim3(512), TL::LDS_BYTES, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
     return MAGE_OK;
 }
@@ -1326,7 +1362,7 @@ int launch_spl(const mage_gemm_desc* d, hipStream_t s) {
     return MAGE_EINVAL;
 }
 
-template <int DT, bool GATHER, int ACT, int EK, int LN = LN_NONE>
+template <int DT, bool GATHER, int ACT, int EK, int LN = LN_NONE, bool RB = false>
 int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
     static int n_cu_dev[MAGE_MAX_DEVICES] = {0};
     const int dev = mage_device_index();
@@ -1355,7 +1391,7 @@ int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
         if (few < 0) few = (getenv("MAGE_GEMM_NO_NARROW") || getenv("MAGE_GEMM_NO_NARROW_FEW")) ? 0 : 1;
         const long tiles4 = (long)((d->M + 127) / 128) * ((d->N + BN - 1) / BN);
         // (tiles4 == n_cu, the B = 64 incremental step, measured on the narrow tile: 31.5 vs 28.2 ms per call -- the 128 x 256 tile stays)
-        if (few && d->n_split == 1 && tiles4 < n_cu && d->N % 64 == 0) return launch_tile<DT, GATHER, ACT, 2, EK, false, LN, 1>(d, s, n_cu);
+        if (few && d->n_split == 1 && tiles4 < n_cu && d->N % 64 == 0) return launch_tile<DT, GATHER, ACT, 2, EK, false, LN, 1, 0, RB>(d, s, n_cu);
     }
     const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + BN - 1) / BN) * d->n_split;
     if constexpr (!GATHER && ACT == MAGE_ACT_NONE && EK == EK_BIAS) {
@@ -1367,9 +1403,9 @@ int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
         }
     }
     if constexpr (DT == MAGE_BF16) {
-        if (tiles256 >= 2L * n_cu) return launch_tile<DT, GATHER, ACT, 8, EK, false, LN>(d, s, n_cu);
+        if (tiles256 >= 2L * n_cu) return launch_tile<DT, GATHER, ACT, 8, EK, false, LN, 4, 0, RB>(d, s, n_cu);
     }
-    return launch_tile<DT, GATHER, ACT, 4, EK, false, LN>(d, s, n_cu);
+    return launch_tile<DT, GATHER, ACT, 4, EK, false, LN, 4, 0, RB>(d, s, n_cu);
 }
 
 template <int DT, bool GATHER, int ACT>
@@ -1377,30 +1413,39 @@ int launch_act(const mage_gemm_desc* d, hipStream_t s) {
     const bool extras = d->scale || d->rowadd || d->residual || d->post_relu;
     if constexpr (DT == MAGE_BF16 && !GATHER && (ACT == MAGE_ACT_NONE || ACT == MAGE_ACT_QUICKGELU)) {
         // LayerNorm folded around the GEMM (see epilogue_lean): whole interior tiles, rows not regrouped
-        if (d->y2 || d->ln_stats) {
+        if (d->y2 || d->ln_stats || d->ln_part) {
             MAGE_CHECK_ARG(d->M % 256 == 0 && d->N % 256 == 0 && d->n_split == 1,
                            "mage_gemm: the LayerNorm-folded forms need M and N multiples of 256");
             MAGE_CHECK_ARG(d->ln_stats || (d->out_h == 1 && d->out_w >= d->M && d->y_mul_x == 1),
-                           "mage_gemm: y2 (bf16 copy + LayerNorm partial sums) needs plain output rows");
+                           "mage_gemm: ln_part (LayerNorm partial sums of the new rows) needs plain output rows");
             if (d->ln_stats) {
                 MAGE_CHECK_ARG(!extras && d->ln_colsum && d->bias && !d->y2, "mage_gemm: ln_stats goes with ln_colsum and bias, nothing else");
                 return launch_ek<DT, GATHER, ACT, EK_BIAS, LN_CONSUME>(d, s);
             }
             if constexpr (ACT == MAGE_ACT_NONE) {
-                MAGE_CHECK_ARG(d->residual && d->res_dtype == MAGE_F32 && !d->scale && !d->rowadd && !d->post_relu && d->y_dtype == MAGE_F32 &&
-                                   d->ln_part && d->ldy2 % 8 == 0 && (((uintptr_t)d->residual | (uintptr_t)d->y2) & 15) == 0,
-                               "mage_gemm: y2 (bf16 copy + LayerNorm partial sums) goes with the fp32 residual form");
+                // the producer forms of x + Linear(.): (fp32 residual) fp32 stream out + bf16 copy y2, or bf16 stream out alone (y2 null);
+                // (bf16 residual) bf16 stream out
+                MAGE_CHECK_ARG(d->residual && !d->scale && !d->rowadd && !d->post_relu && d->ln_part && (((uintptr_t)d->residual | (uintptr_t)d->y2) & 15) == 0,
+                               "mage_gemm: ln_part goes with the residual form x + Linear(.)");
+                MAGE_CHECK_ARG(d->y_dtype == MAGE_F32 ? (d->y2 && d->ldy2 % 8 == 0 && d->res_dtype == MAGE_F32) : !d->y2,
+                               "mage_gemm: ln_part: fp32 stream out + bf16 copy y2 (fp32 residual), or bf16 stream out alone");
+                if (d->res_dtype == MAGE_BF16) return launch_ek<DT, GATHER, ACT, EK_RES_INIT, LN_PRODUCE, true>(d, s);
                 return launch_ek<DT, GATHER, ACT, EK_RES_INIT, LN_PRODUCE>(d, s);
             }
         }
     }
-    MAGE_CHECK_ARG(!d->y2 && !d->ln_stats, "mage_gemm: y2 / ln_stats are bf16 plain-GEMM options (act none or QuickGELU)");
+    MAGE_CHECK_ARG(!d->y2 && !d->ln_stats && !d->ln_part, "mage_gemm: y2 / ln_part / ln_stats are bf16 plain-GEMM options (act none or QuickGELU)");
     if (!extras) return launch_ek<DT, GATHER, ACT, EK_BIAS>(d, s);
     if constexpr (!GATHER && ACT == MAGE_ACT_NONE) {
         // the transformer's "x + Linear(.)": fp32 residual, nothing else after the bias, rows not regrouped
         if (d->residual && d->res_dtype == MAGE_F32 && !d->scale && !d->rowadd && !d->post_relu && d->out_h == 1 &&
             d->out_w >= d->M && (((uintptr_t)d->residual) & 15) == 0)
             return launch_ek<DT, GATHER, ACT, EK_RES_INIT>(d, s);
+        if constexpr (DT == MAGE_BF16) {           // the same on a bf16 residual stream
+            if (d->residual && d->res_dtype == MAGE_BF16 && !d->scale && !d->rowadd && !d->post_relu && d->out_h == 1 &&
+                d->out_w >= d->M && (((uintptr_t)d->residual) & 15) == 0 && d->y_mul_x == 1)
+                return launch_ek<DT, GATHER, ACT, EK_RES_INIT, LN_NONE, true>(d, s);
+        }
     }
     return launch_ek<DT, GATHER, ACT, EK_GENERAL>(d, s);
 }

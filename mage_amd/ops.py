@@ -235,7 +235,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     d.y2, d.ldy2, d.ln_part, d.ln_stats, d.ln_colsum = _p(y2), ldy2, _p(ln_part), _p(ln_stats), _p(ln_colsum)
     d.res_half = int(res_half)
     d.a_half = int(a_half)
-    ln = 2 if ln_stats is not None else (1 if y2 is not None else 0)      # LN_CONSUME / LN_PRODUCE (csrc/gemm.hip)
+    ln = 2 if ln_stats is not None else (1 if (y2 is not None or ln_part is not None) else 0)      # LN_CONSUME / LN_PRODUCE (csrc/gemm.hip)
+    rb = residual is not None and residual.dtype == torch.bfloat16 and d.dtype == BF16      # bf16 residual stream (RB in csrc/gemm.hip)
     if PROFILE.enabled:
         # key = the kernel instantiation mage_gemm dispatches to (mirrors launch_act in csrc/gemm.hip), so that the
         # per-kernel averages line up with rocprofv3's per-symbol statistics
@@ -244,7 +245,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
         mt = 8 if (d.dtype == BF16 and ((M + 255) // 256) * ((N + 255) // 256) * max(n_split, 1) >= 2 * n_cu) else 4
         if scale is None and rowadd is None and residual is None and not post_relu:
             ek = 0
-        elif (not gather and act == ACT_NONE and residual is not None and residual.dtype == torch.float32 and scale is None
+        elif (not gather and act == ACT_NONE and residual is not None and (residual.dtype == torch.float32 or rb) and scale is None
               and rowadd is None and not post_relu and out_h == 1 and out_w >= M and residual.data_ptr() % 16 == 0 and not res_half):
             ek = 1
         else:
@@ -258,11 +259,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
                 and ((M + 127) // 128) * ((N + 255) // 256) < n_cu and not os.environ.get("MAGE_GEMM_NO_NARROW")
                 and not os.environ.get("MAGE_GEMM_NO_NARROW_FEW")):
             mt, nw = 2, 1                                   # few rows: x + Linear(.) of the incremental loop on the narrow tile
-        key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act}, {mt}, {ek}, {sp}, {ln}, {nw}, 0>"
+        rbs = ", true" if (rb and ek == 1) else ""
+        key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act}, {mt}, {ek}, {sp}, {ln}, {nw}, 0{rbs}>"
         a_rows = ((M + out_h * out_w - 1) // (out_h * out_w)) * d.a_img_stride + a_off + 1
         if (d.dtype == BF16 and not gather and mt == 8 and ek != 2 and K % 64 == 0 and a_rows * lda * 2 < 2 ** 32
                 and N * K * 2 < 2 ** 32 and not os.environ.get("MAGE_GEMM_NO_8PHASE")):
-            key = f"gemm8_kernel<{act}, {ek}, {sp}, false, {ln}, 0>"    # the 8-phase ping-pong variant (launch_tile in csrc/gemm.hip)
+            key = f"gemm8_kernel<{act}, {ek}, {sp}, false, {ln}, 0{rbs}>"    # the 8-phase ping-pong variant (launch_tile in csrc/gemm.hip)
         # padded-taps convolutions and row-table Linears on the 8-phase kernel (try_taps8 in csrc/gemm.hip)
         ntaps = taps_h * taps_w
         table, plain = rowadd is not None and residual is None, rowadd is None and residual is None
@@ -284,7 +286,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
             if residual is not None:
                 nb += float(M) * N * residual.element_size()
             if y2 is not None:
-                nb += float(M) * N * 2 + float(M) * (N // 64) * 8
+                nb += float(M) * N * 2
+            if ln_part is not None:
+                nb += float(M) * (N // 64) * 8
             PROFILE.end(key, ev, 2.0 * M * N * K, nb)
             return y
     _lib.check(l.mage_gemm(C.byref(d), s), l)

@@ -510,6 +510,49 @@ def test_layernorm_folded_around_the_gemms(M):
         o.gemm(xb[:100], wq.to(DEV), y, M=100, N=4 * C_, K=C_, lda=C_, ldy=4 * C_, bias=c.to(DEV), ln_stats=stats, ln_colsum=s.to(DEV))
 
 
+@pytest.mark.parametrize("M", [512, 65536])
+def test_x_plus_linear_on_a_bf16_residual_stream(M):
+    """The producer forms of the bf16 mode's bf16 stream (mage_hip.h, ln_part without y2): the residual x is read as bf16 rows, the new
+    rows leave as bf16 only, the LayerNorm partial sums are those of the fp32 values before rounding.  Against the fp32-residual form
+    fed the SAME (bf16-representable) residual: identical sums, and rows = its fp32 stream rounded -- bit for bit; both kernels
+    (M = 512 lockstep, M = 65536 8-phase) and the same rows through the other one."""
+    o = ops()
+    C_ = 512
+    xb0 = (rnd(M, C_, seed=11) + 0.3).bfloat16().to(DEV)
+    ao = rnd(M, C_, seed=12).bfloat16().to(DEV)
+    wo, bo = rnd(C_, C_, seed=13, scale=C_ ** -0.5).bfloat16().to(DEV), rnd(C_, seed=14, scale=0.1).to(DEV)
+    # reference: the fp32-stream producer on float(xb0)
+    x32 = xb0.float()
+    xb_ref = torch.empty(M, C_, device=DEV, dtype=torch.bfloat16)
+    part_ref = torch.empty(M, C_ // 64, 2, device=DEV, dtype=torch.float32)
+    o.gemm(ao, wo, x32, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=x32, ldr=C_, y2=xb_ref, ldy2=C_, ln_part=part_ref)
+    # bf16 residual in, bf16 rows out, in place
+    xb = xb0.clone()
+    part = torch.empty_like(part_ref)
+    o.gemm(ao, wo, xb, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xb, ldr=C_, ln_part=part)
+    assert torch.equal(xb, xb_ref) and torch.equal(part, part_ref)
+    # fp32 residual in, bf16 rows out (the first producer of a pass reads the fp32 rows the frame fill wrote)
+    xb1 = torch.empty_like(xb0)
+    part1 = torch.empty_like(part_ref)
+    o.gemm(ao, wo, xb1, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xb0.float(), ldr=C_, ln_part=part1)
+    assert torch.equal(xb1, xb_ref) and torch.equal(part1, part_ref)
+    # no LayerNorm after it (the last block): bf16 residual, bf16 or fp32 rows out
+    y16 = torch.empty_like(xb0)
+    o.gemm(ao, wo, y16, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xb0, ldr=C_)
+    y32 = torch.empty(M, C_, device=DEV, dtype=torch.float32)
+    o.gemm(ao, wo, y32, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xb0, ldr=C_)
+    assert torch.equal(y32, x32) and torch.equal(y16, xb_ref)
+    want = xb0.double().cpu() + ao.double().cpu() @ wo.double().cpu().t() + bo.double().cpu()
+    torch.testing.assert_close(y32.double().cpu(), want, atol=2e-3, rtol=1e-3)
+    # the same rows through the other kernel
+    xs = xb0[:256].clone()
+    ps = torch.empty(256, C_ // 64, 2, device=DEV, dtype=torch.float32)
+    o.gemm(ao[:256], wo, xs, M=256, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xs, ldr=C_, ln_part=ps)
+    assert torch.equal(xs, xb_ref[:256]) and torch.equal(ps, part_ref[:256])
+    with pytest.raises(Exception):             # fp32 rows out need the bf16 copy y2
+        o.gemm(ao, wo, x32, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=x32, ldr=C_, ln_part=part)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_conv_with_half_resolution_residual_and_narrow_outputs(dt):
     """mage_gemm res_half (the residual of a convolution read at half resolution = nn.Upsample of the skip path folded in) against the

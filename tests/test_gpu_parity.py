@@ -254,6 +254,29 @@ def test_incremental_decoding_is_bit_identical_to_reference_loop(precision):
         torch.testing.assert_close(v_inc.cpu(), t(g["video"]), atol=LOGIT_TOL, rtol=0)
 
 
+@pytest.mark.parametrize("stream_bf16", [True, False])
+def test_bf16_residual_stream_forms(stream_bf16):
+    """bf16 mode keeps x in bf16 between the blocks (default) or as the fp32 stream + bf16 copy (`stream_bf16 = False`): for both, the
+    incremental loop == the full loop bitwise, B = 1 == row 0 of a batch, and the teacher-forced logits stay inside the bf16 gate."""
+    m = build_mage(synth.mnist_model_config(frames_length=6), 5, DEV)
+    batch = dev_batch(synth.synth_batch_mnist(4, 6, seed=5))
+    _, lg32 = m.teacher_forced_logits(batch)
+    m.set_precision("bf16")
+    m.generate_model.stream_bf16 = stream_bf16
+    _, lg16 = m.teacher_forced_logits(batch)
+    err = (lg16 - lg32).abs()
+    print(f"stream_bf16={stream_bf16}: bf16 vs fp32 logits max |d| {err.max().item():.4f}, mean |d| {err.mean().item():.5f}")
+    assert err.max().item() < 0.25 and err.mean().item() < 0.02
+    v_full = m.autoregressive_generate(batch)
+    t_full = m.last_tokens.clone()
+    m.ar_mode = "incremental"
+    v_inc = m.autoregressive_generate(batch)
+    assert torch.equal(m.last_tokens, t_full) and torch.equal(v_inc, v_full)
+    one = {k: v[:1] for k, v in batch.items()}
+    v1 = m.autoregressive_generate(one)
+    assert torch.equal(m.last_tokens, t_full[:1]) and torch.equal(v1, v_full[:1])
+
+
 def test_incremental_decoding_full_size_cfg2():
     m = build_mage(synth.mnist_model_config(frames_length=16), 0, DEV).set_precision("bf16")
     batch = dev_batch(synth.synth_batch_mnist(64, 16, seed=3))
