@@ -434,11 +434,14 @@ def main():
                       "sums the next Linear normalises with (2 = that consumer: QKV, c_fc)]")
             # the GEMM symbol with the second-largest time, same accounting (the x + Linear(.) producers when c_fc leads, or the reverse)
             second = None
-            rest = sorted((k for k in gemms if k != dom_key), key=lambda k: -gemms[k]["ms"])
+            src2 = gemms if len(gemms) > 1 else warm_gemms            # --events dominant: the other symbols were bracketed in the last warm-up call
+            rest = sorted((k for k in src2 if k != dom_key), key=lambda k: -src2[k]["ms"])
             if rest:
-                g2 = gemms[rest[0]]
+                g2 = src2[rest[0]]
                 a2 = g2["flops"] / (g2["ms"] * 1e-3) / 1e12
-                second = {"kernel": rest[0], "achieved": round(a2, 2), "frac": round(a2 / peak, 4), "launches_per_step": g2["calls"] // args.steps,
+                second = {"kernel": rest[0], "achieved": round(a2, 2), "frac": round(a2 / peak, 4),
+                          "measured_in": "timed region" if src2 is gemms else "last warm-up call",
+                          "launches_per_step": g2["calls"] // (args.steps if src2 is gemms else 1),
                           "avg_launch_us": round(g2["ms"] * 1e3 / g2["calls"], 2), "flops_per_launch": g2["flops"] / g2["calls"],
                           "hbm_view": hbm_view(rest[0], g2)}
             roofline = {"bound": "mfma", "kernel": dom_key + legend,

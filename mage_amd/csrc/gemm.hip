@@ -1188,6 +1188,133 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     }
 }
 
+
+// ======================================================================================================================
+// gemm_small_kernel: the bf16 plain GEMM when there are too few rows for the tiled kernels to fill the chip (the reference samples
+// ONE clip per call, main_mage.py:205,239-241: an incremental step is M = 256 rows, i.e. 2-16 tiles of the kernels above on 256 CUs,
+// each walking its K slabs at the LDS-DMA round trip: 13-32 µs per launch).  Here the output is cut into 16*RW x 64 pieces, one
+// 4-wave workgroup each; wave w owns the 16 columns nt = w of the piece for all RW row blocks and streams its operands STRAIGHT from
+// global memory / L2 into the MFMA operand layout (lane (l15, grp) holds 8 consecutive k of row / column l15: one 16-byte load per
+// fragment; the four waves' A loads hit the same lines), two rounds of U k-steps in flight in registers, no LDS and no barrier in
+// the K loop.  Then waves 1-3 hand their accumulators to wave 0 through LDS and wave 0 runs epilogue_lean -- the SAME function on the
+// SAME accumulator layout as the tiled kernels -- so with the same MFMA and the same k order (k-steps of 32 ascending) every output
+// element gets the same bits from all three kernels: B = 1 == row 0 of a batch, incremental == full loop stay exact.
+template <int ACT, int EK, int LN, bool RB, int RW>
+__global__ __launch_bounds__(256) void gemm_small_kernel(const mage_gemm_desc d) {
+    static_assert(EK != EK_GENERAL && (!RB || EK == EK_RES_INIT), "lean epilogue kinds");
+    constexpr int D = RW == 1 ? 16 : RW == 2 ? 8 : 4;  // k-steps (32 columns) in flight; (K / 32) % D == 0 (host check)
+    __shared__ __attribute__((aligned(16))) char sm[4096 + 3 * RW * 1024];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int ntn = (d.N + 63) >> 6;
+    const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;
+    const int m0 = tm * 16 * RW, n0 = tn * 64;
+    const int plane = d.out_h * d.out_w;
+    const unsigned short* ap[RW];
+#pragma unroll
+    for (int a = 0; a < RW; ++a) {
+        const int m = min(m0 + a * 16 + l15, d.M - 1);
+        const int img = m / plane, rem = m - img * plane;
+        const int oy = rem / d.out_w, ox = rem - oy * d.out_w;
+        ap[a] = (const unsigned short*)d.A + ((long)img * d.a_img_stride + (long)oy * d.in_w + ox + d.a_off) * d.lda + grp * 8;
+    }
+    const unsigned short* wp = (const unsigned short*)d.W + (long)min(n0 + w * 16 + l15, d.N - 1) * d.K + grp * 8;
+    f32x4 acc[RW];
+    if constexpr (EK == EK_RES_INIT) {
+        const int nn = n0 + w * 16 + grp * 4;
+#pragma unroll
+        for (int a = 0; a < RW; ++a) {
+            const long row = (long)min(m0 + a * 16 + l15, d.M - 1) * d.y_mul_x + d.y_off;
+            if constexpr (RB) res_bf16_request(acc[a], (const unsigned short*)d.residual + row * d.ldr + (nn < d.N ? nn : 0));
+            else acc[a] = *(const f32x4*)((const float*)d.residual + row * d.ldr + (nn < d.N ? nn : 0));
+        }
+        if constexpr (RB) {
+#pragma unroll
+            for (int a = 0; a < RW; ++a) res_bf16_widen(acc[a]);
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < RW; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // the epilogue's vectors, requested first (they are one more round trip when asked for after the K loop)
+    f32x4 biasm[4];
+    [[maybe_unused]] LnConsume lnc;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int n = n0 + b * 16 + grp * 4;
+        biasm[b] = d.bias ? *(const f32x4*)(d.bias + (n < d.N ? n : 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (LN == LN_CONSUME) lnc.s[b] = *(const f32x4*)(d.ln_colsum + (n < d.N ? n : 0));
+    }
+    if constexpr (LN == LN_CONSUME) {
+#pragma unroll
+        for (int a = 0; a < RW; ++a) {
+            const float2 st = *(const float2*)(d.ln_stats + 2 * (long)min(m0 + a * 16 + l15, d.M - 1));
+            lnc.mean[a] = st.x;
+            lnc.rstd[a] = st.y;
+        }
+    }
+    // a ring of D k-steps in registers: slot u is multiplied and at once re-requested D steps ahead (the loads return in order, so
+    // hipcc's counted vmcnt lets each MFMA start as soon as its own operands are there)
+    uint4 xa[D][RW], wb[D];
+    auto request = [&](int u, int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < RW; ++a) xa[u][a] = *(const uint4*)(ap[a] + ks * 32);
+        wb[u] = *(const uint4*)(wp + ks * 32);
+    };
+    auto multiply = [&](int u) __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < RW; ++a)
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb[u]), __builtin_bit_cast(bf16x8, xa[u][a]), acc[a], 0, 0, 0);
+    };
+    const int nks = d.K >> 5;
+#pragma unroll
+    for (int u = 0; u < D; ++u) request(u, u);
+    for (int ks0 = 0; ks0 + D < nks; ks0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            multiply(u);
+            request(u, ks0 + D + u);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < D; ++u) multiply(u);
+    // waves 1..3 -> wave 0
+    if (w) {
+#pragma unroll
+        for (int a = 0; a < RW; ++a) *(f32x4*)(sm + 4096 + ((w - 1) * RW + a) * 1024 + lane * 16) = acc[a];
+    }
+    __syncthreads();
+    if (w) return;
+    f32x4 accf[RW][4];
+#pragma unroll
+    for (int a = 0; a < RW; ++a) {
+        accf[a][0] = acc[a];
+#pragma unroll
+        for (int nt = 1; nt < 4; ++nt) accf[a][nt] = *(const f32x4*)(sm + 4096 + ((nt - 1) * RW + a) * 1024 + lane * 16);
+    }
+    if constexpr (LN == LN_CONSUME) {
+        if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, RW, false, LN>(d, biasm, accf, m0, n0, lane, plane, sm, 0, &lnc);
+        else epilogue_lean<ACT, unsigned short, RW, false, LN>(d, biasm, accf, m0, n0, lane, plane, sm, 0, &lnc);
+    } else {
+        if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, RW, false, LN>(d, biasm, accf, m0, n0, lane, plane, sm, 0);
+        else epilogue_lean<ACT, unsigned short, RW, false, LN>(d, biasm, accf, m0, n0, lane, plane, sm, 0);
+    }
+}
+
+template <int ACT, int EK, int LN, bool RB>
+int launch_small(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
+    const long p64 = (long)((d->N + 63) / 64);
+    // rows per workgroup: as many as still leave ~2 workgroups per CU (fewer re-reads of W from L2)
+    const int rw = ((long)((d->M + 63) / 64) * p64 >= 2L * n_cu) ? 4 : ((long)((d->M + 31) / 32) * p64 >= 2L * n_cu) ? 2 : 1;
+    const unsigned grid = (unsigned)(((d->M + 16 * rw - 1) / (16 * rw)) * p64);
+    if (rw == 4) hipLaunchKernelGGL((gemm_small_kernel<ACT, EK, LN, RB, 4>), dim3(grid), dim3(256), 0, s, *d);
+    else if (rw == 2) hipLaunchKernelGGL((gemm_small_kernel<ACT, EK, LN, RB, 2>), dim3(grid), dim3(256), 0, s, *d);
+    else hipLaunchKernelGGL((gemm_small_kernel<ACT, EK, LN, RB, 1>), dim3(grid), dim3(256), 0, s, *d);
+    MAGE_CHECK_LAUNCH("mage_gemm");
+    return MAGE_OK;
+}
+
 template <int DT, bool GATHER, int ACT, int MT, int EK, bool SPLIT = false, int LN = LN_NONE, int NW = 4, int SPL = 0, bool RB = false>
 int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     typedef Tile<MT, NW, ring_stages<DT, GATHER, MT, EK, SPLIT, NW>()> TL;
@@ -1374,6 +1501,16 @@ int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
         n_cu_dev[dev] = n;
     }
     const int n_cu = n_cu_dev[dev];
+    if constexpr (DT == MAGE_BF16 && !GATHER && EK != EK_GENERAL && (ACT == MAGE_ACT_NONE || ACT == MAGE_ACT_QUICKGELU)) {
+        // few rows: the 128-row tile list would cover less than half of the chip (one clip per call; see gemm_small_kernel)
+        static int small = -1;
+        if (small < 0) small = getenv("MAGE_GEMM_NO_SMALL") ? 0 : 1;
+        const long tiles4 = (long)((d->M + 127) / 128) * ((d->N + BN - 1) / BN);
+        static int small_m = 0;
+        if (!small_m) small_m = getenv("MAGE_GEMM_SMALL_M") ? atoi(getenv("MAGE_GEMM_SMALL_M")) : 1024;
+        if (small && d->n_split == 1 && 2 * tiles4 <= n_cu && d->K % 512 == 0 && d->N % 16 == 0 && d->M <= small_m)
+            return launch_small<ACT, EK, LN, RB>(d, s, n_cu);
+    }
     // 256-row tiles only where there are enough of them to give every CU at least two (bf16; the fp32 8x4-accumulator
     // variant does not fit the register file)
     if constexpr (EK != EK_RES_INIT && LN == LN_NONE) {

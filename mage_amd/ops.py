@@ -259,7 +259,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
                 and ((M + 127) // 128) * ((N + 255) // 256) < n_cu and not os.environ.get("MAGE_GEMM_NO_NARROW")
                 and not os.environ.get("MAGE_GEMM_NO_NARROW_FEW")):
             mt, nw = 2, 1                                   # few rows: x + Linear(.) of the incremental loop on the narrow tile
-        rbs = ", true" if (rb and ek == 1) else ""
+        rbs = ", true" if (rb and ek == 1) else ", false"       # rocprofv3 prints every template argument: the keys match its symbols
         key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act}, {mt}, {ek}, {sp}, {ln}, {nw}, 0{rbs}>"
         a_rows = ((M + out_h * out_w - 1) // (out_h * out_w)) * d.a_img_stride + a_off + 1
         if (d.dtype == BF16 and not gather and mt == 8 and ek != 2 and K % 64 == 0 and a_rows * lda * 2 < 2 ** 32
@@ -273,9 +273,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
                 and not post_relu and N % 256 == 0 and M % 256 == 0
                 and not os.environ.get("MAGE_GEMM_NO_8PHASE") and not os.environ.get("MAGE_GEMM_NO_TAPS8")):
             if table and act == ACT_NONE:
-                key = "gemm8_kernel<0, 1, false, true, 0, 0>"
+                key = "gemm8_kernel<0, 1, false, true, 0, 0, false>"
             elif plain and act in (ACT_NONE, ACT_RELU):
-                key = f"gemm8_kernel<{act}, 0, false, true, 0, 0>"
+                key = f"gemm8_kernel<{act}, 0, false, true, 0, 0, false>"
         if PROFILE.wants(key):
             ev = PROFILE.begin()
             _lib.check(l.mage_gemm(C.byref(d), s), l)

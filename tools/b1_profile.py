@@ -9,6 +9,8 @@ m = instantiate_from_config(synth.mnist_model_config(frames_length=16)).eval()
 synth.fill_state_dict(m, 0)
 m = m.to("cuda:0").set_precision("bf16")
 m.ar_mode = sys.argv[1] if len(sys.argv) > 1 else "incremental"
+import os
+m.use_graph = bool(os.environ.get("B1_GRAPH"))
 batch = {k: v.to("cuda:0") for k, v in synth.synth_batch_mnist(1, 16, seed=100).items()}
 for _ in range(2):
     m.autoregressive_generate(batch)
