@@ -1199,9 +1199,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
 // the K loop.  Then waves 1-3 hand their accumulators to wave 0 through LDS and wave 0 runs epilogue_lean -- the SAME function on the
 // SAME accumulator layout as the tiled kernels -- so with the same MFMA and the same k order (k-steps of 32 ascending) every output
 // element gets the same bits from all three kernels: B = 1 == row 0 of a batch, incremental == full loop stay exact.
-template <int ACT, int EK, int LN, bool RB, int RW>
+// SPL = 2: split-precision operands of f16 pieces (the fast parity mode at one clip per call): the k-steps walk the physical
+// [hi(64) | lo(64)] slabs in the tiled kernels' order -- (A_hi, W_lo), (A_lo, W_hi) per logical slab, accumulators * 2^-11, then the
+// (A_hi, W_hi) slabs -- on v_mfma_f32_16x16x32_f16.
+template <int ACT, int EK, int LN, bool RB, int RW, int SPL = 0>
 __global__ __launch_bounds__(256) void gemm_small_kernel(const mage_gemm_desc d) {
     static_assert(EK != EK_GENERAL && (!RB || EK == EK_RES_INIT), "lean epilogue kinds");
+    static_assert(SPL == 0 || (SPL == 2 && LN == LN_NONE && !RB), "split-precision form: f16 pieces, no LayerNorm fold");
     constexpr int D = RW == 1 ? 16 : RW == 2 ? 8 : 4;  // k-steps (32 columns) in flight; (K / 32) % D == 0 (host check)
     __shared__ __attribute__((aligned(16))) char sm[4096 + 3 * RW * 1024];
     const int lane = threadIdx.x & 63;
@@ -1219,7 +1223,8 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const mage_gemm_desc d)
         const int oy = rem / d.out_w, ox = rem - oy * d.out_w;
         ap[a] = (const unsigned short*)d.A + ((long)img * d.a_img_stride + (long)oy * d.in_w + ox + d.a_off) * d.lda + grp * 8;
     }
-    const unsigned short* wp = (const unsigned short*)d.W + (long)min(n0 + w * 16 + l15, d.N - 1) * d.K + grp * 8;
+    const unsigned short* wp = (const unsigned short*)d.W + (long)min(n0 + w * 16 + l15, d.N - 1) * (SPL ? d.ldw : d.K) + grp * 8;
+    [[maybe_unused]] const int nk2s = SPL ? (d.K >> 6) * 4 : 0;      // SPL: k-steps of the two small-term passes
     f32x4 acc[RW];
     if constexpr (EK == EK_RES_INIT) {
         const int nn = n0 + w * 16 + grp * 4;
@@ -1232,6 +1237,10 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const mage_gemm_desc d)
         if constexpr (RB) {
 #pragma unroll
             for (int a = 0; a < RW; ++a) res_bf16_widen(acc[a]);
+        }
+        if constexpr (SPL == 2) {                      // the residual gets the lo pieces' scale (exact), undone at k-step nk2s
+#pragma unroll
+            for (int a = 0; a < RW; ++a) acc[a] *= MAGE_F16_LO_SCALE;
         }
     } else {
 #pragma unroll
@@ -1258,27 +1267,46 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const mage_gemm_desc d)
     // hipcc's counted vmcnt lets each MFMA start as soon as its own operands are there)
     uint4 xa[D][RW], wb[D];
     auto request = [&](int u, int ks) __attribute__((always_inline)) {
+        int ao = ks * 32, wo = ks * 32;
+        if constexpr (SPL != 0) {                      // physical 64-element unit along the split row (gemm_kernel's issue_one)
+            const int kt = ks >> 1, t32 = (ks & 1) * 32;
+            const int ua = ks < nk2s ? kt : 2 * (kt - (nk2s >> 1));
+            const int uw = ks < nk2s ? (kt ^ 1) : ua;
+            ao = ua * 64 + t32;
+            wo = uw * 64 + t32;
+        }
 #pragma unroll
-        for (int a = 0; a < RW; ++a) xa[u][a] = *(const uint4*)(ap[a] + ks * 32);
-        wb[u] = *(const uint4*)(wp + ks * 32);
+        for (int a = 0; a < RW; ++a) xa[u][a] = *(const uint4*)(ap[a] + ao);
+        wb[u] = *(const uint4*)(wp + wo);
     };
-    auto multiply = [&](int u) __attribute__((always_inline)) {
+    auto multiply = [&](int u, int ks) __attribute__((always_inline)) {
+        if constexpr (SPL == 2) {
+            if (ks == nk2s) {
 #pragma unroll
-        for (int a = 0; a < RW; ++a)
-            acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb[u]), __builtin_bit_cast(bf16x8, xa[u][a]), acc[a], 0, 0, 0);
+                for (int a = 0; a < RW; ++a) acc[a] *= (1.0f / MAGE_F16_LO_SCALE);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < RW; ++a) {
+            if constexpr (SPL == 2)
+                acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wb[u]), __builtin_bit_cast(f16x8, xa[u][a]), acc[a], 0, 0, 0);
+            else
+                acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb[u]), __builtin_bit_cast(bf16x8, xa[u][a]), acc[a], 0, 0, 0);
+        }
     };
-    const int nks = d.K >> 5;
+    const int nks = SPL ? (d.K >> 6) * 6 : d.K >> 5;
 #pragma unroll
     for (int u = 0; u < D; ++u) request(u, u);
-    for (int ks0 = 0; ks0 + D < nks; ks0 += D) {
+    int ks0 = 0;
+    for (; ks0 + D < nks; ks0 += D) {
 #pragma unroll
         for (int u = 0; u < D; ++u) {
-            multiply(u);
+            multiply(u, ks0 + u);
             request(u, ks0 + D + u);
         }
     }
 #pragma unroll
-    for (int u = 0; u < D; ++u) multiply(u);
+    for (int u = 0; u < D; ++u) multiply(u, ks0 + u);
     // waves 1..3 -> wave 0
     if (w) {
 #pragma unroll
@@ -1293,7 +1321,10 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const mage_gemm_desc d)
 #pragma unroll
         for (int nt = 1; nt < 4; ++nt) accf[a][nt] = *(const f32x4*)(sm + 4096 + ((nt - 1) * RW + a) * 1024 + lane * 16);
     }
-    if constexpr (LN == LN_CONSUME) {
+    if constexpr (SPL != 0) {
+        if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, RW>(d, biasm, accf, m0, n0, lane, plane, sm, 0);
+        else epilogue_lean<ACT, float, RW, false, LN_NONE, SPL>(d, biasm, accf, m0, n0, lane, plane, sm, 0);     // split rows out
+    } else if constexpr (LN == LN_CONSUME) {
         if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, RW, false, LN>(d, biasm, accf, m0, n0, lane, plane, sm, 0, &lnc);
         else epilogue_lean<ACT, unsigned short, RW, false, LN>(d, biasm, accf, m0, n0, lane, plane, sm, 0, &lnc);
     } else {
@@ -1302,15 +1333,15 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const mage_gemm_desc d)
     }
 }
 
-template <int ACT, int EK, int LN, bool RB>
+template <int ACT, int EK, int LN, bool RB, int SPL = 0>
 int launch_small(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     const long p64 = (long)((d->N + 63) / 64);
     // rows per workgroup: as many as still leave ~2 workgroups per CU (fewer re-reads of W from L2)
     const int rw = ((long)((d->M + 63) / 64) * p64 >= 2L * n_cu) ? 4 : ((long)((d->M + 31) / 32) * p64 >= 2L * n_cu) ? 2 : 1;
     const unsigned grid = (unsigned)(((d->M + 16 * rw - 1) / (16 * rw)) * p64);
-    if (rw == 4) hipLaunchKernelGGL((gemm_small_kernel<ACT, EK, LN, RB, 4>), dim3(grid), dim3(256), 0, s, *d);
-    else if (rw == 2) hipLaunchKernelGGL((gemm_small_kernel<ACT, EK, LN, RB, 2>), dim3(grid), dim3(256), 0, s, *d);
-    else hipLaunchKernelGGL((gemm_small_kernel<ACT, EK, LN, RB, 1>), dim3(grid), dim3(256), 0, s, *d);
+    if (rw == 4) hipLaunchKernelGGL((gemm_small_kernel<ACT, EK, LN, RB, 4, SPL>), dim3(grid), dim3(256), 0, s, *d);
+    else if (rw == 2) hipLaunchKernelGGL((gemm_small_kernel<ACT, EK, LN, RB, 2, SPL>), dim3(grid), dim3(256), 0, s, *d);
+    else hipLaunchKernelGGL((gemm_small_kernel<ACT, EK, LN, RB, 1, SPL>), dim3(grid), dim3(256), 0, s, *d);
     MAGE_CHECK_LAUNCH("mage_gemm");
     return MAGE_OK;
 }
@@ -1473,11 +1504,28 @@ int launch_spl(const mage_gemm_desc* d, hipStream_t s) {
                    "mage_gemm: split-precision form: epilogue y = act(acc + bias) | residual + acc + bias | rowadd[..] + acc only");
     MAGE_CHECK_ARG(!d->rowadd, "mage_gemm: split-precision form: row tables only in the padded-taps form");
     const bool big = (long)((d->M + 255) / 256) * ((d->N + BN - 1) / BN) >= 2L * n_cu;
+    // few rows (one clip per call): gemm_small_kernel, f16 pieces
+    bool few = false;
+    if constexpr (SPL == 2) {
+        static int small = -1, small_m = 0;
+        if (small < 0) {
+            small = getenv("MAGE_GEMM_NO_SMALL") ? 0 : 1;
+            small_m = getenv("MAGE_GEMM_SMALL_M") ? atoi(getenv("MAGE_GEMM_SMALL_M")) : 1024;
+        }
+        few = small && 2L * ((d->M + 127) / 128) * ((d->N + BN - 1) / BN) <= n_cu && d->K % 512 == 0 && d->N % 16 == 0 && d->M <= small_m;
+    }
     if (d->residual) {
         MAGE_CHECK_ARG(d->res_dtype == MAGE_F32 && d->act == MAGE_ACT_NONE && d->out_h == 1 && d->out_w >= d->M && (((uintptr_t)d->residual) & 15) == 0,
                        "mage_gemm: split-precision form: the residual is the fp32 stream (plain rows, no activation)");
+        if constexpr (SPL == 2) {
+            if (few) return launch_small<MAGE_ACT_NONE, EK_RES_INIT, LN_NONE, false, 2>(d, s, n_cu);
+        }
         return big ? launch_tile<MAGE_BF16, false, MAGE_ACT_NONE, 8, EK_RES_INIT, false, LN_NONE, 4, SPL>(d, s, n_cu)
                    : launch_tile<MAGE_BF16, false, MAGE_ACT_NONE, 4, EK_RES_INIT, false, LN_NONE, 4, SPL>(d, s, n_cu);
+    }
+    if constexpr (SPL == 2) {
+        if (few && d->act == MAGE_ACT_NONE) return launch_small<MAGE_ACT_NONE, EK_BIAS, LN_NONE, false, 2>(d, s, n_cu);
+        if (few && d->act == MAGE_ACT_QUICKGELU) return launch_small<MAGE_ACT_QUICKGELU, EK_BIAS, LN_NONE, false, 2>(d, s, n_cu);
     }
     if (d->act == MAGE_ACT_NONE)
         return big ? launch_tile<MAGE_BF16, false, MAGE_ACT_NONE, 8, EK_BIAS, false, LN_NONE, 4, SPL>(d, s, n_cu)

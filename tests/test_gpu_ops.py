@@ -452,11 +452,12 @@ def test_padded_taps_conv_on_the_8phase_kernel(n_img, Cc, mode):
     assert torch.equal(buf.cpu().view(n_img, P, P, Cc), want)
 
 
-@pytest.mark.parametrize("M", [512, 32768])
+@pytest.mark.parametrize("M", [512, 2048, 32768])
 def test_layernorm_folded_around_the_gemms(M):
     """bf16: the x + Linear(.) GEMM that also writes a bf16 copy of x and per-row partial (sum, sum of squares); mage_ln_stats;
     the Linear that consumes (copy, stats) with gamma folded into its weights = Linear(LayerNorm(x)) (mage_model.py:35-53).
-    M = 512 runs the lockstep kernel, M = 32768 the 8-phase one; the same rows give the same bits on both."""
+    M = 512 runs the few-rows kernel (gemm_small_kernel), M = 2048 the lockstep one, M = 32768 the 8-phase one; the same rows give
+    the same bits on all of them (the 256-row slices below go through the few-rows kernel)."""
     o = ops()
     C_, eps = 1024, 1e-5
     x0 = rnd(M, C_, seed=1) + 0.3
@@ -510,12 +511,12 @@ def test_layernorm_folded_around_the_gemms(M):
         o.gemm(xb[:100], wq.to(DEV), y, M=100, N=4 * C_, K=C_, lda=C_, ldy=4 * C_, bias=c.to(DEV), ln_stats=stats, ln_colsum=s.to(DEV))
 
 
-@pytest.mark.parametrize("M", [512, 65536])
+@pytest.mark.parametrize("M", [512, 2048, 65536])
 def test_x_plus_linear_on_a_bf16_residual_stream(M):
     """The producer forms of the bf16 mode's bf16 stream (mage_hip.h, ln_part without y2): the residual x is read as bf16 rows, the new
     rows leave as bf16 only, the LayerNorm partial sums are those of the fp32 values before rounding.  Against the fp32-residual form
-    fed the SAME (bf16-representable) residual: identical sums, and rows = its fp32 stream rounded -- bit for bit; both kernels
-    (M = 512 lockstep, M = 65536 8-phase) and the same rows through the other one."""
+    fed the SAME (bf16-representable) residual: identical sums, and rows = its fp32 stream rounded -- bit for bit; all three kernels
+    (M = 512 few-rows, M = 2048 lockstep, M = 65536 8-phase) and the same rows through another one."""
     o = ops()
     C_ = 512
     xb0 = (rnd(M, C_, seed=11) + 0.3).bfloat16().to(DEV)

@@ -7,7 +7,7 @@ from mage_amd.utils import synth  # noqa: E402
 from mage_amd.utils.util import instantiate_from_config  # noqa: E402
 m = instantiate_from_config(synth.mnist_model_config(frames_length=16)).eval()
 synth.fill_state_dict(m, 0)
-m = m.to("cuda:0").set_precision("bf16")
+m = m.to("cuda:0").set_precision(__import__("os").environ.get("B1_PRECISION", "bf16"))
 m.ar_mode = sys.argv[1] if len(sys.argv) > 1 else "incremental"
 import os
 m.use_graph = bool(os.environ.get("B1_GRAPH"))
