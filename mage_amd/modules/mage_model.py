@@ -1145,7 +1145,7 @@ class MAGE(nn.Module):
         if prof != "off" and not ops.graph_events_supported(batch["images"].device):
             return self._generate_eager(batch)              # per-launch events wanted, but they cannot be captured here
         key = (tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items())), self.precision, self.ar_mode, gens, prof,
-               str(batch["images"].device), bool(getattr(self, "frame_table", True)))
+               str(batch["images"].device), bool(getattr(self, "frame_table", True)), self.generate_model._stream_bf16())
         ent = self._graphs.get(key)
         if ent is None:
             self._graphs = {k: v for k, v in self._graphs.items() if k[3] == gens}       # graphs of replaced weights are dead
