@@ -65,6 +65,20 @@ def _wsplit(d: Dict[str, torch.Tensor], name: str, kind: int) -> torch.Tensor:
     return w
 
 
+def _lin_fp32(a, d, name, y, *, M, N, K, sk=0, lo=0, hi=None, a_split=None, **kw):
+    """fp32-class Linear of the once-per-clip prologue (text encoder, motion-anchor encoder): y = a @ W[lo:hi]^T + b[lo:hi] (+ epilogue).
+    sk = 0: the exact-fp32 MFMA chain (precision 'fp32').  sk = F16X3: split-precision operands, three f16 MFMA products per K slab
+    (mage_hip.h) -- 3x the rate, and a smaller error than the fp32 chain's own accumulation (profiles/r03_split_probe.txt); `a` is split
+    here (one small pass) unless the producer already wrote split rows (a_split)."""
+    hi = d[name + ".f32"].shape[0] if hi is None else hi
+    b = d.get(name + ".b")
+    b = None if b is None else b[lo:hi]
+    if sk and K % 64 == 0 and kw.get("act", ops.ACT_NONE) in (ops.ACT_NONE, ops.ACT_QUICKGELU):
+        a_s = a_split if a_split is not None else ops.split(a, sk)
+        return ops.gemm(a_s, _wsplit(d, name, sk)[lo:hi], y, M=M, N=N, K=K, lda=2 * K, ldy=kw.pop("ldy", N), bias=b, split_kind=sk, **kw)
+    return ops.gemm(a, d[name + ".f32"][lo:hi], y, M=M, N=N, K=K, lda=K, ldy=kw.pop("ldy", N), bias=b, **kw)
+
+
 def _need_gpu(t: torch.Tensor, who: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(f"{who} runs on libmage_hip.so kernels: move the model and the batch to a ROCm GPU "
@@ -146,6 +160,7 @@ class MAEncoder(nn.Module):
         self.d_model, self.layers = d_model, layers
         self.blocks = nn.ModuleList([TransformerBlock(d_model, d_model // 32, dropout) for _ in range(layers)])
         self.mage_plus = False          # True = the ln_q/ln_kv variant of mage_model.py:93 (MAGE+); MAGE(use_cids=False) sets it
+        self.split_kind = 0             # ops.F16X3 outside precision 'fp32' (MAGE.set_precision): Linear layers on split operands (_lin_fp32)
         self._derived = _Derived(self)
 
     def _build(self):
@@ -162,17 +177,27 @@ class MAEncoder(nn.Module):
         x = q.float().contiguous().clone()
         kv = kv.float().contiguous()
         inner, qo, qa, ko, ka = (B, 0, B, 0, B) if seq_first else (1, nq, 1, nk, 1)
+        sk = self.split_kind if Cc % 64 == 0 else 0
         for i in range(self.layers):
             p = f"b{i}"
             qin, kvin = x, kv
             if self.mage_plus:
                 qin = ops.layernorm(x, d[p + ".ln_q.w"], d[p + ".ln_q.b"], torch.empty_like(x), 1e-5)
                 kvin = ops.layernorm(kv, d[p + ".ln_kv.w"], d[p + ".ln_kv.b"], torch.empty_like(kv), 1e-5)
-            w, b = d[p + ".in_proj.f32"], d[p + ".in_proj.b"]
-            qp = ops.gemm(qin, w[:Cc], torch.empty(B * nq, Cc, device=dev, dtype=F32), M=B * nq, N=Cc, K=Cc, lda=Cc, ldy=Cc,
-                          bias=b[:Cc])
-            kvp = ops.gemm(kvin, w[Cc:], torch.empty(B * nk, 2 * Cc, device=dev, dtype=F32), M=B * nk, N=2 * Cc, K=Cc, lda=Cc,
-                           ldy=2 * Cc, bias=b[Cc:])
+            qp = _lin_fp32(qin, d, p + ".in_proj", torch.empty(B * nq, Cc, device=dev, dtype=F32), M=B * nq, N=Cc, K=Cc, sk=sk, lo=0, hi=Cc)
+            kvp = _lin_fp32(kvin, d, p + ".in_proj", torch.empty(B * nk, 2 * Cc, device=dev, dtype=F32), M=B * nk, N=2 * Cc, K=Cc, sk=sk,
+                            lo=Cc, hi=3 * Cc)
+            if sk:
+                # split rows straight from the producers: attention output, LayerNorm, the c_fc epilogue (QuickGELU)
+                ao = ops.split_empty(B * nq, Cc, sk, dev)
+                ops.attention(qp, kvp[:, :Cc], kvp[:, Cc:], ao, ldq=Cc, ldk=2 * Cc, ldv=2 * Cc, ldo=2 * Cc, n_seq=B, inner=inner,
+                              nq=nq, nk=nk, n_head=H, q_outer_stride=qo, q_axis_stride=qa, kv_outer_stride=ko, kv_axis_stride=ka, out_split=sk)
+                _lin_fp32(None, d, p + ".out_proj", x, M=B * nq, N=Cc, K=Cc, sk=sk, a_split=ao, residual=x, ldr=Cc)
+                xn = ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], ops.split_empty(B * nq, Cc, sk, dev), 1e-5, split_kind=sk)
+                hdn = _lin_fp32(None, d, p + ".c_fc", ops.split_empty(B * nq, 4 * Cc, sk, dev), M=B * nq, N=4 * Cc, K=Cc, sk=sk, a_split=xn,
+                                ldy=8 * Cc, act=ops.ACT_QUICKGELU, y_split=True)
+                _lin_fp32(None, d, p + ".c_proj", x, M=B * nq, N=Cc, K=4 * Cc, sk=sk, a_split=hdn, residual=x, ldr=Cc)
+                continue
             ao = torch.empty(B * nq, Cc, device=dev, dtype=F32)
             ops.attention(qp, kvp[:, :Cc], kvp[:, Cc:], ao, ldq=Cc, ldk=2 * Cc, ldv=2 * Cc, ldo=Cc, n_seq=B, inner=inner,
                           nq=nq, nk=nk, n_head=H, q_outer_stride=qo, q_axis_stride=qa, kv_outer_stride=ko, kv_axis_stride=ka)
@@ -257,22 +282,23 @@ class TransformerTextEncoder(nn.Module):
         ops.row_affine(x, None, d["pos"], div=1, mod=S)                  # + positions[0..S)       (:227-228)
         ops.layernorm(x, d["layer_norm.w"], d["layer_norm.b"], x, self.layer_norm.eps)
         ops.row_affine(x, keep.reshape(-1).to(F32).contiguous(), None)   # zero padded rows          (:233-235)
+        sk = getattr(self, "split_kind", 0) if Wd % 64 == 0 else 0
         for i in range(self.transformer_layers):
             p = f"l{i}"
-            qkv = _linear(x, d, p + ".in_proj", torch.empty(B * S, 3 * Wd, device=dev, dtype=F32), F32, M=B * S, N=3 * Wd, K=Wd)
-            ao = torch.empty(B * S, Wd, device=dev, dtype=F32)
-            ops.attention(qkv, qkv[:, Wd:], qkv[:, 2 * Wd:], ao, ldq=3 * Wd, ldk=3 * Wd, ldv=3 * Wd, ldo=Wd, n_seq=B, inner=1,
+            qkv = _lin_fp32(x, d, p + ".in_proj", torch.empty(B * S, 3 * Wd, device=dev, dtype=F32), M=B * S, N=3 * Wd, K=Wd, sk=sk)
+            ao = ops.split_empty(B * S, Wd, sk, dev) if sk else torch.empty(B * S, Wd, device=dev, dtype=F32)
+            ops.attention(qkv, qkv[:, Wd:], qkv[:, 2 * Wd:], ao, ldq=3 * Wd, ldk=3 * Wd, ldv=3 * Wd, ldo=2 * Wd if sk else Wd, n_seq=B, inner=1,
                           nq=S, nk=S, n_head=H, q_outer_stride=S, q_axis_stride=1, kv_outer_stride=S, kv_axis_stride=1,
-                          kv_len=kv_len, kv_len_div=1)
-            _linear(ao, d, p + ".out_proj", x, F32, M=B * S, N=Wd, K=Wd, residual=x, ldr=Wd)
+                          kv_len=kv_len, kv_len_div=1, out_split=sk)
+            _lin_fp32(ao, d, p + ".out_proj", x, M=B * S, N=Wd, K=Wd, sk=sk, a_split=ao if sk else None, residual=x, ldr=Wd)
             ops.layernorm(x, d[p + ".norm1.w"], d[p + ".norm1.b"], x, d[p + ".norm1.eps"])
+            # the exact GELU is not a split-GEMM epilogue: its Linear keeps the fp32 chain in every mode
             hdn = _linear(x, d, p + ".fc1", torch.empty(B * S, 4 * Wd, device=dev, dtype=F32), F32, M=B * S, N=4 * Wd, K=Wd,
                           act=ops.ACT_GELU_ERF)
-            _linear(hdn, d, p + ".fc2", x, F32, M=B * S, N=Wd, K=4 * Wd, residual=x, ldr=Wd)
+            _lin_fp32(hdn, d, p + ".fc2", x, M=B * S, N=Wd, K=4 * Wd, sk=sk, residual=x, ldr=Wd)
             ops.layernorm(x, d[p + ".norm2.w"], d[p + ".norm2.b"], x, d[p + ".norm2.eps"])
         ops.layernorm(x, d["ln_text_final.w"], d["ln_text_final.b"], x, self.ln_text_final.eps)
-        out = _linear(x, d, "proj", torch.empty(B * S, self.output_dim, device=dev, dtype=F32), F32, M=B * S, N=self.output_dim,
-                      K=Wd)
+        out = _lin_fp32(x, d, "proj", torch.empty(B * S, self.output_dim, device=dev, dtype=F32), M=B * S, N=self.output_dim, K=Wd, sk=sk)
         return out.view(B, S, self.output_dim)
 
 
@@ -904,6 +930,8 @@ class MAGE(nn.Module):
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         self.precision = precision
         self.generate_model.compute_dtype, self.generate_model.split_kind = PRECISIONS[precision]
+        # the once-per-clip prologue: exact-fp32 MFMA chains only in 'fp32' mode, f16x3 split operands otherwise (_lin_fp32)
+        self.ma_encoder.split_kind = self.text_encoder.split_kind = 0 if precision == "fp32" else ops.F16X3
         if hasattr(self.first_stage_model, "set_precision"):     # an external latent first stage (MAGE+) has no such switch
             self.first_stage_model.set_precision(precision)
         return self
@@ -1184,6 +1212,14 @@ class MAGE(nn.Module):
             if mod is not None and hasattr(mod, "_derived") and hasattr(mod, "_build"):
                 mod._derived.get(mod._build)
         self._frame_tables()
+        for enc, names in ((self.ma_encoder, [f"b{i}.{n}" for i in range(self.ma_encoder.layers) for n in ("in_proj", "out_proj", "c_fc", "c_proj")]),
+                           (self.text_encoder, [f"l{i}.{n}" for i in range(self.text_encoder.transformer_layers)
+                                                for n in ("in_proj", "out_proj", "fc2")] + ["proj"])):
+            if getattr(enc, "split_kind", 0):
+                de = enc._derived.get(enc._build)
+                for n in names:
+                    if de[n + ".f32"].shape[1] % 64 == 0:
+                        _wsplit(de, n, enc.split_kind)
         if hasattr(self.generate_model, "_warm_split"):
             self.generate_model._warm_split()
             if self._sk():
