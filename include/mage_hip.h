@@ -145,10 +145,15 @@ typedef struct mage_gemm_desc {
     int32_t a_half;                    /* gather form: the input lives at HALF resolution ([img, in_h/2, in_w/2, cin] rows, a_img_stride = that
                                         * plane): tap pixel (iy, ix) of the in_h x in_w grid reads row (iy/2)*(in_w/2) + ix/2 -- nn.Upsample
                                         * (scale_factor=2, nearest) in front of a convolution folded into its gather (vqvae_model.py:203-209) */
-    int32_t reserved3;
+    float ln_eps;                      /* consumer with ln_stats null and ln_part set: the epilogue takes (mean, rstd) of its rows straight from
+                                        * the producer's partial sums (mage_ln_stats' arithmetic, eps = ln_eps; K / 64 slices per row) -- no
+                                        * mage_ln_stats launch in between.  Few-rows GEMMs only: ask mage_gemm_is_small first */
 } mage_gemm_desc;
 
 int mage_gemm(const mage_gemm_desc* desc, void* stream);
+/* 1 if a bf16 plain GEMM of this size (lean epilogue: bias / x + Linear(.) / the LayerNorm-folded forms) runs on the few-rows kernel
+ * on the current device (one clip per call), 0 if on the tiled kernels, < 0 on error */
+int mage_gemm_is_small(int32_t M, int32_t N, int32_t K);
 /* stats[row] = (mean, rstd) from the producer GEMM's partial sums: mean = sum_s part[row][s][0] / C,
  * var = sum_s part[row][s][1] / C - mean^2, rstd = 1 / sqrt(max(var, 0) + eps); fixed order. */
 int mage_ln_stats(const float* part, int64_t rows, int32_t n_slices, int32_t C, float eps, float* stats, void* stream);

@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
         ("residual", vp), ("ldr", i32), ("res_dtype", i32),
         ("post_relu", i32), ("ldw", i32), ("n_split", i32),
         ("a_split_stride", i64), ("w_split_stride", i64), ("y_split_stride", i64),
-        ("y2", vp), ("ldy2", i32), ("res_half", i32), ("ln_part", vp), ("ln_stats", vp), ("ln_colsum", vp), ("a_half", i32), ("reserved3", i32),
+        ("y2", vp), ("ldy2", i32), ("res_half", i32), ("ln_part", vp), ("ln_stats", vp), ("ln_colsum", vp), ("a_half", i32), ("ln_eps", C.c_float),
     ]
 
 
@@ -56,6 +56,7 @@ SIGNATURES = {
     "mage_init": (C.c_int, [C.c_int]),
     "mage_check_device_errors": (C.c_int, [vp]),
     "mage_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "mage_gemm_is_small": (C.c_int, [i32, i32, i32]),
     "mage_ln_stats": (C.c_int, [vp, i64, i32, i32, f32, vp, vp]),
     "mage_groupnorm_bwd": (C.c_int, [vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
     "mage_adain_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),

@@ -73,6 +73,20 @@ __device__ __forceinline__ f32x4 load4(const unsigned short* p) {
 }
 __device__ __forceinline__ void store4(float* p, f32x4 v) { *(f32x4*)p = v; }
 // two fp32 -> packed bf16x2 with the hardware converter (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN-safe)
+// (mean, rstd) of a row from the producer GEMM's per-slice partial sums (sum, sum of squares): ONE definition for mage_ln_stats and for the
+// few-rows GEMM that folds it into its prologue, explicit roundings: the same bits from both.
+__device__ __forceinline__ void mage_ln_stats_row(const float2* __restrict__ p, int n_slices, float inv_c, float eps, float& mean, float& rstd) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < n_slices; ++i) {
+        const float2 v = p[i];
+        s1 = __fadd_rn(s1, v.x);
+        s2 = __fadd_rn(s2, v.y);
+    }
+    mean = __fmul_rn(s1, inv_c);
+    const float var = fmaxf(__fmaf_rn(-mean, mean, __fmul_rn(s2, inv_c)), 0.f);
+    rstd = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(var, eps)));
+}
+
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ unsigned int pack_bf16x2(float a, float b) {
     bf16x2_t v = {(__bf16)a, (__bf16)b};

@@ -1256,11 +1256,19 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const mage_gemm_desc d)
         if constexpr (LN == LN_CONSUME) lnc.s[b] = *(const f32x4*)(d.ln_colsum + (n < d.N ? n : 0));
     }
     if constexpr (LN == LN_CONSUME) {
+        if (d.ln_stats) {
 #pragma unroll
-        for (int a = 0; a < RW; ++a) {
-            const float2 st = *(const float2*)(d.ln_stats + 2 * (long)min(m0 + a * 16 + l15, d.M - 1));
-            lnc.mean[a] = st.x;
-            lnc.rstd[a] = st.y;
+            for (int a = 0; a < RW; ++a) {
+                const float2 st = *(const float2*)(d.ln_stats + 2 * (long)min(m0 + a * 16 + l15, d.M - 1));
+                lnc.mean[a] = st.x;
+                lnc.rstd[a] = st.y;
+            }
+        } else if (w == 0) {                           // straight from the producer's partial sums (mage_ln_stats' arithmetic)
+            const int ns = d.K >> 6;
+#pragma unroll
+            for (int a = 0; a < RW; ++a)
+                mage_ln_stats_row((const float2*)d.ln_part + (long)min(m0 + a * 16 + l15, d.M - 1) * ns, ns, 1.0f / (float)d.K, d.ln_eps,
+                                  lnc.mean[a], lnc.rstd[a]);
         }
     }
     // a ring of D k-steps in registers: slot u is multiplied and at once re-requested D steps ahead (the loads return in order, so
@@ -1487,6 +1495,17 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
     return 0;
 }
 
+// few rows: the 128-row tile list would cover less than half of the chip (one clip per call; see gemm_small_kernel)
+bool small_shape(int M, int N, int K, int n_cu) {
+    static int small = -1, small_m = 0;
+    if (small < 0) {
+        small = getenv("MAGE_GEMM_NO_SMALL") ? 0 : 1;
+        small_m = getenv("MAGE_GEMM_SMALL_M") ? atoi(getenv("MAGE_GEMM_SMALL_M")) : 1024;
+    }
+    const long tiles4 = (long)((M + 127) / 128) * ((N + BN - 1) / BN);
+    return small && 2 * tiles4 <= n_cu && K % 512 == 0 && N % 16 == 0 && M <= small_m;
+}
+
 // Split-precision GEMMs (dtype MAGE_BF16X3 / MAGE_F16X3): the decoder's Linear layers and frame convolution in the fast parity mode.
 template <int SPL>
 int launch_spl(const mage_gemm_desc* d, hipStream_t s) {
@@ -1506,14 +1525,7 @@ int launch_spl(const mage_gemm_desc* d, hipStream_t s) {
     const bool big = (long)((d->M + 255) / 256) * ((d->N + BN - 1) / BN) >= 2L * n_cu;
     // few rows (one clip per call): gemm_small_kernel, f16 pieces
     bool few = false;
-    if constexpr (SPL == 2) {
-        static int small = -1, small_m = 0;
-        if (small < 0) {
-            small = getenv("MAGE_GEMM_NO_SMALL") ? 0 : 1;
-            small_m = getenv("MAGE_GEMM_SMALL_M") ? atoi(getenv("MAGE_GEMM_SMALL_M")) : 1024;
-        }
-        few = small && 2L * ((d->M + 127) / 128) * ((d->N + BN - 1) / BN) <= n_cu && d->K % 512 == 0 && d->N % 16 == 0 && d->M <= small_m;
-    }
+    if constexpr (SPL == 2) few = small_shape(d->M, d->N, d->K, n_cu);
     if (d->residual) {
         MAGE_CHECK_ARG(d->res_dtype == MAGE_F32 && d->act == MAGE_ACT_NONE && d->out_h == 1 && d->out_w >= d->M && (((uintptr_t)d->residual) & 15) == 0,
                        "mage_gemm: split-precision form: the residual is the fp32 stream (plain rows, no activation)");
@@ -1550,14 +1562,7 @@ int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
     }
     const int n_cu = n_cu_dev[dev];
     if constexpr (DT == MAGE_BF16 && !GATHER && EK != EK_GENERAL && (ACT == MAGE_ACT_NONE || ACT == MAGE_ACT_QUICKGELU)) {
-        // few rows: the 128-row tile list would cover less than half of the chip (one clip per call; see gemm_small_kernel)
-        static int small = -1;
-        if (small < 0) small = getenv("MAGE_GEMM_NO_SMALL") ? 0 : 1;
-        const long tiles4 = (long)((d->M + 127) / 128) * ((d->N + BN - 1) / BN);
-        static int small_m = 0;
-        if (!small_m) small_m = getenv("MAGE_GEMM_SMALL_M") ? atoi(getenv("MAGE_GEMM_SMALL_M")) : 1024;
-        if (small && d->n_split == 1 && 2 * tiles4 <= n_cu && d->K % 512 == 0 && d->N % 16 == 0 && d->M <= small_m)
-            return launch_small<ACT, EK, LN, RB>(d, s, n_cu);
+        if (d->n_split == 1 && small_shape(d->M, d->N, d->K, n_cu)) return launch_small<ACT, EK, LN, RB>(d, s, n_cu);
     }
     // 256-row tiles only where there are enough of them to give every CU at least two (bf16; the fp32 8x4-accumulator
     // variant does not fit the register file)
@@ -1598,13 +1603,15 @@ int launch_act(const mage_gemm_desc* d, hipStream_t s) {
     const bool extras = d->scale || d->rowadd || d->residual || d->post_relu;
     if constexpr (DT == MAGE_BF16 && !GATHER && (ACT == MAGE_ACT_NONE || ACT == MAGE_ACT_QUICKGELU)) {
         // LayerNorm folded around the GEMM (see epilogue_lean): whole interior tiles, rows not regrouped
-        if (d->y2 || d->ln_stats || d->ln_part) {
+        if (d->y2 || d->ln_stats || d->ln_part || d->ln_colsum) {
             MAGE_CHECK_ARG(d->M % 256 == 0 && d->N % 256 == 0 && d->n_split == 1,
                            "mage_gemm: the LayerNorm-folded forms need M and N multiples of 256");
-            MAGE_CHECK_ARG(d->ln_stats || (d->out_h == 1 && d->out_w >= d->M && d->y_mul_x == 1),
+            MAGE_CHECK_ARG(d->ln_stats || d->ln_colsum || (d->out_h == 1 && d->out_w >= d->M && d->y_mul_x == 1),
                            "mage_gemm: ln_part (LayerNorm partial sums of the new rows) needs plain output rows");
-            if (d->ln_stats) {
+            if (d->ln_stats || d->ln_colsum) {
                 MAGE_CHECK_ARG(!extras && d->ln_colsum && d->bias && !d->y2, "mage_gemm: ln_stats goes with ln_colsum and bias, nothing else");
+                MAGE_CHECK_ARG(d->ln_stats || (d->ln_part && d->ln_eps > 0.f && mage_gemm_is_small(d->M, d->N, d->K) == 1),
+                               "mage_gemm: a LayerNorm consumer without ln_stats needs ln_part + ln_eps and a few-rows size (mage_gemm_is_small)");
                 return launch_ek<DT, GATHER, ACT, EK_BIAS, LN_CONSUME>(d, s);
             }
             if constexpr (ACT == MAGE_ACT_NONE) {
@@ -1669,6 +1676,19 @@ extern "C" int mage_debug_read(void* dst, size_t bytes) {
 }
 #endif
 
+
+extern "C" int mage_gemm_is_small(int32_t M, int32_t N, int32_t K) {
+    const int dev = mage_device_index();
+    MAGE_CHECK_ARG(dev >= 0 && M > 0 && N > 0 && K > 0, "mage_gemm_is_small: no current device / bad sizes");
+    hipDeviceProp_t p;
+    int n_cu = 256;
+    static int n_cu_dev[MAGE_MAX_DEVICES] = {0};
+    if (!n_cu_dev[dev]) {
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= 8) n_cu = p.multiProcessorCount & ~7;
+        n_cu_dev[dev] = n_cu;
+    }
+    return small_shape(M, N, K, n_cu_dev[dev]) ? 1 : 0;
+}
 
 extern "C" int mage_gemm(const mage_gemm_desc* d_in, void* stream) {
     MAGE_CHECK_ARG(d_in != nullptr, "mage_gemm: null descriptor");

@@ -1146,16 +1146,9 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
                                                        float* __restrict__ stats) {
     const long r = (long)blockIdx.x * 256 + threadIdx.x;
     if (r >= rows) return;
-    const float2* p = (const float2*)part + r * n_slices;
-    float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < n_slices; ++i) {
-        const float2 v = p[i];
-        s1 += v.x;
-        s2 += v.y;
-    }
-    const float mean = s1 * inv_c;
-    const float var = fmaxf(s2 * inv_c - mean * mean, 0.f);
-    *(float2*)(stats + 2 * r) = float2{mean, 1.0f / sqrtf(var + eps)};
+    float mean, rstd;
+    mage_ln_stats_row((const float2*)part + r * n_slices, n_slices, inv_c, eps, mean, rstd);
+    *(float2*)(stats + 2 * r) = float2{mean, rstd};
 }
 }  // namespace
 

@@ -459,12 +459,20 @@ class FlatAxialDecoder(nn.Module):
         bf16 GEMM noise.  The incremental loop uses the same kernels on the same rows: still bit-identical to the full loop."""
         return getattr(self, "stream_bf16", True) and not os.environ.get("MAGE_STREAM_FP32")
 
-    def _ln_linear(self, d, p, lin, xb, stats, y, *, M, N, lo=0, hi=None, **kw):
-        """y = Linear(LN(x)) from the bf16 copy of x and its row statistics (rows lo:hi of the Linear's outputs)."""
+    def _ln_linear(self, d, p, lin, xb, stats, y, *, M, N, lo=0, hi=None, part=None, **kw):
+        """y = Linear(LN(x)) from the bf16 copy of x and its row statistics (rows lo:hi of the Linear's outputs).  part (instead of
+        stats): the producer's partial sums -- few-rows GEMMs reduce them in their prologue (_stats_inline), no mage_ln_stats launch."""
         Cc = self.model_channels
         hi = N + lo if hi is None else hi
+        src = dict(ln_part=part, ln_eps=1e-5) if part is not None else dict(ln_stats=stats)
         return ops.gemm(xb, d[f"{p}.{lin}.lnw"][lo:hi], y, M=M, N=hi - lo, K=Cc, lda=Cc, ldy=kw.pop("ldy", hi - lo),
-                        bias=d[f"{p}.{lin}.lnc"][lo:hi], ln_stats=stats, ln_colsum=d[f"{p}.{lin}.lns"][lo:hi], **kw)
+                        bias=d[f"{p}.{lin}.lnc"][lo:hi], ln_colsum=d[f"{p}.{lin}.lns"][lo:hi], **src, **kw)
+
+    def _stats_inline(self, xb, M: int) -> bool:
+        """One clip per call: every Linear that follows a LayerNorm (N = C .. 4C) runs on the few-rows kernel, which reduces the
+        producer's partial sums itself (same arithmetic as mage_ln_stats, mage_ln_stats_row in csrc/common.h)."""
+        Cc = self.model_channels
+        return all(ops.gemm_is_small(xb, M, n, Cc) for n in (Cc, 2 * Cc, 3 * Cc, 4 * Cc))
 
     @torch.no_grad()
     def _run(self, motion: torch.Tensor, imgs: torch.Tensor, *, B: int, hh: int, ww: int) -> torch.Tensor:
@@ -492,10 +500,12 @@ class FlatAxialDecoder(nn.Module):
         hdn = torch.empty(M, 4 * Cc, device=dev, dtype=dt)
         fold, have_stats = self._fold(dt, B, hw), False
         sb = fold and self._stream_bf16()
+        inl = False
         if fold:
             xb = torch.empty(M, Cc, device=dev, dtype=dt)                          # bf16 copy of the stream, written by its producers
             part = torch.empty(M, Cc // 64, 2, device=dev, dtype=F32)
             stats = torch.empty(M, 2, device=dev, dtype=F32)
+            inl = self._stats_inline(xb, M)
         for i in range(self.layers):
             p = f"b{i}"
             axis = i % 3                                                            # 0: L (causal), 1: H, 2: W  (:344,:382)
@@ -506,7 +516,7 @@ class FlatAxialDecoder(nn.Module):
             else:
                 geo = dict(n_seq=B * L * hh, inner=1, nq=ww, nk=ww, q_outer_stride=ww, q_axis_stride=1, causal=False)
             if have_stats:
-                self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=3 * Cc)
+                self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=3 * Cc, part=part if inl else None)
             else:
                 ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], xn, 1e-5)
                 _linear(xn, d, p + ".in_proj", qkv, dt, M=M, N=3 * Cc, K=Cc)
@@ -517,8 +527,9 @@ class FlatAxialDecoder(nn.Module):
                     _linear(ao, d, p + ".out_proj", xb, dt, M=M, N=Cc, K=Cc, residual=xb if i else x, ldr=Cc, ln_part=part)
                 else:
                     _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc, y2=xb, ldy2=Cc, ln_part=part)
-                ops.ln_stats(part, Cc, 1e-5, stats)
-                self._ln_linear(d, p, "c_fc", xb, stats, hdn, M=M, N=4 * Cc, act=ops.ACT_QUICKGELU)
+                if not inl:
+                    ops.ln_stats(part, Cc, 1e-5, stats)
+                self._ln_linear(d, p, "c_fc", xb, stats, hdn, M=M, N=4 * Cc, act=ops.ACT_QUICKGELU, part=part if inl else None)
             else:
                 _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc)
                 ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5)
@@ -534,7 +545,8 @@ class FlatAxialDecoder(nn.Module):
                     _linear(hdn, d, p + ".c_proj", xb, dt, M=M, N=Cc, K=4 * Cc, residual=xb, ldr=Cc, ln_part=part)
                 else:
                     _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc, y2=xb, ldy2=Cc, ln_part=part)
-                ops.ln_stats(part, Cc, 1e-5, stats)
+                if not inl:
+                    ops.ln_stats(part, Cc, 1e-5, stats)
                 have_stats = True
             else:
                 _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=xb if sb else x, ldr=Cc)
@@ -597,10 +609,12 @@ class FlatAxialDecoder(nn.Module):
         hdn = torch.empty(M, 4 * Cc, device=dev, dtype=dt)
         fold, have_stats = self._fold(dt, B, hw), False
         sb = fold and self._stream_bf16()
+        inl = False
         if fold:                                                             # see _run
             xb = torch.empty(M, Cc, device=dev, dtype=dt)
             part = torch.empty(M, Cc // 64, 2, device=dev, dtype=F32)
             stats = torch.empty(M, 2, device=dev, dtype=F32)
+            inl = self._stats_inline(xb, M)
         for i in range(self.layers):
             p = f"b{i}"
             axis = i % 3
@@ -610,9 +624,9 @@ class FlatAxialDecoder(nn.Module):
             if axis == 0:
                 kv = st["kv"][i]                                             # [B, L, hw, K|V]
                 if have_stats:
-                    self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=Cc)                   # q, packed [M, C]
+                    self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=Cc, part=part if inl else None)                   # q, packed [M, C]
                     self._ln_linear(d, p, "in_proj", xb, stats, kv, M=M, N=2 * Cc, lo=Cc, hi=3 * Cc, out_w=P * hw,
-                                    y_img_stride=L * hw, y_off=p0 * hw)                           # k, v -> cache slots
+                                    y_img_stride=L * hw, y_off=p0 * hw, part=part if inl else None)                           # k, v -> cache slots
                 else:
                     ops.gemm(xn, w[:Cc], qkv, M=M, N=Cc, K=Cc, lda=Cc, ldy=Cc, bias=b[:Cc])
                     ops.gemm(xn, w[Cc:], kv, M=M, N=2 * Cc, K=Cc, lda=Cc, ldy=2 * Cc, bias=b[Cc:], out_w=P * hw,
@@ -622,7 +636,7 @@ class FlatAxialDecoder(nn.Module):
                               kv_axis_stride=hw, causal=True)
             else:
                 if have_stats:
-                    self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=3 * Cc)
+                    self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=3 * Cc, part=part if inl else None)
                 else:
                     ops.gemm(xn, w, qkv, M=M, N=3 * Cc, K=Cc, lda=Cc, ldy=3 * Cc, bias=b)
                 if axis == 1:
@@ -636,8 +650,9 @@ class FlatAxialDecoder(nn.Module):
                     _linear(ao, d, p + ".out_proj", xb, dt, M=M, N=Cc, K=Cc, residual=xb if i else x, ldr=Cc, ln_part=part)
                 else:
                     _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc, y2=xb, ldy2=Cc, ln_part=part)
-                ops.ln_stats(part, Cc, 1e-5, stats)
-                self._ln_linear(d, p, "c_fc", xb, stats, hdn, M=M, N=4 * Cc, act=ops.ACT_QUICKGELU)
+                if not inl:
+                    ops.ln_stats(part, Cc, 1e-5, stats)
+                self._ln_linear(d, p, "c_fc", xb, stats, hdn, M=M, N=4 * Cc, act=ops.ACT_QUICKGELU, part=part if inl else None)
             else:
                 _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc)
                 ops.layernorm(x, d[p + ".ln_2.w"], d[p + ".ln_2.b"], xn, 1e-5)
@@ -650,7 +665,8 @@ class FlatAxialDecoder(nn.Module):
                     _linear(hdn, d, p + ".c_proj", xb, dt, M=M, N=Cc, K=4 * Cc, residual=xb, ldr=Cc, ln_part=part)
                 else:
                     _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=x, ldr=Cc, y2=xb, ldy2=Cc, ln_part=part)
-                ops.ln_stats(part, Cc, 1e-5, stats)
+                if not inl:
+                    ops.ln_stats(part, Cc, 1e-5, stats)
                 have_stats = True
             else:
                 _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=xb if sb else x, ldr=Cc)

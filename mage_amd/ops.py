@@ -200,7 +200,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
          bias=None, scale=None, shift=None, act: int = ACT_NONE, rowadd=None, rowadd_div: int = 1, rowadd_mod: int = 1,
          residual=None, ldr: int = 0, post_relu: bool = False, ldw: int = 0, n_split: int = 1, a_split_stride: int = 0,
          w_split_stride: int = 0, y_split_stride: int = 0, y2=None, ldy2: int = 0, ln_part=None, ln_stats=None,
-         ln_colsum=None, res_half: bool = False, a_half: bool = False, split_kind: int = 0, y_split: bool = False) -> torch.Tensor:
+         ln_colsum=None, res_half: bool = False, a_half: bool = False, split_kind: int = 0, y_split: bool = False,
+         ln_eps: float = 0.0) -> torch.Tensor:
     """Y = epilogue(A (*) W^T); see mage_gemm in include/mage_hip.h for the geometry fields.
     split_kind BF16X3 / F16X3: a and w are split-precision tensors (lda / ldw in 16-bit elements); y_split: so is y (ldy likewise)."""
     l, s = _dev(a)
@@ -233,9 +234,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     d.ldw, d.n_split = ldw, n_split
     d.a_split_stride, d.w_split_stride, d.y_split_stride = a_split_stride, w_split_stride, y_split_stride
     d.y2, d.ldy2, d.ln_part, d.ln_stats, d.ln_colsum = _p(y2), ldy2, _p(ln_part), _p(ln_stats), _p(ln_colsum)
+    d.ln_eps = float(ln_eps)
     d.res_half = int(res_half)
     d.a_half = int(a_half)
-    ln = 2 if ln_stats is not None else (1 if (y2 is not None or ln_part is not None) else 0)      # LN_CONSUME / LN_PRODUCE (csrc/gemm.hip)
+    ln = 2 if (ln_stats is not None or ln_colsum is not None) else (1 if (y2 is not None or ln_part is not None) else 0)      # LN_CONSUME / LN_PRODUCE
     rb = residual is not None and residual.dtype == torch.bfloat16 and d.dtype == BF16      # bf16 residual stream (RB in csrc/gemm.hip)
     if PROFILE.enabled:
         # key = the kernel instantiation mage_gemm dispatches to (mirrors launch_act in csrc/gemm.hip), so that the
@@ -293,6 +295,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
             return y
     _lib.check(l.mage_gemm(C.byref(d), s), l)
     return y
+
+
+def gemm_is_small(a: torch.Tensor, M: int, N: int, K: int) -> bool:
+    """True if a bf16 plain GEMM of this size runs on the few-rows kernel on a's device (mage_gemm_is_small): its LayerNorm-consuming form
+    then takes (mean, rstd) straight from the producer's partial sums (ln_part + ln_eps) and the mage_ln_stats launch can be skipped."""
+    l, _ = _dev(a)
+    r = l.mage_gemm_is_small(M, N, K)
+    if r < 0:
+        _lib.check(r, l)
+    return r == 1
 
 
 def _gemm_split(l, s, a, w, y, *, M, N, K, lda, ldy, out_h, out_w, in_h, in_w, a_img_stride, a_off, taps_h, taps_w, cin, y_img_stride, y_mul_y,

@@ -500,13 +500,22 @@ def test_layernorm_folded_around_the_gemms(M):
         o.gemm(xb[:256], wq.to(DEV), y_s, M=256, N=4 * C_, K=C_, lda=C_, ldy=4 * C_, bias=c.to(DEV), act=act, ln_stats=stats[:256],
                ln_colsum=s.to(DEV))
         assert torch.equal(y_s, y[:256])
+        # ... and with (mean, rstd) taken from the partial sums inside the few-rows kernel (no mage_ln_stats launch): the same bits
+        assert o.gemm_is_small(xb, 256, 4 * C_, C_)
+        y_p = torch.empty(256, 4 * C_, device=DEV, dtype=torch.bfloat16)
+        o.gemm(xb[:256], wq.to(DEV), y_p, M=256, N=4 * C_, K=C_, lda=C_, ldy=4 * C_, bias=c.to(DEV), act=act, ln_part=part[:256],
+               ln_eps=eps, ln_colsum=s.to(DEV))
+        assert torch.equal(y_p, y[:256])
     # ... and the producer's extra outputs do not depend on the kernel either
     x_s = xd[:256].clone()
     xb_s = torch.empty(256, C_, device=DEV, dtype=torch.bfloat16)
     part_s = torch.empty(256, C_ // 64, 2, device=DEV, dtype=torch.float32)
     o.gemm(aod[:256], wod, x_s, M=256, N=C_, K=C_, lda=C_, ldy=C_, bias=bod, residual=x_s, ldr=C_, y2=xb_s, ldy2=C_, ln_part=part_s)
     assert torch.equal(x_s, x_new[:256]) and torch.equal(xb_s, xb[:256]) and torch.equal(part_s, part[:256])
-    # loud on shapes the folded forms do not take
+    # loud on shapes the folded forms do not take (the partial-sum form exists in the few-rows kernel only)
+    if M > 1024:
+        with pytest.raises(Exception):
+            o.gemm(xb, wq.to(DEV), y, M=M, N=4 * C_, K=C_, lda=C_, ldy=4 * C_, bias=c.to(DEV), ln_part=part, ln_eps=eps, ln_colsum=s.to(DEV))
     with pytest.raises(Exception):
         o.gemm(xb[:100], wq.to(DEV), y, M=100, N=4 * C_, K=C_, lda=C_, ldy=4 * C_, bias=c.to(DEV), ln_stats=stats, ln_colsum=s.to(DEV))
 
