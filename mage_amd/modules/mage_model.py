@@ -923,7 +923,8 @@ class MAGE(nn.Module):
                                        # 'incremental' = temporal KV cache, each position once
         self.last_call_mode = "eager"
         self._pad_frames: dict = {}    # zero-padded frame buffers of _frame_features (bf16 mode), by (images, device, stream)
-        self.use_graph = False         # True: autoregressive_generate replays a captured HIP graph of the whole call (see there)
+        self.use_graph = None          # True: autoregressive_generate replays a captured HIP graph of the whole call (see _generate_graphed);
+                                       # None (default): only where the call is launch-bound -- a few clips per call (_graph_auto); False: never
         self.frame_table = True        # conv3x3(token embedding) (+ in_linear) as a table sum (_frame_tables); False: the convolution GEMM
         self._graphs: dict = {}
         self._derived = _Derived(self)
@@ -1155,12 +1156,30 @@ class MAGE(nn.Module):
         images = batch["images"]
         _need_gpu(images, "MAGE.autoregressive_generate")
         with torch.cuda.device(images.device):
-            if self.use_graph and int(getattr(self, "streams", 1)) == 1 and not torch.cuda.is_current_stream_capturing():
+            ug = self._graph_auto(batch) if self.use_graph is None else bool(self.use_graph)
+            if ug and int(getattr(self, "streams", 1)) == 1 and not torch.cuda.is_current_stream_capturing():
                 out = self._generate_graphed(batch)
             else:
+                self.last_call_mode = "eager"
                 out = self._generate_eager(batch)
             ops.check_device_errors(images.device)        # e.g. a caption id >= vocab_size: the reference raises IndexError
         return out
+
+    def _graph_auto(self, batch) -> bool:
+        """use_graph = None: replay from a captured graph where the call is launch-bound -- up to 4 clips per call (the reference samples
+        ONE, main_mage.py:205: ~870 launches of 3-15 µs; 13.7 ms eager vs 7.6 ms replayed per 16-frame clip), the VQ-token path only (an
+        external latent first stage is not ours to capture), and not while per-launch profiling is on."""
+        images = batch["images"]
+        return (self.use_cids and images.shape[0] * self.image_resolution ** 2 <= 1024 and not ops.PROFILE.enabled
+                and all(torch.is_tensor(v) for v in batch.values()) and not os.environ.get("MAGE_NO_AUTO_GRAPH"))
+
+    def _graph_fingerprint(self):
+        """Everything besides shapes, precision, AR mode and weights that selects kernels: a captured graph replays only under the same."""
+        fs = self.first_stage_model
+        return (bool(getattr(self, "frame_table", True)), self.generate_model._stream_bf16(), bool(getattr(self.ma_encoder, "mage_plus", False)),
+                getattr(self.ma_encoder, "split_kind", 0), getattr(self.text_encoder, "split_kind", 0),
+                tuple(str(getattr(fs, a, None)) for a in ("decode_dtype", "encode_split", "decode_split")),
+                tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("MAGE_"))))
 
     def _generate_eager(self, batch):
         if not self.use_cids:
@@ -1189,10 +1208,17 @@ class MAGE(nn.Module):
         if prof != "off" and not ops.graph_events_supported(batch["images"].device):
             return self._generate_eager(batch)              # per-launch events wanted, but they cannot be captured here
         key = (tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items())), self.precision, self.ar_mode, gens, prof,
-               str(batch["images"].device), bool(getattr(self, "frame_table", True)), self.generate_model._stream_bf16())
+               str(batch["images"].device), self._graph_fingerprint())
         ent = self._graphs.get(key)
         if ent is None:
             self._graphs = {k: v for k, v in self._graphs.items() if k[3] == gens}       # graphs of replaced weights are dead
+            while len(self._graphs) >= 4:                                                # each graph owns an arena: keep the 4 newest shapes
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[key] = "warm" if self.use_graph else "warm2"
+            return self._generate_eager(batch)
+        if ent == "off":
+            return self._generate_eager(batch)
+        if ent == "warm2":                               # auto mode: a shape has to come back twice before it is worth a capture
             self._graphs[key] = "warm"
             return self._generate_eager(batch)
         if ent == "warm":
@@ -1204,6 +1230,12 @@ class MAGE(nn.Module):
                 with torch.cuda.graph(g):
                     out = self._generate_eager(static)
                     toks, logits = self.last_tokens, self.last_logits
+            except Exception:
+                if self.use_graph:                       # asked for explicitly: loud
+                    raise
+                self._graphs[key] = "off"                # auto mode: this call shape cannot be captured here -- eager from now on
+                torch.cuda.synchronize()
+                return self._generate_eager(batch)
             finally:
                 recs = ops.PROFILE.capture_end(saved)
             ent = self._graphs[key] = {"g": g, "in": static, "out": out, "tok": toks, "logits": logits, "recs": recs}

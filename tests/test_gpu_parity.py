@@ -546,6 +546,7 @@ def test_graph_replay_is_bit_identical_to_eager(precision, ar_mode):
     B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
     m = build_mage(synth.mnist_model_config(frames_length=L), seed, DEV).set_precision(precision)
     m.ar_mode = ar_mode
+    m.use_graph = False                                     # the eager reference (the default, None, replays by itself at this size)
     kw = dict(digits=int(g["digits"]), text_len=int(g["text_len"]), ragged_text=True)
     b1 = dev_batch(synth.synth_batch_mnist(B, L, seed=seed, **kw))
     b2 = dev_batch(synth.synth_batch_mnist(B, L, seed=seed + 1, **kw))
@@ -571,6 +572,34 @@ def test_graph_replay_is_bit_identical_to_eager(precision, ar_mode):
         v = m.autoregressive_generate(b1)
         assert torch.equal(v, v_new)
     assert not torch.equal(v_new, want[0][0])
+
+
+def test_graph_replay_is_the_default_for_a_few_clips_per_call():
+    """use_graph = None (default): calls of up to 4 clips (the reference samples ONE per call, main_mage.py:205) replay from a captured
+    graph from the third call of a shape on -- bitwise the eager result; a changed kernel selection (here: the residual-stream form) or a larger
+    batch does not replay a stale graph."""
+    m = build_mage(synth.mnist_model_config(frames_length=6), 5, DEV).set_precision("bf16")
+    m.ar_mode = "incremental"
+    one = dev_batch(synth.synth_batch_mnist(1, 6, seed=5))
+    assert m.use_graph is None
+    m.use_graph = False
+    want = m.autoregressive_generate(one).clone()
+    m.use_graph = None
+    for _ in range(4):                                      # two eager calls, the third captures + replays, the fourth replays
+        v = m.autoregressive_generate(one)
+        assert torch.equal(v, want)
+    assert m.last_call_mode == "graph"
+    m.generate_model.stream_bf16 = False                    # other kernels: a new capture, not the old graph
+    m.use_graph = False
+    want2 = m.autoregressive_generate(one).clone()
+    m.use_graph = None
+    for _ in range(4):
+        assert torch.equal(m.autoregressive_generate(one), want2)
+    assert m.last_call_mode == "graph" and not torch.equal(want, want2)
+    big = dev_batch(synth.synth_batch_mnist(8, 6, seed=5))
+    for _ in range(3):
+        m.autoregressive_generate(big)
+    assert m.last_call_mode == "eager"
 
 
 def test_graph_replay_carries_per_kernel_events():
