@@ -157,6 +157,9 @@ int mage_gemm_is_small(int32_t M, int32_t N, int32_t K);
 /* stats[row] = (mean, rstd) from the producer GEMM's partial sums: mean = sum_s part[row][s][0] / C,
  * var = sum_s part[row][s][1] / C - mean^2, rstd = 1 / sqrt(max(var, 0) + eps); fixed order. */
 int mage_ln_stats(const float* part, int64_t rows, int32_t n_slices, int32_t C, float eps, float* stats, void* stream);
+/* stats[row] = (mean, rstd) of bf16 rows x[row][0..C) (fp32 sums): the LayerNorm in front of the decoder's first Linear when the residual
+ * stream starts in bf16 (mage_model.py:35-36,47 on the rows mage_model.py:375-378 assembles); consumed like mage_ln_stats' output */
+int mage_row_stats(const void* x, int32_t dtype, int64_t rows, int32_t C, int64_t ldx, float eps, float* stats, void* stream);
 
 /* y = the split-precision form (kind MAGE_BF16X3 | MAGE_F16X3) of fp32 rows x [rows, C] (row stride ldx floats; C % 64 == 0);
  * y rows have ldy 16-bit elements (>= 2C), y 256-byte aligned.  Weights are split once per state_dict (derived caches); activations

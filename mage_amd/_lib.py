@@ -58,6 +58,7 @@ SIGNATURES = {
     "mage_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "mage_gemm_is_small": (C.c_int, [i32, i32, i32]),
     "mage_ln_stats": (C.c_int, [vp, i64, i32, i32, f32, vp, vp]),
+    "mage_row_stats": (C.c_int, [vp, i32, i64, i32, i64, f32, vp, vp]),
     "mage_groupnorm_bwd": (C.c_int, [vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
     "mage_adain_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "mage_reparam_kl_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, vp]),

@@ -1152,6 +1152,49 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
 }
 }  // namespace
 
+// (mean, rstd) of bf16 rows, one wave per row: the first LayerNorm of a decoder pass when the residual stream starts in bf16 (the frame
+// fill and context_linear write bf16 rows; the Linear that follows takes (rows, stats) like every later one).  Sums in fp32 in a fixed
+// order (lane: its 8-column groups left to right; then the xor tree), the closing formula is mage_ln_stats'.
+namespace {
+__global__ __launch_bounds__(256) void row_stats_kernel(const unsigned short* __restrict__ x, long rows, int C, long ldx, float inv_c, float eps,
+                                                        float* __restrict__ stats) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned short* p = x + r * ldx;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane * 8; c < C; c += 512) {
+        const uint4 v = *(const uint4*)(p + c);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = __uint_as_float(w[j] << 16), b = __uint_as_float(w[j] & 0xffff0000u);
+            s1 = __fadd_rn(s1, __fadd_rn(a, b));
+            s2 = __fadd_rn(s2, __fmaf_rn(a, a, __fmul_rn(b, b)));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 = __fadd_rn(s1, __shfl_xor(s1, o));
+        s2 = __fadd_rn(s2, __shfl_xor(s2, o));
+    }
+    if (lane == 0) {
+        const float mean = __fmul_rn(s1, inv_c);
+        const float var = fmaxf(__fmaf_rn(-mean, mean, __fmul_rn(s2, inv_c)), 0.f);
+        *(float2*)(stats + 2 * r) = float2{mean, __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(var, eps)))};
+    }
+}
+}  // namespace
+
+extern "C" int mage_row_stats(const void* x, int32_t dtype, int64_t rows, int32_t C, int64_t ldx, float eps, float* stats, void* stream) {
+    MAGE_CHECK_ARG(x && stats && rows > 0 && C > 0 && C % 8 == 0 && ldx >= C && ldx % 8 == 0 && (((uintptr_t)x) & 15) == 0 && dtype == MAGE_BF16,
+                   "mage_row_stats: bf16 rows, C and ldx multiples of 8, x 16-byte aligned");
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (long)rows, C,
+                       (long)ldx, 1.0f / (float)C, eps, stats);
+    MAGE_CHECK_LAUNCH("mage_row_stats");
+    return MAGE_OK;
+}
+
 extern "C" int mage_ln_stats(const float* part, int64_t rows, int32_t n_slices, int32_t C, float eps, float* stats, void* stream) {
     MAGE_CHECK_ARG(part && stats && rows > 0 && n_slices > 0 && C > 0, "mage_ln_stats: bad arguments");
     hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, (long)rows, n_slices,

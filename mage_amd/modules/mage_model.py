@@ -50,7 +50,8 @@ class FrameTokens:
         self.tokens, self.T2, self.P2, self.R = tokens.contiguous(), T2, P2, R
 
     def fill(self, x: torch.Tensor, *, n_img: int, per_clip: int, P: int, y_off: int, tp: torch.Tensor) -> None:
-        """Rows (clip b, slot y_off/hw + l) of x [B*P*hw, C] fp32 <- in_linear(conv(emb(ids[b, l])) + H/W positions) + T positions."""
+        """Rows (clip b, slot y_off/hw + l) of x [B*P*hw, C] (fp32, or the bf16 stream) <- in_linear(conv(emb(ids[b, l])) + H/W positions)
+        + T positions."""
         hw = self.R * self.R
         ops.table_conv(self.tokens, self.T2, x, n_img=n_img, H=self.R, W=self.R, pos=self.P2, rowadd=tp, rowadd_div=hw, rowadd_mod=P,
                        ldy=x.shape[1], group=per_clip * hw, y_group_stride=P * hw, y_off=y_off)
@@ -485,27 +486,33 @@ class FlatAxialDecoder(nn.Module):
         hw = hh * ww
         M = B * L * hw
         H = Cc // 32
-        x = torch.empty(M, Cc, device=dev, dtype=F32)                              # residual stream, fp32
+        fold, have_stats = self._fold(dt, B, hw), False
+        sb = fold and self._stream_bf16()
+        inl = fill_stats = False
+        if fold:
+            xb = torch.empty(M, Cc, device=dev, dtype=dt)                          # the bf16 stream (or the bf16 copy of the fp32 one)
+            part = torch.empty(M, Cc // 64, 2, device=dev, dtype=F32)
+            stats = torch.empty(M, 2, device=dev, dtype=F32)
+            inl = self._stats_inline(xb, M)
+        # the stream starts in bf16 too: context_linear and the frame fill write bf16 rows, their LayerNorm statistics come from one pass
+        # over those rows (mage_row_stats), block 0 then runs like every other block (no fp32 rows, no LayerNorm launch)
+        x0 = xb if sb else torch.empty(M, Cc, device=dev, dtype=F32)               # residual stream as assembled by :375-378
+        x = x0 if not sb else None
         # context_linear -> slot 0, in_linear -> slots 1..L-1, + T_positional_embedding, no concat copy (:375-378)
-        _linear(motion, d, "context_linear", x, dt, M=B * hw, N=Cc, K=self.context_channels, out_w=hw, y_img_stride=L * hw,
+        _linear(motion, d, "context_linear", x0, dt, M=B * hw, N=Cc, K=self.context_channels, out_w=hw, y_img_stride=L * hw,
                 rowadd=d["tpos"], rowadd_div=hw, rowadd_mod=L)
         if isinstance(imgs, FrameTokens):
-            imgs.fill(x, n_img=B * (L - 1), per_clip=L - 1, P=L, y_off=hw, tp=d["tpos"])
+            imgs.fill(x0, n_img=B * (L - 1), per_clip=L - 1, P=L, y_off=hw, tp=d["tpos"])
         else:
-            _linear(imgs, d, "in_linear", x, dt, M=B * (L - 1) * hw, N=Cc, K=self.in_channels, out_w=(L - 1) * hw,
+            _linear(imgs, d, "in_linear", x0, dt, M=B * (L - 1) * hw, N=Cc, K=self.in_channels, out_w=(L - 1) * hw,
                     y_img_stride=L * hw, y_off=hw, rowadd=d["tpos"], rowadd_div=hw, rowadd_mod=L)
+        if sb:
+            ops.row_stats(xb, 1e-5, stats)
+            have_stats = fill_stats = True
         xn = torch.empty(M, Cc, device=dev, dtype=dt)
         qkv = torch.empty(M, 3 * Cc, device=dev, dtype=dt)
         ao = torch.empty(M, Cc, device=dev, dtype=dt)
         hdn = torch.empty(M, 4 * Cc, device=dev, dtype=dt)
-        fold, have_stats = self._fold(dt, B, hw), False
-        sb = fold and self._stream_bf16()
-        inl = False
-        if fold:
-            xb = torch.empty(M, Cc, device=dev, dtype=dt)                          # bf16 copy of the stream, written by its producers
-            part = torch.empty(M, Cc // 64, 2, device=dev, dtype=F32)
-            stats = torch.empty(M, 2, device=dev, dtype=F32)
-            inl = self._stats_inline(xb, M)
         for i in range(self.layers):
             p = f"b{i}"
             axis = i % 3                                                            # 0: L (causal), 1: H, 2: W  (:344,:382)
@@ -516,15 +523,15 @@ class FlatAxialDecoder(nn.Module):
             else:
                 geo = dict(n_seq=B * L * hh, inner=1, nq=ww, nk=ww, q_outer_stride=ww, q_axis_stride=1, causal=False)
             if have_stats:
-                self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=3 * Cc, part=part if inl else None)
+                self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=3 * Cc, part=part if (inl and not (fill_stats and i == 0)) else None)
             else:
                 ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], xn, 1e-5)
                 _linear(xn, d, p + ".in_proj", qkv, dt, M=M, N=3 * Cc, K=Cc)
             ops.attention(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], ao, ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=Cc, n_head=H,
                           kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], **geo)
             if fold:
-                if sb:                                                   # bf16 stream: block 0 reads the fp32 rows of the fill
-                    _linear(ao, d, p + ".out_proj", xb, dt, M=M, N=Cc, K=Cc, residual=xb if i else x, ldr=Cc, ln_part=part)
+                if sb:
+                    _linear(ao, d, p + ".out_proj", xb, dt, M=M, N=Cc, K=Cc, residual=xb, ldr=Cc, ln_part=part)
                 else:
                     _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc, y2=xb, ldy2=Cc, ln_part=part)
                 if not inl:
@@ -549,6 +556,8 @@ class FlatAxialDecoder(nn.Module):
                     ops.ln_stats(part, Cc, 1e-5, stats)
                 have_stats = True
             else:
+                if x is None:                                            # bf16 stream, MAGE+ head: its GroupNorm reads fp32 rows
+                    x = torch.empty(M, Cc, device=dev, dtype=F32)
                 _linear(hdn, d, p + ".c_proj", x, dt, M=M, N=Cc, K=4 * Cc, residual=xb if sb else x, ldr=Cc)
         if not self.use_cids:
             # GroupNorm statistics span all L-1 frames of a clip (:387-388): this head is NOT causal along L
@@ -593,40 +602,45 @@ class FlatAxialDecoder(nn.Module):
         P = 2 if motion is not None else 1                                  # new positions p0 .. p0+P-1
         assert (p0 == 0) == (motion is not None) and p0 + P <= L
         M = B * P * hw
-        x = torch.empty(M, Cc, device=dev, dtype=F32)
-        tp = d["tpos"][p0:]
-        if motion is not None:
-            _linear(motion, d, "context_linear", x, dt, M=B * hw, N=Cc, K=self.context_channels, out_w=hw, y_img_stride=P * hw,
-                    rowadd=tp, rowadd_div=hw, rowadd_mod=P)
-        if isinstance(imgs, FrameTokens):
-            imgs.fill(x, n_img=B, per_clip=1, P=P, y_off=(P - 1) * hw, tp=tp)
-        else:
-            _linear(imgs, d, "in_linear", x, dt, M=B * hw, N=Cc, K=self.in_channels, out_w=hw, y_img_stride=P * hw,
-                    y_off=(P - 1) * hw, rowadd=tp, rowadd_div=hw, rowadd_mod=P)
-        xn = torch.empty(M, Cc, device=dev, dtype=dt)
-        qkv = torch.empty(M, 3 * Cc, device=dev, dtype=dt)
-        ao = torch.empty(M, Cc, device=dev, dtype=dt)
-        hdn = torch.empty(M, 4 * Cc, device=dev, dtype=dt)
         fold, have_stats = self._fold(dt, B, hw), False
         sb = fold and self._stream_bf16()
-        inl = False
+        inl = fill_stats = False
         if fold:                                                             # see _run
             xb = torch.empty(M, Cc, device=dev, dtype=dt)
             part = torch.empty(M, Cc // 64, 2, device=dev, dtype=F32)
             stats = torch.empty(M, 2, device=dev, dtype=F32)
             inl = self._stats_inline(xb, M)
+        x0 = xb if sb else torch.empty(M, Cc, device=dev, dtype=F32)
+        x = x0 if not sb else None
+        tp = d["tpos"][p0:]
+        if motion is not None:
+            _linear(motion, d, "context_linear", x0, dt, M=B * hw, N=Cc, K=self.context_channels, out_w=hw, y_img_stride=P * hw,
+                    rowadd=tp, rowadd_div=hw, rowadd_mod=P)
+        if isinstance(imgs, FrameTokens):
+            imgs.fill(x0, n_img=B, per_clip=1, P=P, y_off=(P - 1) * hw, tp=tp)
+        else:
+            _linear(imgs, d, "in_linear", x0, dt, M=B * hw, N=Cc, K=self.in_channels, out_w=hw, y_img_stride=P * hw,
+                    y_off=(P - 1) * hw, rowadd=tp, rowadd_div=hw, rowadd_mod=P)
+        if sb:
+            ops.row_stats(xb, 1e-5, stats)
+            have_stats = fill_stats = True
+        xn = torch.empty(M, Cc, device=dev, dtype=dt)
+        qkv = torch.empty(M, 3 * Cc, device=dev, dtype=dt)
+        ao = torch.empty(M, Cc, device=dev, dtype=dt)
+        hdn = torch.empty(M, 4 * Cc, device=dev, dtype=dt)
         for i in range(self.layers):
             p = f"b{i}"
             axis = i % 3
             if not have_stats:
                 ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], xn, 1e-5)
             w, b = d[p + ".in_proj" + _sfx(dt)], d[p + ".in_proj.b"]
+            pin = part if (inl and not (fill_stats and i == 0)) else None        # block 0: the statistics of the fill, not partial sums
             if axis == 0:
                 kv = st["kv"][i]                                             # [B, L, hw, K|V]
                 if have_stats:
-                    self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=Cc, part=part if inl else None)                   # q, packed [M, C]
+                    self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=Cc, part=pin)                   # q, packed [M, C]
                     self._ln_linear(d, p, "in_proj", xb, stats, kv, M=M, N=2 * Cc, lo=Cc, hi=3 * Cc, out_w=P * hw,
-                                    y_img_stride=L * hw, y_off=p0 * hw, part=part if inl else None)                           # k, v -> cache slots
+                                    y_img_stride=L * hw, y_off=p0 * hw, part=pin)                           # k, v -> cache slots
                 else:
                     ops.gemm(xn, w[:Cc], qkv, M=M, N=Cc, K=Cc, lda=Cc, ldy=Cc, bias=b[:Cc])
                     ops.gemm(xn, w[Cc:], kv, M=M, N=2 * Cc, K=Cc, lda=Cc, ldy=2 * Cc, bias=b[Cc:], out_w=P * hw,
@@ -636,7 +650,7 @@ class FlatAxialDecoder(nn.Module):
                               kv_axis_stride=hw, causal=True)
             else:
                 if have_stats:
-                    self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=3 * Cc, part=part if inl else None)
+                    self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=3 * Cc, part=pin)
                 else:
                     ops.gemm(xn, w, qkv, M=M, N=3 * Cc, K=Cc, lda=Cc, ldy=3 * Cc, bias=b)
                 if axis == 1:
@@ -646,8 +660,8 @@ class FlatAxialDecoder(nn.Module):
                 ops.attention(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], ao, ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=Cc, n_head=H,
                               kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], **geo)
             if fold:
-                if sb:                                                   # bf16 stream: block 0 reads the fp32 rows of the fill
-                    _linear(ao, d, p + ".out_proj", xb, dt, M=M, N=Cc, K=Cc, residual=xb if i else x, ldr=Cc, ln_part=part)
+                if sb:
+                    _linear(ao, d, p + ".out_proj", xb, dt, M=M, N=Cc, K=Cc, residual=xb, ldr=Cc, ln_part=part)
                 else:
                     _linear(ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, residual=x, ldr=Cc, y2=xb, ldy2=Cc, ln_part=part)
                 if not inl:

@@ -343,6 +343,17 @@ def _gemm_split(l, s, a, w, y, *, M, N, K, lda, ldy, out_h, out_w, in_h, in_w, a
     return y
 
 
+def row_stats(x: torch.Tensor, eps: float, stats: torch.Tensor) -> torch.Tensor:
+    """(mean, rstd) per row of bf16 rows x [rows, C] (mage_row_stats)."""
+    l, s = _dev(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and stats.is_contiguous() and stats.numel() >= 2 * x.shape[0]
+    ev = PROFILE.begin() if PROFILE.wants("layernorm") else None
+    _lib.check(l.mage_row_stats(x.data_ptr(), BF16, x.shape[0], x.shape[1], x.stride(0), float(eps), stats.data_ptr(), s), l)
+    if ev is not None:
+        PROFILE.end("layernorm", ev, 0.0, float(x.numel()) * 2)
+    return stats
+
+
 def ln_stats(part: torch.Tensor, C_: int, eps: float, stats: torch.Tensor) -> torch.Tensor:
     """(mean, rstd) per row from a producer GEMM's partial sums ``part[rows, n_slices, 2]`` (mage_ln_stats)."""
     l, s = _dev(part)
