@@ -302,6 +302,22 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const mage_attn_des
 // the first MFMA.  The workgroup-per-sequence kernel
 // spends its time in per-workgroup latency at this shape (V staging + barrier for ONE query): 107 us per launch at cfg2 against
 // ~55 us of K,V cache bytes.
+// DPP row shifts (within each 16-lane row): row_shr<N>: lane r takes src of lane r - N (lanes r < N keep old); row_shl<N>: lane r takes
+// lane r + N (lanes r >= 16 - N: themselves).  N = 0: src.
+template <int N> __device__ __forceinline__ float row_shr_f(float old, float src) {
+    if constexpr (N == 0) return src;
+    else return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(old), __float_as_uint(src), 0x110 + N, 0xf, 0xf, false));
+}
+template <int N> __device__ __forceinline__ unsigned row_shl_u(unsigned src) {
+    if constexpr (N == 0) return src;
+    else return __builtin_amdgcn_update_dpp(src, src, 0x100 + N, 0xf, 0xf, false);
+}
+template <int N> __device__ __forceinline__ float row_shl_f(float src) { return __uint_as_float(row_shl_u<N>(__float_as_uint(src))); }
+template <int N> __device__ __forceinline__ ashort4 row_shl_s4(ashort4 src) {
+    const uint2 u = __builtin_bit_cast(uint2, src);
+    return __builtin_bit_cast(ashort4, uint2{row_shl_u<N>(u.x), row_shl_u<N>(u.y)});
+}
+
 template <int NKB>
 __global__ __launch_bounds__(256) void attention_mfma_fewq_kernel(const mage_attn_desc d) {
     const int lane = threadIdx.x & 63;
@@ -319,7 +335,6 @@ __global__ __launch_bounds__(256) void attention_mfma_fewq_kernel(const mage_att
     const int r = lane & 15, g = lane >> 4;
     const int qi = r;                                                         // nq <= 16: one query block
     const long qrow = q_base + (long)min(qi, d.nq - 1) * d.q_axis_stride;
-    const int jmax = d.causal ? min(klen, qi + 1 + (d.nk - d.nq)) : klen;
     long krow[NKB], krow_v[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
@@ -359,39 +374,65 @@ __global__ __launch_bounds__(256) void attention_mfma_fewq_kernel(const mage_att
                     for (int e = 0; e < 4; ++e) vt[buf][t][b][kb][e] = (short)vsm[wv][t][kb * 16 + 4 * g + e][b * 16 + r];
         __builtin_amdgcn_wave_barrier();
     };
+    // One softmax for the CH heads of a chunk.  With nq <= 2 only result columns (lanes l15 =) 0, 1 of a head's 16 x 16 score block
+    // are queries; the other 14 repeat them.  Every VALU instruction costs a wave 4 cycles whatever its useful lanes, and the softmax
+    // (exp, max / sum trees, the hi + lo split) is ~100 of a head's ~200 instructions: so the CH heads' two columns are moved side by
+    // side (head t -> lanes 2t, 2t+1 of each 16-lane row: one DPP row shift per register), scaled / masked / exponentiated / summed ONCE,
+    // and moved back as each head's P operand.  Per element the same operations in the same order as the one-head form (the xor-16 /
+    // xor-32 partners are the same lanes of the other key groups): bit-identical rows.
+    const int jmax_p = d.causal ? min(klen, (r & 1) + 1 + (d.nk - d.nq)) : klen;      // packed lanes: query = lane parity
     auto compute_chunk = [&](int buf, int h0) {
-#pragma unroll
-        for (int t = 0; t < CH; ++t) {
-            const int h = h0 + t;
-            if (h >= d.n_head) break;
-            f32x4 st[NKB];
-            float mx = -INFINITY;
+        f32x4 sp[NKB];                                                        // packed scores
+        auto gather = [&](auto T) {
+            constexpr int t = decltype(T)::value;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
-                st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(abf16x8, kf[buf][t][kb]), __builtin_bit_cast(abf16x8, qf[buf][t]),
-                                                                 f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const f32x4 stt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(abf16x8, kf[buf][t][kb]), __builtin_bit_cast(abf16x8, qf[buf][t]),
+                                                                          f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    st[kb][e] = (kb * 16 + 4 * g + e < jmax) ? st[kb][e] * d.scale : -INFINITY;
-                    mx = fmaxf(mx, st[kb][e]);
-                }
+                for (int e = 0; e < 4; ++e) sp[kb][e] = row_shr_f<2 * t>(sp[kb][e], stt[e]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float den = 0.f;
+        };
+        gather(std::integral_constant<int, 0>{});
+        gather(std::integral_constant<int, 1>{});
+        gather(std::integral_constant<int, 2>{});
+        gather(std::integral_constant<int, 3>{});
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sp[kb][e] = (kb * 16 + 4 * g + e < jmax_p) ? sp[kb][e] * d.scale : -INFINITY;
+                mx = fmaxf(mx, sp[kb][e]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float den = 0.f;
+        ashort4 phi_p[NKB], plo_p[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = (kb * 16 + 4 * g + e < jmax_p) ? expf(sp[kb][e] - mx) : 0.f;
+                den += p;
+                const unsigned hb = __float_as_uint(p) & 0xffff0000u;
+                phi_p[kb][e] = (short)(hb >> 16);
+                plo_p[kb][e] = (short)(__float_as_uint(p - __uint_as_float(hb)) >> 16);
+            }
+        den += __shfl_xor(den, 16);
+        den += __shfl_xor(den, 32);
+        const float inv_p = 1.0f / den;
+        auto finish = [&](auto T) {
+            constexpr int t = decltype(T)::value;
+            const int h = h0 + t;
+            if (h >= d.n_head) return;
             ashort4 phi[NKB], plo[NKB];
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float p = (kb * 16 + 4 * g + e < jmax) ? expf(st[kb][e] - mx) : 0.f;
-                    den += p;
-                    const unsigned hb = __float_as_uint(p) & 0xffff0000u;
-                    phi[kb][e] = (short)(hb >> 16);
-                    plo[kb][e] = (short)(__float_as_uint(p - __uint_as_float(hb)) >> 16);
-                }
-            den += __shfl_xor(den, 16);
-            den += __shfl_xor(den, 32);
+            for (int kb = 0; kb < NKB; ++kb) {
+                phi[kb] = row_shl_s4<2 * t>(phi_p[kb]);
+                plo[kb] = row_shl_s4<2 * t>(plo_p[kb]);
+            }
+            const float inv = row_shl_f<2 * t>(inv_p);
             f32x4 o[2];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
@@ -402,7 +443,6 @@ __global__ __launch_bounds__(256) void attention_mfma_fewq_kernel(const mage_att
                     o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt[buf][t][b][kb], plo[kb], o[b], 0, 0, 0);
                 }
             }
-            const float inv = 1.0f / den;
             f32x4 v0, v1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -414,7 +454,11 @@ __global__ __launch_bounds__(256) void attention_mfma_fewq_kernel(const mage_att
                 const int col = h * 32 + 16 * (g & 1) + 8 * (g >> 1);
                 store8(op + (q_base + (long)qi * d.q_axis_stride) * d.ldo + col, v0, v1);
             }
-        }
+        };
+        finish(std::integral_constant<int, 0>{});
+        finish(std::integral_constant<int, 1>{});
+        finish(std::integral_constant<int, 2>{});
+        finish(std::integral_constant<int, 3>{});
     };
     for (int h0 = 0; h0 < d.n_head; h0 += CH) {
         load_chunk(0, h0);
