@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256) void attention_mfma_split_fewq_kernel(const ma
     const int r = lane & 15, g = lane >> 4;
     const int qi = r;
     const long qrow = (q_base + (long)min(qi, d.nq - 1) * d.q_axis_stride) * d.ldq;
-    const int jmax = d.causal ? min(klen, qi + 1 + (d.nk - d.nq)) : klen;
+    const int jmax_p = d.causal ? min(klen, (r & 1) + 1 + (d.nk - d.nq)) : klen;      // packed lanes: query = lane parity
     constexpr float LO = 1.0f / MAGE_F16_LO_SCALE;
     long krow[NKB], vrow[NKB];
 #pragma unroll
@@ -653,12 +653,10 @@ __global__ __launch_bounds__(256) void attention_mfma_split_fewq_kernel(const ma
             }
         }
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int t = 0; t < CH; ++t) {
-            const int h = h0 + t;
-            if (h >= d.n_head) break;
-            f32x4 st[NKB];
-            float mx = -INFINITY;
+        // one softmax for the chunk's CH = 2 heads (their query columns side by side: attention_mfma_fewq_kernel)
+        f32x4 sp[NKB];
+        auto gather = [&](auto T) {
+            constexpr int t = decltype(T)::value;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[t][kb][0]), __builtin_bit_cast(f16x8, qf[t][1]),
@@ -667,28 +665,47 @@ __global__ __launch_bounds__(256) void attention_mfma_split_fewq_kernel(const ma
                 a *= LO;
                 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[t][kb][0]), __builtin_bit_cast(f16x8, qf[t][0]), a, 0, 0, 0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a[e] = (kb * 16 + 4 * g + e < jmax) ? a[e] * d.scale : -INFINITY;
-                    mx = fmaxf(mx, a[e]);
-                }
-                st[kb] = a;
+                for (int e = 0; e < 4; ++e) sp[kb][e] = row_shr_f<2 * t>(sp[kb][e], a[e]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float den = 0.f;
+        };
+        gather(std::integral_constant<int, 0>{});
+        gather(std::integral_constant<int, 1>{});
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sp[kb][e] = (kb * 16 + 4 * g + e < jmax_p) ? sp[kb][e] * d.scale : -INFINITY;
+                mx = fmaxf(mx, sp[kb][e]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float den = 0.f;
+        ahalf4 phi_p[NKB], plo_p[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = (kb * 16 + 4 * g + e < jmax_p) ? expf(sp[kb][e] - mx) : 0.f;
+                den += p;
+                const _Float16 ph = (_Float16)p;
+                phi_p[kb][e] = ph;
+                plo_p[kb][e] = (_Float16)((p - (float)ph) * MAGE_F16_LO_SCALE);
+            }
+        den += __shfl_xor(den, 16);
+        den += __shfl_xor(den, 32);
+        const float inv_p = 1.0f / den;
+        auto finish = [&](auto T) {
+            constexpr int t = decltype(T)::value;
+            const int h = h0 + t;
+            if (h >= d.n_head) return;
             ahalf4 phi[NKB], plo[NKB];
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float p = (kb * 16 + 4 * g + e < jmax) ? expf(st[kb][e] - mx) : 0.f;
-                    den += p;
-                    const _Float16 ph = (_Float16)p;
-                    phi[kb][e] = ph;
-                    plo[kb][e] = (_Float16)((p - (float)ph) * MAGE_F16_LO_SCALE);
-                }
-            den += __shfl_xor(den, 16);
-            den += __shfl_xor(den, 32);
+            for (int kb = 0; kb < NKB; ++kb) {
+                phi[kb] = __builtin_bit_cast(ahalf4, row_shl_s4<2 * t>(__builtin_bit_cast(ashort4, phi_p[kb])));
+                plo[kb] = __builtin_bit_cast(ahalf4, row_shl_s4<2 * t>(__builtin_bit_cast(ashort4, plo_p[kb])));
+            }
+            const float inv = row_shl_f<2 * t>(inv_p);
             f32x4 o[2];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
@@ -711,7 +728,6 @@ __global__ __launch_bounds__(256) void attention_mfma_split_fewq_kernel(const ma
                 for (int kb = 0; kb < NKB; ++kb) a = __builtin_amdgcn_mfma_f32_16x16x16f16(vth[kb], phi[kb], a, 0, 0, 0);
                 o[b] = a;
             }
-            const float inv = 1.0f / den;
             f32x4 v0, v1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -723,7 +739,9 @@ __global__ __launch_bounds__(256) void attention_mfma_split_fewq_kernel(const ma
                 const int col = h * 32 + 16 * (g & 1) + 8 * (g >> 1);
                 store8(op + (q_base + (long)qi * d.q_axis_stride) * ldo + col, v0, v1);
             }
-        }
+        };
+        finish(std::integral_constant<int, 0>{});
+        finish(std::integral_constant<int, 1>{});
         __builtin_amdgcn_wave_barrier();
     }
 }
