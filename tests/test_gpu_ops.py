@@ -520,6 +520,19 @@ def test_layernorm_folded_around_the_gemms(M):
         o.gemm(xb[:100], wq.to(DEV), y, M=100, N=4 * C_, K=C_, lda=C_, ldy=4 * C_, bias=c.to(DEV), ln_stats=stats, ln_colsum=s.to(DEV))
 
 
+def test_row_stats_of_bf16_rows():
+    """mage_row_stats: (mean, rstd) of bf16 rows = LayerNorm statistics of the rows the frame fill wrote (block 0's ln_1 in bf16 mode),
+    consumed by the LayerNorm-folded Linear exactly like mage_ln_stats' output."""
+    o = ops()
+    for rows, C_ in ((1000, 512), (256, 1024), (77, 64)):
+        x = (rnd(rows, C_, seed=rows) * 1.5 + 0.2).bfloat16().to(DEV)
+        st = torch.empty(rows, 2, device=DEV, dtype=torch.float32)
+        o.row_stats(x, 1e-5, st)
+        xd = x.double()
+        torch.testing.assert_close(st[:, 0].double(), xd.mean(-1), atol=2e-6, rtol=1e-6)
+        torch.testing.assert_close(st[:, 1].double(), (xd.var(-1, unbiased=False) + 1e-5).rsqrt(), atol=1e-5, rtol=1e-5)
+
+
 @pytest.mark.parametrize("M", [512, 2048, 65536])
 def test_x_plus_linear_on_a_bf16_residual_stream(M):
     """The producer forms of the bf16 mode's bf16 stream (mage_hip.h, ln_part without y2): the residual x is read as bf16 rows, the new
