@@ -64,9 +64,32 @@ class _Run:
 
 
 # ----------------------------------------------------------------------------------------------------------------- GEMM helpers
+# fp32 products of the text / motion-anchor encoders (activations, gradients and weights stay fp32 there in every mode).  In bf16 training
+# mode they run on f16x3 split operands (three f16 MFMA products per K slab, fp32-class result: include/mage_hip.h) instead of the
+# exact-fp32 MFMA chain, 3x its rate -- as in generation (mage_model._lin_fp32); precision 'fp32' keeps the exact chain, which is what the
+# 1e-4 gradient gates against the oracle are stated for.  _SPLIT32 is set by train_forward / train_backward.
+_SPLIT32 = {"sk": 0, "w": {}}
+
+
+def _gemm32(a, w, y, *, M, N, K, lda=None, **kw):
+    """ops.gemm for fp32 operands; plain products (bias / fp32 residual / QuickGELU only) go through split copies when _SPLIT32 says so."""
+    sk = _SPLIT32["sk"]
+    lda = K if lda is None else lda
+    ldy = kw.pop("ldy", N)
+    if (sk and a.dtype == F32 and w.dtype == F32 and K % 64 == 0 and N % 8 == 0 and lda == K and ldy == N and a.dim() == 2 and a.stride(1) == 1
+            and w.dim() == 2 and w.is_contiguous() and set(kw) <= {"bias", "residual", "ldr", "act"}
+            and kw.get("act", ops.ACT_NONE) in (ops.ACT_NONE, ops.ACT_QUICKGELU) and (kw.get("residual") is None or kw.get("act", 0) == ops.ACT_NONE)):
+        key = (w.data_ptr(), tuple(w.shape), w._version)
+        ws = _SPLIT32["w"].get(key)
+        if ws is None:
+            ws = _SPLIT32["w"][key] = (ops.split(w, sk), w)          # keeps w alive: the key is its address
+        return ops.gemm(ops.split(a[:M], sk), ws[0], y, M=M, N=N, K=K, lda=2 * K, ldy=N, split_kind=sk, **kw)
+    return ops.gemm(a, w, y, M=M, N=N, K=K, lda=lda, ldy=ldy, **kw)
+
+
 def _gemm_x(a, wT, y, *, M, N, K, lda=None, **kw):
     """y[M, N] = a[M, K] @ wT[N, K]^T (no bias): dX of a Linear, or any plain product."""
-    return ops.gemm(a, wT, y, M=M, N=N, K=K, lda=K if lda is None else lda, ldy=kw.pop("ldy", N), **kw)
+    return _gemm32(a, wT, y, M=M, N=N, K=K, lda=lda, **kw)
 
 
 def _split_plan(M: int, N: int, K: int):
@@ -123,8 +146,8 @@ def _res_linear(run: _Run, a, d, name, x_old, dt, *, M, N, K, seed):
     """x_new = x_old + dropout(a @ W^T + b): a fresh tensor (x_old is the saved LayerNorm input of the backward pass)."""
     w, b = d[name + _sfx(dt)], d.get(name + ".b")
     if run.p == 0:
-        return ops.gemm(a, w, torch.empty_like(x_old), M=M, N=N, K=K, lda=K, ldy=N, bias=b, residual=x_old, ldr=N)
-    br = ops.gemm(a, w, torch.empty(M, N, device=a.device, dtype=F32), M=M, N=N, K=K, lda=K, ldy=N, bias=b)
+        return _gemm32(a, w, torch.empty_like(x_old), M=M, N=N, K=K, lda=K, ldy=N, bias=b, residual=x_old, ldr=N)
+    br = _gemm32(a, w, torch.empty(M, N, device=a.device, dtype=F32), M=M, N=N, K=K, lda=K, ldy=N, bias=b)
     return ops.dropout_add(br, x_old, torch.empty_like(x_old), run.p, seed)
 
 
@@ -322,16 +345,16 @@ def _ma_forward(ma, run: _Run, q, kv, B: int, nq: int, nk: int):
         if ma.mage_plus:                                                     # the ln_q / ln_kv line of mage_model.py:93 (MAGE+)
             qin = ops.layernorm(x, d[p + ".ln_q.w"], d[p + ".ln_q.b"], torch.empty_like(x), 1e-5)
             kvin = ops.layernorm(kv, d[p + ".ln_kv.w"], d[p + ".ln_kv.b"], torch.empty_like(kv), 1e-5)
-        qp = ops.gemm(qin, w[:Cc], torch.empty(B * nq, Cc, device=dev, dtype=F32), M=B * nq, N=Cc, K=Cc, lda=Cc, ldy=Cc, bias=b[:Cc])
-        kvp = ops.gemm(kvin, w[Cc:], torch.empty(B * nk, 2 * Cc, device=dev, dtype=F32), M=B * nk, N=2 * Cc, K=Cc, lda=Cc, ldy=2 * Cc, bias=b[Cc:])
+        qp = _gemm32(qin, w[:Cc], torch.empty(B * nq, Cc, device=dev, dtype=F32), M=B * nq, N=Cc, K=Cc, lda=Cc, ldy=Cc, bias=b[:Cc])
+        kvp = _gemm32(kvin, w[Cc:], torch.empty(B * nk, 2 * Cc, device=dev, dtype=F32), M=B * nk, N=2 * Cc, K=Cc, lda=Cc, ldy=2 * Cc, bias=b[Cc:])
         geo = dict(n_seq=B, inner=1, nq=nq, nk=nk, n_head=H, q_outer_stride=nq, q_axis_stride=1, kv_outer_stride=nk, kv_axis_stride=1)
         ao = torch.empty(B * nq, Cc, device=dev, dtype=F32)
         ops.attention(qp, kvp, kvp[:, Cc:], ao, ldq=Cc, ldk=2 * Cc, ldv=2 * Cc, ldo=Cc, **geo)
         s_attn, s_mlp = run.next_seed(), run.next_seed()
         x1 = _res_linear(run, ao, d, p + ".out_proj", x, F32, M=B * nq, N=Cc, K=Cc, seed=s_attn)
         xn = ops.layernorm(x1, d[p + ".ln_2.w"], d[p + ".ln_2.b"], torch.empty_like(x1), 1e-5)
-        hpre = ops.gemm(xn, d[p + ".c_fc.f32"], torch.empty(B * nq, 4 * Cc, device=dev, dtype=F32), M=B * nq, N=4 * Cc, K=Cc, lda=Cc,
-                        ldy=4 * Cc, bias=d[p + ".c_fc.b"])
+        hpre = _gemm32(xn, d[p + ".c_fc.f32"], torch.empty(B * nq, 4 * Cc, device=dev, dtype=F32), M=B * nq, N=4 * Cc, K=Cc, lda=Cc,
+                       ldy=4 * Cc, bias=d[p + ".c_fc.b"])
         hdn = ops.act(hpre, torch.empty_like(hpre), ops.ACT_QUICKGELU)
         x2 = _res_linear(run, hdn, d, p + ".c_proj", x1, F32, M=B * nq, N=Cc, K=4 * Cc, seed=s_mlp)
         layers.append(dict(x0=x, qin=qin, kvin=kvin, qp=qp, kvp=kvp, ao=ao, x1=x1, xn=xn, hpre=hpre, geo=geo, s_attn=s_attn, s_mlp=s_mlp))
@@ -398,8 +421,8 @@ def _text_forward(te, run: _Run, text):
     layers = []
     for i in range(te.transformer_layers):
         p = f"l{i}"
-        qkv = ops.gemm(x, d[p + ".in_proj.f32"], torch.empty(B * S, 3 * Wd, device=dev, dtype=F32), M=B * S, N=3 * Wd, K=Wd, lda=Wd,
-                       ldy=3 * Wd, bias=d[p + ".in_proj.b"])
+        qkv = _gemm32(x, d[p + ".in_proj.f32"], torch.empty(B * S, 3 * Wd, device=dev, dtype=F32), M=B * S, N=3 * Wd, K=Wd, lda=Wd,
+                      ldy=3 * Wd, bias=d[p + ".in_proj.b"])
         ao = torch.empty(B * S, Wd, device=dev, dtype=F32)
         # nn.TransformerEncoderLayer(dropout=p) also drops attention PROBABILITIES in train() (mage_model.py:193-199)
         sa_seed = run.next_seed()
@@ -407,8 +430,8 @@ def _text_forward(te, run: _Run, text):
         s1_seed, sh_seed, s2_seed = run.next_seed(), run.next_seed(), run.next_seed()
         s1 = _res_linear(run, ao, d, p + ".out_proj", x, F32, M=B * S, N=Wd, K=Wd, seed=s1_seed)
         x1 = ops.layernorm(s1, d[p + ".norm1.w"], d[p + ".norm1.b"], torch.empty_like(s1), d[p + ".norm1.eps"])
-        hpre = ops.gemm(x1, d[p + ".fc1.f32"], torch.empty(B * S, 4 * Wd, device=dev, dtype=F32), M=B * S, N=4 * Wd, K=Wd, lda=Wd,
-                        ldy=4 * Wd, bias=d[p + ".fc1.b"])
+        hpre = _gemm32(x1, d[p + ".fc1.f32"], torch.empty(B * S, 4 * Wd, device=dev, dtype=F32), M=B * S, N=4 * Wd, K=Wd, lda=Wd,
+                       ldy=4 * Wd, bias=d[p + ".fc1.b"])
         hdn = ops.act(hpre, torch.empty_like(hpre), ops.ACT_GELU_ERF)
         if run.p > 0:
             hdn = ops.dropout(hdn, torch.empty_like(hdn), run.p, sh_seed)
@@ -417,7 +440,7 @@ def _text_forward(te, run: _Run, text):
         layers.append(dict(x_in=x, qkv=qkv, ao=ao, s1=s1, x1=x1, hpre=hpre, s2=s2, seeds=(s1_seed, sh_seed, s2_seed), sa_seed=sa_seed))
         x = x2
     xf = ops.layernorm(x, d["ln_text_final.w"], d["ln_text_final.b"], torch.empty_like(x), te.ln_text_final.eps)
-    out = ops.gemm(xf, d["proj.f32"], torch.empty(B * S, te.output_dim, device=dev, dtype=F32), M=B * S, N=te.output_dim, K=Wd, lda=Wd,
+    out = _gemm32(xf, d["proj.f32"], torch.empty(B * S, te.output_dim, device=dev, dtype=F32), M=B * S, N=te.output_dim, K=Wd, lda=Wd,
                    ldy=te.output_dim, bias=d["proj.b"])
     return out, dict(ids=ids, keepf=keepf, e=e, s_emb=s_emb, layers=layers, x_last=x, xf=xf, geo=geo, B=B, S=S)
 
@@ -490,6 +513,8 @@ def train_forward(model, batch):
     run32 = _Run(F32, model.dropout, model.training)
     run32.seed, run32.p = run.seed, run.p
     run32.site = 1 << 20            # its own stream of dropout sites: the decoder's and the encoders' layers never share a seed
+    run32.sk = ops.F16X3 if (dt != F32 and not os.environ.get("MAGE_TRAIN_ENC_FP32")) else 0
+    _SPLIT32["sk"], _SPLIT32["w"] = run32.sk, {}
     d = model._derived.get(model._build)
     dev = images.device
     tok = tok_in = tok0 = lat_all = lat_in = lat0 = None
@@ -564,6 +589,7 @@ def train_forward(model, batch):
 def train_backward(model, tape, grad_out: torch.Tensor) -> Dict[str, torch.Tensor]:
     """Gradients of every trainable parameter, keyed by state_dict name (fp32, the parameter's shape)."""
     run, run32 = tape["run"], tape["run32"]
+    _SPLIT32["sk"] = getattr(run32, "sk", 0)
     dt = run.dt
     R, L, Cc, B = model.image_resolution, model.frames_length, model.vision_width, tape["B"]
     hw = R * R
