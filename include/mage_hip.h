@@ -398,10 +398,12 @@ int mage_act_bwd(const void* x, const void* dy, void* dx, int32_t dtype, int64_t
  * dl_dtype (the A operand of the head's dX / dW GEMMs).  grad_out: device pointer to the upstream scalar gradient. */
 int mage_cross_entropy_bwd(const float* logits, const int64_t* target, int64_t rows, int32_t K, const float* grad_out, void* dlogits,
                            int32_t dl_dtype, void* stream);
-/* nn.Embedding backward: dtable[ids[i], :] += dout[orow(i), :] (fp32 atomics; orow as in mage_embedding; ids equal to padding_idx
- * (< 0: none) contribute nothing, as nn.Embedding(padding_idx=...) does). */
+/* nn.Embedding backward: dtable[ids[i], :] += dout[orow(i), :] (orow as in mage_embedding; ids equal to padding_idx (< 0: none)
+ * contribute nothing, as nn.Embedding(padding_idx=...) does).  fp32 atomics -- or, for tables of up to 512 rows with `scratch` of at
+ * least 64 * n_table * C floats (16-byte aligned), per-chunk partial tables summed in chunk order: no global atomics, deterministic. */
 int mage_embedding_bwd(const int64_t* ids, const void* dout, int32_t dout_dtype, float* dtable, int64_t n, int32_t C, int32_t n_table,
-                       int64_t padding_idx, int64_t group, int64_t group_stride, int64_t off, void* stream);
+                       int64_t padding_idx, int64_t group, int64_t group_stride, int64_t off, float* scratch, int64_t scratch_floats,
+                       void* stream);
 /* out[g, :] = sum over rows r with (r / div) % mod == g of w(r) x[r, :], w(r) = row_scale ? row_scale[r / row_scale_div] : 1.
  * Gradients of the broadcast row tables: T / H / W positional embeddings (mage_model.py:338,489-492), text positions, and (mod = 1,
  * row_scale = speed) the speed embedding (:666-668).  The rows of a group are cut into n_chunk chunks, out[chunk][g][c] holds the

@@ -104,7 +104,7 @@ SIGNATURES = {
     "mage_act": (C.c_int, [vp, vp, i32, i64, i32, vp]),
     "mage_act_bwd": (C.c_int, [vp, vp, vp, i32, i64, i32, vp]),
     "mage_cross_entropy_bwd": (C.c_int, [vp, vp, i64, i32, vp, vp, i32, vp]),
-    "mage_embedding_bwd": (C.c_int, [vp, vp, i32, vp, i64, i32, i32, i64, i64, i64, i64, vp]),
+    "mage_embedding_bwd": (C.c_int, [vp, vp, i32, vp, i64, i32, i32, i64, i64, i64, i64, vp, i64, vp]),
     "mage_group_rowsum": (C.c_int, [vp, i32, i64, i32, i64, i64, vp, i64, vp, i32, vp]),
     "mage_attention_bwd": (C.c_int, [C.POINTER(AttnDesc), vp, vp, vp, vp, i32, i32, i32, vp]),
     "mage_dropout": (C.c_int, [vp, i32, vp, i32, i64, f32, C.c_uint64, i32, vp]),

@@ -382,26 +382,57 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __res
 // a chunk of the rows, accumulates into its private LDS copy of the slice with LDS atomics, and flushes the non-zero entries with one
 // global atomic each: 262144 x 512 global atomics on 512 hot rows (2.1 ms per call) become 64 x 512 x 512.
 template <typename T>
-__global__ __launch_bounds__(256) void embedding_bwd_lds_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dout,
+__global__ __launch_bounds__(512) void embedding_bwd_lds_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dout,
                                                                 float* __restrict__ dtable, long n, int C, int n_table, long padding_idx,
-                                                                long group, long group_stride, long off, long rows_per_chunk) {
+                                                                long group, long group_stride, long off, long rows_per_chunk,
+                                                                float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* tab = (float*)smem_raw;                                        // [n_table][64]
-    const int c0 = blockIdx.y * 64, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int e = threadIdx.x; e < n_table * 64; e += 256) tab[e] = 0.f;
+    const int c0 = blockIdx.y * 64, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int e = threadIdx.x; e < n_table * 64; e += 512) tab[e] = 0.f;
     __syncthreads();
     const long i0 = (long)blockIdx.x * rows_per_chunk, i1 = min(n, i0 + rows_per_chunk);
-    for (long i = i0 + wave; i < i1; i += 4) {
-        const long id = ids[i];
-        if (id < 0 || id >= n_table || id == padding_idx) continue;
-        const long orow = (i / group) * group_stride + (i % group) + off;
-        atomicAdd(&tab[id * 64 + lane], to_f32<T>(dout[orow * C + c0 + lane]));
+    // U rows per wave in flight (one row at a time the kernel ran at one global round trip per row: 1 ms per 250 k rows against ~0.1 ms of bytes)
+    constexpr int U = 16;
+    for (long ib = i0 + wave; ib < i1; ib += 8 * U) {
+        long id[U];
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long i = ib + 8 * u;
+            const long ii = i < i1 ? i : i0;                                // the row's address does not wait for its id
+            id[u] = ids[ii];
+            const bool ok = i < i1 && id[u] >= 0 && id[u] < n_table && id[u] != padding_idx;
+            if (!ok) id[u] = -1;
+            // 32-bit quotient (n, group < 2^31: host check): the two 64-bit divisions per row were most of this kernel's time
+            const unsigned q = (unsigned)ii / (unsigned)group;
+            const long orow = (long)q * group_stride + (long)((unsigned)ii - q * (unsigned)group) + off;
+            v[u] = to_f32<T>(dout[orow * C + c0 + lane]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (id[u] >= 0) atomicAdd(&tab[id[u] * 64 + lane], v[u]);
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < n_table * 64; e += 256) {
+    if (part) {                                                           // this chunk's table slice, plain stores: summed in chunk order by
+        float* pp = part + (long)blockIdx.x * n_table * C;                // embedding_bwd_reduce_kernel (no global atomics, deterministic)
+        for (int e = threadIdx.x; e < n_table * 64; e += 512) pp[(long)(e >> 6) * C + c0 + (e & 63)] = tab[e];
+        return;
+    }
+    for (int e = threadIdx.x; e < n_table * 64; e += 512) {
         const float v = tab[e];
         if (v != 0.f) atomicAdd(dtable + (long)(e >> 6) * C + c0 + (e & 63), v);
     }
+}
+
+// dtable[e] += sum over chunks (ascending) of part[chunk][e]: the flush of embedding_bwd_lds_kernel without global atomics (the 64 chunks'
+// atomics on the same 1 MB table were 0.8 of the kernel's 1.0 ms)
+__global__ __launch_bounds__(256) void embedding_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dtable, long n_elem, int n_chunk) {
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= n_elem) return;
+    f32x4 a = *(const f32x4*)(dtable + e);
+    for (int c = 0; c < n_chunk; ++c) a += *(const f32x4*)(part + (long)c * n_elem + e);
+    *(f32x4*)(dtable + e) = a;
 }
 
 // ------------------------------------------------------------------------------------------------ grouped row sums
@@ -902,14 +933,16 @@ extern "C" int mage_cross_entropy_bwd(const float* logits, const int64_t* target
 }
 
 extern "C" int mage_embedding_bwd(const int64_t* ids, const void* dout, int32_t dout_dtype, float* dtable, int64_t n, int32_t C,
-                                  int32_t n_table, int64_t padding_idx, int64_t group, int64_t group_stride, int64_t off, void* stream) {
+                                  int32_t n_table, int64_t padding_idx, int64_t group, int64_t group_stride, int64_t off, float* scratch,
+                                  int64_t scratch_floats, void* stream) {
     MAGE_CHECK_ARG(ids && dout && dtable && n > 0 && C > 0 && n_table > 0 && group > 0, "mage_embedding_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (n_table <= 512 && C % 64 == 0 && n >= 8192 && (dout_dtype == MAGE_F32 || dout_dtype == MAGE_BF16)) {
+    if (n_table <= 512 && C % 64 == 0 && n >= 8192 && n < (1L << 31) && group < (1L << 31) && (dout_dtype == MAGE_F32 || dout_dtype == MAGE_BF16)) {
         const int n_chunk = (int)(n / 4096 < 64 ? (n + 4095) / 4096 : 64);
         const long rpc = (n + n_chunk - 1) / n_chunk;
-        const dim3 grid(n_chunk, C / 64), blk(256);
+        const dim3 grid(n_chunk, C / 64), blk(512);
         const size_t lds = (size_t)n_table * 64 * sizeof(float);
+        float* part = (scratch && scratch_floats >= (int64_t)n_chunk * n_table * C && (((uintptr_t)scratch | (uintptr_t)dtable) & 15) == 0) ? scratch : nullptr;
         static bool attr_set[MAGE_MAX_DEVICES][2] = {{false}};
         const int dev = mage_device_index();
         MAGE_CHECK_ARG(dev >= 0, "mage_embedding_bwd: no current device");
@@ -919,7 +952,7 @@ extern "C" int mage_embedding_bwd(const int64_t* ids, const void* dout, int32_t 
                 attr_set[dev][0] = true;
             }
             hipLaunchKernelGGL((embedding_bwd_lds_kernel<float>), grid, blk, lds, s, ids, (const float*)dout, dtable, (long)n, C, n_table,
-                               (long)padding_idx, (long)group, (long)group_stride, (long)off, rpc);
+                               (long)padding_idx, (long)group, (long)group_stride, (long)off, rpc, part);
         } else {
             if (!attr_set[dev][1]) {
                 (void)hipFuncSetAttribute((const void*)embedding_bwd_lds_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -927,7 +960,11 @@ extern "C" int mage_embedding_bwd(const int64_t* ids, const void* dout, int32_t 
                 attr_set[dev][1] = true;
             }
             hipLaunchKernelGGL((embedding_bwd_lds_kernel<unsigned short>), grid, blk, lds, s, ids, (const unsigned short*)dout, dtable, (long)n, C,
-                               n_table, (long)padding_idx, (long)group, (long)group_stride, (long)off, rpc);
+                               n_table, (long)padding_idx, (long)group, (long)group_stride, (long)off, rpc, part);
+        }
+        if (part) {
+            const long n_elem = (long)n_table * C;
+            hipLaunchKernelGGL(embedding_bwd_reduce_kernel, dim3((unsigned)((n_elem / 4 + 255) / 256)), dim3(256), 0, s, part, dtable, n_elem, n_chunk);
         }
         MAGE_CHECK_LAUNCH("mage_embedding_bwd");
         return MAGE_OK;

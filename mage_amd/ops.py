@@ -808,8 +808,11 @@ def embedding_bwd(ids, dout, dtable, *, padding_idx: int = -1, group: Optional[i
     n = ids.numel()
     group = n if group is None else group
     group_stride = group if group_stride is None else group_stride
+    scratch = None
+    if dtable.shape[0] <= 512 and dtable.shape[1] % 64 == 0 and n >= 8192:      # small hot table: partial tables instead of global atomics
+        scratch = torch.empty(64 * dtable.numel(), device=dtable.device, dtype=torch.float32)
     _lib.check(l.mage_embedding_bwd(ids.data_ptr(), dout.data_ptr(), code(dout), dtable.data_ptr(), n, dtable.shape[1], dtable.shape[0],
-                                    padding_idx, group, group_stride, off, s), l)
+                                    padding_idx, group, group_stride, off, _p(scratch), 0 if scratch is None else scratch.numel(), s), l)
     return dtable
 
 
