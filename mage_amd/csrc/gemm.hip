@@ -299,7 +299,9 @@ struct LnConsume {
     float mean[8], rstd[8];            // per 16-row tile of the wave: the stats of this lane's row (row l15 of tile mt)
     f32x4 s[4];                        // s_n of this lane's 16 columns (MFMA layout)
 };
-enum { LN_NONE = 0, LN_PRODUCE = 1, LN_CONSUME = 2 };
+// LN_DUAL (training, act = QuickGELU): TWO bf16 outputs from one accumulator tile -- y = the pre-activation rows (the backward pass needs
+// them), y2 = QuickGELU(y) (the next Linear's operand): the forward activation pass (read 2 B + write 2 B per element) is gone.
+enum { LN_NONE = 0, LN_PRODUCE = 1, LN_CONSUME = 2, LN_DUAL = 3 };
 
 // OSPL (1 = bf16 pieces, 2 = f16 pieces; OT = float): the fp32 result leaves as a SPLIT row (common.h): a wave's 64 columns are one
 // K slab of the consumer, [hi(64) | lo(64)] = the same 256 contiguous bytes per row as 64 fp32 values, so only the staging write differs.
@@ -345,7 +347,7 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
         step2 = (long)RPI * d.y_mul_x * d.ldy2;
     }
 
-    auto stage = [&](int mt, u32x4 (&o)[NST]) {     // math + transpose of 16-row tile mt: results land in o[] (row-contiguous)
+    auto stage = [&](int mt, u32x4 (&o)[NST], auto apply_act) {     // math + transpose of 16-row tile mt: results land in o[] (row-contiguous)
         [[maybe_unused]] float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -356,7 +358,8 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
                 s1 += (v[0] + v[1]) + (v[2] + v[3]);
                 s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
             }
-            if constexpr (ACT == MAGE_ACT_QUICKGELU) {
+            if constexpr (!decltype(apply_act)::value) {
+            } else if constexpr (ACT == MAGE_ACT_QUICKGELU) {
                 // x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)): the two transcendentals (quarter rate) are the cost;
                 // everything around them as 4-wide vector arithmetic, which hipcc packs into v_pk_* (one multiply fewer per
                 // element than the scalar form, which scales by -1.702 and by log2(e) separately)
@@ -432,12 +435,30 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
             }
         }
     };
+    if constexpr (LN == LN_DUAL) {                 // interior tiles, plain rows (host check): rows of y, then rows of y2 = act(y)
+        OT* yp2 = (OT*)d.y2 + (long)((m0 + rr) * d.y_mul_x + d.y_off) * d.ldy2 + col;
+        const long step2d = (long)RPI * d.y_mul_x * d.ldy2;
+        u32x4 oa[NST], ob[NST];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            stage(mt, oa, std::false_type{});
+            stage(mt, ob, std::true_type{});
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                __builtin_nontemporal_store(oa[i], (u32x4*)yp);
+                yp += step;
+                __builtin_nontemporal_store(ob[i], (u32x4*)yp2);
+                yp2 += step2d;
+            }
+        }
+        return;
+    }
     // skewed by one tile: the LDS round trip of tile mt+1 is in flight while tile mt's rows are stored
     u32x4 o[2][NST];
-    stage(0, o[0]);
+    stage(0, o[0], std::true_type{});
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        if (mt + 1 < MT) stage(mt + 1, o[(mt + 1) & 1]);
+        if (mt + 1 < MT) stage(mt + 1, o[(mt + 1) & 1], std::true_type{});
         store(mt, o[mt & 1]);
     }
 }
@@ -825,6 +846,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                 // fp32 stream + bf16 copy, or (y_dtype bf16) the bf16 stream alone
                 if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
                 else epilogue_lean<ACT, unsigned short, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
+            } else if constexpr (LN == LN_DUAL) {
+                epilogue_lean<ACT, unsigned short, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);           // bf16 y and y2 (host check)
             } else if constexpr (SPL != 0) {
                 if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
                 else epilogue_lean<ACT, float, MT, false, LN_NONE, SPL>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);   // split rows out
@@ -1177,6 +1200,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             // fp32 stream + bf16 copy, or (y_dtype bf16; always with RB: host check) the bf16 stream alone
             if (RB || d.y_dtype != MAGE_F32) epilogue_lean<ACT, unsigned short, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
             else epilogue_lean<ACT, float, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
+        } else if constexpr (LN == LN_DUAL) {
+            epilogue_lean<ACT, unsigned short, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);               // bf16 y and y2 (host check)
         } else if constexpr (SPL != 0) {
             if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
             else epilogue_lean<ACT, float, MT, TAPS, LN_NONE, SPL>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);   // split rows out
@@ -1561,7 +1586,7 @@ int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
         n_cu_dev[dev] = n;
     }
     const int n_cu = n_cu_dev[dev];
-    if constexpr (DT == MAGE_BF16 && !GATHER && EK != EK_GENERAL && (ACT == MAGE_ACT_NONE || ACT == MAGE_ACT_QUICKGELU)) {
+    if constexpr (DT == MAGE_BF16 && !GATHER && EK != EK_GENERAL && LN != LN_DUAL && (ACT == MAGE_ACT_NONE || ACT == MAGE_ACT_QUICKGELU)) {
         if (d->n_split == 1 && small_shape(d->M, d->N, d->K, n_cu)) return launch_small<ACT, EK, LN, RB>(d, s, n_cu);
     }
     // 256-row tiles only where there are enough of them to give every CU at least two (bf16; the fp32 8x4-accumulator
@@ -1603,6 +1628,14 @@ int launch_act(const mage_gemm_desc* d, hipStream_t s) {
     const bool extras = d->scale || d->rowadd || d->residual || d->post_relu;
     if constexpr (DT == MAGE_BF16 && !GATHER && (ACT == MAGE_ACT_NONE || ACT == MAGE_ACT_QUICKGELU)) {
         // LayerNorm folded around the GEMM (see epilogue_lean): whole interior tiles, rows not regrouped
+        if constexpr (ACT == MAGE_ACT_QUICKGELU) {
+            if (d->y2 && !d->ln_part && !d->ln_stats && !d->ln_colsum) {         // training: pre-activation rows + activated rows (LN_DUAL)
+                MAGE_CHECK_ARG(d->M % 256 == 0 && d->N % 256 == 0 && d->n_split == 1 && !extras && d->out_h == 1 && d->out_w >= d->M && d->y_mul_x == 1 &&
+                                   d->y_dtype == MAGE_BF16 && d->ldy2 % 8 == 0 && (((uintptr_t)d->y2) & 15) == 0,
+                               "mage_gemm: y2 with QuickGELU (pre-activation + activated rows) needs bf16 plain rows, M and N multiples of 256");
+                return launch_ek<DT, GATHER, ACT, EK_BIAS, LN_DUAL>(d, s);
+            }
+        }
         if (d->y2 || d->ln_stats || d->ln_part || d->ln_colsum) {
             MAGE_CHECK_ARG(d->M % 256 == 0 && d->N % 256 == 0 && d->n_split == 1,
                            "mage_gemm: the LayerNorm-folded forms need M and N multiples of 256");

@@ -181,9 +181,15 @@ def _dec_forward(gm, run: _Run, motion, feats, B: int, hh: int, ww: int):
         s_attn, s_mlp = run.next_seed(), run.next_seed()
         x1 = _res_linear(run, ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, seed=s_attn)
         xn2 = ops.layernorm(x1, d[p + ".ln_2.w"], d[p + ".ln_2.b"], torch.empty(M, Cc, device=dev, dtype=dt), 1e-5)
-        hpre = ops.gemm(xn2, d[p + ".c_fc" + _sfx(dt)], torch.empty(M, 4 * Cc, device=dev, dtype=dt), M=M, N=4 * Cc, K=Cc, lda=Cc,
-                        ldy=4 * Cc, bias=d[p + ".c_fc.b"])
-        hdn = ops.act(hpre, torch.empty_like(hpre), ops.ACT_QUICKGELU)
+        if dt != F32 and M % 256 == 0 and Cc % 64 == 0 and not os.environ.get("MAGE_TRAIN_NO_DUAL"):
+            # one launch writes the pre-activation rows (kept for the backward pass) and QuickGELU of them (the next Linear's operand)
+            hdn = torch.empty(M, 4 * Cc, device=dev, dtype=dt)
+            hpre = ops.gemm(xn2, d[p + ".c_fc" + _sfx(dt)], torch.empty(M, 4 * Cc, device=dev, dtype=dt), M=M, N=4 * Cc, K=Cc, lda=Cc,
+                            ldy=4 * Cc, bias=d[p + ".c_fc.b"], act=ops.ACT_QUICKGELU, y2=hdn, ldy2=4 * Cc)
+        else:
+            hpre = ops.gemm(xn2, d[p + ".c_fc" + _sfx(dt)], torch.empty(M, 4 * Cc, device=dev, dtype=dt), M=M, N=4 * Cc, K=Cc, lda=Cc,
+                            ldy=4 * Cc, bias=d[p + ".c_fc.b"])
+            hdn = ops.act(hpre, torch.empty_like(hpre), ops.ACT_QUICKGELU)
         x2 = _res_linear(run, hdn, d, p + ".c_proj", x1, dt, M=M, N=Cc, K=4 * Cc, seed=s_mlp)
         # hdn is kept for the c_proj weight gradient (recomputing it was one more pass over [M, 4C] per block; 288 GB of HBM)
         blocks.append(dict(x0=x, xn1=xn1, qkv=qkv, ao=ao, x1=x1, xn2=xn2, hpre=hpre, hdn=hdn, geo=geo, s_attn=s_attn, s_mlp=s_mlp))

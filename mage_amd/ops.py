@@ -239,6 +239,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     d.a_half = int(a_half)
     ln = 2 if (ln_stats is not None or ln_colsum is not None) else (1 if (y2 is not None or ln_part is not None) else 0)      # LN_CONSUME / LN_PRODUCE
     rb = residual is not None and residual.dtype == torch.bfloat16 and d.dtype == BF16      # bf16 residual stream (RB in csrc/gemm.hip)
+    if y2 is not None and ln_part is None and ln_stats is None and ln_colsum is None and act == ACT_QUICKGELU:
+        ln = 3                                                                                  # LN_DUAL: pre-activation + activated rows
     if PROFILE.enabled:
         # key = the kernel instantiation mage_gemm dispatches to (mirrors launch_act in csrc/gemm.hip), so that the
         # per-kernel averages line up with rocprofv3's per-symbol statistics

@@ -348,6 +348,26 @@ def test_loss_backward_matches_oracle_autograd(cfg_kw, B, L, seed, batch_kw):
     assert n_checked >= 90
 
 
+def test_c_fc_with_pre_activation_and_activated_rows():
+    """mage_gemm LN_DUAL (bf16, act = QuickGELU, y2): one launch writes the pre-activation rows AND QuickGELU of them; against the two-launch
+    form (GEMM, then mage_act on its bf16 rows) on both tiled kernels."""
+    from mage_amd import ops as o
+    g = torch.Generator().manual_seed(3)
+    for M in (2048, 65536):
+        N, K = 1024, 256
+        a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().to(DEV)
+        b = (torch.randn(N, generator=g) * 0.1).to(DEV)
+        pre_ref = o.gemm(a, w, torch.empty(M, N, device=DEV, dtype=torch.bfloat16), M=M, N=N, K=K, lda=K, ldy=N, bias=b)
+        pre = torch.empty_like(pre_ref)
+        act = torch.empty_like(pre_ref)
+        o.gemm(a, w, pre, M=M, N=N, K=K, lda=K, ldy=N, bias=b, act=o.ACT_QUICKGELU, y2=act, ldy2=N)
+        assert torch.equal(pre, pre_ref)
+        x = (a.double() @ w.double().t() + b.double()).cpu()
+        want = x * torch.sigmoid(1.702 * x)
+        torch.testing.assert_close(act.double().cpu(), want, atol=3e-2, rtol=2e-2)
+
+
 def test_bf16_training_gradients_track_fp32():
     cfg = synth.mnist_model_config(frames_length=4, width=64, layers=3, vq_dim=32, K=64)
     m = build_mage(cfg, 35, DEV)
