@@ -43,7 +43,9 @@ extern "C" {
  * resp. 2^-22 of a product; fp32's own accumulation error over K terms is of the same order as the f16 form's). */
 enum { MAGE_F32 = 0, MAGE_BF16 = 1, MAGE_BF16X3 = 2, MAGE_F16X3 = 3 };
 enum { MAGE_OK = 0, MAGE_EINVAL = -1, MAGE_EHIP = -2, MAGE_EUNSUPPORTED = -3 };
-enum { MAGE_ACT_NONE = 0, MAGE_ACT_RELU = 1, MAGE_ACT_QUICKGELU = 2, MAGE_ACT_GELU_ERF = 3, MAGE_ACT_TANH = 4 };
+enum { MAGE_ACT_NONE = 0, MAGE_ACT_RELU = 1, MAGE_ACT_QUICKGELU = 2, MAGE_ACT_GELU_ERF = 3, MAGE_ACT_TANH = 4,
+       MAGE_ACT_QUICKGELU_GRAD = 5 /* mage_gemm only: y = acc * QuickGELU'(y2), y2 = the saved pre-activation rows (bf16, READ): the
+                                      data gradient of Linear -> QuickGELU -> Linear without an activation-backward pass */ };
 
 int mage_abi_version(void);
 const char* mage_last_error(void);

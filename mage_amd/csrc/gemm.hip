@@ -301,7 +301,9 @@ struct LnConsume {
 };
 // LN_DUAL (training, act = QuickGELU): TWO bf16 outputs from one accumulator tile -- y = the pre-activation rows (the backward pass needs
 // them), y2 = QuickGELU(y) (the next Linear's operand): the forward activation pass (read 2 B + write 2 B per element) is gone.
-enum { LN_NONE = 0, LN_PRODUCE = 1, LN_CONSUME = 2, LN_DUAL = 3 };
+// LN_GELUBWD (training, the data-gradient GEMM of c_proj): y = acc * QuickGELU'(aux), aux = the saved pre-activation rows (desc.y2, read
+// here): the activation-backward pass (read 2 x 2 B + write 2 B per element) is gone; the product is taken on the fp32 accumulators.
+enum { LN_NONE = 0, LN_PRODUCE = 1, LN_CONSUME = 2, LN_DUAL = 3, LN_GELUBWD = 4 };
 
 // OSPL (1 = bf16 pieces, 2 = f16 pieces; OT = float): the fp32 result leaves as a SPLIT row (common.h): a wave's 64 columns are one
 // K slab of the consumer, [hi(64) | lo(64)] = the same 256 contiguous bytes per row as 64 fp32 values, so only the staging write differs.
@@ -347,8 +349,19 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
         step2 = (long)RPI * d.y_mul_x * d.ldy2;
     }
 
+    // LN_GELUBWD: the pre-activation rows in the MFMA layout (8 bytes per lane per 16-column block), requested one 16-row tile ahead
+    [[maybe_unused]] uint2 auxb[2][4];
+    [[maybe_unused]] auto aux_request = [&](int mt) {
+        const unsigned short* ap = (const unsigned short*)d.y2 + (long)((m0 + mt * 16 + l15) * d.y_mul_x + d.y_off) * d.ldy2 + n0 + grp * 4;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) auxb[mt & 1][nt] = *(const uint2*)(ap + nt * 16);
+    };
+    if constexpr (LN == LN_GELUBWD) aux_request(0);
     auto stage = [&](int mt, u32x4 (&o)[NST], auto apply_act) {     // math + transpose of 16-row tile mt: results land in o[] (row-contiguous)
         [[maybe_unused]] float s1 = 0.f, s2 = 0.f;
+        if constexpr (LN == LN_GELUBWD) {
+            if (mt + 1 < MT) aux_request(mt + 1);
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             f32x4 v;
@@ -357,6 +370,16 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
             if constexpr (LN == LN_PRODUCE) {
                 s1 += (v[0] + v[1]) + (v[2] + v[3]);
                 s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            }
+            if constexpr (LN == LN_GELUBWD) {              // v *= s (1 + 1.702 x (1 - s)), s = sigmoid(1.702 x)
+                const uint2 ax = auxb[mt & 1][nt];
+                const f32x4 x = f32x4{__uint_as_float(ax.x << 16), __uint_as_float(ax.x & 0xffff0000u), __uint_as_float(ax.y << 16),
+                                      __uint_as_float(ax.y & 0xffff0000u)};
+                const f32x4 t = x * -2.4554669596f;
+                f32x4 sg;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sg[e] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[e]));
+                v = v * (sg * (1.0f + (x * 1.702f) * (1.0f - sg)));
             }
             if constexpr (!decltype(apply_act)::value) {
             } else if constexpr (ACT == MAGE_ACT_QUICKGELU) {
@@ -846,8 +869,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                 // fp32 stream + bf16 copy, or (y_dtype bf16) the bf16 stream alone
                 if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
                 else epilogue_lean<ACT, unsigned short, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
-            } else if constexpr (LN == LN_DUAL) {
-                epilogue_lean<ACT, unsigned short, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);           // bf16 y and y2 (host check)
+            } else if constexpr (LN == LN_DUAL || LN == LN_GELUBWD) {
+                epilogue_lean<ACT, unsigned short, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);           // bf16 rows (host check)
             } else if constexpr (SPL != 0) {
                 if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
                 else epilogue_lean<ACT, float, MT, false, LN_NONE, SPL>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);   // split rows out
@@ -1200,8 +1223,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             // fp32 stream + bf16 copy, or (y_dtype bf16; always with RB: host check) the bf16 stream alone
             if (RB || d.y_dtype != MAGE_F32) epilogue_lean<ACT, unsigned short, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
             else epilogue_lean<ACT, float, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
-        } else if constexpr (LN == LN_DUAL) {
-            epilogue_lean<ACT, unsigned short, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);               // bf16 y and y2 (host check)
+        } else if constexpr (LN == LN_DUAL || LN == LN_GELUBWD) {
+            epilogue_lean<ACT, unsigned short, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);               // bf16 rows (host check)
         } else if constexpr (SPL != 0) {
             if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
             else epilogue_lean<ACT, float, MT, TAPS, LN_NONE, SPL>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);   // split rows out
@@ -1586,7 +1609,7 @@ int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
         n_cu_dev[dev] = n;
     }
     const int n_cu = n_cu_dev[dev];
-    if constexpr (DT == MAGE_BF16 && !GATHER && EK != EK_GENERAL && LN != LN_DUAL && (ACT == MAGE_ACT_NONE || ACT == MAGE_ACT_QUICKGELU)) {
+    if constexpr (DT == MAGE_BF16 && !GATHER && EK != EK_GENERAL && LN != LN_DUAL && LN != LN_GELUBWD && (ACT == MAGE_ACT_NONE || ACT == MAGE_ACT_QUICKGELU)) {
         if (d->n_split == 1 && small_shape(d->M, d->N, d->K, n_cu)) return launch_small<ACT, EK, LN, RB>(d, s, n_cu);
     }
     // 256-row tiles only where there are enough of them to give every CU at least two (bf16; the fp32 8x4-accumulator
@@ -1682,6 +1705,16 @@ int launch(const mage_gemm_desc* d, hipStream_t s) {
         case MAGE_ACT_RELU: return launch_act<DT, GATHER, MAGE_ACT_RELU>(d, s);
         case MAGE_ACT_QUICKGELU: return launch_act<DT, GATHER, MAGE_ACT_QUICKGELU>(d, s);
         case MAGE_ACT_GELU_ERF: return launch_act<DT, GATHER, MAGE_ACT_GELU_ERF>(d, s);
+        case MAGE_ACT_QUICKGELU_GRAD:
+            if constexpr (DT == MAGE_BF16 && !GATHER) {
+                MAGE_CHECK_ARG(d->y2 && d->y_dtype == MAGE_BF16 && d->M % 256 == 0 && d->N % 256 == 0 && d->n_split == 1 && !d->scale && !d->rowadd &&
+                                   !d->residual && !d->post_relu && !d->ln_part && !d->ln_stats && !d->ln_colsum && d->out_h == 1 && d->out_w >= d->M &&
+                                   d->y_mul_x == 1 && d->ldy2 % 4 == 0 && (((uintptr_t)d->y2) & 7) == 0,
+                               "mage_gemm: MAGE_ACT_QUICKGELU_GRAD: y = acc * QuickGELU'(y2) on bf16 plain rows, M and N multiples of 256");
+                return launch_ek<DT, GATHER, MAGE_ACT_NONE, EK_BIAS, LN_GELUBWD>(d, s);
+            }
+            mage_set_error("mage_gemm: MAGE_ACT_QUICKGELU_GRAD is a bf16 plain-GEMM epilogue");
+            return MAGE_EINVAL;
         default: mage_set_error("mage_gemm: activation %d is not available in the GEMM epilogue", d->act); return MAGE_EINVAL;
     }
 }

@@ -222,8 +222,13 @@ def _block_mlp_bwd(run, d, p, pre, grads, dx, x1, xn2, hpre, M, Cc, seed, ln_key
         hdn = ops.act(hpre, torch.empty_like(hpre), act)
     grads[names["proj_w"]], grads[names["proj_b"]] = _wgrad(dxb, hdn, M=M, N=Cc, K=4 * Cc, ld_dy=Cc, ld_x=4 * Cc)
     del hdn
-    dh = _gemm_x(dxb, _wt(d, f"{p}.{proj}", dt), torch.empty(M, 4 * Cc, device=dev, dtype=dt), M=M, N=4 * Cc, K=Cc)
-    ops.act_bwd(hpre, dh, dh, act)
+    if dt != F32 and act == ops.ACT_QUICKGELU and M % 256 == 0 and Cc % 64 == 0 and not os.environ.get("MAGE_TRAIN_NO_DUAL"):
+        # d/d(pre-activation) straight from the data-gradient GEMM: its epilogue multiplies the accumulators by QuickGELU'(hpre)
+        dh = ops.gemm(dxb, _wt(d, f"{p}.{proj}", dt), torch.empty(M, 4 * Cc, device=dev, dtype=dt), M=M, N=4 * Cc, K=Cc, lda=Cc, ldy=4 * Cc,
+                      act=ops.ACT_QUICKGELU_GRAD, y2=hpre, ldy2=4 * Cc)
+    else:
+        dh = _gemm_x(dxb, _wt(d, f"{p}.{proj}", dt), torch.empty(M, 4 * Cc, device=dev, dtype=dt), M=M, N=4 * Cc, K=Cc)
+        ops.act_bwd(hpre, dh, dh, act)
     grads[names["fc_w"]], grads[names["fc_b"]] = _wgrad(dh, xn2, M=M, N=4 * Cc, K=Cc, ld_dy=4 * Cc, ld_x=Cc)
     dxn = _gemm_x(dh, _wt(d, f"{p}.{fc}", dt), torch.empty(M, Cc, device=dev, dtype=F32), M=M, N=Cc, K=4 * Cc)
     del dh

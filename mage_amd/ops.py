@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, BF16X3, F16X3, F32, AttnDesc, GemmDesc
+from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_QUICKGELU_GRAD, ACT_RELU, ACT_TANH, BF16, BF16X3, F16X3, F32, AttnDesc, GemmDesc
 
 __all__ = ["gemm", "layernorm", "attention", "embedding", "table_conv", "split_rows", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
            "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mse", "check_device_errors", "graph_events_supported", "transpose", "row_sum", "sum_partials", "layernorm_bwd", "act", "act_bwd", "cross_entropy_bwd", "embedding_bwd", "group_rowsum", "attention_bwd", "dropout", "adam", "bn_train_stats", "bn_apply", "bn_backward", "convt_unfold_tanh_bwd", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
@@ -241,6 +241,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     rb = residual is not None and residual.dtype == torch.bfloat16 and d.dtype == BF16      # bf16 residual stream (RB in csrc/gemm.hip)
     if y2 is not None and ln_part is None and ln_stats is None and ln_colsum is None and act == ACT_QUICKGELU:
         ln = 3                                                                                  # LN_DUAL: pre-activation + activated rows
+    act_k = act
+    if act == ACT_QUICKGELU_GRAD:                                                               # y = acc * QuickGELU'(y2): LN_GELUBWD, act none
+        ln, act_k = 4, ACT_NONE
     if PROFILE.enabled:
         # key = the kernel instantiation mage_gemm dispatches to (mirrors launch_act in csrc/gemm.hip), so that the
         # per-kernel averages line up with rocprofv3's per-symbol statistics
@@ -264,11 +267,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
                 and not os.environ.get("MAGE_GEMM_NO_NARROW_FEW")):
             mt, nw = 2, 1                                   # few rows: x + Linear(.) of the incremental loop on the narrow tile
         rbs = ", true" if (rb and ek == 1) else ", false"       # rocprofv3 prints every template argument: the keys match its symbols
-        key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act}, {mt}, {ek}, {sp}, {ln}, {nw}, 0{rbs}>"
+        key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act_k}, {mt}, {ek}, {sp}, {ln}, {nw}, 0{rbs}>"
         a_rows = ((M + out_h * out_w - 1) // (out_h * out_w)) * d.a_img_stride + a_off + 1
         if (d.dtype == BF16 and not gather and mt == 8 and ek != 2 and K % 64 == 0 and a_rows * lda * 2 < 2 ** 32
                 and N * K * 2 < 2 ** 32 and not os.environ.get("MAGE_GEMM_NO_8PHASE")):
-            key = f"gemm8_kernel<{act}, {ek}, {sp}, false, {ln}, 0{rbs}>"    # the 8-phase ping-pong variant (launch_tile in csrc/gemm.hip)
+            key = f"gemm8_kernel<{act_k}, {ek}, {sp}, false, {ln}, 0{rbs}>"    # the 8-phase ping-pong variant (launch_tile in csrc/gemm.hip)
         # padded-taps convolutions and row-table Linears on the 8-phase kernel (try_taps8 in csrc/gemm.hip)
         ntaps = taps_h * taps_w
         table, plain = rowadd is not None and residual is None, rowadd is None and residual is None

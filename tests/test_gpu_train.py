@@ -368,6 +368,23 @@ def test_c_fc_with_pre_activation_and_activated_rows():
         torch.testing.assert_close(act.double().cpu(), want, atol=3e-2, rtol=2e-2)
 
 
+def test_data_gradient_gemm_times_quickgelu_derivative():
+    """mage_gemm MAGE_ACT_QUICKGELU_GRAD: y = (a @ w^T) * QuickGELU'(pre) in one launch, against the GEMM followed by mage_act_bwd."""
+    from mage_amd import ops as o
+    g = torch.Generator().manual_seed(4)
+    for M in (2048, 65536):
+        N, K = 1024, 256
+        a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().to(DEV)
+        pre = (torch.randn(M, N, generator=g) * 1.5).bfloat16().to(DEV)
+        y = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        o.gemm(a, w, y, M=M, N=N, K=K, lda=K, ldy=N, act=o.ACT_QUICKGELU_GRAD, y2=pre, ldy2=N)
+        x = pre.double().cpu()
+        sg = torch.sigmoid(1.702 * x)
+        want = (a.double().cpu() @ w.double().cpu().t()) * (sg * (1 + 1.702 * x * (1 - sg)))
+        torch.testing.assert_close(y.double().cpu(), want, atol=3e-2, rtol=2e-2)
+
+
 def test_bf16_training_gradients_track_fp32():
     cfg = synth.mnist_model_config(frames_length=4, width=64, layers=3, vq_dim=32, K=64)
     m = build_mage(cfg, 35, DEV)
