@@ -4,6 +4,8 @@ seeded inputs.  Bar: bit-exact token indices wherever the reference's own top-2 
 rounding noise, fp32 logits / frames within 1e-4 (north_star).  bf16 mode is checked against
 bf16-rounding tolerances and reported, and full-size (BASELINE cfg2) runs are checked through
 size-independent properties (shard invariance, determinism, causality of the AR loop)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -595,7 +597,9 @@ def test_graph_replay_is_the_default_for_a_few_clips_per_call():
     m.use_graph = None
     for _ in range(4):
         assert torch.equal(m.autoregressive_generate(one), want2)
-    assert m.last_call_mode == "graph" and not torch.equal(want, want2)
+    assert m.last_call_mode == "graph"
+    if not os.environ.get("MAGE_STREAM_FP32"):              # (the knob pins both forms to the fp32 stream)
+        assert not torch.equal(want, want2)
     big = dev_batch(synth.synth_batch_mnist(8, 6, seed=5))
     for _ in range(3):
         m.autoregressive_generate(big)
