@@ -16,6 +16,7 @@ products per K slab, fp32 accumulation -- include/mage_hip.h): fp32-class logits
 """
 from __future__ import annotations
 
+import gc
 import os
 from collections import OrderedDict
 from math import exp
@@ -1240,6 +1241,11 @@ class MAGE(nn.Module):
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             saved = ops.PROFILE.capture_begin()
+            # no cyclic garbage collection while the stream is capturing: a collection that frees device memory or another captured
+            # graph in the middle of a capture (older models of the same process going away) aborts the process
+            gc_was = gc.isenabled()
+            gc.collect()
+            gc.disable()
             try:
                 with torch.cuda.graph(g):
                     out = self._generate_eager(static)
@@ -1251,6 +1257,8 @@ class MAGE(nn.Module):
                 torch.cuda.synchronize()
                 return self._generate_eager(batch)
             finally:
+                if gc_was:
+                    gc.enable()
                 recs = ops.PROFILE.capture_end(saved)
             ent = self._graphs[key] = {"g": g, "in": static, "out": out, "tok": toks, "logits": logits, "recs": recs}
         else:
