@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MAGE_ABI_VERSION 3
+#define MAGE_ABI_VERSION 4
 
 /* MAGE_BF16X3 / MAGE_F16X3: SPLIT-PRECISION operands -- the fast parity mode.  A logical fp32 matrix [rows, C] (C % 64 == 0, base
  * 256-byte aligned) is stored as two 16-bit pieces per element, x ~ hi + lo, per row as 64-column slabs [hi(64) | lo(64)] (so a row
@@ -388,9 +388,11 @@ int mage_row_sum(const void* x, int32_t dtype, int64_t ld, int64_t n, int32_t ro
  * gamma/beta partials.  Fixed order: deterministic. */
 int mage_sum_partials(const float* part, int64_t stride, int32_t n_part, int64_t n, float* out, int32_t accumulate, void* stream);
 /* nn.LayerNorm backward (statistics recomputed from the saved input x [rows, C] fp32): dx (+)= dLN/dx, and per-workgroup
- * partial sums partials[n_part][2][C] of (dgamma, dbeta) for mage_sum_partials.  dy in dy_dtype. */
+ * partial sums partials[n_part][2][C] of (dgamma, dbeta) for mage_sum_partials.  dy in dy_dtype.
+ * dx_bf16 (optional, [rows, C] bf16): the updated dx rows once more, through mage_dropout's mask (p, seed; p = 0: a plain cast) -- the
+ * gradient stream as the operand of the next branch's GEMMs (x + dropout(Linear(.)), mage_model.py:48,52) without a separate pass. */
 int mage_layernorm_bwd(const float* x, const float* gamma, const void* dy, int32_t dy_dtype, float* dx, float* partials, int32_t n_part,
-                       int64_t rows, int32_t C, float eps, int32_t accumulate, void* stream);
+                       int64_t rows, int32_t C, float eps, int32_t accumulate, void* dx_bf16, float p, uint64_t seed, void* stream);
 /* y = act(x) and dx = dy * act'(x) elementwise (x = the saved pre-activation; QuickGELU mage_model.py:11-13, erf-GELU of the text
  * encoder, ReLU -- for which the post-activation output serves equally).  mage_act_bwd also takes MAGE_ACT_TANH, with x = the OUTPUT
  * y = tanh(.): dx = dy (1 - y^2).  n % 4 == 0. */
@@ -424,6 +426,11 @@ int mage_dropout(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, int64
 /* y = r + dropout(x) with the same mask as mage_dropout(x, ., p, seed): the residual add x + dropout(Linear(.)) of a block
  * (mage_model.py:48,52) in one pass (r, y fp32; may not alias x). */
 int mage_dropout_add(const void* x, int32_t x_dtype, const float* r, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* The same residual add followed by the LayerNorm that opens the next branch, one pass: y = r + dropout(x) (fp32 rows [rows, C]) and
+ * yn = LayerNorm(y; gamma, beta, eps) in yn_dtype (mage_model.py:48-52: x = x + attn(ln_1(x)); x = x + mlp(ln_2(x))).  x in x_dtype
+ * (fp32, or bf16 with yn bf16); two-pass statistics as mage_layernorm. */
+int mage_dropout_add_layernorm(const void* x, int32_t x_dtype, const float* r, float* y, const float* gamma, const float* beta, void* yn,
+                               int32_t yn_dtype, int64_t rows, int32_t C, float eps, float p, uint64_t seed, void* stream);
 /* BatchNorm2d in TRAINING mode (stage-1 VQ-VAE training, train_vqvae.py:13-35; vqvae_model.py:112-119,174,186) on channels-last
  * rows [rows, C] fp32: batch statistics are column reductions.  mage_bn_colreduce writes per-workgroup partial column sums
  * partials[n_part][NOUT][C] for mage_sum_partials (fixed order): mode 0: sum x; mode 1: sum (x - mean)^2 (two-pass variance);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MAGE_HIP_LIB", os.path.join(_HERE, "lib", "libmage_hi
 
 F32, BF16, BF16X3, F16X3 = 0, 1, 2, 3          # BF16X3 / F16X3: split-precision operands (include/mage_hip.h)
 ACT_NONE, ACT_RELU, ACT_QUICKGELU, ACT_GELU_ERF, ACT_TANH, ACT_QUICKGELU_GRAD = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -100,7 +100,7 @@ SIGNATURES = {
     "mage_colsum": (C.c_int, [vp, i64, i64, i32, vp, i32, vp]),
     "mage_row_sum": (C.c_int, [vp, i32, i64, i64, i32, vp, i32, vp]),
     "mage_sum_partials": (C.c_int, [vp, i64, i32, i64, vp, i32, vp]),
-    "mage_layernorm_bwd": (C.c_int, [vp, vp, vp, i32, vp, vp, i32, i64, i32, f32, i32, vp]),
+    "mage_layernorm_bwd": (C.c_int, [vp, vp, vp, i32, vp, vp, i32, i64, i32, f32, i32, vp, f32, C.c_uint64, vp]),
     "mage_act": (C.c_int, [vp, vp, i32, i64, i32, vp]),
     "mage_act_bwd": (C.c_int, [vp, vp, vp, i32, i64, i32, vp]),
     "mage_cross_entropy_bwd": (C.c_int, [vp, vp, i64, i32, vp, vp, i32, vp]),
@@ -109,6 +109,7 @@ SIGNATURES = {
     "mage_attention_bwd": (C.c_int, [C.POINTER(AttnDesc), vp, vp, vp, vp, i32, i32, i32, vp]),
     "mage_dropout": (C.c_int, [vp, i32, vp, i32, i64, f32, C.c_uint64, i32, vp]),
     "mage_dropout_add": (C.c_int, [vp, i32, vp, vp, i64, f32, C.c_uint64, vp]),
+    "mage_dropout_add_layernorm": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, i32, i64, i32, f32, f32, C.c_uint64, vp]),
     "mage_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp]),
 }
 

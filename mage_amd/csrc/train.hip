@@ -215,10 +215,14 @@ __global__ __launch_bounds__(256) void sum_partials4_kernel(const float* __restr
 //   xhat = (x - mean) rstd;  g = dy * gamma;  dx = rstd (g - mean_c(g) - xhat mean_c(g xhat))       [+= if accumulate]
 // and per-workgroup partial sums of dgamma = sum_rows dy xhat, dbeta = sum_rows dy (part [gridDim.x][2][C], reduced by
 // mage_sum_partials: fixed order, deterministic).
+// dxb (optional): the updated dx row once more as bf16 through the dropout mask of the branch it enters next, keep(i) / (1 - p) of
+// mage_dropout on the flat index i = row * C + c (thresh 0: a plain cast) -- the operand of that branch's data- and weight-gradient
+// GEMMs, which a separate mage_dropout pass (read 4 B + write 2 B per element) produced before.
 template <typename DT, int VPL>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const DT* __restrict__ dy, float* __restrict__ dx, float* __restrict__ part,
-                                                            long rows, int C, float eps, int accumulate) {
+                                                            long rows, int C, float eps, int accumulate, unsigned short* __restrict__ dxb,
+                                                            unsigned thresh, float inv_keep, unsigned long long seedmul) {
     __shared__ float red[4][2][VPL * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 dg[VPL], db[VPL], gm[VPL];
@@ -284,6 +288,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                 for (int e = 0; e < 4; ++e) o[e] = rstd * (d[j][e] - mg - v[j][e] * mgx);
                 if (accumulate) o += *(const f32x4*)(dxr + c);
                 *(f32x4*)(dxr + c) = o;
+                if (dxb) {
+                    const unsigned long long i = (unsigned long long)(row * C + c);
+                    if (thresh) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = hash32(seedmul + i + e) >= thresh ? o[e] * inv_keep : 0.f;
+                    }
+                    store4(dxb + i, o);
+                }
             }
         }
     }
@@ -757,9 +769,13 @@ int transpose_launch(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t y
 
 template <typename DT>
 int ln_bwd_launch(const float* x, const float* gamma, const void* dy, float* dx, float* part, int32_t n_part, int64_t rows, int32_t C,
-                  float eps, int32_t accumulate, hipStream_t s) {
+                  float eps, int32_t accumulate, void* dxb, float p, uint64_t seed, hipStream_t s) {
     const dim3 grid(n_part), blk(256);
-#define LNB(V) hipLaunchKernelGGL((layernorm_bwd_kernel<DT, V>), grid, blk, 0, s, x, gamma, (const DT*)dy, dx, part, (long)rows, C, eps, accumulate)
+    const unsigned thresh = (unsigned)((double)p * 4294967296.0);
+    const float inv_keep = 1.0f / (1.0f - p);
+    const unsigned long long seedmul = (unsigned long long)seed * 0x9e3779b97f4a7c15ULL;
+#define LNB(V) hipLaunchKernelGGL((layernorm_bwd_kernel<DT, V>), grid, blk, 0, s, x, gamma, (const DT*)dy, dx, part, (long)rows, C, eps, accumulate, \
+                                  (unsigned short*)dxb, thresh, inv_keep, seedmul)
     if (C <= 256) LNB(1);
     else if (C <= 512) LNB(2);
     else if (C <= 1024) LNB(4);
@@ -897,12 +913,15 @@ extern "C" int mage_sum_partials(const float* part, int64_t stride, int32_t n_pa
 }
 
 extern "C" int mage_layernorm_bwd(const float* x, const float* gamma, const void* dy, int32_t dy_dtype, float* dx, float* partials,
-                                  int32_t n_part, int64_t rows, int32_t C, float eps, int32_t accumulate, void* stream) {
+                                  int32_t n_part, int64_t rows, int32_t C, float eps, int32_t accumulate, void* dx_bf16, float p, uint64_t seed,
+                                  void* stream) {
     MAGE_CHECK_ARG(x && gamma && dy && dx && partials, "mage_layernorm_bwd: null pointer");
+    MAGE_CHECK_ARG(p >= 0.f && p < 1.f && (!dx_bf16 || ((uintptr_t)dx_bf16 & 7) == 0), "mage_layernorm_bwd: bad dx_bf16 / p");
     MAGE_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048 && n_part >= 1, "mage_layernorm_bwd: rows=%ld C=%d unsupported", (long)rows, C);
     hipStream_t s = (hipStream_t)stream;
-    DT_DISPATCH(dy_dtype, (ln_bwd_launch<float>(x, gamma, dy, dx, partials, n_part, rows, C, eps, accumulate, s)),
-                (ln_bwd_launch<unsigned short>(x, gamma, dy, dx, partials, n_part, rows, C, eps, accumulate, s)), "mage_layernorm_bwd");
+    DT_DISPATCH(dy_dtype, (ln_bwd_launch<float>(x, gamma, dy, dx, partials, n_part, rows, C, eps, accumulate, dx_bf16, p, seed, s)),
+                (ln_bwd_launch<unsigned short>(x, gamma, dy, dx, partials, n_part, rows, C, eps, accumulate, dx_bf16, p, seed, s)),
+                "mage_layernorm_bwd");
 }
 
 extern "C" int mage_act(const void* x, void* y, int32_t dtype, int64_t n, int32_t act, void* stream) {
@@ -1602,6 +1621,94 @@ __global__ __launch_bounds__(256) void dropout_add_kernel(const T* __restrict__ 
     *(f32x4*)(y + i) = o;
 }
 }  // namespace
+
+// y = r + dropout(x) and yn = LayerNorm(y) in one pass (one wave per row, the arithmetic of layernorm_kernel on the registers that hold
+// the new row): the residual add of a transformer block followed by the norm that opens the next branch (mage_model.py:48-52).
+namespace {
+template <typename T, typename OT, int VPL>
+__global__ __launch_bounds__(256) void dropout_add_ln_kernel(const T* __restrict__ x, const float* __restrict__ r, float* __restrict__ y,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             OT* __restrict__ yn, long rows, int C, float eps, unsigned thresh,
+                                                             float inv_keep, unsigned long long seedmul) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    f32x4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int c = j * 256 + lane * 4;
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < C) {
+            const long i = row * C + c;
+            const f32x4 b = load4(x + i);
+            v[j] = *(const f32x4*)(r + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (hash32(seedmul + (unsigned long long)(i + e)) >= thresh) v[j][e] += b[e] * inv_keep;
+            *(f32x4*)(y + i) = v[j];
+        }
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int c = j * 256 + lane * 4;
+        if (c < C) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dlt = v[j][e] - mean;
+                q += dlt * dlt;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    OT* yr = yn + row * C;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int c = j * 256 + lane * 4;
+        if (c < C) {
+            const f32x4 gm = *(const f32x4*)(gamma + c), bt = *(const f32x4*)(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gm[e] + bt[e];
+            store4(yr + c, o);
+        }
+    }
+}
+
+template <typename T, typename OT>
+int dropout_add_ln_launch(const void* x, const float* r, float* y, const float* gamma, const float* beta, void* yn, int64_t rows, int32_t C,
+                          float eps, float p, uint64_t seed, hipStream_t s) {
+    const unsigned thresh = (unsigned)((double)p * 4294967296.0);
+    const float inv_keep = 1.0f / (1.0f - p);
+    const unsigned long long seedmul = (unsigned long long)seed * 0x9e3779b97f4a7c15ULL;
+    const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
+#define DAL(V) hipLaunchKernelGGL((dropout_add_ln_kernel<T, OT, V>), grid, blk, 0, s, (const T*)x, r, y, gamma, beta, (OT*)yn, (long)rows, C, eps, \
+                                  thresh, inv_keep, seedmul)
+    if (C <= 256) DAL(1);
+    else if (C <= 512) DAL(2);
+    else if (C <= 1024) DAL(4);
+    else DAL(8);
+#undef DAL
+    MAGE_CHECK_LAUNCH("mage_dropout_add_layernorm");
+    return MAGE_OK;
+}
+}  // namespace
+
+extern "C" int mage_dropout_add_layernorm(const void* x, int32_t x_dtype, const float* r, float* y, const float* gamma, const float* beta,
+                                          void* yn, int32_t yn_dtype, int64_t rows, int32_t C, float eps, float p, uint64_t seed,
+                                          void* stream) {
+    MAGE_CHECK_ARG(x && r && y && gamma && beta && yn && rows > 0 && C > 0 && C % 4 == 0 && C <= 2048 && p >= 0.f && p < 1.f,
+                   "mage_dropout_add_layernorm: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == MAGE_F32 && yn_dtype == MAGE_F32) return dropout_add_ln_launch<float, float>(x, r, y, gamma, beta, yn, rows, C, eps, p, seed, s);
+    if (x_dtype == MAGE_F32 && yn_dtype == MAGE_BF16) return dropout_add_ln_launch<float, unsigned short>(x, r, y, gamma, beta, yn, rows, C, eps, p, seed, s);
+    if (x_dtype == MAGE_BF16 && yn_dtype == MAGE_BF16) return dropout_add_ln_launch<unsigned short, unsigned short>(x, r, y, gamma, beta, yn, rows, C, eps, p, seed, s);
+    mage_set_error("mage_dropout_add_layernorm: bad dtypes %d %d", x_dtype, yn_dtype);
+    return MAGE_EINVAL;
+}
 
 extern "C" int mage_dropout_add(const void* x, int32_t x_dtype, const float* r, float* y, int64_t n, float p, uint64_t seed, void* stream) {
     MAGE_CHECK_ARG(x && r && y && n > 0 && n % 4 == 0 && p >= 0.f && p < 1.f, "mage_dropout_add: bad arguments");

@@ -69,6 +69,7 @@ class _Run:
 # exact-fp32 MFMA chain, 3x its rate -- as in generation (mage_model._lin_fp32); precision 'fp32' keeps the exact chain, which is what the
 # 1e-4 gradient gates against the oracle are stated for.  _SPLIT32 is set by train_forward / train_backward.
 _SPLIT32 = {"sk": 0, "w": {}}
+_F32_BRANCH = bool(os.environ.get("MAGE_TRAIN_F32_BRANCH"))     # fp32 branch rows / LayerNorm-output gradients in bf16 mode too (the round-2 form)
 
 
 def _gemm32(a, w, y, *, M, N, K, lda=None, **kw):
@@ -142,13 +143,26 @@ def _to_dt(run: _Run, g32: torch.Tensor, seed: Optional[int] = None) -> torch.Te
     return ops.cast(g32, torch.empty(g32.shape, device=g32.device, dtype=run.dt))
 
 
-def _res_linear(run: _Run, a, d, name, x_old, dt, *, M, N, K, seed):
-    """x_new = x_old + dropout(a @ W^T + b): a fresh tensor (x_old is the saved LayerNorm input of the backward pass)."""
+def _res_linear(run: _Run, a, d, name, x_old, dt, *, M, N, K, seed, ln=None):
+    """x_new = x_old + dropout(a @ W^T + b): a fresh tensor (x_old is the saved LayerNorm input of the backward pass).
+    ln = (gamma, beta, out dtype): also returns LayerNorm(x_new) -- the norm that opens the next branch -- as (x_new, xn); with dropout on,
+    the mask-and-add pass and the norm are one launch (mage_dropout_add_layernorm)."""
     w, b = d[name + _sfx(dt)], d.get(name + ".b")
     if run.p == 0:
-        return _gemm32(a, w, torch.empty_like(x_old), M=M, N=N, K=K, lda=K, ldy=N, bias=b, residual=x_old, ldr=N)
-    br = _gemm32(a, w, torch.empty(M, N, device=a.device, dtype=F32), M=M, N=N, K=K, lda=K, ldy=N, bias=b)
-    return ops.dropout_add(br, x_old, torch.empty_like(x_old), run.p, seed)
+        x_new = _gemm32(a, w, torch.empty_like(x_old), M=M, N=N, K=K, lda=K, ldy=N, bias=b, residual=x_old, ldr=N)
+        if ln is None:
+            return x_new
+        return x_new, ops.layernorm(x_new, ln[0], ln[1], torch.empty(M, N, device=a.device, dtype=ln[2]), 1e-5)
+    # the branch rows leave the GEMM in the compute dtype (bf16 mode: half the bytes written here and read by the mask-and-add pass;
+    # the stream x itself stays fp32).  MAGE_TRAIN_F32_BRANCH=1 keeps fp32 branch rows.
+    br = _gemm32(a, w, torch.empty(M, N, device=a.device, dtype=F32 if _F32_BRANCH else a.dtype), M=M, N=N, K=K, lda=K, ldy=N, bias=b)
+    if ln is None:
+        return ops.dropout_add(br, x_old, torch.empty_like(x_old), run.p, seed)
+    if os.environ.get("MAGE_TRAIN_NO_EMIT"):
+        x_new = ops.dropout_add(br, x_old, torch.empty_like(x_old), run.p, seed)
+        return x_new, ops.layernorm(x_new, ln[0], ln[1], torch.empty(M, N, device=a.device, dtype=ln[2]), 1e-5)
+    return ops.dropout_add_layernorm(br, x_old, torch.empty_like(x_old), ln[0], ln[1], torch.empty(M, N, device=a.device, dtype=ln[2]), 1e-5,
+                                     run.p, seed)
 
 
 # ----------------------------------------------------------------------------------------------------------------- decoder stack
@@ -163,6 +177,7 @@ def _dec_forward(gm, run: _Run, motion, feats, B: int, hh: int, ww: int):
     ops.gemm(feats, d["in_linear" + _sfx(dt)], x, M=B * (L - 1) * hw, N=Cc, K=gm.in_channels, lda=gm.in_channels, ldy=Cc,
              bias=d["in_linear.b"], out_w=(L - 1) * hw, y_img_stride=L * hw, y_off=hw, rowadd=d["tpos"], rowadd_div=hw, rowadd_mod=L)
     blocks = []
+    xn1 = None
     for i in range(gm.layers):
         p = f"b{i}"
         axis = i % 3
@@ -173,14 +188,14 @@ def _dec_forward(gm, run: _Run, motion, feats, B: int, hh: int, ww: int):
         else:
             geo = dict(n_seq=B * L * hh, inner=1, nq=ww, nk=ww, q_outer_stride=ww, q_axis_stride=1, causal=False)
         geo.update(kv_outer_stride=geo["q_outer_stride"], kv_axis_stride=geo["q_axis_stride"], n_head=H)
-        xn1 = ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], torch.empty(M, Cc, device=dev, dtype=dt), 1e-5)
+        if xn1 is None:                              # later blocks: written with the previous block's residual add
+            xn1 = ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], torch.empty(M, Cc, device=dev, dtype=dt), 1e-5)
         qkv = ops.gemm(xn1, d[p + ".in_proj" + _sfx(dt)], torch.empty(M, 3 * Cc, device=dev, dtype=dt), M=M, N=3 * Cc, K=Cc, lda=Cc,
                        ldy=3 * Cc, bias=d[p + ".in_proj.b"])
         ao = torch.empty(M, Cc, device=dev, dtype=dt)
         ops.attention(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], ao, ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=Cc, **geo)
         s_attn, s_mlp = run.next_seed(), run.next_seed()
-        x1 = _res_linear(run, ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, seed=s_attn)
-        xn2 = ops.layernorm(x1, d[p + ".ln_2.w"], d[p + ".ln_2.b"], torch.empty(M, Cc, device=dev, dtype=dt), 1e-5)
+        x1, xn2 = _res_linear(run, ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, seed=s_attn, ln=(d[p + ".ln_2.w"], d[p + ".ln_2.b"], dt))
         if dt != F32 and M % 256 == 0 and Cc % 64 == 0 and not os.environ.get("MAGE_TRAIN_NO_DUAL"):
             # one launch writes the pre-activation rows (kept for the backward pass) and QuickGELU of them (the next Linear's operand)
             hdn = torch.empty(M, 4 * Cc, device=dev, dtype=dt)
@@ -190,10 +205,15 @@ def _dec_forward(gm, run: _Run, motion, feats, B: int, hh: int, ww: int):
             hpre = ops.gemm(xn2, d[p + ".c_fc" + _sfx(dt)], torch.empty(M, 4 * Cc, device=dev, dtype=dt), M=M, N=4 * Cc, K=Cc, lda=Cc,
                             ldy=4 * Cc, bias=d[p + ".c_fc.b"])
             hdn = ops.act(hpre, torch.empty_like(hpre), ops.ACT_QUICKGELU)
-        x2 = _res_linear(run, hdn, d, p + ".c_proj", x1, dt, M=M, N=Cc, K=4 * Cc, seed=s_mlp)
+        nxt = f"b{i + 1}" if i + 1 < gm.layers else None
+        if nxt is not None:
+            x2, xn_next = _res_linear(run, hdn, d, p + ".c_proj", x1, dt, M=M, N=Cc, K=4 * Cc, seed=s_mlp,
+                                      ln=(d[nxt + ".ln_1.w"], d[nxt + ".ln_1.b"], dt))
+        else:
+            x2, xn_next = _res_linear(run, hdn, d, p + ".c_proj", x1, dt, M=M, N=Cc, K=4 * Cc, seed=s_mlp), None
         # hdn is kept for the c_proj weight gradient (recomputing it was one more pass over [M, 4C] per block; 288 GB of HBM)
         blocks.append(dict(x0=x, xn1=xn1, qkv=qkv, ao=ao, x1=x1, xn2=xn2, hpre=hpre, hdn=hdn, geo=geo, s_attn=s_attn, s_mlp=s_mlp))
-        x = x2
+        x, xn1 = x2, xn_next
     if not gm.use_cids:
         # MAGE+ head (mage_model.py:350-354,387-388): GroupNorm(32) over all L-1 predicted frames of a clip -> SiLU -> Conv3d 1x1x1
         M1 = B * (L - 1) * hw
@@ -211,13 +231,25 @@ def _dec_forward(gm, run: _Run, motion, feats, B: int, hh: int, ww: int):
     return logits, dict(blocks=blocks, xa=xa, motion=motion, feats=feats, B=B, hh=hh, ww=ww)
 
 
+def _emit_next(run, dx, emit):
+    """layernorm_bwd's extra output for `emit` = (seed of the branch the updated dx enters next, or None for a plain cast): bf16 mode
+    only (the masked / cast copy _to_dt would make in a separate pass); None otherwise."""
+    if emit is None or run.dt != BF16 or os.environ.get("MAGE_TRAIN_NO_EMIT"):
+        return None, {}
+    seed = emit[0]
+    dxb = torch.empty(dx.shape, device=dx.device, dtype=BF16)
+    return dxb, dict(dx_bf16=dxb, p=run.p if seed is not None else 0.0, seed=seed or 0)
+
+
 def _block_mlp_bwd(run, d, p, pre, grads, dx, x1, xn2, hpre, M, Cc, seed, ln_key="ln_2", fc="c_fc", proj="c_proj", act=ops.ACT_QUICKGELU,
-                   names=None, hdn=None):
-    """Backward of x2 = x1 + drop(proj(act(fc(LN(x1))))) given dx = d/dx2 (fp32, updated in place to d/dx1)."""
+                   names=None, hdn=None, dxb=None, emit=None):
+    """Backward of x2 = x1 + drop(proj(act(fc(LN(x1))))) given dx = d/dx2 (fp32, updated in place to d/dx1).  dxb: dx as this branch's
+    GEMM operand if the caller already holds it; emit = (seed,): returns the updated dx as the NEXT branch's operand (see _emit_next)."""
     dt, dev = run.dt, dx.device
     names = names or {"fc_w": f"{pre}.mlp.c_fc.weight", "fc_b": f"{pre}.mlp.c_fc.bias", "proj_w": f"{pre}.mlp.c_proj.weight",
                       "proj_b": f"{pre}.mlp.c_proj.bias", "ln_w": f"{pre}.ln_2.weight", "ln_b": f"{pre}.ln_2.bias"}
-    dxb = _to_dt(run, dx, seed)
+    if dxb is None:
+        dxb = _to_dt(run, dx, seed)
     if hdn is None:
         hdn = ops.act(hpre, torch.empty_like(hpre), act)
     grads[names["proj_w"]], grads[names["proj_b"]] = _wgrad(dxb, hdn, M=M, N=Cc, K=4 * Cc, ld_dy=Cc, ld_x=4 * Cc)
@@ -230,9 +262,12 @@ def _block_mlp_bwd(run, d, p, pre, grads, dx, x1, xn2, hpre, M, Cc, seed, ln_key
         dh = _gemm_x(dxb, _wt(d, f"{p}.{proj}", dt), torch.empty(M, 4 * Cc, device=dev, dtype=dt), M=M, N=4 * Cc, K=Cc)
         ops.act_bwd(hpre, dh, dh, act)
     grads[names["fc_w"]], grads[names["fc_b"]] = _wgrad(dh, xn2, M=M, N=4 * Cc, K=Cc, ld_dy=4 * Cc, ld_x=Cc)
-    dxn = _gemm_x(dh, _wt(d, f"{p}.{fc}", dt), torch.empty(M, Cc, device=dev, dtype=F32), M=M, N=Cc, K=4 * Cc)
-    del dh
-    grads[names["ln_w"]], grads[names["ln_b"]] = ops.layernorm_bwd(x1, d[f"{p}.{ln_key}.w"], dxn, dx, eps=1e-5, accumulate=True)
+    # d/d(LayerNorm output) in the compute dtype: layernorm_bwd reads it once (its dx stream stays fp32)
+    dxn = _gemm_x(dh, _wt(d, f"{p}.{fc}", dt), torch.empty(M, Cc, device=dev, dtype=F32 if _F32_BRANCH else dt), M=M, N=Cc, K=4 * Cc)
+    del dh, dxb
+    nxt, kw = _emit_next(run, dx, emit)
+    grads[names["ln_w"]], grads[names["ln_b"]] = ops.layernorm_bwd(x1, d[f"{p}.{ln_key}.w"], dxn, dx, eps=1e-5, accumulate=True, **kw)
+    return nxt
 
 
 def _dec_backward(gm, run: _Run, tape, dlogits, grads: Dict[str, torch.Tensor], pre: str = "generate_model"):
@@ -255,10 +290,13 @@ def _dec_backward(gm, run: _Run, tape, dlogits, grads: Dict[str, torch.Tensor], 
                                       sample_stride_rows=L * hw, row_off=hw, groups=32, act=2)       # slot 0 rows stay zero
         grads[pre + ".out.0.weight"], grads[pre + ".out.0.bias"] = dg, db
         del dy
+    dxb = None                                                               # dx as the next branch's operand, from layernorm_bwd
     for i in reversed(range(gm.layers)):
         p, bp, t = f"b{i}", f"{pre}.blocks.{i}", tape["blocks"][i]
-        _block_mlp_bwd(run, d, p, bp, grads, dx, t["x1"], t["xn2"], t["hpre"], M, Cc, t["s_mlp"], hdn=t.pop("hdn"))
-        dxb = _to_dt(run, dx, t["s_attn"])
+        dxb = _block_mlp_bwd(run, d, p, bp, grads, dx, t["x1"], t["xn2"], t["hpre"], M, Cc, t["s_mlp"], hdn=t.pop("hdn"), dxb=dxb,
+                             emit=(t["s_attn"],))
+        if dxb is None:
+            dxb = _to_dt(run, dx, t["s_attn"])
         grads[bp + ".attn.out_proj.weight"], grads[bp + ".attn.out_proj.bias"] = _wgrad(dxb, t["ao"], M=M, N=Cc, K=Cc, ld_dy=Cc, ld_x=Cc)
         dao = _gemm_x(dxb, _wt(d, p + ".out_proj", dt), torch.empty(M, Cc, device=dev, dtype=dt), M=M, N=Cc, K=Cc)
         qkv = t["qkv"]
@@ -267,13 +305,16 @@ def _dec_backward(gm, run: _Run, tape, dlogits, grads: Dict[str, torch.Tensor], 
                           ldo=Cc, ld_dq=3 * Cc, ld_dk=3 * Cc, ld_dv=3 * Cc, **t["geo"])
         grads[bp + ".attn.in_proj_weight"], grads[bp + ".attn.in_proj_bias"] = _wgrad(dqkv, t["xn1"], M=M, N=3 * Cc, K=Cc, ld_dy=3 * Cc,
                                                                                      ld_x=Cc)
-        dxn = _gemm_x(dqkv, _wt(d, p + ".in_proj", dt), torch.empty(M, Cc, device=dev, dtype=F32), M=M, N=Cc, K=3 * Cc)
-        grads[bp + ".ln_1.weight"], grads[bp + ".ln_1.bias"] = ops.layernorm_bwd(t["x0"], d[p + ".ln_1.w"], dxn, dx, eps=1e-5, accumulate=True)
+        dxn = _gemm_x(dqkv, _wt(d, p + ".in_proj", dt), torch.empty(M, Cc, device=dev, dtype=F32 if _F32_BRANCH else dt), M=M, N=Cc, K=3 * Cc)
+        del dxb, dao, dqkv
+        dxb, kw = _emit_next(run, dx, (tape["blocks"][i - 1]["s_mlp"] if i > 0 else None,))
+        grads[bp + ".ln_1.weight"], grads[bp + ".ln_1.bias"] = ops.layernorm_bwd(t["x0"], d[p + ".ln_1.w"], dxn, dx, eps=1e-5, accumulate=True, **kw)
         tape["blocks"][i] = None                                             # release the block's activations
     # x_init = [context_linear(motion) | in_linear(feats)] + T_positional_embedding
     tp = ops.group_rowsum(dx, torch.empty(L, Cc, device=dev, dtype=F32), rows=M, C=Cc, div=hw, mod=L)
     grads[pre + ".T_positional_embedding"] = tp.view(L, 1, 1, Cc)
-    dxb = _to_dt(run, dx)
+    if dxb is None:
+        dxb = _to_dt(run, dx)
     head = dict(out_w=hw, img_stride=L * hw, a_off=0)                        # the x[:, 0] rows
     grads[pre + ".in_linear.weight"], grads[pre + ".in_linear.bias"] = _wgrad(dxb, tape["feats"], M=M1, N=Cc, K=gm.in_channels, ld_dy=Cc,
                                                                              ld_x=gm.in_channels, dy_geo=tail)
@@ -549,8 +590,13 @@ def train_forward(model, batch):
         lin = dict(N=Cc, K=E, lda=LD, ldy=Cc, bias=d["emb_lin.b"])
         emb = ops.gemm(lat_in, d["emb_lin.w"], torch.empty(B * (L - 1) * hw, Cc, device=dev, dtype=dt), M=B * (L - 1) * hw, **lin)
         emb0 = ops.gemm(lat0, d["emb_lin.w"], torch.empty(B * hw, Cc, device=dev, dtype=F32), M=B * hw, **lin)
-    feats = VectorQuantizedVAE._conv(emb, d["conv" + _sfx(dt)], torch.empty_like(emb), n_img=B * (L - 1), H=R, W=R, cin=Cc, cout=Cc, k=3,
-                                     rowadd=d["hwpos"], rowadd_div=1, rowadd_mod=hw)
+    if model.use_cids and dt == BF16 and Cc % 64 == 0 and not os.environ.get("MAGE_TRAIN_NO_TAPS"):
+        # the generation path's padded-taps convolution (embedding rows written into a zero-padded frame buffer: the 8-phase kernel
+        # instead of the per-lane gather, 1.45 -> 0.9 ms at cfg2); emb (plain rows) stays the backward pass's operand
+        feats = model._frame_features(tok_in, dt)
+    else:
+        feats = VectorQuantizedVAE._conv(emb, d["conv" + _sfx(dt)], torch.empty_like(emb), n_img=B * (L - 1), H=R, W=R, cin=Cc, cout=Cc, k=3,
+                                         rowadd=d["hwpos"], rowadd_div=1, rowadd_mod=hw)
     first = VectorQuantizedVAE._conv(emb0, d["conv.f32"], torch.empty_like(emb0), n_img=B, H=R, W=R, cin=Cc, cout=Cc, k=3,
                                      rowadd=d["hwpos"], rowadd_div=1, rowadd_mod=hw)
     txt, t_text = _text_forward(model.text_encoder, run32, batch["text"])

@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_QUICKGELU_GRAD, ACT_RELU, ACT_TANH, BF16, BF16X3, F16X3, F32, AttnDesc, GemmDesc
 
 __all__ = ["gemm", "layernorm", "attention", "embedding", "table_conv", "split_rows", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
-           "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mse", "check_device_errors", "graph_events_supported", "transpose", "row_sum", "sum_partials", "layernorm_bwd", "act", "act_bwd", "cross_entropy_bwd", "embedding_bwd", "group_rowsum", "attention_bwd", "dropout", "adam", "bn_train_stats", "bn_apply", "bn_backward", "convt_unfold_tanh_bwd", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
+           "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mse", "check_device_errors", "graph_events_supported", "transpose", "row_sum", "sum_partials", "layernorm_bwd", "dropout_add_layernorm", "act", "act_bwd", "cross_entropy_bwd", "embedding_bwd", "group_rowsum", "attention_bwd", "dropout", "adam", "bn_train_stats", "bn_apply", "bn_backward", "convt_unfold_tanh_bwd", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
            "split", "split_empty", "split_dtype", "PROFILE", "F32", "BF16", "BF16X3", "F16X3", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
 
 
@@ -769,16 +769,18 @@ def sum_partials(part, out, *, stride: int, n_part: int, n: int, accumulate: boo
     return out
 
 
-def layernorm_bwd(x, gamma, dy, dx, *, eps: float, accumulate: bool):
-    """dx (+)= dLN/dx; returns (dgamma, dbeta) fp32 [C]."""
+def layernorm_bwd(x, gamma, dy, dx, *, eps: float, accumulate: bool, dx_bf16=None, p: float = 0.0, seed: int = 0):
+    """dx (+)= dLN/dx; returns (dgamma, dbeta) fp32 [C].  dx_bf16: the updated dx once more as bf16 through dropout(., p, seed)'s mask."""
     l, s = _dev(x)
     assert x.dtype == torch.float32 and dx.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous()
+    assert dx_bf16 is None or (dx_bf16.dtype == torch.bfloat16 and dx_bf16.is_contiguous() and dx_bf16.numel() == dx.numel())
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     n_part = int(min(1024, (rows + 3) // 4))
     part = torch.empty(n_part, 2, Cc, device=x.device, dtype=torch.float32)
     _lib.check(l.mage_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), code(dy), dx.data_ptr(), part.data_ptr(), n_part, rows,
-                                    Cc, float(eps), int(accumulate), s), l)
+                                    Cc, float(eps), int(accumulate), dx_bf16.data_ptr() if dx_bf16 is not None else None, float(p),
+                                    int(seed) & (2 ** 64 - 1), s), l)
     gb = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
     sum_partials(part, gb, stride=2 * Cc, n_part=n_part, n=2 * Cc)
     return gb[0], gb[1]
@@ -865,6 +867,17 @@ def dropout_add(x, r, y, p: float, seed: int):
     assert x.is_contiguous() and r.is_contiguous() and y.is_contiguous() and r.dtype == y.dtype == torch.float32 and x.numel() == y.numel() == r.numel()
     _lib.check(l.mage_dropout_add(x.data_ptr(), code(x), r.data_ptr(), y.data_ptr(), x.numel(), float(p), int(seed) & (2 ** 64 - 1), s), l)
     return y
+
+
+def dropout_add_layernorm(x, r, y, gamma, beta, yn, eps: float, p: float, seed: int):
+    """y = r + dropout(x) (fp32) and yn = LayerNorm(y) in one pass; returns (y, yn)."""
+    l, s = _dev(x)
+    Cc = r.shape[-1]
+    assert x.is_contiguous() and r.is_contiguous() and y.is_contiguous() and yn.is_contiguous() and r.dtype == y.dtype == torch.float32
+    assert x.numel() == y.numel() == r.numel() == yn.numel() and gamma.numel() == beta.numel() == Cc
+    _lib.check(l.mage_dropout_add_layernorm(x.data_ptr(), code(x), r.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), yn.data_ptr(),
+                                            code(yn), r.numel() // Cc, Cc, float(eps), float(p), int(seed) & (2 ** 64 - 1), s), l)
+    return y, yn
 
 
 def adam(p, g, m, v, *, lr: float, beta1: float, beta2: float, eps: float, step: int, grad_scale: float = 1.0):

@@ -93,6 +93,39 @@ def test_layernorm_backward(Cc, rows, dy_dtype):
     assert rel(dx2, x.grad) < 2e-5
 
 
+@pytest.mark.parametrize("p,seed", [(0.0, 0), (0.1, 4321)])
+def test_layernorm_backward_also_writes_the_next_branch_operand(p, seed):
+    """mage_layernorm_bwd's dx_bf16: the updated dx rows through mage_dropout's mask as bf16 (p = 0: the plain cast), bit for bit what the
+    separate mage_dropout / cast pass over the updated dx writes; dx itself and (dgamma, dbeta) are unchanged by the extra output."""
+    o = ops()
+    rows, Cc = 1027, 512
+    x, g = (rnd(rows, Cc, seed=6) * 2 + 0.3).to(DEV), (1 + 0.1 * rnd(Cc, seed=7)).to(DEV)
+    dy = rnd(rows, Cc, seed=9).to(DEV).to(torch.bfloat16)
+    dx0 = rnd(rows, Cc, seed=10).to(DEV)
+    dx_a, dx_b = dx0.clone(), dx0.clone()
+    ga, ba = o.layernorm_bwd(x, g, dy, dx_a, eps=1e-5, accumulate=True)
+    dxb = torch.full((rows, Cc), 7.0, device=DEV, dtype=torch.bfloat16)
+    gb, bb = o.layernorm_bwd(x, g, dy, dx_b, eps=1e-5, accumulate=True, dx_bf16=dxb, p=p, seed=seed)
+    assert torch.equal(dx_a, dx_b) and torch.equal(ga, gb) and torch.equal(ba, bb)
+    want = o.dropout(dx_a, torch.empty(rows, Cc, device=DEV, dtype=torch.bfloat16), p, seed) if p > 0 else dx_a.to(torch.bfloat16)
+    assert torch.equal(dxb, want)
+
+
+@pytest.mark.parametrize("x_dtype,yn_dtype", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16)])
+def test_dropout_add_layernorm_is_the_two_passes_in_one(x_dtype, yn_dtype):
+    """mage_dropout_add_layernorm: y = r + dropout(x) equals mage_dropout_add's rows bit for bit; yn = mage_layernorm of those rows."""
+    o = ops()
+    rows, Cc, p, seed = 515, 512, 0.1, 987
+    x, r = rnd(rows, Cc, seed=1).to(DEV).to(x_dtype), rnd(rows, Cc, seed=2).to(DEV)
+    g, b = (1 + 0.1 * rnd(Cc, seed=3)).to(DEV), rnd(Cc, seed=4).to(DEV)
+    y0 = o.dropout_add(x, r, torch.empty_like(r), p, seed)
+    yn0 = o.layernorm(y0, g, b, torch.empty(rows, Cc, device=DEV, dtype=yn_dtype), 1e-5)
+    y, yn = o.dropout_add_layernorm(x, r, torch.empty_like(r), g, b, torch.empty(rows, Cc, device=DEV, dtype=yn_dtype), 1e-5, p, seed)
+    assert torch.equal(y, y0)
+    tol = 2e-6 if yn_dtype == torch.float32 else 1.6e-2             # one bf16 ulp where the two kernels' fp32 values straddle a rounding point
+    assert (yn.float() - yn0.float()).abs().max().item() <= tol * max(1.0, yn0.float().abs().max().item())
+
+
 @pytest.mark.parametrize("kind", ["quickgelu", "gelu", "relu"])
 def test_activation_forward_backward(kind):
     o = ops()
