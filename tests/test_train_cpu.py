@@ -38,8 +38,15 @@ def test_flat_adam_refuses_cpu_tensors_and_keeps_arena_views():
     assert opt.flat_g.abs().sum() > 0                       # autograd accumulated INTO the arena
     with pytest.raises(RuntimeError, match="mage_adam"):
         opt.step()                                          # no CPU path
-    opt.zero_grad()
+    opt.zero_grad(set_to_none=False)
     assert opt.flat_g.abs().sum() == 0 and all(p.grad.data_ptr() == opt.flat_g.data_ptr() + 4 * off for p, off in zip(opt.params, opt.offsets))
+    # the default (torch.optim's set_to_none=True): autograd hands the gradients over by reference, step() gathers them into the arena
+    opt.zero_grad()
+    assert all(p.grad is None for p in opt.params)
+    net(torch.randn(3, 7)).sum().backward()
+    want = torch.cat([p.grad.reshape(-1) for p in opt.params])
+    opt._collect_grads()
+    assert torch.equal(opt.flat_g[:n], want) and all(p.grad.data_ptr() == opt.flat_g.data_ptr() + 4 * off for p, off in zip(opt.params, opt.offsets))
 
 
 def test_flat_adam_matches_torch_adam_single_process(monkeypatch):
