@@ -424,8 +424,9 @@ int mage_attention_bwd(const mage_attn_desc* desc, const void* dout, void* dq, v
 int mage_dropout(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, int64_t n, float p, uint64_t seed, int32_t accumulate,
                  void* stream);
 /* y = r + dropout(x) with the same mask as mage_dropout(x, ., p, seed): the residual add x + dropout(Linear(.)) of a block
- * (mage_model.py:48,52) in one pass (r, y fp32; may not alias x). */
-int mage_dropout_add(const void* x, int32_t x_dtype, const float* r, float* y, int64_t n, float p, uint64_t seed, void* stream);
+ * (mage_model.py:48,52) in one pass (r, y fp32; may not alias x).  y_bf16 (optional): the same rows once more as bf16 (the last block's
+ * output is the head GEMM's operand). */
+int mage_dropout_add(const void* x, int32_t x_dtype, const float* r, float* y, void* y_bf16, int64_t n, float p, uint64_t seed, void* stream);
 /* The same residual add followed by the LayerNorm that opens the next branch, one pass: y = r + dropout(x) (fp32 rows [rows, C]) and
  * yn = LayerNorm(y; gamma, beta, eps) in yn_dtype (mage_model.py:48-52: x = x + attn(ln_1(x)); x = x + mlp(ln_2(x))).  x in x_dtype
  * (fp32, or bf16 with yn bf16); two-pass statistics as mage_layernorm. */

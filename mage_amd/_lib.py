@@ -108,7 +108,7 @@ SIGNATURES = {
     "mage_group_rowsum": (C.c_int, [vp, i32, i64, i32, i64, i64, vp, i64, vp, i32, vp]),
     "mage_attention_bwd": (C.c_int, [C.POINTER(AttnDesc), vp, vp, vp, vp, i32, i32, i32, vp]),
     "mage_dropout": (C.c_int, [vp, i32, vp, i32, i64, f32, C.c_uint64, i32, vp]),
-    "mage_dropout_add": (C.c_int, [vp, i32, vp, vp, i64, f32, C.c_uint64, vp]),
+    "mage_dropout_add": (C.c_int, [vp, i32, vp, vp, vp, i64, f32, C.c_uint64, vp]),
     "mage_dropout_add_layernorm": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, i32, i64, i32, f32, f32, C.c_uint64, vp]),
     "mage_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp]),
 }

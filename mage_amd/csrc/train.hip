@@ -1610,7 +1610,8 @@ extern "C" int mage_upsample2_bwd(const float* dy, float* dx, int32_t N, int32_t
 namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_add_kernel(const T* __restrict__ x, const float* __restrict__ r, float* __restrict__ y, long n,
-                                                          unsigned thresh, float inv_keep, unsigned long long seed) {
+                                                          unsigned thresh, float inv_keep, unsigned long long seed,
+                                                          unsigned short* __restrict__ yb) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
     const f32x4 v = load4(x + i);
@@ -1619,6 +1620,7 @@ __global__ __launch_bounds__(256) void dropout_add_kernel(const T* __restrict__ 
     for (int e = 0; e < 4; ++e)
         if (hash32(seed * 0x9e3779b97f4a7c15ULL + (unsigned long long)(i + e)) >= thresh) o[e] += v[e] * inv_keep;
     *(f32x4*)(y + i) = o;
+    if (yb) store4(yb + i, o);
 }
 }  // namespace
 
@@ -1710,14 +1712,15 @@ extern "C" int mage_dropout_add_layernorm(const void* x, int32_t x_dtype, const 
     return MAGE_EINVAL;
 }
 
-extern "C" int mage_dropout_add(const void* x, int32_t x_dtype, const float* r, float* y, int64_t n, float p, uint64_t seed, void* stream) {
-    MAGE_CHECK_ARG(x && r && y && n > 0 && n % 4 == 0 && p >= 0.f && p < 1.f, "mage_dropout_add: bad arguments");
+extern "C" int mage_dropout_add(const void* x, int32_t x_dtype, const float* r, float* y, void* y_bf16, int64_t n, float p, uint64_t seed,
+                                void* stream) {
+    MAGE_CHECK_ARG(x && r && y && n > 0 && n % 4 == 0 && p >= 0.f && p < 1.f && ((uintptr_t)y_bf16 & 7) == 0, "mage_dropout_add: bad arguments");
     const unsigned thresh = (unsigned)((double)p * 4294967296.0);
     const float inv_keep = 1.0f / (1.0f - p);
     const dim3 grid((unsigned)((n / 4 + 255) / 256)), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    if (x_dtype == MAGE_F32) hipLaunchKernelGGL((dropout_add_kernel<float>), grid, blk, 0, s, (const float*)x, r, y, (long)n, thresh, inv_keep, (unsigned long long)seed);
-    else if (x_dtype == MAGE_BF16) hipLaunchKernelGGL((dropout_add_kernel<unsigned short>), grid, blk, 0, s, (const unsigned short*)x, r, y, (long)n, thresh, inv_keep, (unsigned long long)seed);
+    if (x_dtype == MAGE_F32) hipLaunchKernelGGL((dropout_add_kernel<float>), grid, blk, 0, s, (const float*)x, r, y, (long)n, thresh, inv_keep, (unsigned long long)seed, (unsigned short*)y_bf16);
+    else if (x_dtype == MAGE_BF16) hipLaunchKernelGGL((dropout_add_kernel<unsigned short>), grid, blk, 0, s, (const unsigned short*)x, r, y, (long)n, thresh, inv_keep, (unsigned long long)seed, (unsigned short*)y_bf16);
     else { mage_set_error("mage_dropout_add: bad dtype %d", x_dtype); return MAGE_EINVAL; }
     MAGE_CHECK_LAUNCH("mage_dropout_add");
     return MAGE_OK;

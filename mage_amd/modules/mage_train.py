@@ -143,7 +143,7 @@ def _to_dt(run: _Run, g32: torch.Tensor, seed: Optional[int] = None) -> torch.Te
     return ops.cast(g32, torch.empty(g32.shape, device=g32.device, dtype=run.dt))
 
 
-def _res_linear(run: _Run, a, d, name, x_old, dt, *, M, N, K, seed, ln=None):
+def _res_linear(run: _Run, a, d, name, x_old, dt, *, M, N, K, seed, ln=None, cast_to=None):
     """x_new = x_old + dropout(a @ W^T + b): a fresh tensor (x_old is the saved LayerNorm input of the backward pass).
     ln = (gamma, beta, out dtype): also returns LayerNorm(x_new) -- the norm that opens the next branch -- as (x_new, xn); with dropout on,
     the mask-and-add pass and the norm are one launch (mage_dropout_add_layernorm)."""
@@ -151,12 +151,15 @@ def _res_linear(run: _Run, a, d, name, x_old, dt, *, M, N, K, seed, ln=None):
     if run.p == 0:
         x_new = _gemm32(a, w, torch.empty_like(x_old), M=M, N=N, K=K, lda=K, ldy=N, bias=b, residual=x_old, ldr=N)
         if ln is None:
-            return x_new
+            return x_new if cast_to is None else (x_new, ops.cast(x_new, torch.empty(M, N, device=a.device, dtype=cast_to)))
         return x_new, ops.layernorm(x_new, ln[0], ln[1], torch.empty(M, N, device=a.device, dtype=ln[2]), 1e-5)
     # the branch rows leave the GEMM in the compute dtype (bf16 mode: half the bytes written here and read by the mask-and-add pass;
     # the stream x itself stays fp32).  MAGE_TRAIN_F32_BRANCH=1 keeps fp32 branch rows.
     br = _gemm32(a, w, torch.empty(M, N, device=a.device, dtype=F32 if _F32_BRANCH else a.dtype), M=M, N=N, K=K, lda=K, ldy=N, bias=b)
     if ln is None:
+        if cast_to is not None:                      # the last block: its rows also as the head GEMM's bf16 operand
+            xb = torch.empty(M, N, device=a.device, dtype=cast_to)
+            return ops.dropout_add(br, x_old, torch.empty_like(x_old), run.p, seed, y_bf16=xb), xb
         return ops.dropout_add(br, x_old, torch.empty_like(x_old), run.p, seed)
     if os.environ.get("MAGE_TRAIN_NO_EMIT"):
         x_new = ops.dropout_add(br, x_old, torch.empty_like(x_old), run.p, seed)
@@ -177,7 +180,7 @@ def _dec_forward(gm, run: _Run, motion, feats, B: int, hh: int, ww: int):
     ops.gemm(feats, d["in_linear" + _sfx(dt)], x, M=B * (L - 1) * hw, N=Cc, K=gm.in_channels, lda=gm.in_channels, ldy=Cc,
              bias=d["in_linear.b"], out_w=(L - 1) * hw, y_img_stride=L * hw, y_off=hw, rowadd=d["tpos"], rowadd_div=hw, rowadd_mod=L)
     blocks = []
-    xn1 = None
+    xn1 = xa = None
     for i in range(gm.layers):
         p = f"b{i}"
         axis = i % 3
@@ -210,7 +213,12 @@ def _dec_forward(gm, run: _Run, motion, feats, B: int, hh: int, ww: int):
             x2, xn_next = _res_linear(run, hdn, d, p + ".c_proj", x1, dt, M=M, N=Cc, K=4 * Cc, seed=s_mlp,
                                       ln=(d[nxt + ".ln_1.w"], d[nxt + ".ln_1.b"], dt))
         else:
-            x2, xn_next = _res_linear(run, hdn, d, p + ".c_proj", x1, dt, M=M, N=Cc, K=4 * Cc, seed=s_mlp), None
+            xa = None
+            if gm.use_cids and dt == BF16:
+                x2, xa = _res_linear(run, hdn, d, p + ".c_proj", x1, dt, M=M, N=Cc, K=4 * Cc, seed=s_mlp, cast_to=dt)
+            else:
+                x2 = _res_linear(run, hdn, d, p + ".c_proj", x1, dt, M=M, N=Cc, K=4 * Cc, seed=s_mlp)
+            xn_next = None
         # hdn is kept for the c_proj weight gradient (recomputing it was one more pass over [M, 4C] per block; 288 GB of HBM)
         blocks.append(dict(x0=x, xn1=xn1, qkv=qkv, ao=ao, x1=x1, xn2=xn2, hpre=hpre, hdn=hdn, geo=geo, s_attn=s_attn, s_mlp=s_mlp))
         x, xn1 = x2, xn_next
@@ -223,7 +231,10 @@ def _dec_forward(gm, run: _Run, motion, feats, B: int, hh: int, ww: int):
         n8 = d["out.f32"].shape[0]
         pred = ops.gemm(y, d["out" + _sfx(dt)], torch.empty(M1, n8, device=dev, dtype=F32), M=M1, N=n8, K=Cc, lda=Cc, ldy=n8, bias=d["out.b"])
         return pred, dict(blocks=blocks, x_last=x, y=y, gn_stats=st, motion=motion, feats=feats, B=B, hh=hh, ww=ww)
-    xa = x if dt == F32 else ops.cast(x, torch.empty(M, Cc, device=dev, dtype=dt))
+    if dt == F32:
+        xa = x
+    elif xa is None:
+        xa = ops.cast(x, torch.empty(M, Cc, device=dev, dtype=dt))
     Kc = gm.out_channels
     logits = torch.empty(B * (L - 1) * hw, Kc, device=dev, dtype=F32)
     ops.gemm(xa, d["out" + _sfx(dt)], logits, M=B * (L - 1) * hw, N=Kc, K=Cc, lda=Cc, ldy=Kc, bias=d["out.b"], out_w=(L - 1) * hw,
@@ -351,12 +362,25 @@ def _frame_backward(model, run_dt, tok_rows, emb, dfeats, grads, acc, lat_rows=N
     n_img = rows // hw
     hp = ops.group_rowsum(dfeats, torch.empty(hw, Cc, device=dev, dtype=F32), rows=rows, C=Cc, div=1, mod=hw)
     acc["hwpos"] = hp if acc.get("hwpos") is None else acc["hwpos"] + hp
-    dfe = dfeats if run_dt == F32 else ops.cast(dfeats, torch.empty(rows, Cc, device=dev, dtype=run_dt))
+    P = R + 2
+    taps = run_dt == BF16 and Cc % 256 == 0 and rows % 256 == 0 and not os.environ.get("MAGE_TRAIN_NO_TAPS")
+    if taps:
+        # dfeats as bf16 rows in the interior of a zero-padded (R+2) x (R+2) frame buffer (border written once): its transposed
+        # convolution below is then the padded-taps form of mage_gemm (8-phase kernel, 1.4 -> 0.9 ms at cfg2), as in _frame_features
+        key = ("dfeats", n_img, str(dev))
+        pad = model._pad_frames.get(key)
+        if pad is None:
+            pad = model._pad_frames[key] = torch.zeros((n_img * P * P + 1) * Cc, device=dev, dtype=run_dt).view(-1, Cc)
+        pad[:n_img * P * P].view(n_img, P, P, Cc)[:, 1:R + 1, 1:R + 1].copy_(dfeats.view(n_img, R, R, Cc))       # cast + placement
+        dfe, dfe_geo = pad, dict(out_h=R, out_w=R, in_h=P, in_w=P, img_stride=P * P, dy=1, dx=1)
+    else:
+        dfe = dfeats if run_dt == F32 else ops.cast(dfeats, torch.empty(rows, Cc, device=dev, dtype=run_dt))
+        dfe_geo = {}
     # dW[co, tap, ci] = sum_p dfeats[p, co] * emb[shift_tap(p), ci]: nine shifted transposes stacked, one split-K GEMM
     S, Mc = _split_plan(rows, Cc, 9 * Cc)
     Mp = S * Mc
     dyT = torch.empty(Cc, Mp, device=dev, dtype=run_dt)
-    ops.transpose(dfe, dyT, M=rows, Mp=Mp, C=Cc, ldx=Cc, ldy=Mp)
+    ops.transpose(dfe, dyT, M=rows, Mp=Mp, C=Cc, ldx=Cc, ldy=Mp, **dfe_geo)
     xT = torch.empty(9 * Cc, Mp, device=dev, dtype=run_dt)
     for ky in range(3):
         for kx in range(3):
@@ -370,8 +394,12 @@ def _frame_backward(model, run_dt, tok_rows, emb, dfeats, grads, acc, lat_rows=N
     acc["conv"] = dW if acc.get("conv") is None else acc["conv"] + dW
     del dyT, xT, part
     # d emb = the transposed convolution of dfeats
-    demb = VectorQuantizedVAE._conv(dfe, _conv_flip(model, d, run_dt), torch.empty(rows, Cc, device=dev, dtype=F32), n_img=n_img, H=R, W=R,
-                                    cin=Cc, cout=Cc, k=3)
+    if taps:
+        demb = ops.gemm(dfe, _conv_flip(model, d, run_dt), torch.empty(rows, Cc, device=dev, dtype=F32), M=rows, N=Cc, K=9 * Cc, lda=Cc, ldy=Cc,
+                        out_h=R, out_w=R, in_h=P, in_w=P, a_img_stride=P * P, taps_h=3, taps_w=3, cin=Cc, stride=1, dy0=0, dx0=0)
+    else:
+        demb = VectorQuantizedVAE._conv(dfe, _conv_flip(model, d, run_dt), torch.empty(rows, Cc, device=dev, dtype=F32), n_img=n_img, H=R, W=R,
+                                        cin=Cc, cout=Cc, k=3)
     if lat_rows is not None:
         LD = lat_rows.shape[1]
         dW, db = _wgrad(demb, lat_rows, M=rows, N=Cc, K=LD, ld_dy=Cc, ld_x=LD)

@@ -861,11 +861,13 @@ def dropout(x, y, p: float, seed: int, accumulate: bool = False):
     return y
 
 
-def dropout_add(x, r, y, p: float, seed: int):
-    """y = r + dropout(x) (the mask of dropout(x, ., p, seed)); r, y fp32."""
+def dropout_add(x, r, y, p: float, seed: int, y_bf16=None):
+    """y = r + dropout(x) (the mask of dropout(x, ., p, seed)); r, y fp32; y_bf16: the same rows once more as bf16."""
     l, s = _dev(x)
     assert x.is_contiguous() and r.is_contiguous() and y.is_contiguous() and r.dtype == y.dtype == torch.float32 and x.numel() == y.numel() == r.numel()
-    _lib.check(l.mage_dropout_add(x.data_ptr(), code(x), r.data_ptr(), y.data_ptr(), x.numel(), float(p), int(seed) & (2 ** 64 - 1), s), l)
+    assert y_bf16 is None or (y_bf16.dtype == torch.bfloat16 and y_bf16.is_contiguous() and y_bf16.numel() == y.numel())
+    _lib.check(l.mage_dropout_add(x.data_ptr(), code(x), r.data_ptr(), y.data_ptr(), y_bf16.data_ptr() if y_bf16 is not None else None,
+                                  x.numel(), float(p), int(seed) & (2 ** 64 - 1), s), l)
     return y
 
 
