@@ -499,6 +499,32 @@ def test_dropout_training_mode_is_consistent_between_forward_and_backward():
     assert abs(fd - an) < 0.05 * max(abs(an), 1e-3) + 2e-4
 
 
+def test_bf16_training_folds_equal_the_separate_passes(monkeypatch):
+    """bf16 train(): the folded passes (residual add + dropout + next LayerNorm in one launch, layernorm_bwd writing the next branch's
+    masked operand, padded-taps frame convolutions) against the separate launches they replace (MAGE_TRAIN_NO_EMIT / MAGE_TRAIN_NO_TAPS),
+    same dropout seed: same masks, same loss and gradients up to bf16 rounding of one intermediate."""
+    cfg = synth.mnist_model_config(frames_length=4, width=256, layers=3, vq_dim=32, K=64)
+    m = build_mage(cfg, 41, DEV).train()
+    m.first_stage_model.eval()
+    m.set_precision("bf16")
+    batch = {k: v.to(DEV) for k, v in synth.synth_batch_mnist(2, 4, seed=41).items()}
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(7)
+        loss, _ = m(batch)
+        loss.backward()
+        return loss.item(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    l1, g1 = run()
+    monkeypatch.setenv("MAGE_TRAIN_NO_EMIT", "1")
+    monkeypatch.setenv("MAGE_TRAIN_NO_TAPS", "1")
+    l0, g0 = run()
+    assert abs(l1 - l0) < 2e-3 * max(1.0, abs(l0))
+    cos = {n: F.cosine_similarity(g1[n].flatten().double(), g0[n].flatten().double(), dim=0).item() for n in g0 if g0[n].abs().max() > 0}
+    print(f"folded vs separate passes: loss {l1:.6f} / {l0:.6f}, min gradient cosine {min(cos.values()):.6f}")
+    assert set(g1) == set(g0) and min(cos.values()) > 0.999
+
+
 @pytest.mark.parametrize("T,N,K,ld_dy,ld_x", [(4096, 256, 256, 256, 256), (5000, 512, 256, 512, 256), (16384, 512, 2048, 1536, 2048), (70000, 1536, 512, 1536, 512)])
 def test_gemm_tn_weight_gradient_against_fp64(T, N, K, ld_dy, ld_x):
     """mage_gemm_tn: dW = dY^T X from row-major bf16 operands through the transposing LDS load (no transposed copies), token slices +
