@@ -80,6 +80,7 @@ struct GemmArgs {
     int ntiles_n, ntiles;
     int tiles_per_split;                   // tiles_m * ntiles_n: tile index = split * tiles_per_split + tm * ntiles_n + tn
     int stagger_groups, stagger_sleeps;    // start group (li % groups) of an XCD's workgroups after group * sleeps s_sleep(16)
+    int res_rows;                          // gemm8, bf16 residual stream: the residual tile may be fetched as whole rows (see the kernel)
 };
 
 template <int DT> struct TT;
@@ -1049,10 +1050,44 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
         const int tm = trem / g.ntiles_n, tn = trem - tm * g.ntiles_n;
         const long ysplit = SPLIT ? (long)ts * d.y_split_stride : 0;
         const int m0 = tm * BM + wr * 128, n0 = tn * BN + wc * 64;
+        [[maybe_unused]] bool res_rows = false;
+        if constexpr (EK == EK_RES_INIT && RB && !TAPS && SPL == 0) {
+            // bf16 residual stream, interior tile, plain rows: the wave's 128 x 64 residual block as 16 loads of 8 rows x 128 B (whole
+            // lines) instead of 32 loads in the accumulator layout (16 rows x 32 B each: the request count, not the byte count, is
+            // what a CU's address path pays for -- the same rule as the epilogue's stores), then through the wave's private staging
+            // window into the accumulator layout: the epilogue's row transposition backwards (same swizzle, DS operations of a wave
+            // execute in order: no barrier).  Pure data movement: the accumulators start from the same bits.
+            res_rows = g.res_rows && m0 + 128 <= d.M && n0 + 64 <= d.N;                                      // wave-uniform
+            if (res_rows) {
+                const int rr = lane >> 3, cc = lane & 7;
+                const unsigned short* rp = (const unsigned short*)d.residual + ((long)(m0 + rr) + d.y_off) * d.ldr + n0 + cc * 8;
+                const long step8 = 8L * d.ldr;
+                u32x4 land[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) land[j] = *(const u32x4*)(rp + j * step8);
+                char* stg_r = smem + 2 * KBUF + wave * 4096;
+#pragma unroll
+                for (int a = 0; a < MT; ++a) {
+                    char* blk = stg_r + (a & 1) * 2048;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int r = rr + 8 * i;
+                        *(u32x4*)(blk + r * 128 + ((cc ^ ((r >> 1) & 7)) << 4)) = land[2 * a + i];
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const uint2 t = *(const uint2*)(blk + l15 * 128 + (((b * 2 + (grp >> 1)) ^ ((l15 >> 1) & 7)) << 4) + (grp & 1) * 8);
+                        acc[a][b] = f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                                          __uint_as_float(t.y & 0xffff0000u)};
+                    }
+                }
+            }
+        }
         if constexpr (EK == EK_RES_INIT) {
             // y = r + (A W^T + b): the accumulators start from r.  r is the fp32 residual stream, or (rowadd set, residual null) a
             // broadcast row table: r[m] = rowadd[(yrow / div) % mod] -- the H/W positional table of the frame convolution
             // (the table form exists in the TAPS instantiation only: the Linear layers' kernel keeps its exact code)
+            if (!res_rows) {
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int m = min(m0 + a * 16 + l15, d.M - 1);
@@ -1072,6 +1107,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
                     if constexpr (RB) res_bf16_request(acc[a][b], rpb + (n < d.N ? n : 0));
                     else acc[a][b] = *(const f32x4*)(rp + (n < d.N ? n : 0));
                 }
+            }
             }
         } else {
 #pragma unroll
@@ -1144,7 +1180,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             read_a(0);
             issue(P_A1);
-            if (EK == EK_RES_INIT && kt == 0) {
+            if (EK == EK_RES_INIT && kt == 0 && !res_rows) {
                 // the residual tile (requested before this slab's two DMA instructions) is in the accumulators: loads return in
                 // order, so "at most 2 outstanding" proves it whatever the previous epilogue's stores are doing
                 __builtin_amdgcn_s_waitcnt(0x0F72);
@@ -1438,6 +1474,12 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     }
     a.stagger_groups = 0;
     a.stagger_sleeps = 0;
+    {
+        static int res_rows_env = -1;
+        if (res_rows_env < 0) res_rows_env = getenv("MAGE_GEMM_RES_MFMA_LAYOUT") ? 0 : 1;
+        a.res_rows = res_rows_env && RB && d->residual && d->y_mul_x == 1 && d->out_h == 1 && d->out_w >= d->M && d->ldr % 8 == 0 &&
+                     ((uintptr_t)d->residual & 15) == 0;
+    }
     const int tiles_per_wg = a.ntiles / grid;
     // Only the residual kind by default: its tile ends in a 512 KB read + write burst per CU that the stagger spreads (out_proj
     // 0.307 -> 0.276 ms, c_proj 0.567 -> 0.542 ms).  The bias kinds (QKV, c_fc) have no drain stall to hide (round-2 tile probe); an
@@ -1496,6 +1538,7 @@ int launch_taps8(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     a.ntiles = a.tiles_per_split;
     a.stagger_groups = 0;
     a.stagger_sleeps = 0;
+    a.res_rows = 0;
     const int grid = a.ntiles >= n_cu ? n_cu : ((a.ntiles + 7) & ~7);
     hipLaunchKernelGGL((gemm8_kernel<ACT, EK, false, true, LN_NONE, SPL>), dim3(grid), dim3(512), 160 * 1024, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
