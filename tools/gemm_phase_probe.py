@@ -8,9 +8,11 @@ N, K, act, res = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1536,5
 M = 262144
 dev = "cuda:0"
 a = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16(); b = torch.randn(N, device=dev)
-y = torch.randn(M, N, device=dev) if res else torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+# res: 0 = plain, 1 = x + Linear(.) on the fp32 stream, 2 = on the bf16 stream with the LayerNorm partial sums (the bf16 mode's producer)
+y = torch.randn(M, N, device=dev) if res == 1 else torch.randn(M, N, device=dev).bfloat16()
 kw = dict(M=M, N=N, K=K, lda=K, ldy=N, bias=b, act=act)
 if res: kw.update(residual=y, ldr=N)
+if res == 2: kw.update(ln_part=torch.empty(M, N // 64, 2, device=dev))
 for _ in range(3): ops.gemm(a, w, y, **kw)
 torch.cuda.synchronize()
 l = _lib.load()
