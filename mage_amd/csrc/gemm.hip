@@ -69,7 +69,9 @@ template <int MT, int NW = 4, int NST = 2> struct Tile {
     static constexpr int A_BYTES = BM * 128;                   // A part of a stage: BM rows x 128 bytes
     static constexpr int STAGE_BYTES = A_BYTES + BNT * 128;    // 64 KiB (MT=8) | 48 KiB (MT=4) | 40 KiB (narrow MT=2)
     static constexpr int RING_BYTES = NST * STAGE_BYTES;       // one workgroup (8 waves, 2 per SIMD) per CU
-    static constexpr int LDS_BYTES = RING_BYTES + (NST == 2 ? 8 * 4096 : 0);    // + 4 KiB per wave of epilogue staging (epilogue_lean)
+    // + 4 KiB per wave of epilogue staging (epilogue_lean); 3-stage ring: the staging lives in a consumed stage, 2 KiB per wave remain for
+    // the residual rows' way into the accumulator layout (x + Linear(.) on the bf16 stream: 160 KiB in all)
+    static constexpr int LDS_BYTES = RING_BYTES + (NST == 2 ? 8 * 4096 : 8 * 2048);
     static constexpr int AU = BM / 64;                         // A units (8 rows x 128 B) per wave per slab
     static constexpr int WU = NW;                              // W units per wave per slab
 };
@@ -669,10 +671,40 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
         const int tm = trem / g.ntiles_n, tn = trem - tm * g.ntiles_n;
         const long ysplit = SPLIT ? (long)ts * d.y_split_stride : 0;
         const int m0 = tm * BM + wm * MT * 16, n0 = tn * BNT + wn * 64;
+        [[maybe_unused]] bool res_rows = false;
+        if constexpr (EK == EK_RES_INIT && RB && MT == 4 && NW == 4 && NST == 3 && SPL == 0) {
+            // bf16 residual stream on the 128 x 256 tile (the incremental AR step): the wave's 64 x 64 residual block as 8 loads of 8 rows x
+            // 128 B (whole lines) and through a private 2 KiB window into the accumulator layout, as in the 8-phase kernel (finding 47)
+            res_rows = g.res_rows && m0 + 64 <= d.M && n0 + 64 <= d.N;                                       // wave-uniform
+            if (res_rows) {
+                const int rr = lane >> 3, cc = lane & 7;
+                const unsigned short* rp = (const unsigned short*)d.residual + ((long)(m0 + rr) + d.y_off) * d.ldr + n0 + cc * 8;
+                const long step8 = 8L * d.ldr;
+                u32x4 land[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) land[j] = *(const u32x4*)(rp + j * step8);
+                char* blk = smem + TL::RING_BYTES + wave * 2048;
+#pragma unroll
+                for (int a = 0; a < MT; ++a) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int r = rr + 8 * i;
+                        *(u32x4*)(blk + r * 128 + ((cc ^ ((r >> 1) & 7)) << 4)) = land[2 * a + i];
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const uint2 t = *(const uint2*)(blk + l15 * 128 + (((b * 2 + (grp >> 1)) ^ ((l15 >> 1) & 7)) << 4) + (grp & 1) * 8);
+                        acc[a][b] = f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                                          __uint_as_float(t.y & 0xffff0000u)};
+                    }
+                }
+            }
+        }
         if constexpr (EK == EK_RES_INIT) {
             // y = x + (A W^T + b): start the accumulators from the fp32 residual.  32 independent 16-byte loads per lane,
             // straight into the MFMA layout (row mt*16 + l15, columns nt*16 + grp*4 + {0..3}), no register cost, one
             // round trip per tile that the first slab's vmcnt(0) below absorbs together with the previous tile's store acks.
+            if (!res_rows) {
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int m = min(m0 + a * 16 + l15, d.M - 1);
@@ -684,6 +716,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                     if constexpr (RB) res_bf16_request(acc[a][b], rpb + (n < d.N ? n : 0));
                     else acc[a][b] = *(const f32x4*)(rp + (n < d.N ? n : 0));
                 }
+            }
             }
         } else {
 #pragma unroll
@@ -730,7 +763,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
         auto slab = [&](int kt) __attribute__((always_inline)) {
             asm volatile("" ::: "memory");
             if constexpr (RB) {
-                if (kt == 0) {                         // the residual rows have landed: widen them in place
+                if (kt == 0 && !res_rows) {            // the residual rows have landed: widen them in place
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
 #pragma unroll
