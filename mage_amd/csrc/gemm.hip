@@ -353,17 +353,28 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
     }
 
     // LN_GELUBWD: the pre-activation rows in the MFMA layout (8 bytes per lane per 16-column block), requested one 16-row tile ahead
-    [[maybe_unused]] uint2 auxb[2][4];
+    // requested as ROWS (2 loads of 8 rows x 128 B per 16-row tile: whole lines, finding 47) and brought into the accumulator layout
+    // through the upper half of the staging window (bf16 output rows use the lower 2 KiB); host: plain rows, M and N multiples of 256
+    [[maybe_unused]] u32x4 auxr[2][2];
     [[maybe_unused]] auto aux_request = [&](int mt) {
-        const unsigned short* ap = (const unsigned short*)d.y2 + (long)((m0 + mt * 16 + l15) * d.y_mul_x + d.y_off) * d.ldy2 + n0 + grp * 4;
+        const unsigned short* ap = (const unsigned short*)d.y2 + (long)((m0 + mt * 16 + (lane >> 3)) * d.y_mul_x + d.y_off) * d.ldy2 + n0 + (lane & 7) * 8;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) auxb[mt & 1][nt] = *(const uint2*)(ap + nt * 16);
+        for (int i = 0; i < 2; ++i) auxr[mt & 1][i] = *(const u32x4*)(ap + (long)(8 * i) * d.y_mul_x * d.ldy2);
     };
     if constexpr (LN == LN_GELUBWD) aux_request(0);
     auto stage = [&](int mt, u32x4 (&o)[NST], auto apply_act) {     // math + transpose of 16-row tile mt: results land in o[] (row-contiguous)
         [[maybe_unused]] float s1 = 0.f, s2 = 0.f;
+        [[maybe_unused]] uint2 auxb[4];
         if constexpr (LN == LN_GELUBWD) {
             if (mt + 1 < MT) aux_request(mt + 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = (lane >> 3) + 8 * i;
+                *(u32x4*)(stg + 2048 + r * 128 + (((lane & 7) ^ ((r >> 1) & 7)) << 4)) = auxr[mt & 1][i];
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                auxb[nt] = *(const uint2*)(stg + 2048 + l15 * 128 + (((nt * 2 + (grp >> 1)) ^ ((l15 >> 1) & 7)) << 4) + (grp & 1) * 8);
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -375,7 +386,7 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
                 s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
             }
             if constexpr (LN == LN_GELUBWD) {              // v *= s (1 + 1.702 x (1 - s)), s = sigmoid(1.702 x)
-                const uint2 ax = auxb[mt & 1][nt];
+                const uint2 ax = auxb[nt];
                 const f32x4 x = f32x4{__uint_as_float(ax.x << 16), __uint_as_float(ax.x & 0xffff0000u), __uint_as_float(ax.y << 16),
                                       __uint_as_float(ax.y & 0xffff0000u)};
                 const f32x4 t = x * -2.4554669596f;
@@ -1785,7 +1796,7 @@ int launch(const mage_gemm_desc* d, hipStream_t s) {
             if constexpr (DT == MAGE_BF16 && !GATHER) {
                 MAGE_CHECK_ARG(d->y2 && d->y_dtype == MAGE_BF16 && d->M % 256 == 0 && d->N % 256 == 0 && d->n_split == 1 && !d->scale && !d->rowadd &&
                                    !d->residual && !d->post_relu && !d->ln_part && !d->ln_stats && !d->ln_colsum && d->out_h == 1 && d->out_w >= d->M &&
-                                   d->y_mul_x == 1 && d->ldy2 % 4 == 0 && (((uintptr_t)d->y2) & 7) == 0,
+                                   d->y_mul_x == 1 && d->ldy2 % 8 == 0 && (((uintptr_t)d->y2) & 15) == 0,
                                "mage_gemm: MAGE_ACT_QUICKGELU_GRAD: y = acc * QuickGELU'(y2) on bf16 plain rows, M and N multiples of 256");
                 return launch_ek<DT, GATHER, MAGE_ACT_NONE, EK_BIAS, LN_GELUBWD>(d, s);
             }
