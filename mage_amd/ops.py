@@ -283,6 +283,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
                 key = "gemm8_kernel<0, 1, false, true, 0, 0, false>"
             elif plain and act in (ACT_NONE, ACT_RELU):
                 key = f"gemm8_kernel<{act}, 0, false, true, 0, 0, false>"
+        # the one-wave-per-SIMD kernel (mage_gemm4_try in csrc/gemm4.hip): QKV / c_fc at full-loop sizes
+        if (d.dtype == BF16 and not gather and n_split <= 1 and M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and 256 <= K <= 1024
+                and out_h == 1 and out_w >= M and y_mul_x == 1 and ek == 0 and not res_half and y2 is None and ln_part is None
+                and bias is not None and (ln_stats is None) == (ln_colsum is None) and act in (ACT_NONE, ACT_QUICKGELU)
+                and lda % 8 == 0 and ldy % 8 == 0 and (M // 256) * (N // 256) >= 2 * n_cu and not os.environ.get("MAGE_GEMM_NO_4W")):
+            key = f"gemm4_kernel<{act}, 0, {2 if ln_stats is not None else 0}, false>"
         if PROFILE.wants(key):
             ev = PROFILE.begin()
             _lib.check(l.mage_gemm(C.byref(d), s), l)
@@ -338,6 +344,12 @@ def _gemm_split(l, s, a, w, y, *, M, N, K, lda, ldy, out_h, out_w, in_h, in_w, a
     d.ldw, d.n_split = ldw, 1
     if PROFILE.enabled:
         key = f"gemm_split<{split_kind}, {act}, {1 if residual is not None else 0}, {taps_h * taps_w}>"
+        # the one-wave-per-SIMD kernel (mage_gemm4_try in csrc/gemm4.hip): QKV / c_fc at full-loop sizes
+        if (d.dtype == BF16 and not gather and n_split <= 1 and M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and 256 <= K <= 1024
+                and out_h == 1 and out_w >= M and y_mul_x == 1 and ek == 0 and not res_half and y2 is None and ln_part is None
+                and bias is not None and (ln_stats is None) == (ln_colsum is None) and act in (ACT_NONE, ACT_QUICKGELU)
+                and lda % 8 == 0 and ldy % 8 == 0 and (M // 256) * (N // 256) >= 2 * n_cu and not os.environ.get("MAGE_GEMM_NO_4W")):
+            key = f"gemm4_kernel<{act}, 0, {2 if ln_stats is not None else 0}, false>"
         if PROFILE.wants(key):
             ev = PROFILE.begin()
             _lib.check(l.mage_gemm(C.byref(d), s), l)

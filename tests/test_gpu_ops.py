@@ -665,3 +665,45 @@ def test_table_conv_equals_convolution_of_embeddings_and_folded_linear():
     o.table_conv(bad, T, torch.empty(B * Lm1 * R * R, C, device=DEV), n_img=B * Lm1, H=R, W=R)
     with pytest.raises(ValueError, match="out of range"):
         o.check_device_errors(DEV)
+
+
+@pytest.mark.parametrize("M,N,K,act,ln,f32out", [(65536, 1536, 512, 0, True, False), (32768, 2048, 512, 2, True, False),
+                                                  (65536, 512, 512, 0, False, True), (32768, 1024, 1024, 2, False, False),
+                                                  (32768, 1024, 256, 0, True, True)])
+def test_gemm_one_wave_per_simd_equals_the_8phase_kernel(M, N, K, act, ln, f32out):
+    """csrc/gemm4.hip (QKV / c_fc at full-loop sizes: 4 waves of 128x128 outputs, accumulators in literal AGPRs behind inline asm) against the
+    8-phase kernel on the same product (MAGE_GEMM_NO_4W is read on every call): bit-identical outputs -- same MFMA, same k order, same
+    epilogue function -- and both against fp64 on a sample of rows; repeated launches agree (race screen of the hand-placed schedule)."""
+    import os
+    o = ops()
+    a = rnd(M, K, seed=11).bfloat16()
+    w, b = rnd(N, K, seed=12, scale=K ** -0.5).bfloat16(), rnd(N, seed=13, scale=0.1)
+    ad, wd, bd = a.to(DEV), w.to(DEV), b.to(DEV)
+    kw = dict(M=M, N=N, K=K, lda=K, ldy=N, bias=bd, act=act)
+    if ln:
+        st = torch.stack([0.05 * rnd(M, seed=14), 1.0 + 0.2 * rnd(M, seed=15).abs()], 1).contiguous()
+        cs = 0.3 * rnd(N, seed=16)
+        kw.update(ln_stats=st.to(DEV), ln_colsum=cs.to(DEV))
+    odt = torch.float32 if f32out else torch.bfloat16
+    ys = []
+    for no4 in (True, False, False, False):
+        if no4:
+            os.environ["MAGE_GEMM_NO_4W"] = "1"
+        else:
+            os.environ.pop("MAGE_GEMM_NO_4W", None)
+        try:
+            y = torch.full((M, N), float("nan"), device=DEV, dtype=odt)
+            o.gemm(ad, wd, y, **kw)
+            ys.append(y)
+        finally:
+            os.environ.pop("MAGE_GEMM_NO_4W", None)
+    torch.cuda.synchronize()
+    for y in ys[1:]:
+        assert torch.equal(y, ys[0])
+    rows = torch.arange(0, M, M // 64) + 5
+    acc = a[rows].double() @ w.double().t()
+    want = ((acc - st[rows, 0:1].double() * cs.double()) * st[rows, 1:2].double() if ln else acc) + b.double()
+    if act == o.ACT_QUICKGELU:
+        want = want * torch.sigmoid(1.702 * want)
+    tol = dict(atol=2e-3, rtol=1e-4) if f32out else dict(atol=6e-2, rtol=3e-2)
+    torch.testing.assert_close(ys[1][rows.to(DEV)].cpu().double(), want, **tol)

@@ -9,6 +9,7 @@ ap.add_argument("--M", type=int, default=262144)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--check", action="store_true")
+ap.add_argument("--vendor", action="store_true", help="also time torch.nn.functional.linear (hipBLASLt / rocBLAS) on the same operands: a bench-only comparator, never used by mage_amd")
 ap.add_argument("--custom", nargs="*", default=None, help="N,K,act,res,outf32 ...")
 args = ap.parse_args()
 dev = "cuda:0"
@@ -58,10 +59,26 @@ for r in range(args.rounds):
         e0.record(); run(*s); run(*s); e1.record()
         torch.cuda.synchronize()
         tot[s[0]] += e0.elapsed_time(e1) / 2
+vend = {}
+if args.vendor and args.dtype == "bf16":
+    import torch.nn.functional as F
+    for name, N, K, o in shapes:
+        a, w, b, y = bufs[name]
+        bb = b.to(torch.bfloat16)
+        for _ in range(2): F.linear(a, w, bb)
+        torch.cuda.synchronize()
+        t = 0.0
+        for r in range(args.rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); F.linear(a, w, bb); F.linear(a, w, bb); e1.record()
+            torch.cuda.synchronize()
+            t += e0.elapsed_time(e1) / 2
+        vend[name] = t / args.rounds
 allms, allfl = 0.0, 0.0
 for name, N, K, o in shapes:
     ms = tot[name] / args.rounds
     fl = 2.0 * M * N * K
     allms += ms; allfl += fl
-    print(f"{name:32s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+    extra = f"   | vendor F.linear(bias, bf16 out, no activation / residual) {vend[name]:8.3f} ms {fl / vend[name] / 1e9:8.1f} TFLOP/s" if name in vend else ""
+    print(f"{name:32s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s{extra}")
 print(f"{'block total (4 GEMMs)':32s} {allms:8.3f} ms  {allfl / allms / 1e9:8.1f} TFLOP/s")
