@@ -1212,7 +1212,7 @@ class MAGE(nn.Module):
         First call with a given (shapes, precision, AR mode, weights): eager, which also builds every derived cache; second:
         captured on static copies of the inputs (all intermediates live in the graph's private pool: an arena that is never
         re-allocated); from then on: inputs are copied into the static buffers, the graph is replayed, the video and tokens are
-        cloned out (last_logits stays a view of the arena, valid until the next call).  Same kernels, same order, same
+        cloned out (last_logits too).  Same kernels, same order, same
         arithmetic: bit-identical to the eager call."""
         self._warm_derived()
         gens = tuple(getattr(m, "_derived").gen for m in (self, self.generate_model, self.ma_encoder, self.text_encoder,
@@ -1270,7 +1270,9 @@ class MAGE(nn.Module):
             torch.cuda.current_stream().synchronize()
             ops.PROFILE.absorb(ent["recs"])
         self.last_tokens = None if ent["tok"] is None else ent["tok"].clone()
-        self.last_logits = ent["logits"]
+        # cloned like the tokens and the output: graph replay is the DEFAULT for small calls (use_graph = None), and a caller that keeps
+        # last_logits across two generations must not find the first one overwritten by the second (0.5 MB per clip at cfg2)
+        self.last_logits = None if ent["logits"] is None else ent["logits"].clone()
         return ent["out"].clone()
 
     def _warm_derived(self) -> None:

@@ -163,6 +163,8 @@ class VectorQuantizedVAE(nn.Module):
         self.apply(weights_init)
         self.decode_dtype = torch.float32          # torch.bfloat16 = MFMA-bf16 performance mode for decode
         self.decode_split = 0                      # ops.F16X3: the f4 decode stack on split-precision operands (set_precision('f16x3'))
+        self.encode_split = False                  # True: the f4 encoder's convolutions on f16x3 split operands (z_e within 7e-7 of the exact-fp32
+                                                   # path, 2.2x faster); every precision except 'fp32', whose encoder stays the exact-fp32 MFMA chain
         self.decode_chunk = 1024                   # frames per decode launch group (bounds workspace: 0.8 GB at dim 256)
         self._pad_bufs = {}                        # zero-padded frame buffers of the bf16 decode, keyed by (frames, grid, device, stream)
         self._derived = _Derived(self)
@@ -184,6 +186,9 @@ class VectorQuantizedVAE(nn.Module):
         bit-exact), or 'f16x3' / 'bf16x3' (the fast parity modes: the f4 decode stack on split-precision operands, fp32-class frames)."""
         self.decode_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16, "f16x3": torch.float32, "bf16x3": torch.float32}[precision]
         self.decode_split = ops.F16X3 if precision in ("f16x3", "bf16x3") else 0     # f16 pieces for both: the encoder's kind
+        # 'fp32' is the exact parity mode end to end: its encoder keeps the exact-fp32 MFMA chain, so that a near-tie token cannot flip
+        # against the reference because of the 7e-7 the split operands move z_e by; the other modes take the split encoder
+        self.encode_split = precision != "fp32"
         return self
 
     # ------------------------------------------------------------------ derived weights
@@ -346,7 +351,7 @@ class VectorQuantizedVAE(nn.Module):
         if self.down_ratio == 4:
             H, W = x.shape[2], x.shape[3]
             if (dim % 256 == 0 and H % 4 == 0 and W % 4 == 0 and (N * (H // 4) * (W // 4)) % 256 == 0 and self.input_dim <= 4
-                    and not os.environ.get("MAGE_ENCODE_FP32") and getattr(self, "encode_split", True)):
+                    and not os.environ.get("MAGE_ENCODE_FP32") and self.encode_split):
                 return self._encode_f4_split(w, x, N, H, W)
             h0 = torch.empty(N * (H // 2) * (W // 2), dim, device=dev, dtype=f)
             ops.conv_in(x, w["e0.wt"], w["e0.b"], w["e0.s"], w["e0.t"], h0, cin=self.input_dim, H=H, W=W, cout=dim, kh=4,

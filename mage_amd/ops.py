@@ -206,6 +206,20 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     split_kind BF16X3 / F16X3: a and w are split-precision tensors (lda / ldw in 16-bit elements); y_split: so is y (ldy likewise)."""
     l, s = _dev(a)
     if split_kind:
+        # the split-precision form takes a subset of the arguments (launch_spl / try_taps8 in csrc/gemm.hip): refuse the rest loudly
+        # instead of dropping them
+        unsupported = dict(scale=scale, shift=shift, y2=y2, ln_part=ln_part, ln_stats=ln_stats, ln_colsum=ln_colsum)
+        bad = [k for k, v_ in unsupported.items() if v_ is not None]
+        bad += [k for k, v_ in dict(post_relu=post_relu, res_half=res_half, a_half=a_half).items() if v_]
+        bad += [k for k, v_ in dict(n_split=n_split).items() if v_ not in (0, 1)]
+        bad += [k for k, v_ in dict(a_split_stride=a_split_stride, w_split_stride=w_split_stride, y_split_stride=y_split_stride, ldy2=ldy2,
+                                    stride=stride - 1, dy0=dy0, dx0=dx0, dys=dys - 1, dxs=dxs - 1).items() if v_]
+        if ln_eps:
+            bad.append("ln_eps")
+        if bad:
+            raise ValueError(f"ops.gemm: split-precision operands (split_kind) do not take {', '.join(bad)}")
+        if residual is not None and residual.dtype != torch.float32:
+            raise ValueError(f"ops.gemm: the split-precision x + Linear(.) form adds an fp32 residual, got {residual.dtype}")
         return _gemm_split(l, s, a, w, y, M=M, N=N, K=K, lda=lda, ldy=ldy, out_h=out_h, out_w=out_w, in_h=in_h, in_w=in_w,
                            a_img_stride=a_img_stride, a_off=a_off, taps_h=taps_h, taps_w=taps_w, cin=cin, y_img_stride=y_img_stride,
                            y_mul_y=y_mul_y, y_mul_x=y_mul_x, y_off=y_off, bias=bias, act=act, rowadd=rowadd, rowadd_div=rowadd_div,

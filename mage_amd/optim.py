@@ -32,10 +32,18 @@ __all__ = ["FlatAdam"]
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.98), eps: float = 1e-6,
                  process_group: Optional[dist.ProcessGroup] = None, shard: Optional[bool] = None):
-        plist = [p for p in params if p.requires_grad]
+        # The reference hands EVERY parameter to optim.Adam (main_mage.py:121: model.parameters(), the frozen first stage included -- its
+        # parameters follow MAGE's three top-level nn.Parameters), so the indices of its checkpoint's 'state' and 'param_groups' count the
+        # frozen ones too.  Keep that numbering: `all_params` is the caller's order, `index[i]` the position of trainable parameter i in it.
+        all_params = list(params)
+        if any(isinstance(p, dict) for p in all_params):
+            raise ValueError("FlatAdam: one parameter group (an iterable of tensors), as the reference's optim.Adam call")
+        plist = [p for p in all_params if p.requires_grad]
         if not plist:
             raise ValueError("FlatAdam: no trainable parameters")
-        super().__init__(plist, dict(lr=lr, betas=tuple(betas), eps=eps))
+        super().__init__(all_params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        self.all_params = all_params
+        self.index = [i for i, p in enumerate(all_params) if p.requires_grad]
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
@@ -67,6 +75,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.v = torch.zeros(self.shard_n, device=dev, dtype=torch.float32)
         self.shard_g = torch.empty(self.shard_n, device=dev, dtype=torch.float32) if self.sharded else None
         self.steps = 0
+        self._consolidated = None                                # (steps, exp_avg, exp_avg_sq) gathered by consolidate_state_dict
         if self.world > 1:
             # DistributedDataParallel broadcasts rank 0's parameters when it wraps a model (main_mage.py:95); a bare model + FlatAdam
             # gets the same guarantee here: replicas that were initialised differently start from rank 0's weights
@@ -134,40 +143,65 @@ class FlatAdam(torch.optim.Optimizer):
         return loss
 
     # ------------------------------------------------------------------ checkpoints (main_mage.py:189-199)
-    def _full_moments(self):
-        """exp_avg / exp_avg_sq over the WHOLE arena on every rank (the shards all-gathered): the reference saves its checkpoint from
-        rank 0 only (main_mage.py:186-193), so a sharded state would lose (W-1)/W of the moments."""
+    def consolidate_state_dict(self, to: int = 0):
+        """COLLECTIVE (every rank calls it, like torch's ZeroRedundancyOptimizer.consolidate_state_dict): gather the sharded moments so that
+        rank `to` can build the checkpoint.  The reference saves from inside its rank-0 branch (main_mage.py:186-193); a sharded optimizer
+        cannot gather there without hanging the other ranks in RCCL, so the loop calls this on all ranks first:
+
+            optimizer.consolidate_state_dict()          # all ranks
+            if rank == 0: torch.save({... 'optimizer': optimizer.state_dict()}, path)
+
+        A no-op when the state is not sharded (one rank, or shard=False)."""
         if not self.sharded or self.world == 1:
-            return self.m[:self.n].clone(), self.v[:self.n].clone()
+            return
         m = torch.empty(self.n_pad, device=self.m.device, dtype=torch.float32)
         v = torch.empty(self.n_pad, device=self.m.device, dtype=torch.float32)
         dist.all_gather_into_tensor(m, self.m, group=self.pg)
         dist.all_gather_into_tensor(v, self.v, group=self.pg)
-        return m[:self.n], v[:self.n]
+        self._consolidated = (self.steps, m[:self.n], v[:self.n]) if self.rank == to else None
+
+    def _full_moments(self):
+        if not self.sharded or self.world == 1:
+            return self.m[:self.n].clone(), self.v[:self.n].clone()
+        if self._consolidated is None or self._consolidated[0] != self.steps:
+            raise RuntimeError("FlatAdam.state_dict(): the optimizer state is sharded over the ranks; call optimizer.consolidate_state_dict() on "
+                               "EVERY rank first (a collective), then state_dict() on the rank that saves -- state_dict() itself is local")
+        return self._consolidated[1], self._consolidated[2]
 
     def state_dict(self):
-        """torch.optim.Adam's layout: state[i] = {step, exp_avg, exp_avg_sq} per parameter (in parameter order) + param_groups, so the
-        'optimizer' entry of a checkpoint is interchangeable with the reference's optim.Adam (main_mage.py:121,189-199,210-228) and
-        independent of the world size it was written with.  A collective call when sharded: every rank must make it."""
+        """torch.optim.Adam's layout, numbered over ALL parameters the optimizer was given (frozen ones included, as the reference's
+        optim.Adam(model.parameters()) numbers them): state[i] = {step, exp_avg, exp_avg_sq} for every TRAINABLE parameter i, and
+        param_groups[0]['params'] = range(len(all parameters)) -- so the 'optimizer' entry of a checkpoint is interchangeable with the
+        reference's (main_mage.py:121,189-199,210-228) and independent of the world size it was written with.  LOCAL: with sharded state
+        call consolidate_state_dict() on every rank first."""
         m, v = self._full_moments()
         state = {}
-        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
+        for i, p, off in zip(self.index, self.params, self.offsets):
             k = p.numel()
             state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": m[off:off + k].view(p.shape).clone(),
                         "exp_avg_sq": v[off:off + k].view(p.shape).clone()}
-        groups = [dict({k: v_ for k, v_ in g.items() if k != "params"}, params=list(range(len(self.params)))) for g in self.param_groups]
+        groups = [dict({k: v_ for k, v_ in g.items() if k != "params"}, params=list(range(len(self.all_params)))) for g in self.param_groups]
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        """Accepts torch.optim.Adam's per-parameter layout (written by this class at ANY world size, or by the reference's optim.Adam)."""
-        st = sd["state"]
-        if len(st) not in (0, len(self.params)):
-            raise ValueError(f"FlatAdam.load_state_dict: {len(st)} parameter states for {len(self.params)} parameters")
+        """Accepts torch.optim.Adam's per-parameter layout (written by this class at ANY world size, or by the reference's optim.Adam over
+        model.parameters()): entries are matched by their index in the full parameter list; a parameter without an entry (one that never
+        received a gradient, e.g. ln_q / ln_kv under find_unused_parameters=True) starts from zero moments; an entry for a frozen parameter
+        or with a different shape is an error, never a silent reassignment."""
+        st = {int(k): e for k, e in sd["state"].items()}
+        groups = sd.get("param_groups") or []
+        if groups and "params" in groups[0] and len(groups[0]["params"]) != len(self.all_params):
+            raise ValueError(f"FlatAdam.load_state_dict: the checkpoint's optimizer was built over {len(groups[0]['params'])} parameters, "
+                             f"this one over {len(self.all_params)} (pass the same model.parameters())")
+        trainable = set(self.index)
+        for i in st:
+            if i not in trainable:
+                raise ValueError(f"FlatAdam.load_state_dict: state entry {i} belongs to a parameter that is frozen (or absent) here")
         m = torch.zeros(self.n_pad, device=self.m.device, dtype=torch.float32)
         v = torch.zeros(self.n_pad, device=self.m.device, dtype=torch.float32)
         steps = 0
-        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
-            e = st.get(i, st.get(str(i)))
+        for i, p, off in zip(self.index, self.params, self.offsets):
+            e = st.get(i)
             if e is None:
                 continue
             if tuple(e["exp_avg"].shape) != tuple(p.shape):
@@ -177,7 +211,8 @@ class FlatAdam(torch.optim.Optimizer):
             v[off:off + k].copy_(e["exp_avg_sq"].reshape(-1))
             steps = max(steps, int(float(e["step"])))
         self.steps = steps
+        self._consolidated = None
         self.m.copy_(m[self.shard_off:self.shard_off + self.shard_n])
         self.v.copy_(v[self.shard_off:self.shard_off + self.shard_n])
-        for g, sg in zip(self.param_groups, sd["param_groups"]):
+        for g, sg in zip(self.param_groups, groups):
             g.update({k: v_ for k, v_ in sg.items() if k != "params"})

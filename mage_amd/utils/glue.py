@@ -106,7 +106,9 @@ class SyntheticMovingMnist(torch.utils.data.Dataset):
 
 # ----------------------------------------------------------------------------------------------------------------- checkpoints
 def make_checkpoint(epoch: int, model: torch.nn.Module, optimizer) -> dict:
-    """main_mage.py:189-193."""
+    """main_mage.py:189-193.  The reference calls this inside its rank-0 branch (:186).  With ``mage_amd.optim.FlatAdam`` on more than one
+    rank the optimizer state is SHARDED: every rank must call ``optimizer.consolidate_state_dict()`` (a collective) before rank 0 builds
+    the checkpoint here; ``optimizer.state_dict()`` itself is local and raises if that gather was skipped (it never hangs in RCCL)."""
     return {"epoch": epoch, "state_dict": model.state_dict(), "optimizer": optimizer.state_dict()}
 
 

@@ -657,14 +657,18 @@ def test_frame_table_path_against_the_convolution_path(precision):
 
 
 def test_f4_encoder_split_precision_path_against_exact_fp32_path():
-    """The f4 encoder's convolutions on f16x3 operands (VectorQuantizedVAE._encode_f4_split, the default) against the exact-fp32 MFMA
-    gather path (encode_split = False) on 64 synthetic frames: features within fp32 rounding of each other, identical tokens wherever
+    """The f4 encoder's convolutions on f16x3 operands (VectorQuantizedVAE._encode_f4_split: every precision except 'fp32', whose
+    encoder is the exact chain -- set_precision flips encode_split) against the exact-fp32 MFMA gather path on 64 synthetic frames: features within fp32 rounding of each other, identical tokens wherever
     the quantiser's own top-2 margin exceeds that noise -- and the reference's golden tokens with BOTH (test_vqvae_f4_golden...)."""
     m = build_vqvae(1, 4, 256, 512, 17, DEV)
     x = synth.synth_batch_mnist(4, 16, seed=23)["images"].reshape(64, 1, 64, 64).to(DEV)
+    assert m.encode_split is False                     # a fresh model is in 'fp32' mode: the exact encoder
+    m.set_precision("bf16")
+    assert m.encode_split is True
     z_s = m._encode_features(x).clone()
     ids_s = m.encode(x)
-    m.encode_split = False
+    m.set_precision("fp32")
+    assert m.encode_split is False
     z_f = m._encode_features(x)
     ids_f = m.encode(x)
     err = (z_s - z_f).abs().max().item()

@@ -110,10 +110,19 @@ def _worker(rank, world, port, q):
     flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
-    # checkpoint: the full moments on EVERY rank (the reference saves from rank 0 only), loadable at another world size
-    sd = opt.state_dict()
-    mom = torch.cat([sd["state"][i]["exp_avg"].reshape(-1) for i in range(len(opt.params))])
-    q.put((rank, flat.tolist(), bool(torch.equal(gathered[0], gathered[1])), mom.tolist()))    # plain lists: no shared-memory handles outlive the worker
+    # checkpoint (main_mage.py:186-193 saves from rank 0 only): state_dict() is LOCAL and refuses sharded state that was not gathered;
+    # consolidate_state_dict() is the collective every rank makes first; the saving rank then holds the full moments
+    try:
+        opt.state_dict()
+        refused = False
+    except RuntimeError as e:
+        refused = "consolidate_state_dict" in str(e)
+    opt.consolidate_state_dict(to=0)
+    mom = []
+    if rank == 0:
+        sd = opt.state_dict()
+        mom = torch.cat([sd["state"][i]["exp_avg"].reshape(-1) for i in range(len(opt.params))]).tolist()
+    q.put((rank, flat.tolist(), bool(torch.equal(gathered[0], gathered[1])) and refused, mom))    # plain lists: no shared-memory handles outlive the worker
     D.barrier()
     dist.destroy_process_group()
 
@@ -141,4 +150,48 @@ def test_sharded_step_over_two_ranks_equals_the_global_batch_step():
     want = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     assert torch.allclose(torch.tensor(res[0][1]), want, atol=2e-6)
     want_m = torch.cat([ref.state_dict()["state"][i]["exp_avg"].reshape(-1) for i in range(len(list(net.parameters())))])
-    assert res[0][3] == res[1][3] and torch.allclose(torch.tensor(res[0][3]), want_m, atol=2e-6)     # sharded moments, gathered
+    assert res[1][3] == [] and torch.allclose(torch.tensor(res[0][3]), want_m, atol=2e-6)     # sharded moments, gathered onto rank 0
+
+
+def test_flat_adam_checkpoint_numbers_frozen_parameters_like_torch_adam(monkeypatch):
+    """The reference builds optim.Adam over model.parameters() with the frozen first stage inside (main_mage.py:121): its checkpoint's
+    state indices count the frozen parameters.  FlatAdam keeps that numbering, so the two 'optimizer' entries load into each other; a
+    parameter without a state entry (never received a gradient) starts from zero moments; an entry that would land on a frozen parameter
+    or a different shape raises instead of being reassigned."""
+    from mage_amd.optim import FlatAdam
+    monkeypatch.setattr(FlatAdam, "_adam", _adam_double)
+
+    def build(seed):
+        torch.manual_seed(seed)
+        net = torch.nn.ModuleDict({"top": torch.nn.Linear(7, 7), "frozen": torch.nn.Linear(7, 7), "body": _net(seed), "unused": torch.nn.Linear(3, 3)})
+        for p in net["frozen"].parameters():                # registered BEFORE the trainable body, same shapes as `top`
+            p.requires_grad_(False)
+        return net
+
+    def fwd(net, x):
+        return net["body"](net["frozen"](net["top"](x))).pow(2).mean()
+
+    a, b = build(3), build(3)
+    ref = torch.optim.Adam(a.parameters(), lr=1e-2, betas=(0.9, 0.98), eps=1e-6)
+    opt = FlatAdam(b.parameters(), lr=1e-2, betas=(0.9, 0.98), eps=1e-6)
+    for i in range(3):
+        x = torch.randn(6, 7, generator=torch.Generator().manual_seed(i))
+        for net, o in ((a, ref), (b, opt)):
+            o.zero_grad()
+            fwd(net, x).backward()
+            o.step()
+    rsd, sd = ref.state_dict(), opt.state_dict()
+    n_all = len(list(a.parameters()))
+    assert rsd["param_groups"][0]["params"] == sd["param_groups"][0]["params"] == list(range(n_all))
+    assert set(rsd["state"]) <= set(sd["state"]) and 2 not in sd["state"] and 3 not in sd["state"]       # 2, 3 = the frozen Linear
+    for i in rsd["state"]:                                  # (`unused` has no entry in torch's dict: it never received a gradient)
+        assert torch.allclose(sd["state"][i]["exp_avg"], rsd["state"][i]["exp_avg"], atol=1e-7)
+    opt2 = FlatAdam(build(3).parameters(), lr=1e-2, betas=(0.9, 0.98), eps=1e-6)
+    opt2.load_state_dict(rsd)                               # the reference's checkpoint entry, unused parameters absent
+    assert opt2.steps == 3 and torch.allclose(opt2.m, opt.m, atol=1e-7)
+    torch.optim.Adam(build(3).parameters(), lr=1e-2).load_state_dict(sd)
+    shifted = {"state": {i + 2: e for i, e in rsd["state"].items() if i < 2}, "param_groups": rsd["param_groups"]}     # top's moments on `frozen`
+    with pytest.raises(ValueError, match="frozen"):
+        FlatAdam(build(3).parameters()).load_state_dict(shifted)
+    with pytest.raises(ValueError, match="built over"):
+        FlatAdam(_net(3).parameters()).load_state_dict(rsd)
