@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 from mage_amd.utils import synth  # noqa: E402
 from tools._ref_import import import_reference, to_cfg  # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("MAGE_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")      # tools/check_goldens.sh regenerates into a temp dir
 torch.set_num_threads(8)
 torch.manual_seed(0)
 

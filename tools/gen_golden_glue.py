@@ -108,7 +108,7 @@ def main():
             b = ds.collate_fn(items)
             out[dset] = {"frames_length": 32, "sample_speed": [3.0, 6.0], "raw_frames": 301, "min_interval": 3.0, "items": recs,
                          "collate_keys": sorted(b.keys()), "collate_text": b["text"].tolist()}
-    path = os.path.join(ROOT, "tests", "golden", "glue_dataload.json")
+    path = os.path.join(os.environ.get("MAGE_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden"), "glue_dataload.json")
     json.dump(out, open(path, "w"), indent=1)
     print("wrote", path, os.path.getsize(path), "bytes")
 
