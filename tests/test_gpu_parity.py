@@ -679,3 +679,20 @@ def test_f4_encoder_split_precision_path_against_exact_fp32_path():
     print(f"f16x3 encoder vs exact fp32: max |d z_e| {err:.2e} (|z_e| max {z_f.abs().max().item():.2f}), token mismatches {int(bad.sum())} of {bad.numel()}")
     assert err < 3e-5
     assert not (bad & (margin > TOK_TOL)).any()
+
+
+def test_bf16_tokens_on_trained_weights_follow_the_oracle_outside_the_error_margin():
+    """north_star: reference-matching token sequences.  On random-init weights the decoder's top-2 margins (1e-5 class) are below bf16's
+    logit error, so the bf16 mode cannot match there; this test gives a small model a trained model's margins -- stage 1 (VQ-VAE) and
+    stage 2 (MAGE) trained IN-TREE on the HIP training path (bench.py's trained_token_agreement leg at a reduced size) -- and compares
+    free-running tokens of held-out clips with the CPU oracle on the same weights: f16x3 identical; bf16 either identical or leaving the
+    oracle's sequence first at a decision the oracle took by less than twice the measured bf16 logit error (every later position of that
+    clip sees other inputs), and overall agreement high."""
+    import bench
+    r = bench.trained_token_agreement(torch.device(DEV), 6, 200, 16, 2, 8, cfg_kw=dict(width=128, layers=3, vq_dim=64, K=64))
+    print({k: v for k, v in r.items() if k != "note"})
+    assert r["stage1"]["distinct_tokens_in_the_oracle_sequences"] >= 3          # a non-degenerate token task
+    assert r["loss_trajectory"][-1] < 0.5 * r["loss_trajectory"][0]
+    assert r["f16x3"]["all_positions"] == 1.0
+    assert r["bf16"]["first_divergences_inside_twice_the_bf16_logit_error"] is True
+    assert r["bf16"]["all_positions"] >= 0.9
