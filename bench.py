@@ -715,6 +715,21 @@ def cpu_baseline(sd, L, clips):
         t0 = time.perf_counter()
         _, o_tok, _, o_trace = O.mage_generate(sd, batch, L, return_trace=True)
         dt = time.perf_counter() - t0
+        # SURVEY 8d asks for "all physical cores": one decoder pass of the same shape on every physical core (host threads / 2 with SMT),
+        # scaled by the calibrated run's (whole call / one decoder pass) ratio -- the figure beside the calibrated one, labelled as such
+        phys = max(1, ncpu // 2)
+        all_cores = None
+        if phys > best[1]:
+            torch.set_num_threads(phys)
+            O.flat_axial_decoder(sd, "generate_model.", ma, imgs)
+            t1 = time.perf_counter()
+            O.flat_axial_decoder(sd, "generate_model.", ma, imgs)
+            t_pass_phys = time.perf_counter() - t1
+            torch.set_num_threads(best[1])
+            all_cores = {"threads": phys, "decoder_pass_s": round(t_pass_phys, 3), "decoder_pass_s_at_calibrated_threads": round(best[0], 3),
+                         "value_estimated": round(clips * L / (dt * t_pass_phys / best[0]), 3), "unit": "frames/s",
+                         "note": "one decoder pass timed on all physical cores; frames/s = the calibrated run's scaled by the pass-time ratio "
+                                 "(torch's intra-op pool oversubscribes: more threads are slower on this host)"}
         top2 = o_trace.topk(2, dim=-1)[0]
         o_margin = (top2[..., 0] - top2[..., 1]).abs()
         # one thread, one clip: first a SHORT clip (6 frames); if that predicts < 40 s for the full clip length (the loop's
@@ -735,7 +750,7 @@ def cpu_baseline(sd, L, clips):
             dt1 = one_thread(L1)
         torch.set_num_threads(best[1])
     return ({"value": round(clips * L / dt, 3), "unit": "frames/s", "cores": best[1], "kind": "port", "cpu": _cpu_model_name(),
-            "host_threads": ncpu,
+            "host_threads": ncpu, "all_physical_cores": all_cores,
             "sample": f"{clips} clips x {L} frames (same model, fp32, oracle/mage_oracle.py mage_generate = the reference's "
                       f"full-recompute AR loop, torch {torch.__version__} CPU ops, {best[1]} of {ncpu} host threads "
                       f"chosen by calibration), {dt:.1f} s",

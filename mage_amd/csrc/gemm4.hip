@@ -481,7 +481,7 @@ int launch4(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
 
 // 1 = launched, 0 = not eligible (the caller falls through to the 8-wave kernels), < 0 = error.
 // Eligible: bf16 plain GEMMs (no gather, rows not regrouped) with a bias and the epilogues y = act(acc + b) or its LayerNorm-consuming form,
-// act = none | QuickGELU, M and N multiples of 256, K a multiple of 128 in [256, 1024], at least two tiles per CU: the decoder's QKV and c_fc
+// act = none | QuickGELU, M and N multiples of 256, K a multiple of 128 in [256, 1024], at least four tiles per CU: the decoder's QKV and c_fc
 // at full-loop sizes (12 of the 24 GEMM launches of a decoder pass, 100 of 187 ms of a cfg2 call).  Measured against the 8-phase kernel
 // (tools/probes/gemm4_probe.hip, same box, interleaved): QKV +11-12 %, c_fc +7-9 %, N = 512 / K = 512 +4 %; K = 2048 with N = 512 is 9 %
 // SLOWER (its A panel is shared by two column tiles only: the loader's HBM latency shows) -- hence the K bound.  The x + Linear(.) kinds
@@ -506,7 +506,9 @@ int mage_gemm4_try(const mage_gemm_desc* d, hipStream_t s) {
         n_cu_dev[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= 8) ? (p.multiProcessorCount & ~7) : 256;
     }
     const int n_cu = n_cu_dev[dev];
-    if ((long)(d->M / 256) * (d->N / 256) < 2L * n_cu) return 0;
+    // at least four tiles per CU: with two (the incremental loop's c_fc at 16 k rows) the prologue's un-overlapped slab pair and the single
+    // tile boundary cost more than the K loop gains (47.5 vs 41 us per launch there): those sizes stay on the lockstep kernel
+    if ((long)(d->M / 256) * (d->N / 256) < 4L * n_cu) return 0;
     const int ldw = d->ldw ? d->ldw : d->K;
     if (((long)d->M + d->a_off) * d->lda * 2 + 16384 >= (1L << 32) || (long)d->N * ldw * 2 + 16384 >= (1L << 32)) return 0;     // 32-bit lane offsets
     if (d->ln_stats) {

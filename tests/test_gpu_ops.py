@@ -668,8 +668,8 @@ def test_table_conv_equals_convolution_of_embeddings_and_folded_linear():
 
 
 @pytest.mark.parametrize("M,N,K,act,ln,f32out", [(65536, 1536, 512, 0, True, False), (32768, 2048, 512, 2, True, False),
-                                                  (65536, 512, 512, 0, False, True), (32768, 1024, 1024, 2, False, False),
-                                                  (32768, 1024, 256, 0, True, True)])
+                                                  (131072, 512, 512, 0, False, True), (65536, 1024, 1024, 2, False, False),
+                                                  (65536, 1024, 256, 0, True, True)])
 def test_gemm_one_wave_per_simd_equals_the_8phase_kernel(M, N, K, act, ln, f32out):
     """csrc/gemm4.hip (QKV / c_fc at full-loop sizes: 4 waves of 128x128 outputs, accumulators in literal AGPRs behind inline asm) against the
     8-phase kernel on the same product (MAGE_GEMM_NO_4W is read on every call): bit-identical outputs -- same MFMA, same k order, same

@@ -608,12 +608,29 @@ def test_graph_replay_is_the_default_for_a_few_clips_per_call():
 
 def test_graph_replay_carries_per_kernel_events():
     """bench.py's roofline needs HIP events around the dominant kernel INSIDE the timed region: under graph replay they are
-    event-record nodes of the captured graph, re-recorded by every replay."""
+    event-record nodes of the captured graph, re-recorded by every replay -- where the runtime has them; where it has not (ROCm 7.2),
+    profiled calls fall back to eager launches (tested in the first branch)."""
     from mage_amd import ops
-    if not ops.graph_events_supported(DEV):
-        pytest.skip("external (event-record-node) events are not supported by this runtime: bench.py then times eagerly")
     m = build_mage(synth.mnist_model_config(frames_length=4), 5, DEV).set_precision("bf16")
     b = dev_batch(synth.synth_batch_mnist(8, 4, seed=5))
+    if not ops.graph_events_supported(DEV):
+        # ROCm 7.2: timing events cannot become event-record nodes.  The documented fallback: a call that wants per-launch events runs
+        # EAGERLY even with graph replay on (so bench.py's roofline events are always real), and replays again once profiling is off
+        try:
+            m.use_graph = True
+            for _ in range(3):
+                m.autoregressive_generate(b)
+            assert m.last_call_mode == "graph"
+            ref_tok = m.last_tokens.clone()
+            ops.PROFILE.reset(enabled=True, only=["layernorm"])
+            m.autoregressive_generate(b)
+            assert m.last_call_mode == "eager" and ops.PROFILE.summary()["layernorm"]["calls"] > 0 and torch.equal(m.last_tokens, ref_tok)
+            ops.PROFILE.reset()
+            m.autoregressive_generate(b)
+            assert m.last_call_mode == "graph" and torch.equal(m.last_tokens, ref_tok)
+        finally:
+            ops.PROFILE.reset()
+        return
     try:
         ops.PROFILE.reset(enabled=True, only=["layernorm"])
         m.autoregressive_generate(b)           # eager, graph off: the number of bracketed launches per call
