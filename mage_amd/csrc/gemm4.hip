@@ -67,13 +67,15 @@ struct Gemm4Args {
 #endif
 
 #ifdef MAGE4_STAMP
-// tuning build: shader-clock stamps of every wave per (workgroup, tile < 32): [0] tile start, [1] K loop done, [2] epilogue done, [3] 100 MHz wall clock at [1]
-__device__ unsigned long long g4_stamps[256 * 32 * 4 * 4];
+// tuning build: shader-clock stamps of every wave per (workgroup, tile < 32): [0] tile start, [1] K loop done, [2] epilogue done, [3] 100 MHz wall clock
+// at [1], [4] 100 MHz wall clock at [0] (shader cycles per wall microsecond over the K loop = the clock the chip actually holds)
+__device__ unsigned long long g4_stamps[256 * 32 * 4 * 8];
 #define G4_STAMP(it, p)                                                                                                   \
     do {                                                                                                                  \
         if (lane == 0 && (it) < 32 && blockIdx.x < 256) {                                                                 \
-            g4_stamps[((blockIdx.x * 32 + (it)) * 4 + wave) * 4 + (p)] = __builtin_readcyclecounter();                    \
-            if ((p) == 1) g4_stamps[((blockIdx.x * 32 + (it)) * 4 + wave) * 4 + 3] = __builtin_amdgcn_s_memrealtime();    \
+            g4_stamps[((blockIdx.x * 32 + (it)) * 4 + wave) * 8 + (p)] = __builtin_readcyclecounter();                    \
+            if ((p) == 1) g4_stamps[((blockIdx.x * 32 + (it)) * 4 + wave) * 8 + 3] = __builtin_amdgcn_s_memrealtime();    \
+            if ((p) == 0) g4_stamps[((blockIdx.x * 32 + (it)) * 4 + wave) * 8 + 4] = __builtin_amdgcn_s_memrealtime();    \
         }                                                                                                                 \
     } while (0)
 #else

@@ -32,6 +32,8 @@ print("epilogue (compute + store issue)           ", st(ep))
 print("first-slab vmcnt(0) wait (store acks, DMA) ", st(wt))
 print("first-slab barrier wait                    ", st(br))
 tot = (t[:, -1, 1] - t[:, 0, 3])
+print(f"shader clock over the K loops (s_memtime ticks per s_memrealtime 10 ns): {100.0 * kl.sum() / (rt[:, 1:, 0] - rt[:, 1:, 3]).sum():.0f} MHz; "
+      f"over whole tile periods: {100.0 * (t[:, -1, 1] - t[:, 0, 3]).sum() / (rt[:, -1, 1] - rt[:, 0, 3]).sum():.0f} MHz")
 print("per-tile period                            ", f"{(tot / (ntile - 1)).mean():.0f}", " kernel span", int(t[:, :, 1].max() - t[:, :, 3].min()))
 # phase spread across workgroups: where in its period each workgroup's epilogue k starts, relative to workgroup 0
 k = ntile // 2

@@ -116,22 +116,23 @@ int main(int argc, char** argv) {
         {
             mage_gemm4_try(&d1, nullptr);
             hipDeviceSynchronize();
-            std::vector<unsigned long long> st4(256 * 32 * 4 * 4);
+            std::vector<unsigned long long> st4(256 * 32 * 4 * 8);
             hipMemcpyFromSymbol(st4.data(), HIP_SYMBOL(g4_stamps), st4.size() * 8);
             const int ntile = (M / 256) * (N / 256) / 256;
-            double kl = 0, ep = 0, gap = 0; int cnt = 0;
+            double kl = 0, ep = 0, gap = 0, rt = 0; int cnt = 0;
             for (int b = 0; b < 256; ++b)
                 for (int t = 1; t < ntile && t < 32; ++t) {
-                    const unsigned long long* q = &st4[((b * 32 + t) * 4 + 0) * 4];
-                    const unsigned long long* qp = &st4[((b * 32 + t - 1) * 4 + 0) * 4];
-                    kl += (double)(q[1] - q[0]); ep += (double)(q[2] - q[1]); gap += (double)(q[0] - qp[2]); ++cnt;
+                    const unsigned long long* q = &st4[((b * 32 + t) * 4 + 0) * 8];
+                    const unsigned long long* qp = &st4[((b * 32 + t - 1) * 4 + 0) * 8];
+                    kl += (double)(q[1] - q[0]); ep += (double)(q[2] - q[1]); gap += (double)(q[0] - qp[2]); rt += (double)(q[3] - q[4]); ++cnt;
                 }
-            printf("   stamps (wave 0, tiles 1..): K loop %.0f cycles, epilogue %.0f, epilogue end -> next tile start %.0f\n", kl / cnt, ep / cnt, gap / cnt);
+            printf("   stamps (wave 0, tiles 1..): K loop %.0f cycles, epilogue %.0f, epilogue end -> next tile start %.0f; shader clock over the K loops %.0f MHz\n",
+                   kl / cnt, ep / cnt, gap / cnt, kl / (rt / 100.0));
             // spread of the K-loop-end wall clock (100 MHz ticks) over the workgroups, per tile round
             for (int t : {1, 4, 8, 16}) {
                 if (t >= ntile) break;
                 unsigned long long lo = ~0ull, hi = 0;
-                for (int b = 0; b < 256; ++b) { const unsigned long long v = st4[((b * 32 + t) * 4 + 0) * 4 + 3]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+                for (int b = 0; b < 256; ++b) { const unsigned long long v = st4[((b * 32 + t) * 4 + 0) * 8 + 3]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
                 printf("   tile round %2d: K-loop-end wall clock spread over the 256 workgroups %.2f us\n", t, (hi - lo) / 100.0);
             }
         }
