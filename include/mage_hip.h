@@ -70,6 +70,11 @@ int mage_check_device_errors(void* stream);
  * of the VQ-VAE (vqvae_model.py:111-214), with BatchNorm(eval), bias, activation, positional
  * tables and the residual add fused into the epilogue.
  *
+ * Kernels behind this entry point (csrc/gemm.hip, csrc/gemm4.hip; chosen from the descriptor, same bits per output element from all of them for
+ * bf16 plain GEMMs): the lockstep persistent kernel (any dtype / gather / epilogue), its 8-phase ping-pong variant (bf16, >= 2 tiles of 256x256
+ * per CU), the one-wave-per-SIMD variant (bf16, bias or LayerNorm-consuming epilogue, K in [256, 1024], >= 4 tiles per CU: the decoder's QKV and
+ * c_fc; MAGE_GEMM_NO_4W=1 disables it), the few-rows kernel (M <= 1024), the padded-taps forms and the split-precision forms.
+ *
  * Row geometry.  A GEMM row m in [0, M) is decoded as img = m / (out_h*out_w),
  * oy = (m / out_w) % out_h, ox = m % out_w.  K = taps_h*taps_w*cin; k -> (ky, kx, ci), ci fastest:
  *     iy = oy*stride + dy0 + ky*dys,   ix = ox*stride + dx0 + kx*dxs      (zero outside [0,in_h)x[0,in_w))
