@@ -312,9 +312,10 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
                 }
             });
             // my reads of this stage are done and my share of the next slab has landed.  FIRST: the next slab's 16 pieces are older than
-            // the previous tile's epilogue traffic (4 or 8 vector loads and >= 32 stores per wave), which may stay in flight
+            // the previous tile's epilogue traffic (4 or 8 vector loads and >= 32 stores per wave), which may stay in flight (the count waited
+            // for is four below that traffic: a margin against any reordering of the epilogue's last stores)
             if constexpr (MAGE4_ABL & 16) __builtin_amdgcn_s_waitcnt(0xC07F);
-            else if constexpr (FIRST) __builtin_amdgcn_s_waitcnt(LN == LN_CONSUME ? 0x8078 : 0x8074);       // vmcnt(40 | 36) lgkmcnt(0)
+            else if constexpr (FIRST) __builtin_amdgcn_s_waitcnt(LN == LN_CONSUME ? 0x8074 : 0x8070);       // vmcnt(36 | 32) lgkmcnt(0): four below the count
             else __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
             ring_barrier();
             __builtin_amdgcn_sched_barrier(0);

@@ -707,3 +707,40 @@ def test_gemm_one_wave_per_simd_equals_the_8phase_kernel(M, N, K, act, ln, f32ou
         want = want * torch.sigmoid(1.702 * want)
     tol = dict(atol=2e-3, rtol=1e-4) if f32out else dict(atol=6e-2, rtol=3e-2)
     torch.testing.assert_close(ys[1][rows.to(DEV)].cpu().double(), want, **tol)
+
+
+def test_gemm_one_wave_per_simd_race_screen_under_memory_load():
+    """The hand-placed schedule of csrc/gemm4.hip orders its LDS-DMA writes and fragment reads by counted waits + ONE barrier per slab; an early
+    read would still pass whenever the DMA happens to land first.  So: 24 launches of the QKV-shaped product while a second stream keeps the HBM
+    busy with large copies (the DMA latency the schedule sees changes from launch to launch), every output compared bit for bit with the
+    8-phase kernel's."""
+    import os
+    o = ops()
+    M, N, K = 65536, 1536, 512
+    a = rnd(M, K, seed=21).bfloat16().to(DEV)
+    w, b = rnd(N, K, seed=22, scale=K ** -0.5).bfloat16().to(DEV), rnd(N, seed=23, scale=0.1).to(DEV)
+    st = torch.stack([0.05 * rnd(M, seed=24), 1.0 + 0.2 * rnd(M, seed=25).abs()], 1).contiguous().to(DEV)
+    cs = (0.3 * rnd(N, seed=26)).to(DEV)
+    kw = dict(M=M, N=N, K=K, lda=K, ldy=N, bias=b, ln_stats=st, ln_colsum=cs)
+    os.environ["MAGE_GEMM_NO_4W"] = "1"
+    try:
+        ref = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        o.gemm(a, w, ref, **kw)
+    finally:
+        os.environ.pop("MAGE_GEMM_NO_4W", None)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    big = torch.empty(1 << 28, device=DEV, dtype=torch.uint8)
+    big2 = torch.empty_like(big)
+    outs = [torch.empty(M, N, device=DEV, dtype=torch.bfloat16) for _ in range(4)]
+    bad = 0
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(rep + 1):                  # a different amount of competing traffic every round
+                big2.copy_(big, non_blocking=True)
+        for y in outs:
+            y.fill_(float("nan"))
+            o.gemm(a, w, y, **kw)
+        torch.cuda.synchronize()
+        bad += sum(int(not torch.equal(y, ref)) for y in outs)
+    assert bad == 0, f"{bad} of 24 launches differ from the 8-phase kernel's output"
