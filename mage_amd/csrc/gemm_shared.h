@@ -200,7 +200,11 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
 #ifdef MAGE_EPI_NO_STORE                               // tuning build: the epilogue's arithmetic and LDS transposition without its global stores
                 asm volatile("" ::"v"(o[i]), "v"(yp));
 #else
+#ifdef MAGE_EPI_PLAIN_STORE                            // tuning build: cached instead of streaming stores (does the Infinity Cache keep the rows?)
+                *(u32x4*)yp = o[i];
+#else
                 __builtin_nontemporal_store(o[i], (u32x4*)yp);
+#endif
 #endif
                 yp += step;
                 if constexpr (LN == LN_PRODUCE && F32) {
