@@ -15,7 +15,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #define MAGE_MAX_DEVICES 16
 void mage_set_error(const char* fmt, ...);
 int mage_device_index();               // current HIP device, or -1 (per-device caches of launch attributes are indexed by it)
-const void* mage_zero_page();          // device pointer, >= 4096 zero bytes; null before mage_init
+const void* mage_zero_page();          // device pointer, 16384 zero bytes (padding source of the gather loads; a zero bias vector of up to 4096
+                                       // columns); null before mage_init
 int* mage_error_word();                // device pointer to the deferred-error word of the current device (mage_check_device_errors)
 enum { MAGE_DEVERR_EMBEDDING_ID = 1, MAGE_DEVERR_CE_TARGET = 2 };
 // raise a deferred error from a kernel: the first one wins, the offending value and the bound are kept for the message

@@ -407,6 +407,8 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
                 for (int b = 0; b < 4; ++b) lnc.s[b] = lns[h][b];
                 if (g.y_dtype == MAGE_F32) epilogue_lean<ACT, float, 4, false, LN>(e, biasm[h], t, m0 + mh * 64, n0 + h * 64, lane, 1, win, 0, &lnc);
                 else epilogue_lean<ACT, unsigned short, 4, false, LN>(e, biasm[h], t, m0 + mh * 64, n0 + h * 64, lane, 1, win, 0, &lnc);
+            } else if constexpr (LN == LN_DUAL || LN == LN_GELUBWD) {
+                epilogue_lean<ACT, unsigned short, 4, false, LN>(e, biasm[h], t, m0 + mh * 64, n0 + h * 64, lane, 1, win, 0);       // bf16 rows (host check)
             } else {
                 if (g.y_dtype == MAGE_F32) epilogue_lean<ACT, float, 4, false, LN>(e, biasm[h], t, m0 + mh * 64, n0 + h * 64, lane, 1, win, 0);
                 else epilogue_lean<ACT, unsigned short, 4, false, LN>(e, biasm[h], t, m0 + mh * 64, n0 + h * 64, lane, 1, win, 0);
@@ -438,7 +440,7 @@ int launch4(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     a.A = d->A;
     a.W = d->W;
     a.Y = d->Y;
-    a.bias = d->bias;
+    a.bias = d->bias ? d->bias : (const float*)mage_zero_page();      // no bias (the data-gradient GEMMs of training): 16 KiB of zeros, N <= 4096
     a.ln_stats = d->ln_stats;
     a.ln_colsum = d->ln_colsum;
     a.residual = d->residual;
@@ -483,7 +485,8 @@ int launch4(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
 }  // namespace
 
 // 1 = launched, 0 = not eligible (the caller falls through to the 8-wave kernels), < 0 = error.
-// Eligible: bf16 plain GEMMs (no gather, rows not regrouped) with a bias and the epilogues y = act(acc + b) or its LayerNorm-consuming form,
+// Eligible: bf16 plain GEMMs (no gather, rows not regrouped) with the epilogues y = act(acc + b) (b optional), its LayerNorm-consuming form, or
+// training's two c_fc forms (pre-activation + activated rows; data gradient times QuickGELU' of the saved rows),
 // act = none | QuickGELU, M and N multiples of 256, K a multiple of 128 in [256, 1024], at least four tiles per CU: the decoder's QKV and c_fc
 // at full-loop sizes (12 of the 24 GEMM launches of a decoder pass, 100 of 187 ms of a cfg2 call).  Measured against the 8-phase kernel
 // (tools/probes/gemm4_probe.hip, same box, interleaved): QKV +11-12 %, c_fc +7-9 %, N = 512 / K = 512 +4 %; K = 2048 with N = 512 is 9 %
@@ -496,9 +499,16 @@ int mage_gemm4_try(const mage_gemm_desc* d, hipStream_t s) {
     if (d->taps_h * d->taps_w != 1 || d->stride != 1 || d->dy0 || d->dx0 || d->in_h != d->out_h || d->in_w != d->out_w || d->a_half) return 0;
     if (d->out_h != 1 || d->out_w < d->M || d->y_mul_x != 1) return 0;                     // plain rows in, plain rows out
     if (d->scale || d->rowadd || d->post_relu || d->res_half) return 0;
-    if (d->residual || d->y2 || d->ln_part || !d->bias) return 0;
+    if (d->residual || d->ln_part || d->rowadd) return 0;
+    if (!d->bias && (d->N > 4096 || d->ln_stats || mage_zero_page() == nullptr)) return 0;
     if ((d->ln_colsum != nullptr) != (d->ln_stats != nullptr)) return 0;
-    if (d->act != MAGE_ACT_NONE && d->act != MAGE_ACT_QUICKGELU) return 0;
+    // training's two c_fc forms: y2 with QuickGELU = pre-activation rows AND activated rows (LN_DUAL); MAGE_ACT_QUICKGELU_GRAD = the data gradient
+    // times QuickGELU'(saved pre-activation rows y2) (LN_GELUBWD); both bf16 rows, no LayerNorm fold
+    const bool dual = d->y2 && d->act == MAGE_ACT_QUICKGELU && !d->ln_stats;
+    const bool gbwd = d->y2 && d->act == MAGE_ACT_QUICKGELU_GRAD && !d->ln_stats;
+    if (d->y2 && !dual && !gbwd) return 0;
+    if ((dual || gbwd) && (d->y_dtype != MAGE_BF16 || d->ldy2 % 8 || (((uintptr_t)d->y2) & 15))) return 0;
+    if (!dual && !gbwd && d->act != MAGE_ACT_NONE && d->act != MAGE_ACT_QUICKGELU) return 0;
     if (d->y_dtype != MAGE_F32 && d->y_dtype != MAGE_BF16) return 0;
     if (d->ldy % 8 || d->lda % 8 || (((uintptr_t)d->bias | (uintptr_t)d->ln_colsum) & 15) || (((uintptr_t)d->ln_stats) & 7)) return 0;
     const int dev = mage_device_index();
@@ -514,6 +524,8 @@ int mage_gemm4_try(const mage_gemm_desc* d, hipStream_t s) {
     if ((long)(d->M / 256) * (d->N / 256) < 4L * n_cu) return 0;
     const int ldw = d->ldw ? d->ldw : d->K;
     if (((long)d->M + d->a_off) * d->lda * 2 + 16384 >= (1L << 32) || (long)d->N * ldw * 2 + 16384 >= (1L << 32)) return 0;     // 32-bit lane offsets
+    if (dual) return launch4<MAGE_ACT_QUICKGELU, EK_BIAS, LN_DUAL, false>(d, s, n_cu);
+    if (gbwd) return launch4<MAGE_ACT_NONE, EK_BIAS, LN_GELUBWD, false>(d, s, n_cu);
     if (d->ln_stats) {
         if (d->act == MAGE_ACT_NONE) return launch4<MAGE_ACT_NONE, EK_BIAS, LN_CONSUME, false>(d, s, n_cu);
         return launch4<MAGE_ACT_QUICKGELU, EK_BIAS, LN_CONSUME, false>(d, s, n_cu);

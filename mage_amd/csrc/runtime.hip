@@ -52,8 +52,8 @@ extern "C" int mage_init(int device) {
     int* flag = nullptr;
     if (e == hipSuccess) e = hipGetDevice(&prev);
     if (e == hipSuccess) e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipMalloc(&zero, 4096);
-    if (e == hipSuccess) e = hipMemset(zero, 0, 4096);
+    if (e == hipSuccess) e = hipMalloc(&zero, 16384);
+    if (e == hipSuccess) e = hipMemset(zero, 0, 16384);
     if (e == hipSuccess) e = hipMalloc((void**)&flag, 16);
     if (e == hipSuccess) e = hipMemset(flag, 0, 16);
     if (e == hipSuccess) e = hipDeviceSynchronize();

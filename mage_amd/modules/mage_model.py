@@ -1363,12 +1363,13 @@ class MAGE(nn.Module):
             # each position once, temporal K,V cached; bit-identical tokens to the reference loop below
             st = self.generate_model._inc_begin(B, R, R, images.device)
             prev = tok0.contiguous()
-            for i in range(Lm1):
+            gen_t = torch.empty(Lm1, B, hw, device=images.device, dtype=torch.int64)         # frame-major: a frame's tokens are contiguous,
+            for i in range(Lm1):                                                              # the argmax writes them where the next step reads them
                 feats = self._frame_source(prev, dt)                                          # newest frame only
                 step_logits = self.generate_model._inc_step(st, ma_dt if i == 0 else None, feats)
-                prev = torch.empty(B, hw, device=images.device, dtype=torch.int64)
+                prev = gen_t[i]
                 ops.argmax(step_logits, prev, rows=B * hw, K=K)
-                gen[:, i] = prev.view(B, R, R)                                                # index plumbing
+            gen = gen_t.permute(1, 0, 2).reshape(B, Lm1, R, R) if B == 1 else gen_t.permute(1, 0, 2).contiguous().view(B, Lm1, R, R)   # index plumbing, once
             self.last_tokens, self.last_logits = gen, None
             video = self.first_stage_decode(gen)
             return torch.cat([images[:, 0:1].to(video.dtype), video], 1)

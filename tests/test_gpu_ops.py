@@ -744,3 +744,36 @@ def test_gemm_one_wave_per_simd_race_screen_under_memory_load():
         torch.cuda.synchronize()
         bad += sum(int(not torch.equal(y, ref)) for y in outs)
     assert bad == 0, f"{bad} of 24 launches differ from the 8-phase kernel's output"
+
+
+def test_gemm_one_wave_per_simd_training_forms_equal_the_8phase_kernel():
+    """The forms the training path sends to csrc/gemm4.hip: no bias (data-gradient GEMMs), c_fc with pre-activation AND activated rows (y2 with
+    QuickGELU), the data gradient times QuickGELU'(saved rows) (MAGE_ACT_QUICKGELU_GRAD): bit-identical to the 8-phase kernel's outputs."""
+    import os
+    o = ops()
+    M, N, K = 65536, 1024, 512
+    a = rnd(M, K, seed=31).bfloat16().to(DEV)
+    w, b = rnd(N, K, seed=32, scale=K ** -0.5).bfloat16().to(DEV), rnd(N, seed=33, scale=0.1).to(DEV)
+    pre_saved = (1.5 * rnd(M, N, seed=34)).bfloat16().to(DEV)
+
+    def run(form):
+        y = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        y2 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        if form == "nobias":
+            o.gemm(a, w, y, M=M, N=N, K=K, lda=K, ldy=N)
+            return (y,)
+        if form == "dual":
+            o.gemm(a, w, y, M=M, N=N, K=K, lda=K, ldy=N, bias=b, act=o.ACT_QUICKGELU, y2=y2, ldy2=N)
+            return (y, y2)
+        o.gemm(a, w, y, M=M, N=N, K=K, lda=K, ldy=N, act=o.ACT_QUICKGELU_GRAD, y2=pre_saved, ldy2=N)
+        return (y,)
+    for form in ("nobias", "dual", "gelu_grad"):
+        os.environ["MAGE_GEMM_NO_4W"] = "1"
+        try:
+            ref = run(form)
+        finally:
+            os.environ.pop("MAGE_GEMM_NO_4W", None)
+        got = run(form)
+        torch.cuda.synchronize()
+        for r, g_ in zip(ref, got):
+            assert not torch.isnan(g_.float()).any() and torch.equal(r, g_), form
