@@ -484,6 +484,224 @@ int launch4(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
 
 }  // namespace
 
+namespace {
+
+// ======================================================================================================================================
+// gemm_tn4_kernel: the weight-gradient GEMM  P[s][n][k] = sum over the tokens t of slice s of dY[t][n] X[t][k]  (gemm_tn.hip, mage_gemm_tn) on the
+// one-wave-per-SIMD schedule: 4 waves x 128 (dY columns) x 128 (X columns), the accumulator file behind inline-asm MFMAs, ONE barrier per
+// 64-token slab at the 3/4 point, the loads placed between the MFMAs.  LDS image, transposing fragment reads (ds_read_b64_tr_b16), operand
+// roles and the order of the MFMAs per accumulator are gemm_tn_kernel's: the same bits in every partial sum (and in the bias-gradient column
+// sums, which the first column of waves of the first X tile takes from the dY fragments with v_dot2_f32_bf16 as before).
+struct Tn4Args {
+    const unsigned short* A;   // dY [T, lda]
+    const unsigned short* B;   // X  [T, ldb]
+    float* P;                  // [n_split][N][K]
+    float* DB;                 // [n_split][N] or null
+    long lda, ldb, T, tps;
+    int N, K, n_split, ntk;
+};
+typedef short g4_tr4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ g4_tr4 g4_lds_tr(const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) g4_tr4*)p); }
+
+template <bool DB>
+__global__ __launch_bounds__(256) void gemm_tn4_kernel(const Tn4Args g) {
+    constexpr int PART = 32768, STAGE = 2 * PART;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    g4_claim_accumulators();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x / g.n_split, s = blockIdx.x - tile * g.n_split;
+    const int tm = tile / g.ntk, tk = tile - tm * g.ntk;
+    const long t_begin = (long)s * g.tps;
+    const long t_end = t_begin + g.tps < g.T ? t_begin + g.tps : g.T;
+    const int nslab = (int)((t_end - t_begin) >> 6);                 // whole slabs only (host: T % 64 == 0), >= 2 (host)
+    // ---- loader: wave w moves the 8 token blocks of column strip w (64 columns) of each operand per slab: units w*8 + u
+    const int rr = lane >> 3, pc = lane & 7;
+    unsigned voffA[8], voffB[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int col_in_strip = (((pc >> 1) ^ (rr & 3) ^ (u & 1)) << 4) + ((pc & 1) << 3);
+        voffA[u] = (unsigned)(((long)(u * 8 + rr) * g.lda + wave * 64 + col_in_strip) * 2 + 8192 - u * 1024);
+        voffB[u] = (unsigned)(((long)(u * 8 + rr) * g.ldb + wave * 64 + col_in_strip) * 2 + 8192 - u * 1024);
+    }
+    const char* a_src = (const char*)(g.A + t_begin * g.lda + (long)tm * 256) - 4096;
+    const char* b_src = (const char*)(g.B + t_begin * g.ldb + (long)tk * 256) - 4096;
+    const long da = 64 * g.lda * 2, db_ = 64 * g.ldb * 2;
+    int a_slab = 0, b_slab = 0;                                       // slab index the cursors point at (they stop at the last slab)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 8192 + 4096;
+    auto dma_m0 = [&](unsigned lds_group) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds0 + lds_group) : "memory");
+    };
+    auto a_advance = [&]() __attribute__((always_inline)) {
+        const bool more = a_slab + 1 < nslab;
+        a_src = more ? a_src + da : a_src;
+        a_slab = more ? a_slab + 1 : a_slab;
+    };
+    auto b_advance = [&]() __attribute__((always_inline)) {
+        const bool more = b_slab + 1 < nslab;
+        b_src = more ? b_src + db_ : b_src;
+        b_slab = more ? b_slab + 1 : b_slab;
+    };
+    // ---- compute state
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i15 = lane & 15, grp = lane >> 4;
+    const int lane_off = grp * 1024 + (i15 >> 2) * 128 + (i15 & 3) * 8;
+    const int sw = (i15 >> 2) ^ (grp & 1);
+    g4_tr4 bfh[2][8][2], afh[2][4][2];                 // fragment halves: [buffer][16-column block][tokens 0-3 | 4-7 of the lane group's 8]
+    auto rd_b = [&](int buf, int stage, int t, int nt, int h) __attribute__((always_inline)) {       // X columns wn*128 + nt*16
+        bfh[buf][nt][h] = g4_lds_tr(smem + stage * STAGE + PART + ((wn * 2 + (nt >> 2)) * 8 + t * 4) * 1024 + lane_off + (((nt & 3) ^ sw) << 5) + h * 512);
+    };
+    auto rd_a = [&](int buf, int stage, int t, int mt, int h) __attribute__((always_inline)) {       // dY columns wm*128 + mt*16
+        afh[buf][mt & 3][h] = g4_lds_tr(smem + stage * STAGE + ((wm * 2 + (mt >> 2)) * 8 + t * 4) * 1024 + lane_off + (((mt & 3) ^ sw) << 5) + h * 512);
+    };
+    auto frag = [](const g4_tr4 (&h)[2]) __attribute__((always_inline)) {
+        return __builtin_bit_cast(u32x4, __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
+    const bf16x2v ones2 = {(__bf16)1.0f, (__bf16)1.0f};
+    [[maybe_unused]] float dbs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] auto db_acc = [&](int mt, const g4_tr4 (&h)[2]) __attribute__((always_inline)) {       // column sums of dY from its fragments (gemm_tn_kernel's order)
+        const uint2 w0 = __builtin_bit_cast(uint2, h[0]), w1 = __builtin_bit_cast(uint2, h[1]);
+        float d = dbs[mt];
+        d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, w0.x), ones2, d, false);
+        d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, w0.y), ones2, d, false);
+        d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, w1.x), ones2, d, false);
+        d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, w1.y), ones2, d, false);
+        dbs[mt] = d;
+    };
+
+    // prologue: slabs 0 and 1 complete, slab 0's first fragments in registers
+    dma_m0(0);
+    g4_for<8>([&](auto u_) { g4_dma<decltype(u_)::value>(voffA[decltype(u_)::value], a_src); });
+    dma_m0(PART);
+    g4_for<8>([&](auto u_) { g4_dma<decltype(u_)::value>(voffB[decltype(u_)::value], b_src); });
+    a_advance();
+    b_advance();
+    dma_m0(STAGE);
+    g4_for<8>([&](auto u_) { g4_dma<decltype(u_)::value>(voffA[decltype(u_)::value], a_src); });
+    dma_m0(STAGE + PART);
+    g4_for<8>([&](auto u_) { g4_dma<decltype(u_)::value>(voffB[decltype(u_)::value], b_src); });
+    a_advance();
+    b_advance();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    ring_barrier();
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) { rd_b(0, 0, 0, nt, 0); rd_b(0, 0, 0, nt, 1); }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { rd_a(0, 0, 0, m, 0); rd_a(0, 0, 0, m, 1); }
+
+    // one slab (stage S); accumulator block of (mt, nt) = mt*8 + nt.  Quarters as in gemm4_kernel: (t0, mt 0-3) (t0, mt 4-7) (t1, mt 0-3) | barrier |
+    // (t1, mt 4-7); 8 / 24 / 8 / 24 transposing 8-byte fragment reads and the 16 LDS-DMA pieces between the MFMAs
+    auto slab = [&](auto S_, auto FIRST_) __attribute__((always_inline)) {
+        constexpr int S = decltype(S_)::value;
+        constexpr bool FIRST = decltype(FIRST_)::value;
+        // ---- Q0: (t0, mt 0-3) from bfh[0], afh[0]; reads dY(t0, mt 4-7) -> afh[1]; X pieces of slab j+1... (sent one slab ahead: see below)
+        g4_for<32>([&](auto i_) {
+            constexpr int i = decltype(i_)::value, m = i >> 3, nt = i & 7;
+            g4_mfma<m * 8 + nt, FIRST, i == 0>(frag(bfh[0][nt]), frag(afh[0][m]));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i < 8) {
+                rd_a(1, S, 0, 4 + (i >> 1), i & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (DB && nt == 7) {
+                db_acc(m, afh[0][m]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (!FIRST && i == 8) {
+                dma_m0((S ^ 1) * STAGE + PART);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (!FIRST && i > 8 && (i & 1) == 1 && i < 25) {
+                g4_dma<((i - 9) >> 1)>(voffB[(i - 9) >> 1], b_src);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        if constexpr (!FIRST) b_advance();
+        // ---- Q1: (t0, mt 4-7) from bfh[0], afh[1]; reads dY(t1, mt 0-3) -> afh[0], X(t1) -> bfh[1]
+        g4_for<32>([&](auto i_) {
+            constexpr int i = decltype(i_)::value, m = i >> 3, nt = i & 7;
+            g4_mfma<(4 + m) * 8 + nt, FIRST, i == 0>(frag(bfh[0][nt]), frag(afh[1][m]));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i < 24) {
+                if constexpr (i < 8) rd_a(0, S, 1, i >> 1, i & 1);
+                else rd_b(1, S, 1, (i - 8) >> 1, i & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (DB && nt == 7) {
+                db_acc(4 + m, afh[1][m]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        // ---- Q2: (t1, mt 0-3) from bfh[1], afh[0]; reads dY(t1, mt 4-7) -> afh[1]
+        g4_for<32>([&](auto i_) {
+            constexpr int i = decltype(i_)::value, m = i >> 3, nt = i & 7;
+            g4_mfma<m * 8 + nt, false, i == 0>(frag(bfh[1][nt]), frag(afh[0][m]));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i < 8) {
+                rd_a(1, S, 1, 4 + (i >> 1), i & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (DB && nt == 7) {
+                db_acc(m, afh[0][m]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0) lgkmcnt(0)
+        ring_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- Q3: (t1, mt 4-7) from bfh[1], afh[1]; next slab's first fragments from the other stage; dY pieces of slab j+2 -> this stage
+        g4_for<32>([&](auto i_) {
+            constexpr int i = decltype(i_)::value, m = i >> 3, nt = i & 7;
+            g4_mfma<(4 + m) * 8 + nt, false, i == 0>(frag(bfh[1][nt]), frag(afh[1][m]));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i < 24) {
+                if constexpr (i < 8) rd_a(0, S ^ 1, 0, i >> 1, i & 1);
+                else rd_b(0, S ^ 1, 0, (i - 8) >> 1, i & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (DB && nt == 7) {
+                db_acc(4 + m, afh[1][m]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (i == 24) {
+                dma_m0(S * STAGE);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        g4_for<8>([&](auto u_) { g4_dma<decltype(u_)::value>(voffA[decltype(u_)::value], a_src); });
+        __builtin_amdgcn_sched_barrier(0);
+        a_advance();
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    slab(S0{}, std::true_type{});
+    int j = 1;
+    for (; j + 1 < nslab; j += 2) {
+        slab(S1{}, std::false_type{});
+        slab(S0{}, std::false_type{});
+    }
+    if (j < nslab) slab(S1{}, std::false_type{});
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    // ---- epilogue: lane (i, grp) of block (mt, nt) holds row (dY column) mt*16 + i, columns (X columns) nt*16 + grp*4 + {0..3}
+    float* out = g.P + ((long)s * g.N + (long)tm * 256 + wm * 128) * g.K + (long)tk * 256 + wn * 128;
+    g4_for<64>([&](auto q_) {
+        constexpr int q = decltype(q_)::value, mt = q >> 3, nt = q & 7;
+        *(f32x4*)(out + (long)(mt * 16 + i15) * g.K + nt * 16 + grp * 4) = g4_acc_read<q, (q & 15) == 0>();
+    });
+    if constexpr (DB) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            float v = dbs[mt];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (grp == 0) g.DB[(long)s * g.N + (long)tm * 256 + wm * 128 + mt * 16 + i15] = v;
+        }
+    }
+}
+
+}  // namespace
+
 // 1 = launched, 0 = not eligible (the caller falls through to the 8-wave kernels), < 0 = error.
 // Eligible: bf16 plain GEMMs (no gather, rows not regrouped) with the epilogues y = act(acc + b) (b optional), its LayerNorm-consuming form, or
 // training's two c_fc forms (pre-activation + activated rows; data gradient times QuickGELU' of the saved rows),
@@ -532,4 +750,38 @@ int mage_gemm4_try(const mage_gemm_desc* d, hipStream_t s) {
     }
     if (d->act == MAGE_ACT_NONE) return launch4<MAGE_ACT_NONE, EK_BIAS, LN_NONE, false>(d, s, n_cu);
     return launch4<MAGE_ACT_QUICKGELU, EK_BIAS, LN_NONE, false>(d, s, n_cu);
+}
+
+// mage_gemm_tn on the one-wave-per-SIMD schedule: 1 = launched, 0 = not eligible (gemm_tn.hip then runs its 8-wave kernel)
+int mage_gemm_tn4_try(const void* dY, int64_t lda, const void* X, int64_t ldb, int64_t T, int32_t N, int32_t K, int32_t n_split, int64_t tps,
+                      float* partials, float* db_partials, hipStream_t stream) {
+    if (getenv("MAGE_GEMM_NO_4W")) return 0;
+    if (T % 64 || tps % 64 || tps < 128 || (T - (int64_t)(n_split - 1) * tps) < 128) return 0;          // whole slabs, at least two per slice
+    if (lda * 2 * 64 + 16384 >= (1L << 31) || ldb * 2 * 64 + 16384 >= (1L << 31)) return 0;              // 32-bit lane offsets inside a slab
+    const int dev = mage_device_index();
+    if (dev < 0) return 0;
+    static bool attr[MAGE_MAX_DEVICES] = {false};
+    if (!attr[dev]) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_tn4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr[dev] = true;
+    }
+    Tn4Args a;
+    a.A = (const unsigned short*)dY;
+    a.B = (const unsigned short*)X;
+    a.P = partials;
+    a.DB = db_partials;
+    a.lda = lda;
+    a.ldb = ldb;
+    a.T = T;
+    a.tps = tps;
+    a.N = N;
+    a.K = K;
+    a.n_split = n_split;
+    a.ntk = K / 256;
+    const long grid = (long)(N / 256) * (K / 256) * n_split;
+    if (db_partials) hipLaunchKernelGGL(gemm_tn4_kernel<true>, dim3((unsigned)grid), dim3(256), 128 * 1024, stream, a);
+    else hipLaunchKernelGGL(gemm_tn4_kernel<false>, dim3((unsigned)grid), dim3(256), 128 * 1024, stream, a);
+    MAGE_CHECK_LAUNCH("mage_gemm_tn");
+    return 1;
 }

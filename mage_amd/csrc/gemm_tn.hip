@@ -17,6 +17,9 @@
 
 #include "common.h"
 
+int mage_gemm_tn4_try(const void* dY, int64_t lda, const void* X, int64_t ldb, int64_t T, int32_t N, int32_t K, int32_t n_split, int64_t tps,
+                      float* partials, float* db_partials, hipStream_t stream);      // gemm4.hip: the one-wave-per-SIMD form of this kernel
+
 namespace {
 
 struct TnArgs {
@@ -209,6 +212,8 @@ extern "C" int mage_gemm_tn(const void* dY, int64_t lda, const void* X, int64_t 
                    "mage_gemm_tn: n_split slices of tokens_per_split (a multiple of 64) tokens must cover T");
     MAGE_CHECK_ARG(((((uintptr_t)dY | (uintptr_t)X | (uintptr_t)partials)) & 15) == 0, "mage_gemm_tn: operands must be 16-byte aligned");
     MAGE_CHECK_ARG(mage_zero_page() != nullptr, "mage_gemm_tn: mage_init() has not been called");
+    if (const int r = mage_gemm_tn4_try(dY, lda, X, ldb, T, N, K, n_split, tokens_per_split, partials, db_partials, (hipStream_t)stream))
+        return r < 0 ? r : MAGE_OK;
     static bool attr[MAGE_MAX_DEVICES] = {false};
     const int dev = mage_device_index();
     MAGE_CHECK_ARG(dev >= 0, "mage_gemm_tn: no current device");

@@ -525,7 +525,8 @@ def test_bf16_training_folds_equal_the_separate_passes(monkeypatch):
     assert set(g1) == set(g0) and min(cos.values()) > 0.999
 
 
-@pytest.mark.parametrize("T,N,K,ld_dy,ld_x", [(4096, 256, 256, 256, 256), (5000, 512, 256, 512, 256), (16384, 512, 2048, 1536, 2048), (70000, 1536, 512, 1536, 512)])
+@pytest.mark.parametrize("T,N,K,ld_dy,ld_x", [(4096, 256, 256, 256, 256), (5000, 512, 256, 512, 256), (16384, 512, 2048, 1536, 2048), (70000, 1536, 512, 1536, 512),
+                                               (262144, 1536, 512, 1536, 512), (65536, 512, 2048, 512, 2048), (8192, 256, 512, 256, 512)])
 def test_gemm_tn_weight_gradient_against_fp64(T, N, K, ld_dy, ld_x):
     """mage_gemm_tn: dW = dY^T X from row-major bf16 operands through the transposing LDS load (no transposed copies), token slices +
     fixed-order partial sums, and the column sums of dY (bias gradient); ragged token counts, strided operands (a column slice of a wider
@@ -544,6 +545,17 @@ def test_gemm_tn_weight_gradient_against_fp64(T, N, K, ld_dy, ld_x):
     assert (db.double() - want_b).abs().max().item() < 1e-4 * want_b.abs().max().item() + 1e-3
     dW2, db2 = o.gemm_tn(dy, x_full, T=T, N=N, K=K, ld_dy=ld_dy, ld_x=ld_x)
     assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    # whole 64-token slabs run on the one-wave-per-SIMD form (csrc/gemm4.hip, gemm_tn4_kernel): same LDS image, same MFMA order per
+    # accumulator, same dot2 order for the bias gradient -> the same bits as the 8-wave kernel (MAGE_GEMM_NO_4W is read on every call)
+    import os
+    os.environ["MAGE_GEMM_NO_4W"] = "1"
+    try:
+        dW8, db8 = o.gemm_tn(dy, x_full, T=T, N=N, K=K, ld_dy=ld_dy, ld_x=ld_x)
+        dW8n, _ = o.gemm_tn(dy, x_full, T=T, N=N, K=K, ld_dy=ld_dy, ld_x=ld_x, want_bias=False)
+    finally:
+        os.environ.pop("MAGE_GEMM_NO_4W", None)
+    dWn, _ = o.gemm_tn(dy, x_full, T=T, N=N, K=K, ld_dy=ld_dy, ld_x=ld_x, want_bias=False)
+    assert torch.equal(dW, dW8) and torch.equal(db, db8) and torch.equal(dWn, dW8n) and torch.equal(dWn, dW)
     cs = o.colsum(dy, T=T, C_=N, ld=ld_dy)
     assert (cs.double() - want_b).abs().max().item() < 1e-4 * want_b.abs().max().item() + 1e-3
 
