@@ -725,6 +725,10 @@ int mage_gemm4_try(const mage_gemm_desc* d, hipStream_t s) {
     const bool dual = d->y2 && d->act == MAGE_ACT_QUICKGELU && !d->ln_stats;
     const bool gbwd = d->y2 && d->act == MAGE_ACT_QUICKGELU_GRAD && !d->ln_stats;
     if (d->y2 && !dual && !gbwd) return 0;
+    // measured in the training step (rocprofv3, same box): the data-gradient form 736 us per launch on the 8-phase kernel, 840 here (its saved
+    // rows are requested inside the epilogue: two waves per SIMD hide that round trip, one does not); the two-output form 787 vs 794.  Both
+    // stay on the 8-phase kernel unless MAGE_GEMM4_TRAIN_FORMS=1 asks for them here (the instantiations are kept: tests compare the bits)
+    if ((dual || gbwd) && !getenv("MAGE_GEMM4_TRAIN_FORMS")) return 0;
     if ((dual || gbwd) && (d->y_dtype != MAGE_BF16 || d->ldy2 % 8 || (((uintptr_t)d->y2) & 15))) return 0;
     if (!dual && !gbwd && d->act != MAGE_ACT_NONE && d->act != MAGE_ACT_QUICKGELU) return 0;
     if (d->y_dtype != MAGE_F32 && d->y_dtype != MAGE_BF16) return 0;

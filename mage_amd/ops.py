@@ -303,7 +303,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
         if (d.dtype == BF16 and not gather and n_split <= 1 and M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and 256 <= K <= 1024
                 and out_h == 1 and out_w >= M and y_mul_x == 1 and ek == 0 and not res_half and ln_part is None
                 and (bias is not None or (N <= 4096 and ln_stats is None)) and (ln_stats is None) == (ln_colsum is None)
-                and (act in (ACT_NONE, ACT_QUICKGELU) if y2 is None else (ln in (3, 4) and y.dtype == torch.bfloat16 and ldy2 % 8 == 0))
+                and (act in (ACT_NONE, ACT_QUICKGELU) if y2 is None else (ln in (3, 4) and y.dtype == torch.bfloat16 and ldy2 % 8 == 0
+                                                                          and bool(os.environ.get("MAGE_GEMM4_TRAIN_FORMS"))))
                 and lda % 8 == 0 and ldy % 8 == 0 and (M // 256) * (N // 256) >= 4 * n_cu and not os.environ.get("MAGE_GEMM_NO_4W")):
             key = f"gemm4_kernel<{act_k}, 0, {ln}, false>"
         if PROFILE.wants(key):
