@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MAGE_ABI_VERSION 4
+#define MAGE_ABI_VERSION 5
 
 /* MAGE_BF16X3 / MAGE_F16X3: SPLIT-PRECISION operands -- the fast parity mode.  A logical fp32 matrix [rows, C] (C % 64 == 0, base
  * 256-byte aligned) is stored as two 16-bit pieces per element, x ~ hi + lo, per row as 64-column slabs [hi(64) | lo(64)] (so a row
@@ -155,6 +155,12 @@ typedef struct mage_gemm_desc {
     float ln_eps;                      /* consumer with ln_stats null and ln_part set: the epilogue takes (mean, rstd) of its rows straight from
                                         * the producer's partial sums (mage_ln_stats' arithmetic, eps = ln_eps; K / 64 slices per row) -- no
                                         * mage_ln_stats launch in between.  Few-rows GEMMs only: ask mage_gemm_is_small first */
+    const void* head_w;                /* bf16 padded-taps form with N == 256 (one column tile holds whole rows), bias, ReLU: a second, narrow Linear
+                                        * taken on the tile before it leaves the CU.  head_w is bf16 [16][N]; the rows y = relu(acc + bias), rounded
+                                        * to bf16 as a store would round them, are NOT written; Y (y_dtype MAGE_F32, ldy >= 16 floats) receives
+                                        *     Y[yrow][t] = sum_n y[n] * head_w[t][n],  t = 0..15      (fp32 sums, fixed order)
+                                        * -- the 4 x 4 taps of the VQ-VAE's last ConvTranspose2d (vqvae_model.py:187) computed inside the
+                                        * sub-pixel GEMMs of the one before it (:184), whose 4x-resolution activation is then never stored */
 } mage_gemm_desc;
 
 int mage_gemm(const mage_gemm_desc* desc, void* stream);

@@ -671,6 +671,59 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     }
 }
 
+// LN_HEAD epilogue of the 8-phase padded-taps kernel (gemm_shared.h): the tile's rows y = act(acc + bias), rounded to bf16 as a store would
+// round them, never leave the CU; head[row][t] = sum_n y[row][n] head_w[t][n] (t < 16) does.  Wave (wr, wc) holds rows wr*128 + [0,128) x
+// columns wc*64 + [0,64) in the MFMA output layout: lane (l15, grp) has row l15 of each 16-row tile, columns nt*16 + grp*4 + {0..3}.  Packed
+// to bf16, two 16-column blocks (nt = 2t, 2t+1) ARE a B operand of v_mfma_f32_16x16x32_bf16 for row l15 -- 8 values of "k" per lane; which
+// channel sits at which k position only has to agree with the A operand, so the head weights are fetched in that order (hw[t]: tap l15,
+// channels n0 + 32t + {grp*4 + 0..3, 16 + grp*4 + 0..3}).  16 MFMAs per wave and tile give the wave's 64-channel partial sums; the four
+// wave columns are added in the fixed order wc = 0..3 through the staging windows (4 KiB per wave = 64 rows x 16 taps: two halves), each
+// wave finishing 16 of the 64 rows.  All eight waves run this in step (the K loop's half-offset is closed before the epilogue).
+template <int ACT>
+__device__ __forceinline__ void epilogue_head(const mage_gemm_desc& d, const f32x4 (&bias)[4], f32x4 (&acc)[8][4], const u32x4 (&hw)[2],
+                                              int tile_m0, int lane, int wave, int plane, char* stg_all) {
+    const int l15 = lane & 15, grp = lane >> 4, wr = wave >> 2, wc = wave & 3;
+    f32x4 h[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        h[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 v0 = acc[a][2 * t] + bias[2 * t], v1 = acc[a][2 * t + 1] + bias[2 * t + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v0[e] = act_apply<ACT>(v0[e]);
+                v1[e] = act_apply<ACT>(v1[e]);
+            }
+            const u32x4 y = u32x4{pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+            h[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, hw[t]), __builtin_bit_cast(bf16x8, y), h[a], 0, 0, 0);
+        }
+    }
+    // h[a] = taps grp*4 + {0..3} of row a*16 + l15, summed over this wave's 64 channels
+    char* mine = stg_all + wave * 4096;
+    const char* col0 = stg_all + wr * 4 * 4096;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(mine + (i * 16 + l15) * 64 + grp * 16) = h[half * 4 + i];
+        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the partial sums are in LDS before the barrier says so
+        ring_barrier();
+        const int r = wc * 16 + l15;                   // this wave finishes rows [wc*16, wc*16 + 16) of the half
+        f32x4 s = *(const f32x4*)(col0 + r * 64 + grp * 16);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) s += *(const f32x4*)(col0 + w * 4096 + r * 64 + grp * 16);
+        const int m = tile_m0 + wr * 128 + half * 64 + r;
+        const int img = m / plane, rem = m - img * plane;
+        const int oy = rem / d.out_w, ox = rem - oy * d.out_w;
+        const long yrow = (long)img * d.y_img_stride + (long)oy * d.y_mul_y + (long)ox * d.y_mul_x + d.y_off;
+        __builtin_nontemporal_store(s, (f32x4*)((float*)d.Y + yrow * d.ldy + grp * 4));
+        if (half == 0) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);        // the reads of half 0 are done before anyone overwrites a window
+            ring_barrier();
+        }
+    }
+}
+
 // ======================================================================================================================
 // gemm8_kernel: the 8-phase ping-pong variant of the bf16 256x256 plain GEMM with a lean epilogue (the decoder's Linear
 // layers).  Structure after cdna_hip_programming.md "The 256^2 8-phase template": the wave's 128x64 output is four 64x32
@@ -903,6 +956,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
         }
         f32x4 biasm[4];
         [[maybe_unused]] LnConsume lnc;                // LN_CONSUME: requested with the bias vector in the tile's last slab
+        [[maybe_unused]] u32x4 headw[2];               // LN_HEAD: likewise
         [[maybe_unused]] const bool seg_on = c_tile == chunk0 + li + 2 * nwg8;     // probe build: stamp the third tile
         if (wr) ring_barrier();                        // the trailing half drops one barrier behind
         for (int kt = 0; kt < nk; ++kt) {
@@ -1007,6 +1061,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
                         lnc.rstd[a] = st.y;
                     }
                 }
+                if constexpr (LN == LN_HEAD) {         // the head's weight fragments in the packed accumulators' k order (epilogue_head)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const unsigned short* hp = (const unsigned short*)d.head_w + (long)l15 * d.N + n0 + 32 * t + grp * 4;
+                        const uint2 lo = *(const uint2*)hp, hi = *(const uint2*)(hp + 16);
+                        headw[t] = u32x4{lo.x, lo.y, hi.x, hi.y};
+                    }
+                }
             }
             mfma_quadrant(1, 1);
             // phase 4: quadrant (1,0)
@@ -1038,7 +1100,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
         char* stg = smem + 2 * KBUF + wave * 4096;
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));               // keep the epilogue's lane-derived constants out of the K loop's registers
-        if constexpr (LN == LN_CONSUME) {
+        if constexpr (LN == LN_HEAD) {
+            epilogue_head<ACT>(d, biasm, acc, headw, tm * BM, lane_e, wave, plane, smem + 2 * KBUF);
+        } else if constexpr (LN == LN_CONSUME) {
             if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit, &lnc);
             else epilogue_lean<ACT, unsigned short, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit, &lnc);
         } else if constexpr (LN == LN_PRODUCE) {
@@ -1306,13 +1370,13 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
 
 // Padded-taps convolutions on the 8-phase kernel (gemm8_kernel TAPS): eligible shapes only; returns 1 if launched, 0 if not
 // eligible (the caller falls through to the generic gather kernel), < 0 on error.
-template <int ACT, int EK, int SPL = 0>
+template <int ACT, int EK, int SPL = 0, int LN = LN_NONE>
 int launch_taps8(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     const int dev = mage_device_index();
     MAGE_CHECK_ARG(dev >= 0, "mage_gemm: no current device");
     static bool attr[MAGE_MAX_DEVICES] = {false};
     if (!attr[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK, false, true, LN_NONE, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK, false, true, LN, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr[dev] = true;
     }
     GemmArgs a;
@@ -1326,7 +1390,7 @@ int launch_taps8(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     a.stagger_sleeps = 0;
     a.res_rows = 0;
     const int grid = a.ntiles >= n_cu ? n_cu : ((a.ntiles + 7) & ~7);
-    hipLaunchKernelGGL((gemm8_kernel<ACT, EK, false, true, LN_NONE, SPL>), dim3(grid), dim3(512), 160 * 1024, s, a);
+    hipLaunchKernelGGL((gemm8_kernel<ACT, EK, false, true, LN, SPL>), dim3(grid), dim3(512), 160 * 1024, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
     return 1;
 }
@@ -1361,6 +1425,13 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
     const long a_span = (n_img * d->a_img_stride + d->a_off + (long)d->in_h * d->in_w) * d->lda;
     if (a_span * 2 >= (1L << 32) || (long)d->N * (SPL ? d->ldw : d->K) * 2 >= (1L << 32)) return 0;
     if (table && d->act == MAGE_ACT_NONE && (((uintptr_t)d->rowadd) & 15) == 0) return launch_taps8<MAGE_ACT_NONE, EK_RES_INIT, SPL>(d, s, n_cu);
+    if (d->head_w) {
+        // the narrow Linear on the tile's rows (LN_HEAD): one column tile must hold whole rows; refused loudly, the caller asked for a fusion
+        MAGE_CHECK_ARG(SPL == 0 && plain && d->act == MAGE_ACT_RELU && d->N == 256 && d->y_dtype == MAGE_F32 && d->ldy >= 16 && d->ldy % 4 == 0
+                           && d->bias && (((uintptr_t)d->head_w) & 7) == 0 && (((uintptr_t)d->Y) & 15) == 0,
+                       "mage_gemm: head_w takes the bf16 padded-taps form with N = 256, bias, ReLU, fp32 [row][ldy >= 16] output");
+        if constexpr (SPL == 0) return launch_taps8<MAGE_ACT_RELU, EK_BIAS, 0, LN_HEAD>(d, s, n_cu);
+    }
     if constexpr (SPL == 0) {
         if (plain && d->act == MAGE_ACT_NONE) return launch_taps8<MAGE_ACT_NONE, EK_BIAS>(d, s, n_cu);
         if (plain && d->act == MAGE_ACT_RELU) return launch_taps8<MAGE_ACT_RELU, EK_BIAS>(d, s, n_cu);
@@ -1627,6 +1698,7 @@ extern "C" int mage_gemm(const mage_gemm_desc* d_in, void* stream) {
                    "mage_gemm: res_half needs a residual and an even out_h x out_w output plane");
     if (spl) {
         const bool tapsform = gather_ || d->rowadd;
+        MAGE_CHECK_ARG(!d->head_w, "mage_gemm: head_w is a fusion of the bf16 padded-taps form");
         if (tapsform) {
             const int r = d->dtype == MAGE_BF16X3 ? try_taps8<1>(d, s) : try_taps8<2>(d, s);
             if (r) return r < 0 ? r : MAGE_OK;
@@ -1636,6 +1708,7 @@ extern "C" int mage_gemm(const mage_gemm_desc* d_in, void* stream) {
         return d->dtype == MAGE_BF16X3 ? launch_spl<1>(d, s) : launch_spl<2>(d, s);
     }
     if (const int r = try_taps8(d, s)) return r < 0 ? r : MAGE_OK;
+    MAGE_CHECK_ARG(!d->head_w, "mage_gemm: head_w is a fusion of the bf16 padded-taps form; this geometry does not run there");
     if (const int r = mage_gemm4_try(d, s)) return r < 0 ? r : MAGE_OK;          // the one-wave-per-SIMD kernel (gemm4.hip): QKV / c_fc at full-loop sizes
     const bool gather = d->taps_h * d->taps_w > 1 || d->stride != 1 || d->dy0 != 0 || d->dx0 != 0 || d->in_h != d->out_h ||
                         d->in_w != d->out_w || d->a_half;

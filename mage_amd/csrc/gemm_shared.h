@@ -58,7 +58,11 @@ struct LnConsume {
 // them), y2 = QuickGELU(y) (the next Linear's operand): the forward activation pass (read 2 B + write 2 B per element) is gone.
 // LN_GELUBWD (training, the data-gradient GEMM of c_proj): y = acc * QuickGELU'(aux), aux = the saved pre-activation rows (desc.y2, read
 // here): the activation-backward pass (read 2 x 2 B + write 2 B per element) is gone; the product is taken on the fp32 accumulators.
-enum { LN_NONE = 0, LN_PRODUCE = 1, LN_CONSUME = 2, LN_DUAL = 3, LN_GELUBWD = 4 };
+// LN_HEAD (8-phase padded-taps kernel only, N = 256 = one column tile; desc.head_w): the rows y = act(acc + bias) are NOT stored.  The tile holds
+// whole rows, so the narrow Linear that follows (16 outputs per row: the 4 x 4 taps of the VQ-VAE's last transposed convolution,
+// vqvae_model.py:187) is taken on the bf16-rounded rows where they are: an MFMA whose B operand IS the packed accumulator layout (with a
+// k-permuted weight fragment), a fixed-order sum over the four wave columns through LDS, fp32 [row][16] out (gemm.hip: epilogue_head).
+enum { LN_NONE = 0, LN_PRODUCE = 1, LN_CONSUME = 2, LN_DUAL = 3, LN_GELUBWD = 4, LN_HEAD = 5 };
 
 // OSPL (1 = bf16 pieces, 2 = f16 pieces; OT = float): the fp32 result leaves as a SPLIT row (common.h): a wave's 64 columns are one
 // K slab of the consumer, [hi(64) | lo(64)] = the same 256 contiguous bytes per row as 64 fp32 values, so only the staging write differs.

@@ -584,15 +584,20 @@ class VectorQuantizedVAE(nn.Module):
                              act=ops.ACT_RELU, **win)
                 ops.gemm(t, w[rp + ".w1.bf16"], pads[i + 1], M=N * hw, N=dim, K=dim, lda=dim, ldy=dim, bias=w[rp + ".b1"], scale=w[rp + ".s1"],
                          shift=w[rp + ".t1"], residual=pads[i], ldr=dim, post_relu=True, **inner)                # decoder[2] ReLU folded
-            up = torch.empty(N * 4 * hw, dim, device=dev, dtype=dt)
-            for py in range(2):
-                for px in range(2):
-                    ops.gemm(pads[2], w[f"d3.w{py}{px}f.bf16"], up, M=N * hw, N=dim, K=4 * dim, lda=dim, ldy=dim, taps_h=2, taps_w=2,
-                             a_off=py * Pw + px, y_img_stride=4 * hw, y_mul_y=4 * wd, y_mul_x=2, y_off=py * 2 * wd + px, bias=w["d3.bf"],
-                             act=ops.ACT_RELU, **win)
             nt = 16 * self.input_dim
             taps = torch.empty(N * 4 * hw, nt, device=dev, dtype=torch.float32)
-            ops.gemm(up, w["d6.w16" + s], taps, M=N * 4 * hw, N=nt, K=dim, lda=dim, ldy=nt)
+            # one output channel and dim == 256 (one column tile of the GEMM holds whole rows): the last transposed convolution's 4 x 4 taps
+            # are taken on the sub-pixel GEMMs' tiles before they leave the CU (mage_gemm_desc::head_w) -- the 4x-resolution activation
+            # `up` (0.5 GB per 960 frames, written once and read once) and the head GEMM's launch are gone
+            head = nt == 16 and dim == 256 and not os.environ.get("MAGE_DECODE_NO_HEAD_FUSION")
+            up = None if head else torch.empty(N * 4 * hw, dim, device=dev, dtype=dt)
+            for py in range(2):
+                for px in range(2):
+                    ops.gemm(pads[2], w[f"d3.w{py}{px}f.bf16"], taps if head else up, M=N * hw, N=dim, K=4 * dim, lda=dim, ldy=nt if head else dim,
+                             taps_h=2, taps_w=2, a_off=py * Pw + px, y_img_stride=4 * hw, y_mul_y=4 * wd, y_mul_x=2, y_off=py * 2 * wd + px,
+                             bias=w["d3.bf"], act=ops.ACT_RELU, head_w=w["d6.w16" + s] if head else None, **win)
+            if not head:
+                ops.gemm(up, w["d6.w16" + s], taps, M=N * 4 * hw, N=nt, K=dim, lda=dim, ldy=nt)
             ops.convt_fold_tanh(taps, w["d6.b"], out, N=N, IH=2 * h, IW=2 * wd, cout=self.input_dim)
             return
         if self.down_ratio == 4:

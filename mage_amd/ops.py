@@ -203,14 +203,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
          residual=None, ldr: int = 0, post_relu: bool = False, ldw: int = 0, n_split: int = 1, a_split_stride: int = 0,
          w_split_stride: int = 0, y_split_stride: int = 0, y2=None, ldy2: int = 0, ln_part=None, ln_stats=None,
          ln_colsum=None, res_half: bool = False, a_half: bool = False, split_kind: int = 0, y_split: bool = False,
-         ln_eps: float = 0.0) -> torch.Tensor:
+         ln_eps: float = 0.0, head_w=None) -> torch.Tensor:
     """Y = epilogue(A (*) W^T); see mage_gemm in include/mage_hip.h for the geometry fields.
-    split_kind BF16X3 / F16X3: a and w are split-precision tensors (lda / ldw in 16-bit elements); y_split: so is y (ldy likewise)."""
+    split_kind BF16X3 / F16X3: a and w are split-precision tensors (lda / ldw in 16-bit elements); y_split: so is y (ldy likewise).
+    head_w (bf16 [16, N], padded-taps form with N == 256, bias, ReLU): y (fp32, ldy >= 16) receives the narrow Linear head_w on the
+    bf16-rounded rows relu(acc + bias), which are not stored (mage_gemm_desc::head_w)."""
     l, s = _dev(a)
     if split_kind:
         # the split-precision form takes a subset of the arguments (launch_spl / try_taps8 in csrc/gemm.hip): refuse the rest loudly
         # instead of dropping them
-        unsupported = dict(scale=scale, shift=shift, y2=y2, ln_part=ln_part, ln_stats=ln_stats, ln_colsum=ln_colsum)
+        unsupported = dict(scale=scale, shift=shift, y2=y2, ln_part=ln_part, ln_stats=ln_stats, ln_colsum=ln_colsum, head_w=head_w)
         bad = [k for k, v_ in unsupported.items() if v_ is not None]
         bad += [k for k, v_ in dict(post_relu=post_relu, res_half=res_half, a_half=a_half).items() if v_]
         bad += [k for k, v_ in dict(n_split=n_split).items() if v_ not in (0, 1)]
@@ -251,6 +253,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     d.a_split_stride, d.w_split_stride, d.y_split_stride = a_split_stride, w_split_stride, y_split_stride
     d.y2, d.ldy2, d.ln_part, d.ln_stats, d.ln_colsum = _p(y2), ldy2, _p(ln_part), _p(ln_stats), _p(ln_colsum)
     d.ln_eps = float(ln_eps)
+    if head_w is not None:
+        assert head_w.dtype == torch.bfloat16 and head_w.is_contiguous() and tuple(head_w.shape) == (16, N) and y.dtype == torch.float32, \
+            (head_w.dtype, tuple(head_w.shape), y.dtype)
+    d.head_w = _p(head_w)
     d.res_half = int(res_half)
     d.a_half = int(a_half)
     ln = 2 if (ln_stats is not None or ln_colsum is not None) else (1 if (y2 is not None or ln_part is not None) else 0)      # LN_CONSUME / LN_PRODUCE
@@ -298,7 +304,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
             if table and act == ACT_NONE:
                 key = "gemm8_kernel<0, 1, false, true, 0, 0, false>"
             elif plain and act in (ACT_NONE, ACT_RELU):
-                key = f"gemm8_kernel<{act}, 0, false, true, 0, 0, false>"
+                key = f"gemm8_kernel<{act}, 0, false, true, {5 if head_w is not None else 0}, 0, false>"
         # the one-wave-per-SIMD kernel (mage_gemm4_try in csrc/gemm4.hip): QKV / c_fc at full-loop sizes
         if (d.dtype == BF16 and not gather and n_split <= 1 and M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and 256 <= K <= 1024
                 and out_h == 1 and out_w >= M and y_mul_x == 1 and ek == 0 and not res_half and ln_part is None
@@ -320,7 +326,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
                 nb += float(M) * N * 2
             if ln_part is not None:
                 nb += float(M) * (N // 64) * 8
-            PROFILE.end(key, ev, 2.0 * M * N * K, nb)
+            fl = 2.0 * M * N * K
+            if head_w is not None:                           # the rows stay on the CU; 16 fp32 values per row leave it
+                nb += float(M) * 16 * 4 - float(M) * N * ys
+                fl += 2.0 * M * N * 16
+            PROFILE.end(key, ev, fl, nb)
             return y
     _lib.check(l.mage_gemm(C.byref(d), s), l)
     return y

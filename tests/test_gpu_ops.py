@@ -452,6 +452,51 @@ def test_padded_taps_conv_on_the_8phase_kernel(n_img, Cc, mode):
     assert torch.equal(buf.cpu().view(n_img, P, P, Cc), want)
 
 
+@pytest.mark.parametrize("n_img", [2, 5, 264])
+def test_padded_taps_gemm_with_the_narrow_head_on_its_tile(n_img):
+    """mage_gemm_desc::head_w: the sub-pixel GEMMs of ConvTranspose2d(256, 256, 4, 2, 1) + BN + ReLU (vqvae_model.py:184-186; 2 x 2 taps over
+    the padded frame buffer, rows interleaved into the 2x grid) with the last ConvTranspose2d's 16 taps (:187) taken on each tile's
+    bf16-rounded rows before they leave the CU.  Three checks: (1) against fp64 sums over the SAME bf16 rows the unfused kernel stores
+    (the fusion changes the summation order of the head only: fp32-sum tolerance); (2) rows the launch does not own keep their bits
+    (the other sub-pixel phases' slots); (3) a second launch gives the same bits (fixed-order reduction over the four wave columns).
+    n_img = 264: more than one tile per workgroup on 256 CUs -- the staging windows are reused under the next tile's loads."""
+    o = ops()
+    R, P, Cc = 16, 18, 256
+    x = torch.relu(rnd(n_img, R, R, Cc, seed=170)).bfloat16()
+    w = rnd(Cc, 2, 2, Cc, seed=171, scale=(4 * Cc) ** -0.5).bfloat16()                     # [co, ky, kx, ci]
+    bias = rnd(Cc, seed=172, scale=0.1)
+    hw = rnd(16, Cc, seed=173, scale=Cc ** -0.5).bfloat16()
+    pad = torch.zeros(n_img * P * P + 1, Cc, dtype=torch.bfloat16)
+    pad[:-1].view(n_img, P, P, Cc)[:, 1:-1, 1:-1] = x
+    pad_d, wd, hwd, bd = pad.to(DEV), w.reshape(Cc, 4 * Cc).to(DEV), hw.to(DEV), bias.to(DEV)
+    hwp = R * R
+    M = n_img * hwp
+    win = dict(out_h=R, out_w=R, in_h=P, in_w=P, a_img_stride=P * P, cin=Cc, stride=1, dy0=0, dx0=0, taps_h=2, taps_w=2)
+    for py, px in ((0, 0), (1, 1)):
+        geo = dict(a_off=py * P + px, y_img_stride=4 * hwp, y_mul_y=4 * R, y_mul_x=2, y_off=py * 2 * R + px)
+        up = torch.zeros(4 * M, Cc, device=DEV, dtype=torch.bfloat16)
+        o.gemm(pad_d, wd, up, M=M, N=Cc, K=4 * Cc, lda=Cc, ldy=Cc, bias=bd, act=o.ACT_RELU, **geo, **win)
+        taps = torch.full((4 * M, 16), -7.0, device=DEV)
+        o.gemm(pad_d, wd, taps, M=M, N=Cc, K=4 * Cc, lda=Cc, ldy=16, bias=bd, act=o.ACT_RELU, head_w=hwd, **geo, **win)
+        upc, tc = up.cpu(), taps.cpu()
+        rows = (torch.arange(n_img)[:, None, None] * 4 * hwp + torch.arange(R)[None, :, None] * 4 * R + torch.arange(R)[None, None, :] * 2
+                + py * 2 * R + px).reshape(-1)
+        want = (upc[rows].double() @ hw.double().t())
+        got = tc[rows].double()
+        assert upc[rows].abs().max().item() > 0.5                                            # not a test of zeros
+        scale = (upc[rows].double().abs() @ hw.double().abs().t()).clamp_min(1e-3)         # the size of the sums that were added up
+        assert ((got - want).abs() / scale).max().item() < 2e-6, ((got - want).abs() / scale).max().item()
+        other = torch.ones(4 * M, dtype=torch.bool)
+        other[rows] = False
+        assert torch.all(tc[other] == -7.0)
+        taps2 = torch.full((4 * M, 16), -7.0, device=DEV)
+        o.gemm(pad_d, wd, taps2, M=M, N=Cc, K=4 * Cc, lda=Cc, ldy=16, bias=bd, act=o.ACT_RELU, head_w=hwd, **geo, **win)
+        assert torch.equal(taps2.cpu(), tc)
+    # a geometry the fusion does not cover is refused, not silently run unfused
+    with pytest.raises(Exception, match="head_w"):
+        o.gemm(pad_d, wd, taps, M=M, N=Cc, K=4 * Cc, lda=Cc, ldy=16, bias=bd, act=o.ACT_NONE, head_w=hwd, **geo, **win)
+
+
 @pytest.mark.parametrize("M", [512, 2048, 32768])
 def test_layernorm_folded_around_the_gemms(M):
     """bf16: the x + Linear(.) GEMM that also writes a bf16 copy of x and per-row partial (sum, sum of squares); mage_ln_stats;

@@ -52,6 +52,14 @@ def test_vqvae_f4_golden_tokens_and_frames():
     m.set_precision("bf16")
     rec16 = m.decode(t(g["ids"]).long().to(DEV))
     assert (rec16.cpu() - t(g["rec"])).abs().max().item() < 5e-2
+    # the last transposed convolution's taps are taken on the sub-pixel GEMMs' tiles (mage_gemm_desc::head_w): the same bf16 rows in another
+    # summation order than the separate head GEMM
+    os.environ["MAGE_DECODE_NO_HEAD_FUSION"] = "1"
+    try:
+        rec16_unfused = m.decode(t(g["ids"]).long().to(DEV))
+    finally:
+        del os.environ["MAGE_DECODE_NO_HEAD_FUSION"]
+    assert (rec16 - rec16_unfused).abs().max().item() < 5e-6
 
 
 def test_vqvae_f8_golden_tokens_and_frames():
