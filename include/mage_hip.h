@@ -260,6 +260,18 @@ int mage_table_conv(const int64_t* ids, int64_t n_img, int32_t H, int32_t W, int
                     int64_t rowadd_div, int32_t rowadd_mod, void* y, int32_t y_dtype, int64_t ldy, int64_t group, int64_t y_group_stride,
                     int64_t y_off, void* stream);
 
+/* The FIRST ResBlock of the f4 VQ-VAE decoder in one launch (vqvae_model.py:111-124 applied at :180 to codebook.embedding(latents); bf16):
+ * its input is x = relu(codebook[ids]) (the block's in-place ReLU), so with table[tap][code] = (BatchNorm-folded) W3_tap relu(codebook[code])
+ *     t = relu(bias3 + sum_{taps inside the image} table[tap][ids[neighbour]])        rounded to bf16 (mage_table_conv's sum, same order)
+ *     y = max(x + ((t W1^T + b1) * scale1 + shift1), post_relu ? 0 : -inf)            x rounded to bf16 first, as a bf16 frame buffer holds it
+ * y row of pixel (img, py, px) = img*y_img_stride + py*y_row_pitch + px + y_off (ldy bf16 elements per row): the interior of a zero-padded
+ * frame buffer.  Replaces mage_embedding + mage_table_conv + the 1x1 mage_gemm (general epilogue) with the same bits out: t and x never
+ * reach HBM.  Built for W == 16, even H, C == 256; table bf16 [9][n_codes][C], codebook fp32 [n_codes][C], w1 bf16 [C][C] row-major;
+ * scale1 / shift1 optional (both or none).  An id outside [0, n_codes) is recorded for mage_check_device_errors like mage_embedding's. */
+int mage_resblock_table(const int64_t* ids, int64_t n_img, int32_t H, int32_t W, const void* table, int32_t n_codes, int32_t C,
+                        const float* bias3, const float* codebook, const void* w1, const float* b1, const float* scale1, const float* shift1,
+                        int32_t post_relu, void* y, int64_t ldy, int64_t y_img_stride, int64_t y_row_pitch, int64_t y_off, void* stream);
+
 /* Nearest codebook entry, reference formula and tie-break (vqvae_model.py:8-25):
  *   dist[m,k] = (|c_k|^2 + |z_m|^2) - 2 * <z_m, c_k>,  idx[m] = first k attaining the minimum.
  * z [M, D] fp32 rows (channels-last encoder output), codebook_t [D, K] fp32 (transposed copy),

@@ -572,9 +572,19 @@ class VectorQuantizedVAE(nn.Module):
                 pads = self._pad_bufs[key] = [torch.zeros(N * PP + 1, dim, device=dev, dtype=dt) for _ in range(3)]
             inner = dict(out_h=h, out_w=wd, y_img_stride=PP, y_mul_y=Pw, y_off=Pw + 1)      # a producer's rows inside the padding
             win = dict(out_h=h, out_w=wd, in_h=h + 2, in_w=Pw, a_img_stride=PP, cin=dim, stride=1, dy0=0, dx0=0)
-            ops.embedding(ids, w["cb"], pads[0], relu=True, group=hw, group_stride=PP, off=Pw + 1, inner=wd, inner_stride=Pw)
+            # the first ResBlock reads relu(codebook[ids]): its 3x3 convolution is a table sum, and with 16-wide frames and dim == 256 the
+            # whole block is ONE launch (mage_resblock_table): neither the embedded frames nor t ever reach HBM
+            fused0 = (self._d0_table(w) is not None and wd == 16 and h % 2 == 0 and dim == 256
+                      and not os.environ.get("MAGE_DECODE_NO_RESBLOCK_FUSION"))
+            if not fused0:
+                ops.embedding(ids, w["cb"], pads[0], relu=True, group=hw, group_stride=PP, off=Pw + 1, inner=wd, inner_stride=Pw)
             t = torch.empty(N * hw, dim, device=dev, dtype=dt)
             for i, rp in enumerate(("d0", "d1")):
+                if i == 0 and fused0:
+                    ops.resblock_table(ids.reshape(-1), w["d0.tab"], w["cb"], w["d0.w1.bf16"], pads[1], n_img=N, H=h, W=wd, bias3=w["d0.b3f"],
+                                       b1=w["d0.b1"], scale1=w["d0.s1"], shift1=w["d0.t1"], post_relu=True, ldy=dim, y_img_stride=PP,
+                                       y_row_pitch=Pw, y_off=Pw + 1)
+                    continue
                 if i == 0 and self._d0_table(w) is not None:
                     # the first 3x3 convolution reads relu(codebook[ids]): K distinct input vectors -> a table sum (mage_table_conv;
                     # 9 x K x dim bf16 = 2.4 MB: resident in every XCD's L2), a quarter of the stack's matrix-core FLOPs not spent

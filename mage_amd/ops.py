@@ -479,6 +479,27 @@ def table_conv(ids: torch.Tensor, table: torch.Tensor, y: torch.Tensor, *, n_img
     return y
 
 
+def resblock_table(ids: torch.Tensor, table: torch.Tensor, codebook: torch.Tensor, w1: torch.Tensor, y: torch.Tensor, *, n_img: int, H: int, W: int,
+                   bias3: torch.Tensor, b1: torch.Tensor, scale1=None, shift1=None, post_relu: bool = False, ldy: int, y_img_stride: int,
+                   y_row_pitch: int, y_off: int = 0) -> torch.Tensor:
+    """The first ResBlock of the f4 VQ-VAE decoder on codebook rows in one launch (mage_resblock_table): y rows (bf16, the interior of a
+    zero-padded frame buffer) = relu(x + BN(conv1x1(relu(table sum)))), x = relu(codebook[ids])."""
+    l, s = _dev(table)
+    Cc = table.shape[2]
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == n_img * H * W
+    assert table.dtype == torch.bfloat16 and table.dim() == 3 and table.shape[0] == 9 and table.is_contiguous()
+    assert codebook.dtype == torch.float32 and codebook.is_contiguous() and tuple(codebook.shape) == (table.shape[1], Cc)
+    assert w1.dtype == torch.bfloat16 and w1.is_contiguous() and tuple(w1.shape) == (Cc, Cc) and y.dtype == torch.bfloat16
+    ev = PROFILE.begin() if PROFILE.wants("resblock_table") else None
+    _lib.check(l.mage_resblock_table(ids.data_ptr(), n_img, H, W, table.data_ptr(), table.shape[1], Cc, bias3.data_ptr(), codebook.data_ptr(),
+                                     w1.data_ptr(), b1.data_ptr(), _p(scale1), _p(shift1), int(post_relu), y.data_ptr(), ldy, y_img_stride,
+                                     y_row_pitch, y_off, s), l)
+    if ev is not None:
+        npix = float(n_img) * H * W
+        PROFILE.end("resblock_table", ev, 2.0 * npix * Cc * Cc, npix * (8 + 2 * Cc))       # HBM: the ids in, the bf16 rows out
+    return y
+
+
 def vq_prepare(codebook: torch.Tensor):
     l, s = _dev(codebook)
     K, D = codebook.shape

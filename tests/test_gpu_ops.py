@@ -712,6 +712,64 @@ def test_table_conv_equals_convolution_of_embeddings_and_folded_linear():
         o.check_device_errors(DEV)
 
 
+@pytest.mark.parametrize("n_img,H", [(3, 16), (1, 2), (300, 16), (7, 6)])
+def test_resblock_table_equals_its_three_launches(n_img, H):
+    """mage_resblock_table (the f4 decoder's first ResBlock on codebook rows, vqvae_model.py:111-124,180, in one launch) against the three
+    launches it replaces -- mage_embedding into the padded frame buffer, mage_table_conv, the 1x1 mage_gemm with BatchNorm scale / shift,
+    the bf16 residual and the trailing ReLU: the same bits (same table-sum order, same MFMA operand placement and k order, same epilogue
+    arithmetic), the halo of the padded buffer untouched; and against an fp64 restatement from the embedded frames.  n_img = 300: several
+    tiles per workgroup (the double-buffered operand image and the id staging two tiles ahead); H = 2 / 6: every row at an image border."""
+    o = ops()
+    Kc, C, Wd = 40, 256, 16
+    P_w = Wd + 2
+    PP = (H + 2) * P_w
+    g = torch.Generator().manual_seed(300 + n_img)
+    cb = torch.randn(Kc, C, generator=g).to(DEV)
+    w3 = (torch.randn(C, C, 3, 3, generator=g) * (9 * C) ** -0.5)                   # [co, ci, ky, kx], BatchNorm folded
+    b3 = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    w1 = (torch.randn(C, C, generator=g) * C ** -0.5).bfloat16().to(DEV)
+    b1, s1, t1 = [(torch.randn(C, generator=g) * sc + off).to(DEV) for sc, off in ((0.1, 0.0), (0.2, 1.0), (0.1, 0.0))]
+    ids = torch.randint(0, Kc, (n_img, H, Wd), generator=g).to(DEV)
+    rcb = torch.relu(cb)
+    T = torch.stack([(rcb.double() @ w3[:, :, ky, kx].double().t().to(DEV)) for ky in range(3) for kx in range(3)]).float().bfloat16().contiguous()
+    hw = H * Wd
+    for post_relu, scaled in ((True, True), (False, False)):
+        # three launches
+        pad0 = torch.zeros(n_img * PP + 1, C, device=DEV, dtype=torch.bfloat16)
+        o.embedding(ids, cb, pad0, relu=True, group=hw, group_stride=PP, off=P_w + 1, inner=Wd, inner_stride=P_w)
+        t = torch.empty(n_img * hw, C, device=DEV, dtype=torch.bfloat16)
+        o.table_conv(ids.reshape(-1), T, t, n_img=n_img, H=H, W=Wd, bias=b3, relu=True)
+        want = torch.full((n_img * PP + 1, C), 3.0, device=DEV, dtype=torch.bfloat16)
+        o.gemm(t, w1, want, M=n_img * hw, N=C, K=C, lda=C, ldy=C, bias=b1, scale=s1 if scaled else None, shift=t1 if scaled else None,
+               residual=pad0, ldr=C, post_relu=post_relu, out_h=H, out_w=Wd, y_img_stride=PP, y_mul_y=P_w, y_off=P_w + 1)
+        # one launch
+        got = torch.full((n_img * PP + 1, C), 3.0, device=DEV, dtype=torch.bfloat16)
+        o.resblock_table(ids.reshape(-1), T, cb, w1, got, n_img=n_img, H=H, W=Wd, bias3=b3, b1=b1, scale1=s1 if scaled else None,
+                         shift1=t1 if scaled else None, post_relu=post_relu, ldy=C, y_img_stride=PP, y_row_pitch=P_w, y_off=P_w + 1)
+        assert torch.equal(got.float().cpu(), want.float().cpu()), (got.float() - want.float()).abs().max().item()
+        inner = got[:-1].view(n_img, H + 2, P_w, C)
+        assert (inner[:, 0] == 3.0).all() and (inner[:, -1] == 3.0).all() and (inner[:, :, 0] == 3.0).all() and (inner[:, :, -1] == 3.0).all()
+        # fp64 from the embedded frames (t rounded to bf16 as the kernel rounds it)
+        x = rcb.bfloat16().double()[ids]                                                               # [n, H, W, C]
+        xt = torch.zeros(n_img, H + 2, P_w, dtype=torch.long)
+        xt[:, 1:-1, 1:-1] = ids.cpu() + 1
+        Tz = torch.cat([torch.zeros(9, 1, C, dtype=torch.float64), T.double().cpu()], 1)            # code 0 = outside the image
+        tsum = b3.double().cpu() + sum(Tz[ky * 3 + kx][xt[:, ky:ky + H, kx:kx + Wd]] for ky in range(3) for kx in range(3))
+        tt = torch.relu(tsum).float().bfloat16().double()
+        v = tt @ w1.double().cpu().t() + b1.double().cpu()
+        if scaled:
+            v = v * s1.double().cpu() + t1.double().cpu()
+        v = v + x.cpu()
+        if post_relu:
+            v = torch.relu(v)
+        torch.testing.assert_close(inner[:, 1:-1, 1:-1].double().cpu(), v, atol=3e-2, rtol=2e-2)
+    bad = ids.clone()
+    bad[0, 0, 0] = Kc
+    o.resblock_table(bad.reshape(-1), T, cb, w1, got, n_img=n_img, H=H, W=Wd, bias3=b3, b1=b1, ldy=C, y_img_stride=PP, y_row_pitch=P_w, y_off=P_w + 1)
+    with pytest.raises(ValueError, match="out of range"):
+        o.check_device_errors(DEV)
+
+
 @pytest.mark.parametrize("M,N,K,act,ln,f32out", [(65536, 1536, 512, 0, True, False), (32768, 2048, 512, 2, True, False),
                                                   (131072, 512, 512, 0, False, True), (65536, 1024, 1024, 2, False, False),
                                                   (65536, 1024, 256, 0, True, True)])
