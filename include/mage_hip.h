@@ -272,6 +272,15 @@ int mage_resblock_table(const int64_t* ids, int64_t n_img, int32_t H, int32_t W,
                         const float* bias3, const float* codebook, const void* w1, const float* b1, const float* scale1, const float* shift1,
                         int32_t post_relu, void* y, int64_t ldy, int64_t y_img_stride, int64_t y_row_pitch, int64_t y_off, void* stream);
 
+/* The tail of a ResBlock whose 3x3 convolution ran as a GEMM (vqvae_model.py:111-124; bf16): t = relu(BN(conv3x3(relu x))) in plain rows
+ * [n_img*H*W][C] (lda), x and y in frame buffers whose row of pixel (img, py, px) is img*img_stride + py*row_pitch + px + off (ldr / ldy):
+ *     y = max(x + ((t W1^T + b1) * scale1 + shift1), post_relu ? 0 : -inf)
+ * -- the 1x1 mage_gemm with scale / shift, bf16 residual and post_relu, same bits, as an HBM-bound row kernel (whole 512-byte rows in and
+ * out, W1 in registers).  C == 256, n_img*H*W a multiple of 64; w1 bf16 [C][C]; scale1 / shift1 optional; y may alias residual. */
+int mage_resblock_rows(const void* t, int64_t lda, const void* w1, const float* b1, const float* scale1, const float* shift1,
+                       const void* residual, int64_t ldr, int32_t post_relu, void* y, int64_t ldy, int64_t n_img, int32_t H, int32_t W,
+                       int32_t C, int64_t img_stride, int64_t row_pitch, int64_t off, void* stream);
+
 /* Nearest codebook entry, reference formula and tie-break (vqvae_model.py:8-25):
  *   dist[m,k] = (|c_k|^2 + |z_m|^2) - 2 * <z_m, c_k>,  idx[m] = first k attaining the minimum.
  * z [M, D] fp32 rows (channels-last encoder output), codebook_t [D, K] fp32 (transposed copy),

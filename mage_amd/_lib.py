@@ -73,6 +73,7 @@ SIGNATURES = {
     "mage_embedding": (C.c_int, [vp, vp, vp, i32, i64, i32, i32, i32, i64, i64, i64, i64, i64, vp]),
     "mage_table_conv": (C.c_int, [vp, i64, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp, i32, vp, i64, i32, vp, i32, i64, i64, i64, i64, vp]),
     "mage_resblock_table": (C.c_int, [vp, i64, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, i64, i64, i64, i64, vp]),
+    "mage_resblock_rows": (C.c_int, [vp, i64, vp, vp, vp, vp, vp, i64, i32, vp, i64, i64, i32, i32, i32, i64, i64, i64, vp]),
     "mage_vq_nearest": (C.c_int, [vp, vp, vp, i64, i32, i32, vp, vp, vp]),
     "mage_vq_prepare": (C.c_int, [vp, i32, i32, vp, vp, vp]),
     "mage_argmax": (C.c_int, [vp, i64, i32, i64, i64, i64, i64, vp, i64, i64, vp, vp]),

@@ -186,6 +186,52 @@ __global__ __launch_bounds__(256) void convt_fold_tanh_kernel(const float* __res
     y[gid] = tanhf(s);
 }
 
+// The same fold for ONE output channel and a tap plane that fits LDS (IH*IW <= 1024: the f4 decoder's 32 x 32 grid, 64 KB of taps per
+// image): workgroup = image.  The per-pixel kernel above reads 4 bytes from each of 4 different 64-byte tap rows per thread (2 TB/s); here
+// the image's taps come in as whole rows (16 B per lane, contiguous), sit in LDS at a pitch of 17 floats (bank = (17 p + tap) mod 64: the
+// lanes of an output row hit 64 different banks), and the output rows leave contiguous.  Same sum order, same tanhf: same bits.
+__global__ __launch_bounds__(256) void convt_fold_tanh_img_kernel(const float* __restrict__ taps, const float* __restrict__ bias,
+                                                                  float* __restrict__ y, int IH, int IW) {
+    extern __shared__ float tl[];                      // [IH*IW][17]
+    const int n = blockIdx.x, npx = IH * IW;
+    const f32x4* src = (const f32x4*)(taps + (long)n * npx * 16);
+    for (int base = 0; base < npx * 4; base += 256 * 16) {          // 16 loads in flight per thread (a loop of dependent round trips otherwise)
+        f32x4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[min(base + u * 256 + (int)threadIdx.x, npx * 4 - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = base + u * 256 + threadIdx.x;
+            if (i < npx * 4) {
+                float* d = tl + (i >> 2) * 17 + (i & 3) * 4;
+                d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
+            }
+        }
+    }
+    __syncthreads();
+    const int OH = IH * 2, OW = IW * 2;
+    const float b0 = bias ? bias[0] : 0.f;
+    float* yo = y + (long)n * OH * OW;
+    for (int o = threadIdx.x; o < OH * OW; o += 256) {
+        const int oy = o / OW, ox = o - oy * OW;
+        const int iy0 = (oy + 1) >> 1, ky0 = oy + 1 - 2 * iy0;
+        const int ix0 = (ox + 1) >> 1, kx0 = ox + 1 - 2 * ix0;
+        float s = b0;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int iy = iy0 - a, ky = ky0 + 2 * a;
+            if ((unsigned)iy >= (unsigned)IH) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ix = ix0 - b, kx = kx0 + 2 * b;
+                if ((unsigned)ix >= (unsigned)IW) continue;
+                s += tl[(iy * IW + ix) * 17 + ky * 4 + kx];
+            }
+        }
+        yo[o] = tanhf(s);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
                                                        int C, int relu) {
@@ -298,6 +344,18 @@ extern "C" int mage_convt_fold_tanh(const float* taps, const float* bias, float*
     MAGE_CHECK_ARG(taps && y, "mage_convt_fold_tanh: null pointer");
     MAGE_CHECK_ARG(N > 0 && IH > 0 && IW > 0 && cout >= 1 && cout <= 4, "mage_convt_fold_tanh: bad shape N=%d IH=%d IW=%d cout=%d", N,
                    IH, IW, cout);
+    if (cout == 1 && IH * IW <= 1024 && N >= 64) {         // one image per workgroup through LDS (same bits)
+        const int dev = mage_device_index();
+        MAGE_CHECK_ARG(dev >= 0, "mage_convt_fold_tanh: no current device");
+        static bool attr[MAGE_MAX_DEVICES] = {false};
+        if (!attr[dev]) {
+            (void)hipFuncSetAttribute((const void*)convt_fold_tanh_img_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 17 * 4);
+            attr[dev] = true;
+        }
+        hipLaunchKernelGGL(convt_fold_tanh_img_kernel, dim3(N), dim3(256), (size_t)IH * IW * 17 * 4, (hipStream_t)stream, taps, bias, y, IH, IW);
+        MAGE_CHECK_LAUNCH("mage_convt_fold_tanh");
+        return MAGE_OK;
+    }
     const long items = (long)N * cout * IH * 2 * IW * 2;
     hipLaunchKernelGGL(convt_fold_tanh_kernel, grid1(items), dim3(256), 0, (hipStream_t)stream, taps, bias, y, N, IH, IW, cout);
     MAGE_CHECK_LAUNCH("mage_convt_fold_tanh");

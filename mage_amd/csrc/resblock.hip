@@ -205,7 +205,170 @@ __global__ __launch_bounds__(512) void resblock_table_kernel(const ResblockTable
     }
 }
 
+// mage_resblock_rows: the tail of a ResBlock whose 3x3 convolution ran as a GEMM -- y = relu(x + BN(conv1x1(t))) with t in plain bf16
+// rows and x, y in zero-padded frame buffers (vqvae_model.py:111-124: the decoder's second block).  The same MFMA stage and epilogue
+// as above on 64-row tiles; the producer is two row fetches (t and x: whole 512-byte rows, two per instruction, 8 KB per wave in flight
+// under the previous tile's MFMAs and stores) into LDS images.  HBM-bound: three 0.5 KB rows per pixel.  Replaces the 1x1 mage_gemm
+// with the general epilogue (lockstep kernel, 32-byte residual / output pieces per lane) with the same bits out.
+constexpr int RR_ROWS = 64;
+constexpr int RR_IMG = RR_ROWS * RT_C * 2;
+
+struct ResblockRowsArgs {
+    const unsigned short* t;
+    const unsigned short* res;
+    const unsigned short* w1;
+    const float* b1;
+    const float* scale1;
+    const float* shift1;
+    unsigned short* y;
+    long lda, ldr, ldy, img_stride, row_pitch, off;
+    int n_tiles, hw, Wd, post_relu;
+};
+
+__global__ __launch_bounds__(512) void resblock_rows_kernel(const ResblockRowsArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char rr_smem[];
+    char* t_img = rr_smem;
+    char* r_img = rr_smem + RR_IMG;
+    char* y_img = rr_smem + 2 * RR_IMG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int hh = lane >> 5, c8 = lane & 31;
+    u32x4 wf[2][8];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) wf[n][ks] = *(const u32x4*)(g.w1 + (long)(32 * wave + 16 * n + l15) * RT_C + ks * 32 + grp * 8);
+    f32x4 b1v[2], s1v[2], t1v[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int co = 32 * wave + 16 * n + grp * 4;
+        b1v[n] = *(const f32x4*)(g.b1 + co);
+        s1v[n] = g.scale1 ? *(const f32x4*)(g.scale1 + co) : f32x4{1.f, 1.f, 1.f, 1.f};
+        t1v[n] = g.scale1 ? *(const f32x4*)(g.shift1 + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float lo_clamp = g.post_relu ? 0.f : -INFINITY;
+    auto widen_lo = [](unsigned u) { return __uint_as_float(u << 16); };
+    auto widen_hi = [](unsigned u) { return __uint_as_float(u & 0xffff0000u); };
+    auto frame_row = [&](long m) {                     // row of pixel m in the padded frame buffers
+        const long img = m / g.hw;
+        const int rem = (int)(m - img * g.hw), py = rem / g.Wd, px = rem - py * g.Wd;
+        return img * g.img_stride + (long)py * g.row_pitch + px + g.off;
+    };
+    // this wave's rows of a tile: 8*wave + 2*j + hh
+    u32x4 lt[4], lr[4];
+    auto request = [&](int tile) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long m = (long)tile * RR_ROWS + 8 * wave + 2 * j + hh;
+            lt[j] = *(const u32x4*)(g.t + m * g.lda + c8 * 8);
+            lr[j] = *(const u32x4*)(g.res + frame_row(m) * g.ldr + c8 * 8);
+        }
+    };
+    auto produce = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = 8 * wave + 2 * j + hh, o = p * 512 + ((c8 ^ (p & 15)) << 4);
+            *(u32x4*)(t_img + o) = lt[j];
+            *(u32x4*)(r_img + o) = lr[j];
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile >= g.n_tiles) return;
+    request(tile);
+    produce();
+    rt_barrier();
+    for (; tile < g.n_tiles; tile += gridDim.x) {
+        const int nxt = tile + gridDim.x;
+        const bool more = nxt < g.n_tiles;             // workgroup-uniform
+        if (more) request(nxt);
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            u32x4 af[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = *(const u32x4*)(t_img + (16 * m + l15) * 512 + (((ks * 4 + grp) ^ l15) << 4));
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[n][ks]), __builtin_bit_cast(bf16x8, af[m]),
+                                                                        acc[m][n], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int o = (16 * m + l15) * 512 + (((4 * wave + 2 * n + (grp >> 1)) ^ l15) << 4) + (grp & 1) * 8;
+                const uint2 r = *(const uint2*)(r_img + o);
+                f32x4 v = acc[m][n] + b1v[n];
+                v = v * s1v[n] + t1v[n];
+                v += f32x4{widen_lo(r.x), widen_hi(r.x), widen_lo(r.y), widen_hi(r.y)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo_clamp);
+                *(uint2*)(y_img + o) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+        rt_barrier();                                  // y_img complete; every wave is done with t_img and r_img
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 8 * wave + 2 * q + hh;
+            const u32x4 o = *(const u32x4*)(y_img + row * 512 + ((c8 ^ (row & 15)) << 4));
+            __builtin_nontemporal_store(o, (u32x4*)(g.y + frame_row((long)tile * RR_ROWS + row) * g.ldy + c8 * 8));
+        }
+        if (more) produce();
+        rt_barrier();                                  // the next tile's images complete; y_img read out
+    }
+}
+
 }  // namespace
+
+extern "C" int mage_resblock_rows(const void* t, int64_t lda, const void* w1, const float* b1, const float* scale1, const float* shift1,
+                                  const void* residual, int64_t ldr, int32_t post_relu, void* y, int64_t ldy, int64_t n_img, int32_t H,
+                                  int32_t W, int32_t C, int64_t img_stride, int64_t row_pitch, int64_t off, void* stream) {
+    MAGE_CHECK_ARG(t && w1 && b1 && residual && y, "mage_resblock_rows: null pointer");
+    MAGE_CHECK_ARG(n_img > 0 && H > 0 && W > 0 && C == RT_C && (n_img * H * W) % RR_ROWS == 0 && n_img * H * W / RR_ROWS < (1L << 31) &&
+                       (long)H * W < (1L << 31),
+                   "mage_resblock_rows: this kernel is built for C = 256 and a multiple of 64 pixels (got C=%d, %ld pixels)", C, (long)(n_img * H * W));
+    MAGE_CHECK_ARG(!scale1 == !shift1, "mage_resblock_rows: scale1 and shift1 must be given together");
+    MAGE_CHECK_ARG(lda >= C && ldr >= C && ldy >= C && (lda | ldr | ldy) % 8 == 0 && row_pitch >= W && img_stride >= (int64_t)(H - 1) * row_pitch + W,
+                   "mage_resblock_rows: bad row geometry");
+    MAGE_CHECK_ARG((((uintptr_t)t | (uintptr_t)w1 | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)b1 | (uintptr_t)scale1 | (uintptr_t)shift1) & 15) == 0,
+                   "mage_resblock_rows: operands must be 16-byte aligned");
+    ResblockRowsArgs a;
+    a.t = (const unsigned short*)t;
+    a.res = (const unsigned short*)residual;
+    a.w1 = (const unsigned short*)w1;
+    a.b1 = b1;
+    a.scale1 = scale1;
+    a.shift1 = shift1;
+    a.y = (unsigned short*)y;
+    a.lda = lda;
+    a.ldr = ldr;
+    a.ldy = ldy;
+    a.img_stride = img_stride;
+    a.row_pitch = row_pitch;
+    a.off = off;
+    a.n_tiles = (int)(n_img * H * W / RR_ROWS);
+    a.hw = H * W;
+    a.Wd = W;
+    a.post_relu = post_relu;
+    const int dev = mage_device_index();
+    MAGE_CHECK_ARG(dev >= 0, "mage_resblock_rows: no current device");
+    static int n_cu_dev[MAGE_MAX_DEVICES] = {0};
+    if (!n_cu_dev[dev]) {
+        hipDeviceProp_t p;
+        n_cu_dev[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+        (void)hipFuncSetAttribute((const void*)resblock_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * RR_IMG);
+    }
+    const int grid = a.n_tiles < n_cu_dev[dev] ? a.n_tiles : n_cu_dev[dev];
+    hipLaunchKernelGGL(resblock_rows_kernel, dim3(grid), dim3(512), 3 * RR_IMG, (hipStream_t)stream, a);
+    MAGE_CHECK_LAUNCH("mage_resblock_rows");
+    return MAGE_OK;
+}
 
 extern "C" int mage_resblock_table(const int64_t* ids, int64_t n_img, int32_t H, int32_t W, const void* table, int32_t n_codes, int32_t C,
                                    const float* bias3, const float* codebook, const void* w1, const float* b1, const float* scale1,

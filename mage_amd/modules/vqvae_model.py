@@ -592,6 +592,11 @@ class VectorQuantizedVAE(nn.Module):
                 else:
                     ops.gemm(pads[i], w[rp + ".w3f.bf16"], t, M=N * hw, N=dim, K=9 * dim, lda=dim, ldy=dim, taps_h=3, taps_w=3, bias=w[rp + ".b3f"],
                              act=ops.ACT_RELU, **win)
+                if dim == 256 and (N * hw) % 64 == 0 and not os.environ.get("MAGE_DECODE_NO_RESBLOCK_FUSION"):
+                    # the block's tail as an HBM-bound row kernel (mage_resblock_rows: whole rows in and out, W1 in registers): same bits
+                    ops.resblock_rows(t, w[rp + ".w1.bf16"], pads[i], pads[i + 1], n_img=N, H=h, W=wd, b1=w[rp + ".b1"], scale1=w[rp + ".s1"],
+                                      shift1=w[rp + ".t1"], post_relu=True, lda=dim, ldr=dim, ldy=dim, img_stride=PP, row_pitch=Pw, off=Pw + 1)
+                    continue
                 ops.gemm(t, w[rp + ".w1.bf16"], pads[i + 1], M=N * hw, N=dim, K=dim, lda=dim, ldy=dim, bias=w[rp + ".b1"], scale=w[rp + ".s1"],
                          shift=w[rp + ".t1"], residual=pads[i], ldr=dim, post_relu=True, **inner)                # decoder[2] ReLU folded
             nt = 16 * self.input_dim

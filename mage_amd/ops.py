@@ -500,6 +500,23 @@ def resblock_table(ids: torch.Tensor, table: torch.Tensor, codebook: torch.Tenso
     return y
 
 
+def resblock_rows(t: torch.Tensor, w1: torch.Tensor, residual: torch.Tensor, y: torch.Tensor, *, n_img: int, H: int, W: int, b1: torch.Tensor,
+                  scale1=None, shift1=None, post_relu: bool = False, lda: int, ldr: int, ldy: int, img_stride: int, row_pitch: int,
+                  off: int = 0) -> torch.Tensor:
+    """y = relu(x + BN(conv1x1(t))) on bf16 rows, x and y in (padded) frame buffers (mage_resblock_rows): the tail of a ResBlock."""
+    l, s = _dev(t)
+    Cc = w1.shape[0]
+    assert t.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16 and y.dtype == torch.bfloat16
+    assert w1.is_contiguous() and tuple(w1.shape) == (Cc, Cc)
+    ev = PROFILE.begin() if PROFILE.wants("resblock_rows") else None
+    _lib.check(l.mage_resblock_rows(t.data_ptr(), lda, w1.data_ptr(), b1.data_ptr(), _p(scale1), _p(shift1), residual.data_ptr(), ldr,
+                                    int(post_relu), y.data_ptr(), ldy, n_img, H, W, Cc, img_stride, row_pitch, off, s), l)
+    if ev is not None:
+        npix = float(n_img) * H * W
+        PROFILE.end("resblock_rows", ev, 2.0 * npix * Cc * Cc, npix * 3 * 2 * Cc)
+    return y
+
+
 def vq_prepare(codebook: torch.Tensor):
     l, s = _dev(codebook)
     K, D = codebook.shape

@@ -350,6 +350,17 @@ def test_direct_convs_pool_upsample_adain():
         out = torch.empty(2, cout, 16, 16, device=DEV)
         o.convt_fold_tanh(taps, bt.to(DEV), out, N=2, IH=8, IW=8, cout=cout)
         torch.testing.assert_close(out.cpu(), torch.tanh(F.conv_transpose2d(xi, wt, bt, stride=2, padding=1)), atol=2e-5, rtol=1e-5)
+    # many images, one output channel: the fold runs one image per workgroup through LDS -- the same bits as the per-pixel kernel
+    # (which fewer than 64 images take), borders included
+    for IH, IW in ((32, 32), (6, 10)):
+        tp = rnd(70 * IH * IW, 16, seed=171).to(DEV)
+        bt = rnd(1, seed=172).to(DEV)
+        big = torch.empty(70, 1, 2 * IH, 2 * IW, device=DEV)
+        o.convt_fold_tanh(tp, bt, big, N=70, IH=IH, IW=IW, cout=1)
+        parts = torch.empty_like(big)
+        for s0 in (0, 35):
+            o.convt_fold_tanh(tp[s0 * IH * IW:(s0 + 35) * IH * IW], bt, parts[s0:s0 + 35], N=35, IH=IH, IW=IW, cout=1)
+        assert torch.equal(big, parts)
     w1, b1 = rnd(3, 64, 1, 1, seed=71, scale=0.2), rnd(3, seed=72)
     out = torch.empty(2, 3, 8, 8, device=DEV)
     o.conv_out(xi.permute(0, 2, 3, 1).contiguous().to(DEV), w1.reshape(3, 64).contiguous().to(DEV), b1.to(DEV), out, N=2, IH=8, IW=8,
@@ -768,6 +779,45 @@ def test_resblock_table_equals_its_three_launches(n_img, H):
     o.resblock_table(bad.reshape(-1), T, cb, w1, got, n_img=n_img, H=H, W=Wd, bias3=b3, b1=b1, ldy=C, y_img_stride=PP, y_row_pitch=P_w, y_off=P_w + 1)
     with pytest.raises(ValueError, match="out of range"):
         o.check_device_errors(DEV)
+
+
+@pytest.mark.parametrize("n_img,H,Wd", [(3, 16, 16), (6, 8, 8), (520, 16, 16), (1, 4, 16)])
+def test_resblock_rows_equals_the_1x1_gemm(n_img, H, Wd):
+    """mage_resblock_rows (the tail of a ResBlock: y = relu(x + BN(conv1x1(t))), t in plain bf16 rows, x and y inside zero-padded frame
+    buffers; vqvae_model.py:111-124) against the mage_gemm it replaces (scale / shift, bf16 residual, post_relu, regrouped output rows):
+    the same bits, the halo untouched, y allowed to alias x.  n_img = 520: more than two 64-row tiles per workgroup."""
+    o = ops()
+    C = 256
+    P_w = Wd + 2
+    PP = (H + 2) * P_w
+    hw = H * Wd
+    g = torch.Generator().manual_seed(400 + n_img)
+    tt = torch.relu(torch.randn(n_img * hw, C, generator=g)).bfloat16().to(DEV)
+    xpad = torch.zeros(n_img * PP + 1, C, dtype=torch.bfloat16)
+    xpad[:-1].view(n_img, H + 2, P_w, C)[:, 1:-1, 1:-1] = torch.randn(n_img, H, Wd, C, generator=g).bfloat16()
+    xpad = xpad.to(DEV)
+    w1 = (torch.randn(C, C, generator=g) * C ** -0.5).bfloat16().to(DEV)
+    b1, s1, t1 = [(torch.randn(C, generator=g) * sc + off).to(DEV) for sc, off in ((0.1, 0.0), (0.2, 1.0), (0.1, 0.0))]
+    for post_relu, scaled in ((True, True), (False, False)):
+        kw = dict(scale=s1, shift=t1) if scaled else {}
+        want = torch.full((n_img * PP + 1, C), 3.0, device=DEV, dtype=torch.bfloat16)
+        o.gemm(tt, w1, want, M=n_img * hw, N=C, K=C, lda=C, ldy=C, bias=b1, residual=xpad, ldr=C, post_relu=post_relu, out_h=H, out_w=Wd,
+               y_img_stride=PP, y_mul_y=P_w, y_off=P_w + 1, **kw)
+        got = torch.full((n_img * PP + 1, C), 3.0, device=DEV, dtype=torch.bfloat16)
+        kw2 = dict(scale1=s1, shift1=t1) if scaled else {}
+        o.resblock_rows(tt, w1, xpad, got, n_img=n_img, H=H, W=Wd, b1=b1, post_relu=post_relu, lda=C, ldr=C, ldy=C, img_stride=PP, row_pitch=P_w,
+                        off=P_w + 1, **kw2)
+        assert torch.equal(got.float().cpu(), want.float().cpu()), (got.float() - want.float()).abs().max().item()
+        assert want[:-1].view(n_img, H + 2, P_w, C)[:, 1:-1, 1:-1].float().abs().max().item() > 0.5
+        # in place on the frame buffer
+        xin = xpad.clone()
+        o.resblock_rows(tt, w1, xin, xin, n_img=n_img, H=H, W=Wd, b1=b1, post_relu=post_relu, lda=C, ldr=C, ldy=C, img_stride=PP, row_pitch=P_w,
+                        off=P_w + 1, **kw2)
+        inner = torch.zeros(n_img * PP + 1, dtype=torch.bool)
+        inner[:-1].view(n_img, H + 2, P_w)[:, 1:-1, 1:-1] = True
+        assert torch.equal(xin.float().cpu()[inner], want.float().cpu()[inner]) and torch.equal(xin.cpu()[~inner], xpad.cpu()[~inner])
+    with pytest.raises(Exception, match="multiple of 64"):
+        o.resblock_rows(tt, w1, xpad, got, n_img=1, H=3, W=5, b1=b1, lda=C, ldr=C, ldy=C, img_stride=PP, row_pitch=P_w, off=P_w + 1)
 
 
 @pytest.mark.parametrize("M,N,K,act,ln,f32out", [(65536, 1536, 512, 0, True, False), (32768, 2048, 512, 2, True, False),
