@@ -73,22 +73,31 @@ __global__ __launch_bounds__(512) void resblock_table_kernel(const ResblockTable
     const f32x4 b3lo = *(const f32x4*)(g.bias3 + c8 * 8), b3hi = *(const f32x4*)(g.bias3 + c8 * 8 + 4);
     const float lo_clamp = g.post_relu ? 0.f : -INFINITY;
 
-    // ids of a tile -> id_img[buf]: rows (2*tr - 1 .. 2*tr + 2) x columns (-1 .. 16); -1 = outside the image
-    auto stage_ids = [&](int tile, int buf) {
+    // ids of a tile -> id_img[buf]: rows (2*tr - 1 .. 2*tr + 2) x columns (-1 .. 16); -1 = outside the image.  Two steps, a whole tile
+    // apart: the global load (fetch_ids, into a register) and the checked write into LDS (put_ids) -- as one step the load's round trip
+    // sat on the critical path of every tile (threads 0..71 waiting for it, everybody else for them at the barrier)
+    auto fetch_ids = [&](int tile) -> long {
+        long id = -1;
         if (tid < 72) {
             const int img = tile / tiles_per_img, tr = tile - img * tiles_per_img;
             const int r = tid / 18, c = tid - r * 18;
             const int iy = 2 * tr - 1 + r, ix = c - 1;
+            if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < 16u && tile < g.n_tiles) id = g.ids[((long)img * g.H + iy) * 16 + ix];
+            else id = -2;                                  // outside the image / past the last tile
+        }
+        return id;
+    };
+    auto put_ids = [&](long id, int buf) {
+        if (tid < 72) {
             int v = -1;
-            if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < 16u && tile < g.n_tiles) {
-                long id = g.ids[((long)img * g.H + iy) * 16 + ix];
-                if (id < 0 || id >= g.n_codes) {       // the reference's nn.Embedding raises IndexError: reported by mage_check_device_errors
+            if (id != -2) {
+                if (id < 0 || id >= g.n_codes) {           // the reference's nn.Embedding raises IndexError: reported by mage_check_device_errors
                     mage_raise(g.err, MAGE_DEVERR_EMBEDDING_ID, id, g.n_codes);
                     id = id < 0 ? 0 : g.n_codes - 1;
                 }
                 v = (int)id;
             }
-            id_img[buf][r][c] = v;
+            id_img[buf][tid / 18][tid % 18] = v;
         }
     };
     // the producer's loads: pixel pair j of this wave = tile rows 4*wave + 2*j + hh; 9 taps each
@@ -131,10 +140,11 @@ __global__ __launch_bounds__(512) void resblock_table_kernel(const ResblockTable
 
     int tile = blockIdx.x;
     if (tile >= g.n_tiles) return;
-    stage_ids(tile, 0);
+    put_ids(fetch_ids(tile), 0);
     rt_barrier();
     request(0);
-    stage_ids(tile + gridDim.x, 1);
+    put_ids(fetch_ids(tile + gridDim.x), 1);
+    long ids_ahead = fetch_ids(tile + 2 * gridDim.x);
     produce(0);
     rt_barrier();
 
@@ -188,7 +198,8 @@ __global__ __launch_bounds__(512) void resblock_table_kernel(const ResblockTable
                 *(uint2*)(y_img + row * 512 + ((chunk ^ l15) << 4) + (grp & 1) * 8) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             }
         rt_barrier();                                  // y_img complete; every wave is done with t_img[buf] and with id_img[buf]
-        if (more) stage_ids(nxt + gridDim.x, buf);     // the ids of the tile after next (read by the next iteration's request)
+        put_ids(ids_ahead, buf);                       // the ids of the tile after next (read by the next iteration's request), fetched a tile ago
+        ids_ahead = fetch_ids(nxt + 2 * gridDim.x);
         // ---- whole rows out: wave w stores tile rows 4w .. 4w + 3, two rows per instruction
         {
             const int img = tile / tiles_per_img, tr = tile - img * tiles_per_img;
