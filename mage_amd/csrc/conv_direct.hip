@@ -52,6 +52,64 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     }
 }
 
+// The f4 encoder's stem, Conv2d(1, dim, 4, 2, 1) (vqvae_model.py:170), at many frames.  The kernel above re-reads the [taps][cout] weights
+// from L1 for every pixel (16 KB per pixel-wave at dim = 256) and decodes and bounds-tests every tap per thread: 1.1 TB/s of output at 1024
+// frames.  Here workgroup = image: the image sits in LDS with a one-pixel zero border (so no tap is ever outside: (2 oy + ky, 2 ox + kx)
+// of the padded plane), a wave keeps its 4 channels x 16 taps per lane in registers and walks output pixels; a pixel's 16 taps are 8
+// ds_read2_b32 off ONE address register (row pitch W + 2 <= 84 words: every tap offset fits the instruction's 8-bit field), the same
+// address in every lane of a pixel (a broadcast).  Same products in the same order: the same values (acc + 0 * w where the other kernel
+// skips a border tap: a -0 / +0 is the only possible difference).
+template <typename OT>
+__global__ __launch_bounds__(256) void conv_in_4x4s2_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                            const float* __restrict__ bias, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, OT* __restrict__ y, int H, int W, int cout,
+                                                            int act, int s2d) {
+    extern __shared__ float img[];                      // [(H + 2)][(W + 2)]
+    const int n = blockIdx.x, PW = W + 2, OH = H / 2, OW = W / 2;
+    for (int i = threadIdx.x; i < (H + 2) * PW; i += 256) img[i] = 0.f;
+    __syncthreads();
+    const float* xp = x + (long)n * H * W;
+    for (int i = threadIdx.x * 4; i < H * W; i += 1024) {              // W % 4 == 0 (host): a 16-byte piece stays inside a row
+        const f32x4 v = *(const f32x4*)(xp + i);
+        const int r = i / W, c = i - r * W;
+        float* d = img + (r + 1) * PW + c + 1;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    const int cq = cout / 4;                            // lanes per pixel (host: cq divides 64; 64 at cout = 256)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ppw = 64 / cq, sub = lane / cq, co = (lane % cq) * 4;
+    f32x4 w[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w[t] = *(const f32x4*)(wt + (long)t * cout + co);
+    const f32x4 b4 = bias ? *(const f32x4*)(bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 s4 = scale ? *(const f32x4*)(scale + co) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 t4 = scale ? *(const f32x4*)(shift + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const int npx = OH * OW;
+    for (int p = wave * ppw + sub; p < npx; p += 4 * ppw) {
+        const int oy = p / OW, ox = p - oy * OW;
+        const float* tp = img + (2 * oy) * PW + 2 * ox;
+        f32x4 acc = b4;
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) acc += tp[ky * PW + kx] * w[ky * 4 + kx];
+        if (scale) acc = acc * s4 + t4;
+        if (act == MAGE_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+        }
+        if (s2d) {
+            const int BW = OW / 2 + 1, BH = OH / 2 + 1;
+            const long row = (long)n * (BH * BW) + ((oy + 1) >> 1) * BW + ((ox + 1) >> 1);
+            const int q = ((oy + 1) & 1) * 2 + ((ox + 1) & 1);
+            store4(y + row * (4 * cout) + q * cout + co, acc);
+        } else {
+            store4(y + ((long)n * npx + p) * cout + co, acc);
+        }
+    }
+}
+
 // The 1x1 head (the f8 decoder's Conv2d(dim, C, 1) + Tanh at full resolution: 16 M pixels x 512 B per call at cfg4): 16 lanes per pixel,
 // 4 pixels per wave, every lane reads 16-byte chunks (a wave instruction covers four contiguous 256-byte runs), 4 xor-shuffles per
 // output channel.  The wave-per-pixel kernel below spent its time in 6-step reductions: 7.8 ms = 1.06 TB/s on that call.
@@ -289,6 +347,21 @@ extern "C" int mage_conv_in(const float* x, const float* weight_t, const float* 
     const long items = (long)N * OH * OW * (cout / 4);
     hipStream_t s = (hipStream_t)stream;
     MAGE_CHECK_ARG(!s2d || (OH % 2 == 0 && OW % 2 == 0), "mage_conv_in: the space-to-depth output needs an even output plane");
+    const int cq = cout / 4;
+    if (cin == 1 && kh == 4 && kw == 4 && stride == 2 && pad == 1 && N >= 64 && H % 2 == 0 && W % 4 == 0 && W <= 80 && (H + 2) * (W + 2) * 4 <= 48 * 1024 &&
+        cq <= 64 && 64 % cq == 0 &&
+        (y_dtype == MAGE_F32 || ((y_dtype == MAGE_BF16X3 || y_dtype == MAGE_F16X3) && cout % 64 == 0 && (((uintptr_t)y) & 255) == 0))) {
+        // one image per workgroup through LDS, weights in registers (conv_in_4x4s2_kernel)
+        const dim3 grid(N), blk(256);
+        const size_t lds = (size_t)(H + 2) * (W + 2) * 4;
+#define CI16(T_) hipLaunchKernelGGL((conv_in_4x4s2_kernel<T_>), grid, blk, lds, s, x, weight_t, bias, scale, shift, (T_*)y, H, W, cout, act, s2d)
+        if (y_dtype == MAGE_F32) CI16(float);
+        else if (y_dtype == MAGE_BF16X3) CI16(split_bf16);
+        else CI16(split_f16);
+#undef CI16
+        MAGE_CHECK_LAUNCH("mage_conv_in");
+        return MAGE_OK;
+    }
     if (y_dtype == MAGE_F32)
         hipLaunchKernelGGL((conv_in_kernel<float>), grid1(items), dim3(256), 0, s, x, weight_t, bias, scale, shift, (float*)y, N,
                            cin, H, W, cout, kh, kw, stride, pad, OH, OW, act, s2d);

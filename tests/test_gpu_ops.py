@@ -327,6 +327,26 @@ def test_direct_convs_pool_upsample_adain():
     o.conv_in(x.to(DEV), w.permute(1, 2, 3, 0).contiguous().to(DEV), b.to(DEV), sc.to(DEV), sh.to(DEV), y, cin=1, H=64, W=64,
               cout=64, kh=4, kw=4, stride=2, pad=1, act=o.ACT_RELU)
     torch.testing.assert_close(y.cpu().view(2, 32, 32, 64).permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5)
+    # many frames (>= 65536 output pixels, <= 16 taps): persistent waves with the weights in registers and scalar tap loads -- the same
+    # bits as the per-pixel kernel that smaller calls take; plain fp32 rows (64 and 256 channels) and the split space-to-depth layout
+    for cout_, ydt in ((64, "f32"), (256, "f32"), (256, "s2d")):
+        xb = rnd(64, 1, 64, 64, seed=160).to(DEV)
+        wb = rnd(cout_, 1, 4, 4, seed=161, scale=0.25).permute(1, 2, 3, 0).contiguous().to(DEV)
+        bb, scb, shb = rnd(cout_, seed=162).to(DEV), (rnd(cout_, seed=163).abs() + 0.5).to(DEV), rnd(cout_, seed=164).to(DEV)
+        kwc = dict(cin=1, H=64, W=64, cout=cout_, kh=4, kw=4, stride=2, pad=1, act=o.ACT_RELU)
+        if ydt == "f32":
+            big = torch.empty(64 * 32 * 32, cout_, device=DEV)
+            o.conv_in(xb, wb, bb, scb, shb, big, **kwc)
+            parts = torch.empty_like(big)
+            for s0 in (0, 32):
+                o.conv_in(xb[s0:s0 + 32].contiguous(), wb, bb, scb, shb, parts[s0 * 1024:(s0 + 32) * 1024], **kwc)
+        else:
+            big = o.split_empty(64 * 17 * 17 + 1, 4 * cout_, o.F16X3, DEV, zero=True)
+            o.conv_in(xb, wb, bb, scb, shb, big, split_kind=o.F16X3, s2d=True, **kwc)
+            parts = o.split_empty(64 * 17 * 17 + 1, 4 * cout_, o.F16X3, DEV, zero=True)
+            for s0 in (0, 32):
+                o.conv_in(xb[s0:s0 + 32].contiguous(), wb, bb, scb, shb, parts[s0 * 289:], split_kind=o.F16X3, s2d=True, **kwc)
+        assert torch.equal(big.float(), parts.float())              # as values: a tap outside the image adds 0 * w here, nothing there (-0 / +0)
     # f8 stem: Conv2d(3, 32, 7, padding=3)
     x, w, b = rnd(1, 3, 32, 32, seed=65), rnd(32, 3, 7, 7, seed=66, scale=0.1), rnd(32, seed=67)
     y = torch.empty(32 * 32, 32, device=DEV)
