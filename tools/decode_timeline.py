@@ -1,3 +1,5 @@
+"""One VectorQuantizedVAE.decode call launch by launch from a rocprofv3 --kernel-trace directory: start offset, gap to the previous kernel, duration.
+usage: python tools/decode_timeline.py <rocprof output dir>   (tools/refresh_profiles.sh runs it on tools/bench_vqvae.py's trace)"""
 import csv, sys, glob
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))

@@ -27,4 +27,5 @@ PY
 rm -rf /tmp/kd
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kd -o k -- python $GRAFT_REPO_ROOT/tools/bench_vqvae.py > $OUT/${TAG}_decode_bench.txt 2>&1
 cp /tmp/kd/k_kernel_stats.csv $OUT/${TAG}_decode_kernel_stats.csv
+python $GRAFT_REPO_ROOT/tools/decode_timeline.py /tmp/kd > $OUT/${TAG}_decode_timeline.txt 2>&1      # one decode call, launch by launch, with the gaps
 cat $OUT/${TAG}_gpu_busy.txt; head -c 600 $OUT/${TAG}_bench_cfg2_bf16.json; echo; tail -9 $OUT/pmc_$TAG.txt
