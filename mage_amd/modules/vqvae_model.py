@@ -604,7 +604,7 @@ class VectorQuantizedVAE(nn.Module):
             # one output channel and dim == 256 (one column tile of the GEMM holds whole rows): the last transposed convolution's 4 x 4 taps
             # are taken on the sub-pixel GEMMs' tiles before they leave the CU (mage_gemm_desc::head_w) -- the 4x-resolution activation
             # `up` (0.5 GB per 960 frames, written once and read once) and the head GEMM's launch are gone
-            head = nt == 16 and dim == 256 and not os.environ.get("MAGE_DECODE_NO_HEAD_FUSION")
+            head = nt == 16 and dim == 256 and (N * PP + PP) * dim * 2 < 2 ** 32 and not os.environ.get("MAGE_DECODE_NO_HEAD_FUSION")
             up = None if head else torch.empty(N * 4 * hw, dim, device=dev, dtype=dt)
             for py in range(2):
                 for px in range(2):
