@@ -496,8 +496,17 @@ def main():
         gbs = by / (ms * 1e-3) / 1e9
         tf = DEC_FLOP_PER_FRAME * frames / (ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        # HBM bytes of one decode call from PMC counters (tools/pmc_decode.sh: two rocprofv3 --pmc passes over tools/bench_vqvae.py at 960
+        # frames, corrected as the guide prescribes); reported only for the size it was measured at
+        dec_traffic, dec_src = None, None
+        dec_pmc = os.path.join(ROOT, "profiles", "r04_pmc_decode.json")
+        if os.path.exists(dec_pmc) and args.precision == "bf16":
+            pj = json.load(open(dec_pmc))
+            if pj.get("frames") == frames:
+                dec_traffic = pj.get("hbm_bytes_per_call")
+                dec_src = "profiles/r04_pmc_decode.json (builder's rocprofv3 --pmc passes via tools/pmc_decode.sh; not re-measured in this run)"
         decode = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                  "traffic": None, "frames": frames, "ms": round(ms, 4), "bytes_model_per_frame": DEC_BYTES_PER_FRAME["bf16" if args.precision == "bf16" else "fp32"],
+                  "traffic": dec_traffic, "traffic_source": dec_src, "frames": frames, "ms": round(ms, 4), "bytes_model_per_frame": DEC_BYTES_PER_FRAME["bf16" if args.precision == "bf16" else "fp32"],
                   "mfma": {"achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)},
                   "note": "VectorQuantizedVAE.decode of the call's generated frames (median of 10, HIP events); bytes = SURVEY 8d's "
                           "layer-materialised model (sum over the 6 conv layers of input+output activations at the storage dtype); "
