@@ -747,9 +747,10 @@ __device__ __forceinline__ void epilogue_head(const mage_gemm_desc& d, const f32
 // its epilogue).  At a tile's end the leading half gives the trailing half one barrier (both then run the epilogue in
 // step), and the trailing half drops back by one barrier before the next tile's first phase.
 // TAPS: implicit-GEMM convolution over a ZERO-PADDED input (in_h >= out_h + taps_h - 1, in_w = row pitch >= out_w + taps_w - 1, stride 1): every tap
-// of every output pixel is a valid row, so the gather is the plain loader plus ONE scalar offset per K slab -- slab kt lies in tap
-// kt / (cin/64), whose rows sit (ky*in_w + kx) rows further -- kept as three scalar cursors per A piece (no vector instruction in a
-// load section, which is what this kernel's schedule depends on).  The lockstep kernel's generic gather decodes the tap per lane
+// of every output pixel is a valid row, so the gather is the plain loader plus ONE scalar offset per K slab -- a slab lies in one tap,
+// whose rows sit (ky*in_w + kx) rows further -- kept as scalar cursors per A piece (no vector instruction in a load section, which is
+// what this kernel's schedule depends on).  Slab order: bf16 form (channel slab, tap) with the tap fastest (CMAJ below: L2 reuse of the
+// padded rows); split-precision forms tap-major, slab kt in tap kt / (cin/64).  The lockstep kernel's generic gather decodes the tap per lane
 // and per slab and re-tests the bounds (frame conv3x3: 773 TFLOP/s, 6.7x its algorithmic bytes fetched: round-1 PMC).
 // SPL: split-precision operands (see gemm_kernel): 3 * K/64 slabs per tile, the slab -> source offset map in issue(), accumulators scaled
 // once between the small-term passes and the main pass (f16 pieces), the MFMA opcode.  Schedule, hazards and LDS image are unchanged.
@@ -813,6 +814,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     int tap_ci[2] = {0, 0}, tap_kx[2] = {0, 0};
     long tap_off[2] = {0, 0};
     const int spt = TAPS ? d.cin >> 6 : 1;             // 64-wide slabs per tap
+    // CMAJ (bf16 padded-taps form): the K loop walks (channel slab, tap) with the TAP fastest -- a tile's nine (four) visits to the same
+    // 128-byte pieces of its padded input rows are then nine consecutive slabs (41 KB of unique input per group at 16 x 16 latents)
+    // instead of one visit per 4-slab tap, 36 slabs apart: with 32 workgroups per XCD the tap-major order re-fetched the input 3-4x from
+    // beyond L2 (PMC, DESIGN finding 64).  W keeps its documented [N][(ky, kx, ci)] layout: the W pieces read slab tap*spt + c.
+    // The split-precision forms (the parity-critical encoder convolutions) keep the tap-major order and its summation order.
+    constexpr bool CMAJ = TAPS && SPL == 0;
+    [[maybe_unused]] int tap_ky[2] = {0, 0};
+    [[maybe_unused]] int w_tap[2] = {0, 0}, w_c[2] = {0, 0}, w_slab[2] = {0, 0};
+    [[maybe_unused]] const int ntaps_k = TAPS ? d.taps_h * d.taps_w : 1;
     auto issue = [&](int P) {
         char* dst = smem + cur_buf[P] * KBUF + P * PIECE + (2 * wave) * 1024;
         const bool isA = P == P_A0 || P == P_A1;
@@ -827,12 +837,33 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             else sbase = (const char*)(isA ? d.A : d.W) + ((low ? (kt_ & ~1) : 2 * (kt_ - nk2)) + piece) * 128;
         } else {
             if (TAPS && isA) sbase = (const char*)d.A + tap_off[P] + tap_ci[P] * 128;       // P_A0 = 0, P_A1 = 1 index the cursors
+            else if (CMAJ) sbase = (const char*)d.W + w_slab[P & 1] * 128;                  // P_W0 = 2, P_W1 = 3
             else sbase = (const char*)(isA ? d.A : d.W) + cur_kt[P] * 128;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) glds16(sbase + voff[P][i], dst + i * 1024);
         cur_buf[P] ^= 1;
-        if (TAPS && isA && (SPL == 0 || !low || (kt_ & 1))) {         // SPL: the tap cursor follows the LOGICAL slab
+        if constexpr (CMAJ) {
+            if (isA) {                                 // next tap of this channel slab; after the last one, the next slab's first
+                tap_off[P] += (long)d.lda * 2;
+                if (++tap_kx[P] == d.taps_w) {
+                    tap_kx[P] = 0;
+                    tap_off[P] += (long)(d.in_w - d.taps_w) * d.lda * 2;
+                    if (++tap_ky[P] == d.taps_h) {
+                        tap_ky[P] = 0;
+                        tap_off[P] = 0;
+                        ++tap_ci[P];
+                    }
+                }
+            } else {
+                w_slab[P & 1] += spt;
+                if (++w_tap[P & 1] == ntaps_k) {
+                    w_tap[P & 1] = 0;
+                    w_slab[P & 1] = ++w_c[P & 1];
+                }
+            }
+        }
+        if (!CMAJ && TAPS && isA && (SPL == 0 || !low || (kt_ & 1))) {         // SPL: the tap cursor follows the LOGICAL slab
             if (++tap_ci[P] == spt) {
                 tap_ci[P] = 0;
                 tap_off[P] += (long)d.lda * 2;
@@ -848,6 +879,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
                 tap_ci[P] = 0;
                 tap_kx[P] = 0;
                 tap_off[P] = 0;
+                if constexpr (CMAJ) tap_ky[P] = 0;
+            }
+            if constexpr (CMAJ) {
+                if (!isA) {
+                    w_tap[P & 1] = 0;
+                    w_c[P & 1] = 0;
+                    w_slab[P & 1] = 0;
+                }
             }
             cur_tile[P] += nwg8;
             set_rows(P);
