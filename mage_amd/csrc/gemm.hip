@@ -750,7 +750,7 @@ __device__ __forceinline__ void epilogue_head(const mage_gemm_desc& d, const f32
 // of every output pixel is a valid row, so the gather is the plain loader plus ONE scalar offset per K slab -- a slab lies in one tap,
 // whose rows sit (ky*in_w + kx) rows further -- kept as scalar cursors per A piece (no vector instruction in a load section, which is
 // what this kernel's schedule depends on).  Slab order: bf16 form (channel slab, tap) with the tap fastest (CMAJ below: L2 reuse of the
-// padded rows); split-precision forms tap-major, slab kt in tap kt / (cin/64).  The lockstep kernel's generic gather decodes the tap per lane
+// padded rows), in every form (the split-precision forms walk both of their passes that way).  The lockstep kernel's generic gather decodes the tap per lane
 // and per slab and re-tests the bounds (frame conv3x3: 773 TFLOP/s, 6.7x its algorithmic bytes fetched: round-1 PMC).
 // SPL: split-precision operands (see gemm_kernel): 3 * K/64 slabs per tile, the slab -> source offset map in issue(), accumulators scaled
 // once between the small-term passes and the main pass (f16 pieces), the MFMA opcode.  Schedule, hazards and LDS image are unchanged.
@@ -818,8 +818,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     // 128-byte pieces of its padded input rows are then nine consecutive slabs (41 KB of unique input per group at 16 x 16 latents)
     // instead of one visit per 4-slab tap, 36 slabs apart: with 32 workgroups per XCD the tap-major order re-fetched the input 3-4x from
     // beyond L2 (PMC, DESIGN finding 64).  W keeps its documented [N][(ky, kx, ci)] layout: the W pieces read slab tap*spt + c.
-    // The split-precision forms (the parity-critical encoder convolutions) keep the tap-major order and its summation order.
-    constexpr bool CMAJ = TAPS && SPL == 0;
+    // The split-precision forms walk their two passes (small terms, then main) in the same order: their padded split rows are twice as wide,
+    // and the encoder's 3x3 convolutions fetched 3.0-6.3 GB per launch for 0.3-1.1 GB of input (PMC) -- HBM-bound, not matrix-core-bound.
+    constexpr bool CMAJ = TAPS;
     [[maybe_unused]] int tap_ky[2] = {0, 0};
     [[maybe_unused]] int w_tap[2] = {0, 0}, w_c[2] = {0, 0}, w_slab[2] = {0, 0};
     [[maybe_unused]] const int ntaps_k = TAPS ? d.taps_h * d.taps_w : 1;
@@ -834,6 +835,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
         [[maybe_unused]] const int piece = low ? (isA ? (kt_ & 1) : ((kt_ & 1) ^ 1)) : 0;
         if constexpr (SPL != 0) {
             if (TAPS && isA) sbase = (const char*)d.A + tap_off[P] + (tap_ci[P] * 2 + piece) * 128;
+            else if (CMAJ) sbase = (const char*)d.W + (2 * w_slab[P & 1] + piece) * 128;                 // w_slab: the LOGICAL slab tap*spt + c
             else sbase = (const char*)(isA ? d.A : d.W) + ((low ? (kt_ & ~1) : 2 * (kt_ - nk2)) + piece) * 128;
         } else {
             if (TAPS && isA) sbase = (const char*)d.A + tap_off[P] + tap_ci[P] * 128;       // P_A0 = 0, P_A1 = 1 index the cursors
@@ -843,7 +845,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) glds16(sbase + voff[P][i], dst + i * 1024);
         cur_buf[P] ^= 1;
-        if constexpr (CMAJ) {
+        if (CMAJ && (SPL == 0 || !low || (kt_ & 1))) {        // (SPL: the cursors follow the LOGICAL slab)
             if (isA) {                                 // next tap of this channel slab; after the last one, the next slab's first
                 tap_off[P] += (long)d.lda * 2;
                 if (++tap_kx[P] == d.taps_w) {
@@ -860,16 +862,6 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
                 if (++w_tap[P & 1] == ntaps_k) {
                     w_tap[P & 1] = 0;
                     w_slab[P & 1] = ++w_c[P & 1];
-                }
-            }
-        }
-        if (!CMAJ && TAPS && isA && (SPL == 0 || !low || (kt_ & 1))) {         // SPL: the tap cursor follows the LOGICAL slab
-            if (++tap_ci[P] == spt) {
-                tap_ci[P] = 0;
-                tap_off[P] += (long)d.lda * 2;
-                if (++tap_kx[P] == d.taps_w) {
-                    tap_kx[P] = 0;
-                    tap_off[P] += (long)(d.in_w - d.taps_w) * d.lda * 2;
                 }
             }
         }
@@ -890,10 +882,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             }
             cur_tile[P] += nwg8;
             set_rows(P);
-        } else if (SPL != 0 && TAPS && isA && cur_kt[P] == nk2) {      // the main pass walks the taps again from the first
-            tap_ci[P] = 0;
-            tap_kx[P] = 0;
-            tap_off[P] = 0;
+        } else if (SPL != 0 && TAPS && cur_kt[P] == nk2) {             // the main pass walks the (slab, tap) sequence again from the first
+            if (isA) {
+                tap_ci[P] = 0;
+                tap_kx[P] = 0;
+                tap_off[P] = 0;
+                tap_ky[P] = 0;
+            } else {
+                w_tap[P & 1] = 0;
+                w_c[P & 1] = 0;
+                w_slab[P & 1] = 0;
+            }
         }
     };
 #pragma unroll
