@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MAGE_ABI_VERSION 5
+#define MAGE_ABI_VERSION 6
 
 /* MAGE_BF16X3 / MAGE_F16X3: SPLIT-PRECISION operands -- the fast parity mode.  A logical fp32 matrix [rows, C] (C % 64 == 0, base
  * 256-byte aligned) is stored as two 16-bit pieces per element, x ~ hi + lo, per row as 64-column slabs [hi(64) | lo(64)] (so a row
@@ -161,6 +161,11 @@ typedef struct mage_gemm_desc {
                                         *     Y[yrow][t] = sum_n y[n] * head_w[t][n],  t = 0..15      (fp32 sums, fixed order)
                                         * -- the 4 x 4 taps of the VQ-VAE's last ConvTranspose2d (vqvae_model.py:187) computed inside the
                                         * sub-pixel GEMMs of the one before it (:184), whose 4x-resolution activation is then never stored */
+    int32_t head_phases;               /* with head_w: 0, or 4 = the four sub-pixel phases of that ConvTranspose2d(., ., 4, 2, 1) in ONE launch:
+                                        * N = 4 * 256, W and bias hold the phases' [256][K] / [256] blocks in the order (py, px) = (0,0) (0,1)
+                                        * (1,0) (1,1); column tile p reads its 2 x 2 window at a_off + py*in_w + px and writes the rows
+                                        * y_off + py*(y_mul_y/2) + px*(y_mul_x/2) (y_mul_x == 2): four launches' tiles, bit for bit, from one tile
+                                        * list in which a frame's four phases are neighbours (its padded rows are fetched once) */
 } mage_gemm_desc;
 
 int mage_gemm(const mage_gemm_desc* desc, void* stream);

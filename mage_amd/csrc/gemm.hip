@@ -681,7 +681,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
 // wave finishing 16 of the 64 rows.  All eight waves run this in step (the K loop's half-offset is closed before the epilogue).
 template <int ACT>
 __device__ __forceinline__ void epilogue_head(const mage_gemm_desc& d, const f32x4 (&bias)[4], f32x4 (&acc)[8][4], const u32x4 (&hw)[2],
-                                              int tile_m0, int lane, int wave, int plane, char* stg_all) {
+                                              int tile_m0, int lane, int wave, int plane, char* stg_all, long phase_rows) {
     const int l15 = lane & 15, grp = lane >> 4, wr = wave >> 2, wc = wave & 3;
     f32x4 h[8];
 #pragma unroll
@@ -715,7 +715,7 @@ __device__ __forceinline__ void epilogue_head(const mage_gemm_desc& d, const f32
         const int m = tile_m0 + wr * 128 + half * 64 + r;
         const int img = m / plane, rem = m - img * plane;
         const int oy = rem / d.out_w, ox = rem - oy * d.out_w;
-        const long yrow = (long)img * d.y_img_stride + (long)oy * d.y_mul_y + (long)ox * d.y_mul_x + d.y_off;
+        const long yrow = (long)img * d.y_img_stride + (long)oy * d.y_mul_y + (long)ox * d.y_mul_x + d.y_off + phase_rows;
         __builtin_nontemporal_store(s, (f32x4*)((float*)d.Y + yrow * d.ldy + grp * 4));
         if (half == 0) {
             __builtin_amdgcn_s_waitcnt(0xC07F);        // the reads of half 0 are done before anyone overwrites a window
@@ -802,7 +802,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
                 const int rem = m - img * plane;
                 const int oy = rem / d.out_w;
                 const int ox = rem - oy * d.out_w;
-                const long arow = (long)img * d.a_img_stride + (long)oy * d.in_w + ox + d.a_off;
+                // head_phases: column tile tn is sub-pixel phase (py, px) = (tn >> 1, tn & 1); its window starts py rows and px columns further
+                const int ph_a = (LN == LN_HEAD && d.head_phases) ? (tn >> 1) * d.in_w + (tn & 1) : 0;
+                const long arow = (long)img * d.a_img_stride + (long)oy * d.in_w + ox + d.a_off + ph_a;
                 voff[P][i] = (unsigned)(arow * d.lda * 2 + (SPLIT ? (long)ts * d.a_split_stride * 2 : 0) + lc[i] * 16);
             } else {
                 const int n = min(tn * BN + (r >> 5) * 64 + (P == P_W1 ? 32 : 0) + (r & 31), d.N - 1);
@@ -1102,7 +1104,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
                 if constexpr (LN == LN_HEAD) {         // the head's weight fragments in the packed accumulators' k order (epilogue_head)
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        const unsigned short* hp = (const unsigned short*)d.head_w + (long)l15 * d.N + n0 + 32 * t + grp * 4;
+                        const unsigned short* hp = (const unsigned short*)d.head_w + (long)l15 * BN + (n0 & (BN - 1)) + 32 * t + grp * 4;
                         const uint2 lo = *(const uint2*)hp, hi = *(const uint2*)(hp + 16);
                         headw[t] = u32x4{lo.x, lo.y, hi.x, hi.y};
                     }
@@ -1139,7 +1141,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));               // keep the epilogue's lane-derived constants out of the K loop's registers
         if constexpr (LN == LN_HEAD) {
-            epilogue_head<ACT>(d, biasm, acc, headw, tm * BM, lane_e, wave, plane, smem + 2 * KBUF);
+            epilogue_head<ACT>(d, biasm, acc, headw, tm * BM, lane_e, wave, plane, smem + 2 * KBUF,
+                               d.head_phases ? (long)(tn >> 1) * (d.y_mul_y >> 1) + (long)(tn & 1) * (d.y_mul_x >> 1) : 0L);
         } else if constexpr (LN == LN_CONSUME) {
             if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit, &lnc);
             else epilogue_lean<ACT, unsigned short, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit, &lnc);
@@ -1465,9 +1468,11 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
     if (table && d->act == MAGE_ACT_NONE && (((uintptr_t)d->rowadd) & 15) == 0) return launch_taps8<MAGE_ACT_NONE, EK_RES_INIT, SPL>(d, s, n_cu);
     if (d->head_w) {
         // the narrow Linear on the tile's rows (LN_HEAD): one column tile must hold whole rows; refused loudly, the caller asked for a fusion
-        MAGE_CHECK_ARG(SPL == 0 && plain && d->act == MAGE_ACT_RELU && d->N == 256 && d->y_dtype == MAGE_F32 && d->ldy >= 16 && d->ldy % 4 == 0
+        MAGE_CHECK_ARG(d->head_phases == 0 || (d->head_phases == 4 && d->taps_h == 2 && d->taps_w == 2 && d->y_mul_x == 2 && d->y_mul_y % 2 == 0),
+                       "mage_gemm: head_phases is 0 or 4 (the sub-pixel phases of a 4 x 4 / stride 2 transposed convolution: 2 x 2 taps, y_mul_x = 2)");
+        MAGE_CHECK_ARG(SPL == 0 && plain && d->act == MAGE_ACT_RELU && d->N == (d->head_phases ? 1024 : 256) && d->y_dtype == MAGE_F32 && d->ldy >= 16 && d->ldy % 4 == 0
                            && d->bias && (((uintptr_t)d->head_w) & 7) == 0 && (((uintptr_t)d->Y) & 15) == 0,
-                       "mage_gemm: head_w takes the bf16 padded-taps form with N = 256, bias, ReLU, fp32 [row][ldy >= 16] output");
+                       "mage_gemm: head_w takes the bf16 padded-taps form with N = 256 (1024 with head_phases), bias, ReLU, fp32 [row][ldy >= 16] output");
         if constexpr (SPL == 0) return launch_taps8<MAGE_ACT_RELU, EK_BIAS, 0, LN_HEAD>(d, s, n_cu);
     }
     if constexpr (SPL == 0) {

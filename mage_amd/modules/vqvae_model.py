@@ -249,6 +249,9 @@ class VectorQuantizedVAE(nn.Module):
                     wsub = d[f"d3.w{py}{px}.f32"].view(co, 2, 2, -1).flip(1, 2).reshape(co, -1)
                     d[f"d3.w{py}{px}f.bf16"] = (wsub * d["d3.s"][:, None]).to(torch.bfloat16)
             d["d3.bf"] = (d["d3.b"] * d["d3.s"] + d["d3.t"]).contiguous()
+            # the four phases stacked (py, px) = (0,0) (0,1) (1,0) (1,1): one launch of the padded-taps GEMM (mage_gemm_desc::head_phases)
+            d["d3.wallf.bf16"] = torch.cat([d[f"d3.w{py}{px}f.bf16"] for py in range(2) for px in range(2)], 0).contiguous()
+            d["d3.bf4"] = d["d3.bf"].repeat(4).contiguous()
             d["d6.wt"] = dec[6].weight.float().permute(2, 3, 1, 0).contiguous()         # [4,4,cout,cin]
             # the same taps as GEMM rows [(ky*4+kx)*cout + co, cin], padded to a multiple of 8 rows (mage_gemm: N % 8 == 0)
             taps = d["d6.wt"].reshape(16 * self.input_dim, -1)
@@ -606,6 +609,13 @@ class VectorQuantizedVAE(nn.Module):
             # `up` (0.5 GB per 960 frames, written once and read once) and the head GEMM's launch are gone
             head = nt == 16 and dim == 256 and (N * PP + PP) * dim * 2 < 2 ** 32 and not os.environ.get("MAGE_DECODE_NO_HEAD_FUSION")
             up = None if head else torch.empty(N * 4 * hw, dim, device=dev, dtype=dt)
+            if head and not os.environ.get("MAGE_DECODE_NO_PHASE_MERGE"):
+                # ... and the four sub-pixel launches are one: a frame's four phases are neighbouring tiles (same bits as four launches)
+                ops.gemm(pads[2], w["d3.wallf.bf16"], taps, M=N * hw, N=4 * dim, K=4 * dim, lda=dim, ldy=nt, taps_h=2, taps_w=2, a_off=0,
+                         y_img_stride=4 * hw, y_mul_y=4 * wd, y_mul_x=2, y_off=0, bias=w["d3.bf4"], act=ops.ACT_RELU, head_w=w["d6.w16" + s],
+                         head_phases=4, **win)
+                ops.convt_fold_tanh(taps, w["d6.b"], out, N=N, IH=2 * h, IW=2 * wd, cout=self.input_dim)
+                return
             for py in range(2):
                 for px in range(2):
                     ops.gemm(pads[2], w[f"d3.w{py}{px}f.bf16"], taps if head else up, M=N * hw, N=dim, K=4 * dim, lda=dim, ldy=nt if head else dim,

@@ -203,7 +203,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
          residual=None, ldr: int = 0, post_relu: bool = False, ldw: int = 0, n_split: int = 1, a_split_stride: int = 0,
          w_split_stride: int = 0, y_split_stride: int = 0, y2=None, ldy2: int = 0, ln_part=None, ln_stats=None,
          ln_colsum=None, res_half: bool = False, a_half: bool = False, split_kind: int = 0, y_split: bool = False,
-         ln_eps: float = 0.0, head_w=None) -> torch.Tensor:
+         ln_eps: float = 0.0, head_w=None, head_phases: int = 0) -> torch.Tensor:
     """Y = epilogue(A (*) W^T); see mage_gemm in include/mage_hip.h for the geometry fields.
     split_kind BF16X3 / F16X3: a and w are split-precision tensors (lda / ldw in 16-bit elements); y_split: so is y (ldy likewise).
     head_w (bf16 [16, N], padded-taps form with N == 256, bias, ReLU): y (fp32, ldy >= 16) receives the narrow Linear head_w on the
@@ -254,9 +254,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     d.y2, d.ldy2, d.ln_part, d.ln_stats, d.ln_colsum = _p(y2), ldy2, _p(ln_part), _p(ln_stats), _p(ln_colsum)
     d.ln_eps = float(ln_eps)
     if head_w is not None:
-        assert head_w.dtype == torch.bfloat16 and head_w.is_contiguous() and tuple(head_w.shape) == (16, N) and y.dtype == torch.float32, \
-            (head_w.dtype, tuple(head_w.shape), y.dtype)
+        assert head_w.dtype == torch.bfloat16 and head_w.is_contiguous() and tuple(head_w.shape) == (16, N // (head_phases or 1)) \
+            and y.dtype == torch.float32, (head_w.dtype, tuple(head_w.shape), y.dtype)
     d.head_w = _p(head_w)
+    d.head_phases = head_phases if head_w is not None else 0
     d.res_half = int(res_half)
     d.a_half = int(a_half)
     ln = 2 if (ln_stats is not None or ln_colsum is not None) else (1 if (y2 is not None or ln_part is not None) else 0)      # LN_CONSUME / LN_PRODUCE
@@ -327,8 +328,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
             if ln_part is not None:
                 nb += float(M) * (N // 64) * 8
             fl = 2.0 * M * N * K
-            if head_w is not None:                           # the rows stay on the CU; 16 fp32 values per row leave it
-                nb += float(M) * 16 * 4 - float(M) * N * ys
+            if head_w is not None:                           # the rows stay on the CU; 16 fp32 values per row (and phase) leave it
+                nb += float(M) * 16 * 4 * (head_phases or 1) - float(M) * N * ys
                 fl += 2.0 * M * N * 16
             PROFILE.end(key, ev, fl, nb)
             return y

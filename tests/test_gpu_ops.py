@@ -523,6 +523,16 @@ def test_padded_taps_gemm_with_the_narrow_head_on_its_tile(n_img):
         taps2 = torch.full((4 * M, 16), -7.0, device=DEV)
         o.gemm(pad_d, wd, taps2, M=M, N=Cc, K=4 * Cc, lda=Cc, ldy=16, bias=bd, act=o.ACT_RELU, head_w=hwd, **geo, **win)
         assert torch.equal(taps2.cpu(), tc)
+    # the four phases in ONE launch (head_phases = 4: stacked weights, column tile = phase): the four launches' bits
+    w4 = [rnd(Cc, 2, 2, Cc, seed=180 + i, scale=(4 * Cc) ** -0.5).bfloat16().reshape(Cc, 4 * Cc).to(DEV) for i in range(4)]
+    four = torch.full((4 * M, 16), -7.0, device=DEV)
+    for i, (py, px) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+        o.gemm(pad_d, w4[i], four, M=M, N=Cc, K=4 * Cc, lda=Cc, ldy=16, bias=bd, act=o.ACT_RELU, head_w=hwd, a_off=py * P + px, y_img_stride=4 * hwp,
+               y_mul_y=4 * R, y_mul_x=2, y_off=py * 2 * R + px, **win)
+    one = torch.full((4 * M, 16), -7.0, device=DEV)
+    o.gemm(pad_d, torch.cat(w4, 0).contiguous(), one, M=M, N=4 * Cc, K=4 * Cc, lda=Cc, ldy=16, bias=bd.repeat(4).contiguous(), act=o.ACT_RELU, head_w=hwd,
+           head_phases=4, a_off=0, y_img_stride=4 * hwp, y_mul_y=4 * R, y_mul_x=2, y_off=0, **win)
+    assert torch.equal(one.cpu(), four.cpu()) and not (one == -7.0).any()
     # a geometry the fusion does not cover is refused, not silently run unfused
     with pytest.raises(Exception, match="head_w"):
         o.gemm(pad_d, wd, taps, M=M, N=Cc, K=4 * Cc, lda=Cc, ldy=16, bias=bd, act=o.ACT_NONE, head_w=hwd, **geo, **win)

@@ -60,6 +60,12 @@ def test_vqvae_f4_golden_tokens_and_frames():
     finally:
         del os.environ["MAGE_DECODE_NO_HEAD_FUSION"]
     assert (rec16 - rec16_unfused).abs().max().item() < 5e-6
+    os.environ["MAGE_DECODE_NO_PHASE_MERGE"] = "1"               # the four sub-pixel launches instead of one: the same bits
+    try:
+        rec16_four = m.decode(t(g["ids"]).long().to(DEV))
+    finally:
+        del os.environ["MAGE_DECODE_NO_PHASE_MERGE"]
+    assert torch.equal(rec16, rec16_four)
     # the first ResBlock in one launch (mage_resblock_table) against embedding + table sum + 1x1 GEMM: the same bits
     os.environ["MAGE_DECODE_NO_RESBLOCK_FUSION"] = "1"
     try:

@@ -13,7 +13,7 @@ python - <<PY
 import csv, collections, json, re
 # launches of one decode call (mage_amd/modules/vqvae_model.py: _decode_chunk, bf16, 16x16 latents, dim 256)
 per_call = {"resblock_table_kernel": 1, "gemm8_kernel<1, 0, false, true, 0, 0, false>": 1, "resblock_rows_kernel": 1,
-            "gemm8_kernel<1, 0, false, true, 5, 0, false>": 4, "convt_fold_tanh_img_kernel": 1}
+            "gemm8_kernel<1, 0, false, true, 5, 0, false>": 1, "convt_fold_tanh_img_kernel": 1}
 out = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(list)
