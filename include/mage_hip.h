@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MAGE_ABI_VERSION 6
+#define MAGE_ABI_VERSION 7
 
 /* MAGE_BF16X3 / MAGE_F16X3: SPLIT-PRECISION operands -- the fast parity mode.  A logical fp32 matrix [rows, C] (C % 64 == 0, base
  * 256-byte aligned) is stored as two 16-bit pieces per element, x ~ hi + lo, per row as 64-column slabs [hi(64) | lo(64)] (so a row
@@ -41,7 +41,12 @@ extern "C" {
  *     A W^T ~ A_hi W_lo^T + A_lo W_hi^T (all K slabs; f16: the sum is then scaled by 2^-11)  +  A_hi W_hi^T (all K slabs),
  * i.e. 3/16 of the exact-fp32 MFMA cost for an fp32-class result (the dropped lo*lo term and the representation error are 2^-18
  * resp. 2^-22 of a product; fp32's own accumulation error over K terms is of the same order as the f16 form's). */
-enum { MAGE_F32 = 0, MAGE_BF16 = 1, MAGE_BF16X3 = 2, MAGE_F16X3 = 3 };
+/* MAGE_F16: IEEE half storage + v_mfma_f32_16x16x32_f16 with fp32 accumulation -- the bf16 kernels' schedules, LDS images and epilogues with
+ * the other 16-bit type (same MFMA rate, 11 significand bits instead of 8: operand rounding 2^-12 instead of 2^-9; range +-65504, no clamp).
+ * Accepted where the decoder stack of the generation path needs it: mage_gemm (plain rows and the padded-taps row-table form; act none /
+ * QuickGELU; the LayerNorm-folded and x + Linear(.) forms; no split-K, no training forms, no head_w), mage_attention, mage_layernorm,
+ * mage_row_stats, mage_table_conv, mage_embedding, mage_cast. */
+enum { MAGE_F32 = 0, MAGE_BF16 = 1, MAGE_BF16X3 = 2, MAGE_F16X3 = 3, MAGE_F16 = 4 };
 enum { MAGE_OK = 0, MAGE_EINVAL = -1, MAGE_EHIP = -2, MAGE_EUNSUPPORTED = -3 };
 enum { MAGE_ACT_NONE = 0, MAGE_ACT_RELU = 1, MAGE_ACT_QUICKGELU = 2, MAGE_ACT_GELU_ERF = 3, MAGE_ACT_TANH = 4,
        MAGE_ACT_QUICKGELU_GRAD = 5 /* mage_gemm only: y = acc * QuickGELU'(y2), y2 = the saved pre-activation rows (bf16, READ): the

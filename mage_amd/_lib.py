@@ -12,9 +12,9 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MAGE_HIP_LIB", os.path.join(_HERE, "lib", "libmage_hip.so"))   # override: kernel-tuning builds only
 
-F32, BF16, BF16X3, F16X3 = 0, 1, 2, 3          # BF16X3 / F16X3: split-precision operands (include/mage_hip.h)
+F32, BF16, BF16X3, F16X3, F16 = 0, 1, 2, 3, 4  # BF16X3 / F16X3: split-precision operands; F16: single-pass half operands (include/mage_hip.h)
 ACT_NONE, ACT_RELU, ACT_QUICKGELU, ACT_GELU_ERF, ACT_TANH, ACT_QUICKGELU_GRAD = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 

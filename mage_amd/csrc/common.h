@@ -61,6 +61,14 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ unsigned short from_f32<unsigned short>(float v) { return f2bf_bits(v); }
 
+// MAGE_F16 storage: IEEE half as `_Float16` (a type of its own, so that every kernel templated on its 16-bit element type picks the f16
+// conversions by overload; `unsigned short` stays the bf16 storage type).  fp32 -> f16 is the hardware's round-to-nearest-even
+// (v_cvt_pk_f16_f32); |x| > 65504 becomes inf -- the single-pass f16 mode is for tensors of the decoder stack (weights ~ N(0, 0.02..0.06),
+// LayerNorm-ed activations, a residual stream of O(10)), not for arbitrary data.
+typedef _Float16 f16_t;
+template <> __device__ __forceinline__ float to_f32<f16_t>(f16_t v) { return (float)v; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }
+
 // load / store 4 consecutive elements as fp32
 __device__ __forceinline__ f32x4 load4(const float* p) { return *(const f32x4*)p; }
 __device__ __forceinline__ f32x4 load4(const unsigned short* p) {
@@ -111,6 +119,45 @@ __device__ __forceinline__ void store8(unsigned short* p, f32x4 a, f32x4 b) {
 }
 __device__ __forceinline__ void store8(float* p, f32x4 a, f32x4 b) { *(f32x4*)p = a; *(f32x4*)(p + 4) = b; }
 
+// ---- f16 rows (MAGE_F16): the same helpers on `f16_t`
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ unsigned int pack_f16x2(float a, float b) {
+    const f16x2_t v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned int, v);
+}
+__device__ __forceinline__ float2 unpack_f16x2(unsigned int u) {
+    const f16x2_t v = __builtin_bit_cast(f16x2_t, u);
+    return float2{(float)v[0], (float)v[1]};
+}
+__device__ __forceinline__ float2 unpack_bf16x2(unsigned int u) { return float2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+// two fp32 -> one packed pair of the 16-bit type T / back
+template <typename T> __device__ __forceinline__ unsigned int pack16x2(float a, float b) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, unsigned short)) return pack_f16x2(a, b);
+    else return pack_bf16x2(a, b);
+}
+template <typename T> __device__ __forceinline__ float2 unpack16x2(unsigned int u) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, unsigned short)) return unpack_f16x2(u);
+    else return unpack_bf16x2(u);
+}
+// 4 packed 16-bit values (8 bytes) -> fp32
+template <typename T> __device__ __forceinline__ f32x4 widen4(uint2 r) {
+    const float2 a = unpack16x2<T>(r.x), b = unpack16x2<T>(r.y);
+    return f32x4{a.x, a.y, b.x, b.y};
+}
+// v_mfma_f32_16x16x32 on 8 packed 16-bit values per operand, by the storage type: bf16 (unsigned short) or f16 (f16_t); same rate
+template <typename T> __device__ __forceinline__ f32x4 mfma16x16x32(const u32x4& a, const u32x4& b, const f32x4& c) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, unsigned short))
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 load4(const f16_t* p) { return widen4<f16_t>(*(const uint2*)p); }
+__device__ __forceinline__ void store4(f16_t* p, f32x4 v) { *(uint2*)p = uint2{pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3])}; }
+__device__ __forceinline__ void store8(f16_t* p, f32x4 a, f32x4 b) {
+    *(uint4*)p = uint4{pack_f16x2(a[0], a[1]), pack_f16x2(a[2], a[3]), pack_f16x2(b[0], b[1]), pack_f16x2(b[2], b[3])};
+}
+
 // ---- split-precision storage (MAGE_BF16X3 / MAGE_F16X3, include/mage_hip.h) -------------------------------------------------
 // A logical fp32 matrix [rows, C] (C % 64 == 0) kept as TWO 16-bit pieces per element, x ~ hi + lo / LO_SCALE, laid out per row as
 // 64-column slabs  [hi(64) | lo(64)]  (256 bytes per slab: the GEMM's K slab of the hi piece, then of the lo piece).
@@ -122,8 +169,6 @@ __device__ __forceinline__ void store8(float* p, f32x4 a, f32x4 b) { *(f32x4*)p 
 struct split_bf16 { unsigned int pair; };
 struct split_f16 { unsigned int pair; };
 #define MAGE_F16_LO_SCALE 2048.0f
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 // KIND 1 = bf16 pieces, 2 = f16 pieces: two values -> packed hi pair, packed lo pair
 template <int KIND>
 __device__ __forceinline__ void split_pack2(float a, float b, unsigned int& hi, unsigned int& lo) {

@@ -477,6 +477,10 @@ extern "C" int mage_cast(const void* x, int32_t x_dtype, void* y, int32_t y_dtyp
         hipLaunchKernelGGL((map_kernel<unsigned short, float, false>), grid1(n / 4), dim3(256), 0, s, (const unsigned short*)x, (float*)y, (long)n);
     else if (x_dtype == MAGE_F32 && y_dtype == MAGE_F32)
         hipLaunchKernelGGL((map_kernel<float, float, false>), grid1(n / 4), dim3(256), 0, s, (const float*)x, (float*)y, (long)n);
+    else if (x_dtype == MAGE_F32 && y_dtype == MAGE_F16)
+        hipLaunchKernelGGL((map_kernel<float, f16_t, false>), grid1(n / 4), dim3(256), 0, s, (const float*)x, (f16_t*)y, (long)n);
+    else if (x_dtype == MAGE_F16 && y_dtype == MAGE_F32)
+        hipLaunchKernelGGL((map_kernel<f16_t, float, false>), grid1(n / 4), dim3(256), 0, s, (const f16_t*)x, (float*)y, (long)n);
     else { mage_set_error("mage_cast: unsupported %d -> %d", x_dtype, y_dtype); return MAGE_EINVAL; }
     MAGE_CHECK_LAUNCH("mage_cast");
     return MAGE_OK;

@@ -106,12 +106,18 @@ __device__ __forceinline__ void g4_for(F&& f) {
 // acc block I (a[4I .. 4I+3]) (+)= W-fragment x A-fragment; ZERO: C = 0 (the tile's first k-step)
 // (CLOB: this statement carries the clobber list -- the first MFMA of every quarter and the first read of every epilogue chunk do; on
 // all ~800 statements the list cost a minute of compile time per instantiation)
-template <int I, bool ZERO, bool CLOB>
+// HF: f16 operands (MAGE_F16) -- the other 16-bit opcode, same rate, same operand and accumulator layout
+#define G4_MFMA_STMT(OP)                                                                                                                                   \
+    do {                                                                                                                                                   \
+        if constexpr (ZERO && CLOB) asm volatile(OP " a[%c2:%c3], %0, %1, 0" ::"v"(w), "v"(x), "i"(4 * I), "i"(4 * I + 3) : G4_ALL_ACC);                   \
+        else if constexpr (ZERO) asm volatile(OP " a[%c2:%c3], %0, %1, 0" ::"v"(w), "v"(x), "i"(4 * I), "i"(4 * I + 3));                                  \
+        else if constexpr (CLOB) asm volatile(OP " a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(x), "i"(4 * I), "i"(4 * I + 3) : G4_ALL_ACC);             \
+        else asm volatile(OP " a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(x), "i"(4 * I), "i"(4 * I + 3));                                             \
+    } while (0)
+template <int I, bool ZERO, bool CLOB, bool HF = false>
 __device__ __forceinline__ void g4_mfma(const u32x4& w, const u32x4& x) {
-    if constexpr (ZERO && CLOB) asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(w), "v"(x), "i"(4 * I), "i"(4 * I + 3) : G4_ALL_ACC);
-    else if constexpr (ZERO) asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(w), "v"(x), "i"(4 * I), "i"(4 * I + 3));
-    else if constexpr (CLOB) asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(x), "i"(4 * I), "i"(4 * I + 3) : G4_ALL_ACC);
-    else asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(x), "i"(4 * I), "i"(4 * I + 3));
+    if constexpr (HF) G4_MFMA_STMT("v_mfma_f32_16x16x32_f16");
+    else G4_MFMA_STMT("v_mfma_f32_16x16x32_bf16");
 }
 template <int I, bool CLOB = false>
 __device__ __forceinline__ f32x4 g4_acc_read() {
@@ -140,9 +146,11 @@ __device__ __forceinline__ void g4_dma(unsigned voff, const char* base) {
     asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(voff), "s"(base), "i"((U - 4) * 1024) : "memory");
 }
 
-template <int ACT, int EK, int LN, bool RB>
+template <int ACT, int EK, int LN, bool RB, bool HF = false>
 __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
     static_assert(EK != EK_GENERAL, "lean epilogue kinds");
+    static_assert(!HF || (LN != LN_DUAL && LN != LN_GELUBWD), "f16 form: the generation path's epilogues");
+    typedef std::conditional_t<HF, f16_t, unsigned short> H16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     g4_claim_accumulators();
     const int tid = threadIdx.x;
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
             // ---- Q0: (t0, rows 0-63) from wf[0], xf[0]
             g4_for<32>([&](auto i_) {
                 constexpr int i = decltype(i_)::value, m = i >> 3, nt = i & 7;
-                g4_mfma<((nt >> 2) * 8 + m) * 4 + (nt & 3), FIRST, i == 0>(wf[0][nt], xf[0][m]);
+                g4_mfma<((nt >> 2) * 8 + m) * 4 + (nt & 3), FIRST, i == 0, HF>(wf[0][nt], xf[0][m]);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!(MAGE4_ABL & 4) && i < 4) {
                     rd_x1(1, S, 0, 4 + i);
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
             // ---- Q1: (t0, rows 64-127) from wf[0], xf[1]
             g4_for<32>([&](auto i_) {
                 constexpr int i = decltype(i_)::value, m = i >> 3, nt = i & 7;
-                g4_mfma<((nt >> 2) * 8 + 4 + m) * 4 + (nt & 3), FIRST, i == 0>(wf[0][nt], xf[1][m]);
+                g4_mfma<((nt >> 2) * 8 + 4 + m) * 4 + (nt & 3), FIRST, i == 0, HF>(wf[0][nt], xf[1][m]);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!(MAGE4_ABL & 4) && i < 12) {
                     if constexpr (i < 4) rd_x1(0, S, 1, i);
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
             }
             g4_for<32>([&](auto i_) {
                 constexpr int i = decltype(i_)::value, m = i >> 3, nt = i & 7;
-                g4_mfma<((nt >> 2) * 8 + m) * 4 + (nt & 3), false, i == 0>(wf[1][nt], xf[0][m]);
+                g4_mfma<((nt >> 2) * 8 + m) * 4 + (nt & 3), false, i == 0, HF>(wf[1][nt], xf[0][m]);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!(MAGE4_ABL & 4) && i < 4) {
                     rd_x1(1, S, 1, 4 + i);
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
             // ---- Q3: (t1, rows 64-127) from wf[1], xf[1]; next slab's first fragments into wf[0], xf[0]
             g4_for<32>([&](auto i_) {
                 constexpr int i = decltype(i_)::value, m = i >> 3, nt = i & 7;
-                g4_mfma<((nt >> 2) * 8 + 4 + m) * 4 + (nt & 3), false, i == 0>(wf[1][nt], xf[1][m]);
+                g4_mfma<((nt >> 2) * 8 + 4 + m) * 4 + (nt & 3), false, i == 0, HF>(wf[1][nt], xf[1][m]);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!(MAGE4_ABL & 4) && i < 12 && !LAST) {     // (a tile's last slab: after the epilogue, whose registers these would occupy)
                     if constexpr (i < 4) rd_x1(0, S ^ 1, 0, i);
@@ -406,12 +414,12 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) lnc.s[b] = lns[h][b];
                 if (g.y_dtype == MAGE_F32) epilogue_lean<ACT, float, 4, false, LN>(e, biasm[h], t, m0 + mh * 64, n0 + h * 64, lane, 1, win, 0, &lnc);
-                else epilogue_lean<ACT, unsigned short, 4, false, LN>(e, biasm[h], t, m0 + mh * 64, n0 + h * 64, lane, 1, win, 0, &lnc);
+                else epilogue_lean<ACT, H16, 4, false, LN>(e, biasm[h], t, m0 + mh * 64, n0 + h * 64, lane, 1, win, 0, &lnc);
             } else if constexpr (LN == LN_DUAL || LN == LN_GELUBWD) {
                 epilogue_lean<ACT, unsigned short, 4, false, LN>(e, biasm[h], t, m0 + mh * 64, n0 + h * 64, lane, 1, win, 0);       // bf16 rows (host check)
             } else {
                 if (g.y_dtype == MAGE_F32) epilogue_lean<ACT, float, 4, false, LN>(e, biasm[h], t, m0 + mh * 64, n0 + h * 64, lane, 1, win, 0);
-                else epilogue_lean<ACT, unsigned short, 4, false, LN>(e, biasm[h], t, m0 + mh * 64, n0 + h * 64, lane, 1, win, 0);
+                else epilogue_lean<ACT, H16, 4, false, LN>(e, biasm[h], t, m0 + mh * 64, n0 + h * 64, lane, 1, win, 0);
             }
         });
 #endif
@@ -427,13 +435,13 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
     }
 }
 
-template <int ACT, int EK, int LN, bool RB>
+template <int ACT, int EK, int LN, bool RB, bool HF = false>
 int launch4(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     static bool attr[MAGE_MAX_DEVICES] = {false};
     const int dev = mage_device_index();
     MAGE_CHECK_ARG(dev >= 0, "mage_gemm: no current device");
     if (!attr[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm4_kernel<ACT, EK, LN, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm4_kernel<ACT, EK, LN, RB, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS);
         attr[dev] = true;
     }
     Gemm4Args a;
@@ -477,7 +485,7 @@ int launch4(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
         a.stagger_groups = st_groups;
         a.stagger_sleeps = (int)(period * st_percent / 100 / st_groups / 1024);
     }
-    hipLaunchKernelGGL((gemm4_kernel<ACT, EK, LN, RB>), dim3(grid), dim3(256), G4_LDS, s, a);
+    hipLaunchKernelGGL((gemm4_kernel<ACT, EK, LN, RB, HF>), dim3(grid), dim3(256), G4_LDS, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
     return 1;
 }
@@ -711,7 +719,8 @@ __global__ __launch_bounds__(256) void gemm_tn4_kernel(const Tn4Args g) {
 // SLOWER (its A panel is shared by two column tiles only: the loader's HBM latency shows) -- hence the K bound.  The x + Linear(.) kinds
 // stay on the 8-wave kernels: their tiles are bounded by the residual / output bursts, not by the K loop.
 int mage_gemm4_try(const mage_gemm_desc* d, hipStream_t s) {
-    if (d->dtype != MAGE_BF16 || d->n_split > 1) return 0;
+    const bool hf = d->dtype == MAGE_F16;              // f16 operands: the bias and LayerNorm-consuming forms of the generation path
+    if ((d->dtype != MAGE_BF16 && !hf) || d->n_split > 1) return 0;
     if (getenv("MAGE_GEMM_NO_4W")) return 0;           // read on every call (not cached): tests run the same product on both kernels in one process
     if (d->M % 256 || d->N % 256 || d->K % 128 || d->K < 256 || d->K > 1024) return 0;
     if (d->taps_h * d->taps_w != 1 || d->stride != 1 || d->dy0 || d->dx0 || d->in_h != d->out_h || d->in_w != d->out_w || d->a_half) return 0;
@@ -731,7 +740,8 @@ int mage_gemm4_try(const mage_gemm_desc* d, hipStream_t s) {
     if ((dual || gbwd) && !getenv("MAGE_GEMM4_TRAIN_FORMS")) return 0;
     if ((dual || gbwd) && (d->y_dtype != MAGE_BF16 || d->ldy2 % 8 || (((uintptr_t)d->y2) & 15))) return 0;
     if (!dual && !gbwd && d->act != MAGE_ACT_NONE && d->act != MAGE_ACT_QUICKGELU) return 0;
-    if (d->y_dtype != MAGE_F32 && d->y_dtype != MAGE_BF16) return 0;
+    if (d->y_dtype != MAGE_F32 && d->y_dtype != d->dtype) return 0;
+    if (hf && (dual || gbwd)) return 0;
     if (d->ldy % 8 || d->lda % 8 || (((uintptr_t)d->bias | (uintptr_t)d->ln_colsum) & 15) || (((uintptr_t)d->ln_stats) & 7)) return 0;
     const int dev = mage_device_index();
     if (dev < 0) return 0;
@@ -748,6 +758,14 @@ int mage_gemm4_try(const mage_gemm_desc* d, hipStream_t s) {
     if (((long)d->M + d->a_off) * d->lda * 2 + 16384 >= (1L << 32) || (long)d->N * ldw * 2 + 16384 >= (1L << 32)) return 0;     // 32-bit lane offsets
     if (dual) return launch4<MAGE_ACT_QUICKGELU, EK_BIAS, LN_DUAL, false>(d, s, n_cu);
     if (gbwd) return launch4<MAGE_ACT_NONE, EK_BIAS, LN_GELUBWD, false>(d, s, n_cu);
+    if (hf) {
+        if (d->ln_stats) {
+            if (d->act == MAGE_ACT_NONE) return launch4<MAGE_ACT_NONE, EK_BIAS, LN_CONSUME, false, true>(d, s, n_cu);
+            return launch4<MAGE_ACT_QUICKGELU, EK_BIAS, LN_CONSUME, false, true>(d, s, n_cu);
+        }
+        if (d->act == MAGE_ACT_NONE) return launch4<MAGE_ACT_NONE, EK_BIAS, LN_NONE, false, true>(d, s, n_cu);
+        return launch4<MAGE_ACT_QUICKGELU, EK_BIAS, LN_NONE, false, true>(d, s, n_cu);
+    }
     if (d->ln_stats) {
         if (d->act == MAGE_ACT_NONE) return launch4<MAGE_ACT_NONE, EK_BIAS, LN_CONSUME, false>(d, s, n_cu);
         return launch4<MAGE_ACT_QUICKGELU, EK_BIAS, LN_CONSUME, false>(d, s, n_cu);

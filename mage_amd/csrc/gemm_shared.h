@@ -66,10 +66,14 @@ enum { LN_NONE = 0, LN_PRODUCE = 1, LN_CONSUME = 2, LN_DUAL = 3, LN_GELUBWD = 4,
 
 // OSPL (1 = bf16 pieces, 2 = f16 pieces; OT = float): the fp32 result leaves as a SPLIT row (common.h): a wave's 64 columns are one
 // K slab of the consumer, [hi(64) | lo(64)] = the same 256 contiguous bytes per row as 64 fp32 values, so only the staging write differs.
-template <int ACT, typename OT, int MT, bool AFFINE = false, int LN = LN_NONE, int OSPL = 0>
+// HT: the kernel's 16-bit element type (unsigned short = bf16, f16_t = f16): the type of the LN_PRODUCE copy y2 when OT is float, and of
+// 16-bit rows OT themselves.
+template <int ACT, typename OT, int MT, bool AFFINE = false, int LN = LN_NONE, int OSPL = 0,
+          typename HT = std::conditional_t<sizeof(OT) == 2, OT, unsigned short>>
 __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32x4 (&bias)[4], f32x4 (&acc)[MT][4], int m0, int n0,
                                               int lane, int plane, char* stg, long ysplit, const LnConsume* lnc = nullptr) {
     constexpr bool F32 = sizeof(OT) == 4;
+    static_assert((LN != LN_DUAL && LN != LN_GELUBWD) || std::is_same<HT, unsigned short>::value, "training forms: bf16 rows");
     constexpr int RB = F32 ? 256 : 128;            // bytes of one staged row (64 columns)
     constexpr int NCH = RB / 16;                   // 16-byte chunks per row: 16 | 8
     constexpr int RPI = 64 / NCH;                  // rows per store instruction: 4 | 8
@@ -101,10 +105,10 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
     OT* yp = (OT*)d.Y + ysplit + ((long)((m0 + rr) * d.y_mul_x + d.y_off) + row_shift) * ldy + col;      // row m0 + rr, then steps
     const long step = (long)RPI * d.y_mul_x * ldy;
     // LN_PRODUCE (fp32 out): the bf16 copy of the same rows (8 bytes per lane: 4 rows x 128 B per instruction)
-    [[maybe_unused]] unsigned short* y2p = nullptr;
+    [[maybe_unused]] HT* y2p = nullptr;
     [[maybe_unused]] long step2 = 0;
     if constexpr (LN == LN_PRODUCE) {
-        y2p = (unsigned short*)d.y2 + (long)((m0 + rr) * d.y_mul_x + d.y_off) * d.ldy2 + col;
+        y2p = (HT*)d.y2 + (long)((m0 + rr) * d.y_mul_x + d.y_off) * d.ldy2 + col;
         step2 = (long)RPI * d.y_mul_x * d.ldy2;
     }
 
@@ -177,7 +181,7 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
             } else if constexpr (F32) {
                 *(f32x4*)(stg + woff[nt]) = v;
             } else {
-                *(uint2*)(stg + woff[nt]) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *(uint2*)(stg + woff[nt]) = uint2{pack16x2<OT>(v[0], v[1]), pack16x2<OT>(v[2], v[3])};
             }
         }
         if constexpr (LN == LN_PRODUCE) {
@@ -212,8 +216,8 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
 #endif
                 yp += step;
                 if constexpr (LN == LN_PRODUCE && F32) {
-                    const uint2 pk = uint2{pack_bf16x2(__uint_as_float(o[i][0]), __uint_as_float(o[i][1])),
-                                           pack_bf16x2(__uint_as_float(o[i][2]), __uint_as_float(o[i][3]))};
+                    const uint2 pk = uint2{pack16x2<HT>(__uint_as_float(o[i][0]), __uint_as_float(o[i][1])),
+                                           pack16x2<HT>(__uint_as_float(o[i][2]), __uint_as_float(o[i][3]))};
                     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
                     __builtin_nontemporal_store(u32x2_t{pk.x, pk.y}, (u32x2_t*)y2p);
                     y2p += step2;
@@ -268,13 +272,13 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
 // its blocks: half the residual bytes in, and LN_PRODUCE then writes the bf16 rows as its ONLY output).  The 8 bytes of a lane's 4 columns
 // land in the first two registers of the accumulator they seed and are widened in place once the tile's first wait has passed: no staging
 // registers, all 32 loads of a tile in flight at once, as in the fp32 form.
-__device__ __forceinline__ void res_bf16_request(f32x4& a, const unsigned short* p) {
+__device__ __forceinline__ void res_bf16_request(f32x4& a, const void* p) {
     const uint2 t = *(const uint2*)p;
     a = f32x4{__uint_as_float(t.x), __uint_as_float(t.y), 0.f, 0.f};
 }
+template <typename HT = unsigned short>
 __device__ __forceinline__ void res_bf16_widen(f32x4& a) {
-    const unsigned lo = __float_as_uint(a[0]), hi = __float_as_uint(a[1]);
-    a = f32x4{__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+    a = widen4<HT>(uint2{__float_as_uint(a[0]), __float_as_uint(a[1])});
 }
 
 // raw barrier that LDS-DMA may stay in flight across (a __syncthreads() would drain vmcnt to 0); the empty asm

@@ -73,6 +73,12 @@ __device__ __forceinline__ void copy8(const float* src, float* dst) {
     *(f32x4*)(dst + 4) = *(const f32x4*)(src + 4);
 }
 __device__ __forceinline__ void copy8(const unsigned short* src, unsigned short* dst) { *(uint4*)dst = *(const uint4*)src; }
+__device__ __forceinline__ void load8f(const f16_t* p, f32x4& a, f32x4& b) {
+    const uint4 r = *(const uint4*)p;
+    a = widen4<f16_t>(uint2{r.x, r.y});
+    b = widen4<f16_t>(uint2{r.z, r.w});
+}
+__device__ __forceinline__ void copy8(const f16_t* src, f16_t* dst) { *(uint4*)dst = *(const uint4*)src; }
 
 template <typename T, int NK_MAX, typename OT = T>   // OT: T, or (T = float) split_bf16 / split_f16: the output leaves as split rows (common.h)
 __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, int hg) {
@@ -178,11 +184,35 @@ __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, 
 // vector instructions per (sequence, head).  Output: a lane swap gives every lane 8 consecutive dims -> one 16-byte store.
 typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
 typedef __attribute__((ext_vector_type(4))) short ashort4;
+typedef __attribute__((ext_vector_type(4))) _Float16 ahalf4;
+// HT = the 16-bit element type of q, k, v and out: unsigned short (bf16) or f16_t (MAGE_F16).  P = hi + lo in that type -- bf16: hi = the
+// truncation of p, lo = the truncated residue (8 + 8 bits); f16: hi = round(p), lo = round(p - hi) (11 + 11 bits; p <= 1, the residue is
+// >= 2^-24 p: inside the f16 subnormal grid's 6e-8) -- so that P V keeps fp32-class weights in both.
+template <typename HT> __device__ __forceinline__ void attn_p_split(float p, short& hi, short& lo) {
+    if constexpr (std::is_same<HT, f16_t>::value) {
+        const _Float16 h = (_Float16)p;
+        hi = __builtin_bit_cast(short, h);
+        lo = __builtin_bit_cast(short, (_Float16)(p - (float)h));
+    } else {
+        const unsigned hb = __float_as_uint(p) & 0xffff0000u;
+        hi = (short)(hb >> 16);
+        lo = (short)(__float_as_uint(p - __uint_as_float(hb)) >> 16);
+    }
+}
+template <typename HT> __device__ __forceinline__ f32x4 attn_mfma_pv(const ashort4& vt, const ashort4& p, const f32x4& o) {
+    if constexpr (std::is_same<HT, f16_t>::value)
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(ahalf4, vt), __builtin_bit_cast(ahalf4, p), o, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, p, o, 0, 0, 0);
+}
+template <typename HT> __device__ __forceinline__ f32x4 attn_mfma_qk(const uint4& k, const uint4& q) {
+    return mfma16x16x32<HT>(__builtin_bit_cast(u32x4, k), __builtin_bit_cast(u32x4, q), f32x4{0.f, 0.f, 0.f, 0.f});
+}
 
 // NKB = key blocks of 16 (nk <= 16*NKB); queries are walked in blocks of 16 (nq <= 32 at the call sites: frames_length 32).
 // MAXH = heads per wave (ceil(n_head / 4) rounded up to 2, 4 or 8): sizes the preloaded fragment registers; 16 heads -> 4, which
 // keeps the kernel at a register count that lets 4-5 workgroups share a CU (a memory-bound kernel lives off that).
-template <int NKB, int MAXH>
+template <int NKB, int MAXH, typename HT = unsigned short>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const mage_attn_desc d) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned short* vs = (unsigned short*)smem_raw;     // [16*NKB][n_head*32 + 16]: rows >= nk are zero
@@ -194,7 +224,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const mage_attn_des
     const unsigned short* qp = (const unsigned short*)d.q;
     const unsigned short* kp = (const unsigned short*)d.k;
     const unsigned short* vp = (const unsigned short*)d.v;
-    unsigned short* op = (unsigned short*)d.out;
+    HT* op = (HT*)d.out;
     const int vec_per_row = rowf / 8;
     for (int e = threadIdx.x; e < 16 * NKB * vec_per_row; e += 256) {
         const int j = e / vec_per_row, c = (e - j * vec_per_row) * 8;
@@ -239,8 +269,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const mage_attn_des
             float mx = -INFINITY;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
-                st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(abf16x8, kf[t][kb]), __builtin_bit_cast(abf16x8, qf[t]),
-                                                                 f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                st[kb] = attn_mfma_qk<HT>(kf[t][kb], qf[t]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     st[kb][e] = (kb * 16 + 4 * g + e < jmax) ? st[kb][e] * d.scale : -INFINITY;
@@ -257,9 +286,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const mage_attn_des
                 for (int e = 0; e < 4; ++e) {
                     const float p = (kb * 16 + 4 * g + e < jmax) ? expf(st[kb][e] - mx) : 0.f;
                     den += p;
-                    const unsigned hb = __float_as_uint(p) & 0xffff0000u;
-                    phi[kb][e] = (short)(hb >> 16);
-                    plo[kb][e] = (short)(__float_as_uint(p - __uint_as_float(hb)) >> 16);
+                    short ph, pl;
+                    attn_p_split<HT>(p, ph, pl);
+                    phi[kb][e] = ph;
+                    plo[kb][e] = pl;
                 }
             den += __shfl_xor(den, 16);
             den += __shfl_xor(den, 32);
@@ -273,8 +303,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const mage_attn_des
                     ashort4 vt;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) vt[e] = (short)vr[e * vpitch];
-                    o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, phi[kb], o[b], 0, 0, 0);
-                    o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, plo[kb], o[b], 0, 0, 0);
+                    o[b] = attn_mfma_pv<HT>(vt, phi[kb], o[b]);
+                    o[b] = attn_mfma_pv<HT>(vt, plo[kb], o[b]);
                 }
             }
             // lane (i = r, g) holds O[i][b*16 + 4g + e]; swap halves between neighbouring lane groups: 8 consecutive dims per lane
@@ -318,7 +348,7 @@ template <int N> __device__ __forceinline__ ashort4 row_shl_s4(ashort4 src) {
     return __builtin_bit_cast(ashort4, uint2{row_shl_u<N>(u.x), row_shl_u<N>(u.y)});
 }
 
-template <int NKB>
+template <int NKB, typename HT = unsigned short>
 __global__ __launch_bounds__(256) void attention_mfma_fewq_kernel(const mage_attn_desc d) {
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -329,7 +359,7 @@ __global__ __launch_bounds__(256) void attention_mfma_fewq_kernel(const mage_att
     const unsigned short* qp = (const unsigned short*)d.q;
     const unsigned short* kp = (const unsigned short*)d.k;
     const unsigned short* vp = (const unsigned short*)d.v;
-    unsigned short* op = (unsigned short*)d.out;
+    HT* op = (HT*)d.out;
     int klen = d.nk;
     if (d.kv_len) klen = min(klen, d.kv_len[s / d.kv_len_div]);
     const int r = lane & 15, g = lane >> 4;
@@ -387,8 +417,7 @@ __global__ __launch_bounds__(256) void attention_mfma_fewq_kernel(const mage_att
             constexpr int t = decltype(T)::value;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
-                const f32x4 stt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(abf16x8, kf[buf][t][kb]), __builtin_bit_cast(abf16x8, qf[buf][t]),
-                                                                          f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const f32x4 stt = attn_mfma_qk<HT>(kf[buf][t][kb], qf[buf][t]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sp[kb][e] = row_shr_f<2 * t>(sp[kb][e], stt[e]);
             }
@@ -415,9 +444,10 @@ __global__ __launch_bounds__(256) void attention_mfma_fewq_kernel(const mage_att
             for (int e = 0; e < 4; ++e) {
                 const float p = (kb * 16 + 4 * g + e < jmax_p) ? expf(sp[kb][e] - mx) : 0.f;
                 den += p;
-                const unsigned hb = __float_as_uint(p) & 0xffff0000u;
-                phi_p[kb][e] = (short)(hb >> 16);
-                plo_p[kb][e] = (short)(__float_as_uint(p - __uint_as_float(hb)) >> 16);
+                short ph, pl;
+                attn_p_split<HT>(p, ph, pl);
+                phi_p[kb][e] = ph;
+                plo_p[kb][e] = pl;
             }
         den += __shfl_xor(den, 16);
         den += __shfl_xor(den, 32);
@@ -439,8 +469,8 @@ __global__ __launch_bounds__(256) void attention_mfma_fewq_kernel(const mage_att
                 o[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) {
-                    o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt[buf][t][b][kb], phi[kb], o[b], 0, 0, 0);
-                    o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt[buf][t][b][kb], plo[kb], o[b], 0, 0, 0);
+                    o[b] = attn_mfma_pv<HT>(vt[buf][t][b][kb], phi[kb], o[b]);
+                    o[b] = attn_mfma_pv<HT>(vt[buf][t][b][kb], plo[kb], o[b]);
                 }
             }
             f32x4 v0, v1;
@@ -471,7 +501,6 @@ __global__ __launch_bounds__(256) void attention_mfma_fewq_kernel(const mage_att
 // softmax in fp32, P = hi + lo 2^-11 in f16 pieces, O^T = (V_hi^T P_lo^T + V_lo^T P_hi^T) 2^-11 + V_hi^T P_hi^T by 16x16x16 --
 // 22-bit operands, fp32 accumulation: fp32-class like the split GEMMs, in place of the thread-per-(query, head) fp32 kernel (540 vs
 // ~200 us per launch at cfg2).  Logical column c of a split row sits at 16-bit index (c / 64) * 128 + piece * 64 + c % 64.
-typedef __attribute__((ext_vector_type(4))) _Float16 ahalf4;
 __device__ __forceinline__ int split_col(int c, int piece) { return ((c >> 6) << 7) + (piece << 6) + (c & 63); }
 
 template <int NKB, int MAXH>
@@ -819,14 +848,14 @@ int attn_launch(const mage_attn_desc* d, hipStream_t s) {
             const int nkb = d->nk <= 16 ? 1 : 2;
             if (d->nq <= 2 && d->n_seq >= 1024 && !getenv("MAGE_ATTN_NO_FEWQ")) {      // the incremental step's temporal attention
                 const dim3 grid((unsigned)((d->n_seq + 3) / 4));
-                if (nkb == 1) hipLaunchKernelGGL((attention_mfma_fewq_kernel<1>), grid, dim3(256), 0, s, *d);
-                else hipLaunchKernelGGL((attention_mfma_fewq_kernel<2>), grid, dim3(256), 0, s, *d);
+                if (nkb == 1) hipLaunchKernelGGL((attention_mfma_fewq_kernel<1, T>), grid, dim3(256), 0, s, *d);
+                else hipLaunchKernelGGL((attention_mfma_fewq_kernel<2, T>), grid, dim3(256), 0, s, *d);
                 MAGE_CHECK_LAUNCH("mage_attention");
                 return MAGE_OK;
             }
             const size_t lds = (size_t)16 * nkb * (d->n_head * 32 + 16) * 2;
             const int hpw = (d->n_head + 3) / 4;
-#define ATTN_MFMA(NKB, MH) hipLaunchKernelGGL((attention_mfma_kernel<NKB, MH>), dim3(d->n_seq), dim3(256), lds, s, *d)
+#define ATTN_MFMA(NKB, MH) hipLaunchKernelGGL((attention_mfma_kernel<NKB, MH, T>), dim3(d->n_seq), dim3(256), lds, s, *d)
             if (nkb == 1) { if (hpw <= 2) ATTN_MFMA(1, 2); else if (hpw <= 4) ATTN_MFMA(1, 4); else ATTN_MFMA(1, 8); }
             else { if (hpw <= 2) ATTN_MFMA(2, 2); else if (hpw <= 4) ATTN_MFMA(2, 4); else ATTN_MFMA(2, 8); }
 #undef ATTN_MFMA
@@ -868,6 +897,7 @@ extern "C" int mage_layernorm(const float* x, const float* gamma, const float* b
     MAGE_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, "mage_layernorm: rows=%ld C=%d unsupported", (long)rows, C);
     if (y_dtype == MAGE_F32) return ln_launch<float>(x, gamma, beta, y, rows, C, eps, (hipStream_t)stream);
     if (y_dtype == MAGE_BF16) return ln_launch<unsigned short>(x, gamma, beta, y, rows, C, eps, (hipStream_t)stream);
+    if (y_dtype == MAGE_F16) return ln_launch<f16_t>(x, gamma, beta, y, rows, C, eps, (hipStream_t)stream);
     if (y_dtype == MAGE_BF16X3 || y_dtype == MAGE_F16X3) {
         MAGE_CHECK_ARG(C % 64 == 0 && (((uintptr_t)y) & 255) == 0, "mage_layernorm: split output needs C %% 64 == 0 and y 256-byte aligned");
         if (y_dtype == MAGE_BF16X3) return ln_launch<split_bf16>(x, gamma, beta, y, rows, C, eps, (hipStream_t)stream);
@@ -988,6 +1018,7 @@ extern "C" int mage_attention(const mage_attn_desc* d, void* stream) {
                    "mage_attention: out_split needs fp32 q/k/v, an even head count, ldo a multiple of 128 16-bit elements, out 256-byte aligned");
     if (d->dtype == MAGE_F32) return attn_launch<float>(d, (hipStream_t)stream);
     if (d->dtype == MAGE_BF16) return attn_launch<unsigned short>(d, (hipStream_t)stream);
+    if (d->dtype == MAGE_F16) return attn_launch<f16_t>(d, (hipStream_t)stream);
     if (d->dtype == MAGE_F16X3) return attn_split_launch(d, (hipStream_t)stream);
     mage_set_error("mage_attention: bad dtype %d", d->dtype);
     return MAGE_EINVAL;
@@ -1218,6 +1249,7 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
 // fill and context_linear write bf16 rows; the Linear that follows takes (rows, stats) like every later one).  Sums in fp32 in a fixed
 // order (lane: its 8-column groups left to right; then the xor tree), the closing formula is mage_ln_stats'.
 namespace {
+template <typename HT>                                  // unsigned short = bf16 rows, f16_t = f16 rows
 __global__ __launch_bounds__(256) void row_stats_kernel(const unsigned short* __restrict__ x, long rows, int C, long ldx, float inv_c, float eps,
                                                         float* __restrict__ stats) {
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1230,7 +1262,8 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const unsigned short* __
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float a = __uint_as_float(w[j] << 16), b = __uint_as_float(w[j] & 0xffff0000u);
+            const float2 ab = unpack16x2<HT>(w[j]);
+            const float a = ab.x, b = ab.y;
             s1 = __fadd_rn(s1, __fadd_rn(a, b));
             s2 = __fadd_rn(s2, __fmaf_rn(a, a, __fmul_rn(b, b)));
         }
@@ -1249,10 +1282,15 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const unsigned short* __
 }  // namespace
 
 extern "C" int mage_row_stats(const void* x, int32_t dtype, int64_t rows, int32_t C, int64_t ldx, float eps, float* stats, void* stream) {
-    MAGE_CHECK_ARG(x && stats && rows > 0 && C > 0 && C % 8 == 0 && ldx >= C && ldx % 8 == 0 && (((uintptr_t)x) & 15) == 0 && dtype == MAGE_BF16,
-                   "mage_row_stats: bf16 rows, C and ldx multiples of 8, x 16-byte aligned");
-    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (long)rows, C,
-                       (long)ldx, 1.0f / (float)C, eps, stats);
+    MAGE_CHECK_ARG(x && stats && rows > 0 && C > 0 && C % 8 == 0 && ldx >= C && ldx % 8 == 0 && (((uintptr_t)x) & 15) == 0 &&
+                       (dtype == MAGE_BF16 || dtype == MAGE_F16),
+                   "mage_row_stats: bf16 or f16 rows, C and ldx multiples of 8, x 16-byte aligned");
+    if (dtype == MAGE_F16)
+        hipLaunchKernelGGL(row_stats_kernel<f16_t>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
+                           (long)rows, C, (long)ldx, 1.0f / (float)C, eps, stats);
+    else
+        hipLaunchKernelGGL(row_stats_kernel<unsigned short>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)x, (long)rows, C, (long)ldx, 1.0f / (float)C, eps, stats);
     MAGE_CHECK_LAUNCH("mage_row_stats");
     return MAGE_OK;
 }

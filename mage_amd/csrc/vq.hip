@@ -416,8 +416,10 @@ extern "C" int mage_table_conv(const int64_t* ids, int64_t n_img, int32_t H, int
                    "mage_table_conv: bad sizes (odd taps, C %% 4 == 0, C <= 2048)");
     MAGE_CHECK_ARG(!rowadd || (rowadd_div >= 1 && rowadd_mod >= 1), "mage_table_conv: bad rowadd div/mod");
     const bool ysplit = y_dtype == MAGE_BF16X3 || y_dtype == MAGE_F16X3;
-    MAGE_CHECK_ARG((table_dtype == MAGE_F32 || table_dtype == MAGE_BF16) && (y_dtype == MAGE_F32 || y_dtype == MAGE_BF16 || ysplit),
-                   "mage_table_conv: bad table / y dtype %d %d", table_dtype, y_dtype);
+    MAGE_CHECK_ARG((table_dtype == MAGE_F32 || table_dtype == MAGE_BF16 || table_dtype == MAGE_F16) &&
+                       (y_dtype == MAGE_F32 || y_dtype == MAGE_BF16 || y_dtype == MAGE_F16 || ysplit) &&
+                       (table_dtype == MAGE_F32 || y_dtype == MAGE_F32 || table_dtype == y_dtype),
+                   "mage_table_conv: bad table / y dtype %d %d (fp32, bf16 or f16; a 16-bit table writes fp32 or its own type)", table_dtype, y_dtype);
     MAGE_CHECK_ARG(!ysplit || (C % 64 == 0 && ldy == C && (((uintptr_t)y) & 255) == 0 && table_dtype == MAGE_F32),
                    "mage_table_conv: split output needs an fp32 table, C %% 64 == 0, packed rows, y 256-byte aligned");
     int* err = mage_error_word();
@@ -432,6 +434,9 @@ extern "C" int mage_table_conv(const int64_t* ids, int64_t n_img, int32_t H, int
     if (y_dtype == MAGE_F16X3) TCV(float, split_f16);
     else if (y_dtype == MAGE_BF16X3) TCV(float, split_bf16);
     else if (table_dtype == MAGE_F32 && y_dtype == MAGE_F32) TCV(float, float);
+    else if (table_dtype == MAGE_F32 && y_dtype == MAGE_F16) TCV(float, f16_t);
+    else if (table_dtype == MAGE_F16 && y_dtype == MAGE_F32) TCV(f16_t, float);
+    else if (table_dtype == MAGE_F16) TCV(f16_t, f16_t);
     else if (table_dtype == MAGE_F32) TCV(float, unsigned short);
     else if (y_dtype == MAGE_F32) TCV(unsigned short, float);
     else TCV(unsigned short, unsigned short);
@@ -460,6 +465,9 @@ extern "C" int mage_embedding(const int64_t* ids, const float* table, void* out,
     else if (out_dtype == MAGE_BF16)
         hipLaunchKernelGGL((embedding_kernel<unsigned short>), grid, blk, 0, s, ids, table, (unsigned short*)out, (long)n, C,
                            n_table, relu, (long)group, (long)group_stride, (long)off, (long)inner, (long)inner_stride, err);
+    else if (out_dtype == MAGE_F16)
+        hipLaunchKernelGGL((embedding_kernel<f16_t>), grid, blk, 0, s, ids, table, (f16_t*)out, (long)n, C, n_table, relu, (long)group,
+                           (long)group_stride, (long)off, (long)inner, (long)inner_stride, err);
     else if (out_dtype == MAGE_BF16X3 || out_dtype == MAGE_F16X3) {     // split rows (common.h): the frame convolution's A operand in the fast parity mode
         MAGE_CHECK_ARG(C % 64 == 0 && (((uintptr_t)out) & 255) == 0, "mage_embedding: split output needs C %% 64 == 0 and out 256-byte aligned");
         if (out_dtype == MAGE_BF16X3)

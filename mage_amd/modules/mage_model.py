@@ -34,13 +34,25 @@ __all__ = ["QuickGELU", "AxialAttentionBlock", "TransformerBlock", "MAEncoder", 
 
 F32 = torch.float32
 BF16 = torch.bfloat16
+F16 = torch.float16
+HALF_TYPES = (BF16, F16)                      # the 16-bit compute dtypes: the same kernels on v_mfma_f32_16x16x32_bf16 / _f16
 
 
 def _sfx(dt: torch.dtype) -> str:
-    return ".f32" if dt == F32 else ".bf16"
+    return ".f32" if dt == F32 else ".bf16" if dt == BF16 else ".f16"
 
 
-PRECISIONS = {"fp32": (F32, 0), "bf16": (BF16, 0), "bf16x3": (F32, ops.BF16X3), "f16x3": (F32, ops.F16X3)}   # name -> (dtype, split kind)
+def _wdt(d: Dict[str, torch.Tensor], name: str, dt: torch.dtype) -> torch.Tensor:
+    """The copy of the fp32 weight d[name + '.f32'] in the compute dtype (the f16 copies are built on first use: most models never ask)."""
+    w = d.get(name + _sfx(dt))
+    if w is None:
+        w = d[name + _sfx(dt)] = d[name + ".f32"].to(dt)
+    return w
+
+
+# name -> (compute dtype of the decoder stack, split kind).  'f16' = the bf16 mode's kernels, schedules and data flow with IEEE half operands
+# (11 significand bits instead of 8, same MFMA rate): every rounding of 'bf16' mode is 8x smaller; values must stay inside +-65504.
+PRECISIONS = {"fp32": (F32, 0), "bf16": (BF16, 0), "f16": (F16, 0), "bf16x3": (F32, ops.BF16X3), "f16x3": (F32, ops.F16X3)}
 
 
 class FrameTokens:
@@ -96,7 +108,7 @@ def _pack_linear(d: Dict[str, torch.Tensor], name: str, weight: torch.Tensor, bi
 
 
 def _linear(a, d, name, y, dt, *, M, N, K, **kw):
-    return ops.gemm(a, d[name + _sfx(dt)], y, M=M, N=N, K=K, lda=kw.pop("lda", K), ldy=kw.pop("ldy", N),
+    return ops.gemm(a, _wdt(d, name, dt), y, M=M, N=N, K=K, lda=kw.pop("lda", K), ldy=kw.pop("ldy", N),
                     bias=d.get(name + ".b"), **kw)
 
 
@@ -440,7 +452,7 @@ class FlatAxialDecoder(nn.Module):
             for ln, lin in (("ln_1", "in_proj"), ("ln_2", "c_fc")):
                 w, g, bt = d[f"b{i}.{lin}.f32"], d[f"b{i}.{ln}.w"], d[f"b{i}.{ln}.b"]
                 wq = (w * g[None, :]).to(BF16)
-                d[f"b{i}.{lin}.lnw"] = wq
+                d[f"b{i}.{lin}.lnw"] = wq                   # (f16 mode: `.lnw.f16` / `.lns.f16`, built on first use by _ln_fold_w)
                 d[f"b{i}.{lin}.lns"] = wq.float().sum(dim=1).contiguous()
                 # c_n = sum_k W_nk beta_k + b_n in fp64 (a row-wise reduction: derived-cache bookkeeping, no BLAS call)
                 d[f"b{i}.{lin}.lnc"] = ((w.double() * bt.double()[None, :]).sum(1) + d[f"b{i}.{lin}.b"].double()).float().contiguous()
@@ -451,7 +463,7 @@ class FlatAxialDecoder(nn.Module):
         the x + Linear(.) GEMM also writes a bf16 copy of x and per-row partial (sum, sum of squares); the next Linear takes that
         copy with gamma folded into its weights and finishes the normalisation in its epilogue.  Needs whole 256-row tiles per
         frame slot (so that the full pass and the incremental loop take the same route: their tokens stay bit-identical)."""
-        return (dt == BF16 and (B * hw) % 256 == 0 and self.model_channels % 256 == 0 and not os.environ.get("MAGE_NO_LN_FOLD"))
+        return (dt in HALF_TYPES and (B * hw) % 256 == 0 and self.model_channels % 256 == 0 and not os.environ.get("MAGE_NO_LN_FOLD"))
 
     def _stream_bf16(self) -> bool:
         """bf16 mode with the LayerNorm fold: x itself stays in bf16 between the blocks -- every x + Linear(.) reads the bf16 rows as its
@@ -467,8 +479,22 @@ class FlatAxialDecoder(nn.Module):
         Cc = self.model_channels
         hi = N + lo if hi is None else hi
         src = dict(ln_part=part, ln_eps=1e-5) if part is not None else dict(ln_stats=stats)
-        return ops.gemm(xb, d[f"{p}.{lin}.lnw"][lo:hi], y, M=M, N=hi - lo, K=Cc, lda=Cc, ldy=kw.pop("ldy", hi - lo),
-                        bias=d[f"{p}.{lin}.lnc"][lo:hi], ln_colsum=d[f"{p}.{lin}.lns"][lo:hi], **src, **kw)
+        lnw, lns = self._ln_fold_w(d, p, lin, xb.dtype)
+        return ops.gemm(xb, lnw[lo:hi], y, M=M, N=hi - lo, K=Cc, lda=Cc, ldy=kw.pop("ldy", hi - lo),
+                        bias=d[f"{p}.{lin}.lnc"][lo:hi], ln_colsum=lns[lo:hi], **src, **kw)
+
+    @staticmethod
+    def _ln_fold_w(d, p, lin, dt):
+        """(W' = gamma * W rounded to dt, s_n = the row sums of the ROUNDED W') of the LayerNorm fold (see _build): bf16 from _build, f16 on
+        first use."""
+        if dt == BF16:
+            return d[f"{p}.{lin}.lnw"], d[f"{p}.{lin}.lns"]
+        kw_, ks_ = f"{p}.{lin}.lnw.f16", f"{p}.{lin}.lns.f16"
+        if kw_ not in d:
+            ln = "ln_1" if lin == "in_proj" else "ln_2"
+            wq = (d[f"{p}.{lin}.f32"] * d[f"{p}.{ln}.w"][None, :]).to(F16)
+            d[kw_], d[ks_] = wq, wq.float().sum(dim=1).contiguous()
+        return d[kw_], d[ks_]
 
     def _stats_inline(self, xb, M: int) -> bool:
         """One clip per call: every Linear that follows a LayerNorm (N = C .. 4C) runs on the few-rows kernel, which reduces the
@@ -634,7 +660,7 @@ class FlatAxialDecoder(nn.Module):
             axis = i % 3
             if not have_stats:
                 ops.layernorm(x, d[p + ".ln_1.w"], d[p + ".ln_1.b"], xn, 1e-5)
-            w, b = d[p + ".in_proj" + _sfx(dt)], d[p + ".in_proj.b"]
+            w, b = _wdt(d, p + ".in_proj", dt), d[p + ".in_proj.b"]
             pin = part if (inl and not (fill_stats and i == 0)) else None        # block 0: the statistics of the fill, not partial sums
             if axis == 0:
                 kv = st["kv"][i]                                             # [B, L, hw, K|V]
@@ -1064,12 +1090,12 @@ class MAGE(nn.Module):
         ft = self._frame_tables()
         if ft["ft.T2"] is not None and getattr(self, "frame_table", True):
             T2 = ft["ft.T2"]
-            if dt == BF16 and self._sk() == 0:
-                # bf16 mode: the table itself in bf16 (half the L2 / Infinity-Cache bytes per gathered row; entries rounded once, sums
-                # and positions stay fp32 -- the same class of error as the bf16 operands of the convolution it replaces)
-                if "ft.T2.bf16" not in ft:
-                    ft["ft.T2.bf16"] = T2.to(BF16)
-                T2 = ft["ft.T2.bf16"]
+            if dt in HALF_TYPES and self._sk() == 0:
+                # bf16 / f16 mode: the table itself in that type (half the L2 / Infinity-Cache bytes per gathered row; entries rounded once,
+                # sums and positions stay fp32 -- the same class of error as the 16-bit operands of the convolution it replaces)
+                if "ft.T2" + _sfx(dt) not in ft:
+                    ft["ft.T2" + _sfx(dt)] = T2.to(dt)
+                T2 = ft["ft.T2" + _sfx(dt)]
             return FrameTokens(tokens.reshape(-1, self.image_resolution ** 2), T2, ft["ft.P2"], self.image_resolution)
         return self._frame_features(tokens, dt, split=True)
 
@@ -1106,7 +1132,7 @@ class MAGE(nn.Module):
                             split_kind=sk, y_split=True)
         if dt == F32 or Cc % 64:
             emb = ops.embedding(tokens.reshape(-1), d["emb"], torch.empty(n * R * R, Cc, device=tokens.device, dtype=dt))
-            return VectorQuantizedVAE._conv(emb, d["conv" + _sfx(dt)], torch.empty_like(emb), n_img=n, H=R, W=R, cin=Cc, cout=Cc,
+            return VectorQuantizedVAE._conv(emb, _wdt(d, "conv", dt), torch.empty_like(emb), n_img=n, H=R, W=R, cin=Cc, cout=Cc,
                                             k=3, rowadd=d["hwpos"], rowadd_div=1, rowadd_mod=R * R)
         P = R + 2
         key = (n, str(tokens.device), torch.cuda.current_stream(tokens.device).cuda_stream if tokens.is_cuda else 0)
@@ -1117,7 +1143,7 @@ class MAGE(nn.Module):
             pad = self._pad_frames[key] = torch.zeros((n * P * P + 1) * Cc, device=tokens.device, dtype=dt).view(-1, Cc)
         ops.embedding(tokens.reshape(-1), d["emb"], pad, group=R * R, group_stride=P * P, off=P + 1, inner=R, inner_stride=P)
         out = torch.empty(n * R * R, Cc, device=tokens.device, dtype=dt)
-        return ops.gemm(pad, d["conv" + _sfx(dt)], out, M=n * R * R, N=Cc, K=9 * Cc, lda=Cc, ldy=Cc, out_h=R, out_w=R, in_h=P, in_w=P,
+        return ops.gemm(pad, _wdt(d, "conv", dt), out, M=n * R * R, N=Cc, K=9 * Cc, lda=Cc, ldy=Cc, out_h=R, out_w=R, in_h=P, in_w=P,
                         a_img_stride=P * P, taps_h=3, taps_w=3, cin=Cc, stride=1, dy0=0, dx0=0, rowadd=d["hwpos"], rowadd_div=1,
                         rowadd_mod=R * R)
 
@@ -1130,7 +1156,7 @@ class MAGE(nn.Module):
         E = d["emb_lin.w"].shape[1]
         emb = ops.gemm(lat, d["emb_lin.w"], torch.empty(rows, Cc, device=lat.device, dtype=dt), M=rows, N=Cc, K=E, lda=ld, ldy=Cc,
                        bias=d["emb_lin.b"])                                                   # K = 4: fp32 MFMA path
-        return VectorQuantizedVAE._conv(emb, d["conv" + _sfx(dt)], torch.empty_like(emb), n_img=rows // (R * R), H=R, W=R, cin=Cc,
+        return VectorQuantizedVAE._conv(emb, _wdt(d, "conv", dt), torch.empty_like(emb), n_img=rows // (R * R), H=R, W=R, cin=Cc,
                                         cout=Cc, k=3, rowadd=d["hwpos"], rowadd_div=1, rowadd_mod=R * R)
 
     def _motion_anchor(self, tok0: torch.Tensor, batch, noise: Optional[torch.Tensor], first: Optional[torch.Tensor] = None,

@@ -589,6 +589,9 @@ def train_forward(model, batch):
     R, L, Cc = model.image_resolution, model.frames_length, model.vision_width
     hw = R * R
     dt = model._dt()
+    if dt == torch.float16:
+        raise ValueError("precision 'f16' is a generation mode (forward values, autoregressive_generate): the backward kernels are bf16 / fp32 -- "
+                         "train with set_precision('bf16') or 'fp32'")
     run = _Run(dt, model.dropout, model.training)
     run32 = _Run(F32, model.dropout, model.training)
     run32.seed, run32.p = run.seed, run.p

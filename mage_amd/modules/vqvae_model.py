@@ -184,7 +184,10 @@ class VectorQuantizedVAE(nn.Module):
     def set_precision(self, precision: str) -> "VectorQuantizedVAE":
         """'fp32' (parity: exact-fp32 MFMA), 'bf16' (decode stack on bf16 MFMA; encode + VQ stay fp32-class so token indices stay
         bit-exact), or 'f16x3' / 'bf16x3' (the fast parity modes: the f4 decode stack on split-precision operands, fp32-class frames)."""
-        self.decode_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16, "f16x3": torch.float32, "bf16x3": torch.float32}[precision]
+        # 'f16' (the decoder stack's single-pass half mode): frames come from the bf16 decode stack -- tokens -> pixels is not on the token
+        # path, and the fused decode kernels (resblock_table, the sub-pixel head) are bf16
+        self.decode_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16, "f16": torch.bfloat16, "f16x3": torch.float32,
+                             "bf16x3": torch.float32}[precision]
         self.decode_split = ops.F16X3 if precision in ("f16x3", "bf16x3") else 0     # f16 pieces for both: the encoder's kind
         # 'fp32' is the exact parity mode end to end: its encoder keeps the exact-fp32 MFMA chain, so that a near-tie token cannot flip
         # against the reference because of the 7e-7 the split operands move z_e by; the other modes take the split encoder

@@ -13,11 +13,11 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_QUICKGELU_GRAD, ACT_RELU, ACT_TANH, BF16, BF16X3, F16X3, F32, AttnDesc, GemmDesc
+from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_QUICKGELU_GRAD, ACT_RELU, ACT_TANH, BF16, BF16X3, F16, F16X3, F32, AttnDesc, GemmDesc
 
 __all__ = ["gemm", "layernorm", "attention", "embedding", "table_conv", "split_rows", "vq_prepare", "vq_nearest", "argmax", "cross_entropy",
            "conv_in", "conv_out", "convt_fold_tanh", "row_affine", "groupnorm_silu", "groupnorm_act", "reparam_kl", "mse", "check_device_errors", "graph_events_supported", "transpose", "row_sum", "sum_partials", "layernorm_bwd", "dropout_add_layernorm", "act", "act_bwd", "cross_entropy_bwd", "embedding_bwd", "group_rowsum", "attention_bwd", "dropout", "adam", "bn_train_stats", "bn_apply", "bn_backward", "convt_unfold_tanh_bwd", "maxpool2", "upsample2", "relu", "cast", "adain", "add_scaled_rowvec",
-           "split", "split_empty", "split_dtype", "PROFILE", "F32", "BF16", "BF16X3", "F16X3", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
+           "split", "split_empty", "split_dtype", "PROFILE", "F32", "BF16", "F16", "BF16X3", "F16X3", "ACT_NONE", "ACT_RELU", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_TANH", "tdtype", "code"]
 
 
 def code(t: torch.Tensor) -> int:
@@ -25,11 +25,13 @@ def code(t: torch.Tensor) -> int:
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == torch.float16:
+        return F16
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
 def tdtype(c: int) -> torch.dtype:
-    return torch.float32 if c == F32 else torch.bfloat16
+    return {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[c]
 
 
 # ---- split-precision tensors (MAGE_BF16X3 / MAGE_F16X3, include/mage_hip.h): a logical fp32 [rows, C] matrix kept as two 16-bit pieces
@@ -261,7 +263,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     d.res_half = int(res_half)
     d.a_half = int(a_half)
     ln = 2 if (ln_stats is not None or ln_colsum is not None) else (1 if (y2 is not None or ln_part is not None) else 0)      # LN_CONSUME / LN_PRODUCE
-    rb = residual is not None and residual.dtype == torch.bfloat16 and d.dtype == BF16      # bf16 residual stream (RB in csrc/gemm.hip)
+    h16 = d.dtype in (BF16, F16)                                                             # 16-bit operands: the same kernels, bf16 or f16 MFMA
+    hf = "true" if d.dtype == F16 else "false"                                               # HF, the kernels' last template argument
+    rb = residual is not None and residual.dtype == a.dtype and h16                          # 16-bit residual stream (RB in csrc/gemm_impl.h)
     if y2 is not None and ln_part is None and ln_stats is None and ln_colsum is None and act == ACT_QUICKGELU:
         ln = 3                                                                                  # LN_DUAL: pre-activation + activated rows
     act_k = act
@@ -272,7 +276,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
         # per-kernel averages line up with rocprofv3's per-symbol statistics
         gather = taps_h * taps_w > 1 or stride != 1 or dy0 != 0 or dx0 != 0 or d.in_h != d.out_h or d.in_w != d.out_w or a_half
         n_cu = torch.cuda.get_device_properties(a.device).multi_processor_count & ~7
-        mt = 8 if (d.dtype == BF16 and ((M + 255) // 256) * ((N + 255) // 256) * max(n_split, 1) >= 2 * n_cu) else 4
+        mt = 8 if (h16 and ((M + 255) // 256) * ((N + 255) // 256) * max(n_split, 1) >= 2 * n_cu) else 4
         if scale is None and rowadd is None and residual is None and not post_relu:
             ek = 0
         elif (not gather and act == ACT_NONE and residual is not None and (residual.dtype == torch.float32 or rb) and scale is None
@@ -285,35 +289,35 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
         if (ek != 1 and ln == 0 and N <= 128 and n_split == 1 and ((M + 255) // 256) * ((N + 63) // 64) >= n_cu
                 and not os.environ.get("MAGE_GEMM_NO_NARROW")):
             mt, nw = 2, 1                                   # the narrow 256 x 64 tile (launch_ek in csrc/gemm.hip)
-        if (ek == 1 and d.dtype == BF16 and not gather and act == ACT_NONE and n_split == 1 and N % 64 == 0
+        if (ek == 1 and h16 and not gather and act == ACT_NONE and n_split == 1 and N % 64 == 0
                 and ((M + 127) // 128) * ((N + 255) // 256) < n_cu and not os.environ.get("MAGE_GEMM_NO_NARROW")
                 and not os.environ.get("MAGE_GEMM_NO_NARROW_FEW")):
             mt, nw = 2, 1                                   # few rows: x + Linear(.) of the incremental loop on the narrow tile
         rbs = ", true" if (rb and ek == 1) else ", false"       # rocprofv3 prints every template argument: the keys match its symbols
         key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act_k}, {mt}, {ek}, {sp}, {ln}, {nw}, 0{rbs}>"
         a_rows = ((M + out_h * out_w - 1) // (out_h * out_w)) * d.a_img_stride + a_off + 1
-        if (d.dtype == BF16 and not gather and mt == 8 and ek != 2 and K % 64 == 0 and a_rows * lda * 2 < 2 ** 32
+        if (h16 and not gather and mt == 8 and ek != 2 and K % 64 == 0 and a_rows * lda * 2 < 2 ** 32
                 and N * K * 2 < 2 ** 32 and not os.environ.get("MAGE_GEMM_NO_8PHASE")):
-            key = f"gemm8_kernel<{act_k}, {ek}, {sp}, false, {ln}, 0{rbs}>"    # the 8-phase ping-pong variant (launch_tile in csrc/gemm.hip)
+            key = f"gemm8_kernel<{act_k}, {ek}, {sp}, false, {ln}, 0{rbs}, {hf}>"    # the 8-phase ping-pong variant (launch_tile in csrc/gemm_impl.h)
         # padded-taps convolutions and row-table Linears on the 8-phase kernel (try_taps8 in csrc/gemm.hip)
         ntaps = taps_h * taps_w
         table, plain = rowadd is not None and residual is None, rowadd is None and residual is None
-        if (d.dtype == BF16 and n_split == 1 and (ntaps > 1 or table) and stride == 1 and dys == 1 and dxs == 1 and dy0 == 0 and dx0 == 0
+        if (h16 and n_split == 1 and (ntaps > 1 or table) and stride == 1 and dys == 1 and dxs == 1 and dy0 == 0 and dx0 == 0
                 and d.in_h >= out_h + taps_h - 1 and d.in_w >= out_w + taps_w - 1 and d.cin % 64 == 0 and K % 64 == 0 and scale is None
                 and not post_relu and N % 256 == 0 and M % 256 == 0
                 and not os.environ.get("MAGE_GEMM_NO_8PHASE") and not os.environ.get("MAGE_GEMM_NO_TAPS8")):
             if table and act == ACT_NONE:
-                key = "gemm8_kernel<0, 1, false, true, 0, 0, false>"
-            elif plain and act in (ACT_NONE, ACT_RELU):
-                key = f"gemm8_kernel<{act}, 0, false, true, {5 if head_w is not None else 0}, 0, false>"
+                key = f"gemm8_kernel<0, 1, false, true, 0, 0, false, {hf}>"
+            elif plain and act in (ACT_NONE, ACT_RELU) and d.dtype == BF16:
+                key = f"gemm8_kernel<{act}, 0, false, true, {5 if head_w is not None else 0}, 0, false, false>"
         # the one-wave-per-SIMD kernel (mage_gemm4_try in csrc/gemm4.hip): QKV / c_fc at full-loop sizes
-        if (d.dtype == BF16 and not gather and n_split <= 1 and M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and 256 <= K <= 1024
+        if (h16 and not gather and n_split <= 1 and M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and 256 <= K <= 1024
                 and out_h == 1 and out_w >= M and y_mul_x == 1 and ek == 0 and not res_half and ln_part is None
                 and (bias is not None or (N <= 4096 and ln_stats is None)) and (ln_stats is None) == (ln_colsum is None)
                 and (act in (ACT_NONE, ACT_QUICKGELU) if y2 is None else (ln in (3, 4) and y.dtype == torch.bfloat16 and ldy2 % 8 == 0
                                                                           and bool(os.environ.get("MAGE_GEMM4_TRAIN_FORMS"))))
                 and lda % 8 == 0 and ldy % 8 == 0 and (M // 256) * (N // 256) >= 4 * n_cu and not os.environ.get("MAGE_GEMM_NO_4W")):
-            key = f"gemm4_kernel<{act_k}, 0, {ln}, false>"
+            key = f"gemm4_kernel<{act_k}, 0, {ln}, false, {hf}>"
         if PROFILE.wants(key):
             ev = PROFILE.begin()
             _lib.check(l.mage_gemm(C.byref(d), s), l)
@@ -386,9 +390,9 @@ def _gemm_split(l, s, a, w, y, *, M, N, K, lda, ldy, out_h, out_w, in_h, in_w, a
 def row_stats(x: torch.Tensor, eps: float, stats: torch.Tensor) -> torch.Tensor:
     """(mean, rstd) per row of bf16 rows x [rows, C] (mage_row_stats)."""
     l, s = _dev(x)
-    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and stats.is_contiguous() and stats.numel() >= 2 * x.shape[0]
+    assert x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 2 and x.stride(1) == 1 and stats.is_contiguous() and stats.numel() >= 2 * x.shape[0]
     ev = PROFILE.begin() if PROFILE.wants("layernorm") else None
-    _lib.check(l.mage_row_stats(x.data_ptr(), BF16, x.shape[0], x.shape[1], x.stride(0), float(eps), stats.data_ptr(), s), l)
+    _lib.check(l.mage_row_stats(x.data_ptr(), code(x), x.shape[0], x.shape[1], x.stride(0), float(eps), stats.data_ptr(), s), l)
     if ev is not None:
         PROFILE.end("layernorm", ev, 0.0, float(x.numel()) * 2)
     return stats
