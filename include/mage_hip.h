@@ -445,8 +445,10 @@ int mage_act_bwd(const void* x, const void* dy, void* dx, int32_t dtype, int64_t
 int mage_cross_entropy_bwd(const float* logits, const int64_t* target, int64_t rows, int32_t K, const float* grad_out, void* dlogits,
                            int32_t dl_dtype, void* stream);
 /* nn.Embedding backward: dtable[ids[i], :] += dout[orow(i), :] (orow as in mage_embedding; ids equal to padding_idx (< 0: none)
- * contribute nothing, as nn.Embedding(padding_idx=...) does).  fp32 atomics -- or, for tables of up to 512 rows with `scratch` of at
- * least 64 * n_table * C floats (16-byte aligned), per-chunk partial tables summed in chunk order: no global atomics, deterministic. */
+ * contribute nothing, as nn.Embedding(padding_idx=...) does).  fp32 atomics -- or, for tables of up to 512 rows (C % 64 == 0) with `scratch`
+ * of at least min(64, ceil(n / 4096)) * n_table * C floats (16-byte aligned), DETERMINISTIC: per-chunk partial tables whose entries add
+ * the chunk's rows in ascending order (no atomics between waves), summed in chunk order -- a fixed-order fp32 sum, bit-identical from run
+ * to run (what makes the in-tree training reproducible). */
 int mage_embedding_bwd(const int64_t* ids, const void* dout, int32_t dout_dtype, float* dtable, int64_t n, int32_t C, int32_t n_table,
                        int64_t padding_idx, int64_t group, int64_t group_stride, int64_t off, float* scratch, int64_t scratch_floats,
                        void* stream);

@@ -437,6 +437,53 @@ __global__ __launch_bounds__(512) void embedding_bwd_lds_kernel(const int64_t* _
     }
 }
 
+// The DETERMINISTIC form of the same scatter (scratch given): the workgroup's geometry is unchanged -- a 64-channel slice, a chunk of the rows,
+// an LDS table of the slice -- but the WAVES split the slice's channels instead of the chunk's rows: wave w owns channels 8w .. 8w + 7, a wave
+// instruction covers 8 rows x 8 channels (32 bytes of bf16 / 64 of fp32 per row), and the 8 rows are added one after the other in ascending
+// order (LDS adds of one wave execute in program order; no other wave touches these channels).  Every (code, channel) sum therefore runs
+// over the chunk's rows in ascending row order, whatever the scheduling: with the chunk-order sum of embedding_bwd_reduce_kernel the whole
+// gradient is a fixed-order fp32 sum, bit-identical from run to run.  (The row-split kernel above let 8 waves race their LDS atomics on the
+// same entries: associativity differences of ~1 ulp per step, enough to move a trained model's near-tie token decisions between runs.)
+template <typename T>
+__global__ __launch_bounds__(512) void embedding_bwd_det_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dout, long n, int C, int n_table,
+                                                                long padding_idx, long group, long group_stride, long off, long rows_per_chunk,
+                                                                float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* tab = (float*)smem_raw;                                        // [n_table][64]
+    const int c0 = blockIdx.y * 64, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int e = threadIdx.x; e < n_table * 64; e += 512) tab[e] = 0.f;
+    __syncthreads();
+    const long i0 = (long)blockIdx.x * rows_per_chunk, i1 = min(n, i0 + rows_per_chunk);
+    const int rs = lane >> 3, ch = wave * 8 + (lane & 7);                  // row slot of the instruction, channel inside the slice
+    constexpr int U = 8;                                                   // 8-row groups in flight per wave
+    for (long ib = i0; ib < i1; ib += 8 * U) {
+        long id[U];
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long i = ib + 8 * u + rs;
+            const long ii = i < i1 ? i : i0;
+            id[u] = ids[ii];
+            const bool ok = i < i1 && id[u] >= 0 && id[u] < n_table && id[u] != padding_idx;
+            if (!ok) id[u] = -1;
+            const unsigned q = (unsigned)ii / (unsigned)group;
+            const long orow = (long)q * group_stride + (long)((unsigned)ii - q * (unsigned)group) + off;
+            v[u] = to_f32<T>(dout[orow * C + c0 + ch]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {                                  // the instruction's 8 rows, ascending: one exec-masked LDS add each
+                if (rs == r && id[u] >= 0) atomicAdd(&tab[id[u] * 64 + ch], v[u]);
+                __builtin_amdgcn_wave_barrier();                           // keeps the eight adds eight instructions, in this order
+            }
+        }
+    }
+    __syncthreads();
+    float* pp = part + (long)blockIdx.x * n_table * C;
+    for (int e = threadIdx.x; e < n_table * 64; e += 512) pp[(long)(e >> 6) * C + c0 + (e & 63)] = tab[e];
+}
+
 // dtable[e] += sum over chunks (ascending) of part[chunk][e]: the flush of embedding_bwd_lds_kernel without global atomics (the 64 chunks'
 // atomics on the same 1 MB table were 0.8 of the kernel's 1.0 ms)
 __global__ __launch_bounds__(256) void embedding_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dtable, long n_elem, int n_chunk) {
@@ -956,12 +1003,34 @@ extern "C" int mage_embedding_bwd(const int64_t* ids, const void* dout, int32_t 
                                   int64_t scratch_floats, void* stream) {
     MAGE_CHECK_ARG(ids && dout && dtable && n > 0 && C > 0 && n_table > 0 && group > 0, "mage_embedding_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (n_table <= 512 && C % 64 == 0 && n >= 8192 && n < (1L << 31) && group < (1L << 31) && (dout_dtype == MAGE_F32 || dout_dtype == MAGE_BF16)) {
+    const bool small_tab = n_table <= 512 && C % 64 == 0 && n < (1L << 31) && group < (1L << 31) && (dout_dtype == MAGE_F32 || dout_dtype == MAGE_BF16);
+    if (small_tab && (n >= 8192 || scratch)) {
         const int n_chunk = (int)(n / 4096 < 64 ? (n + 4095) / 4096 : 64);
-        const long rpc = (n + n_chunk - 1) / n_chunk;
+        const long rpc = (((n + n_chunk - 1) / n_chunk) + 7) & ~7L;       // whole 8-row groups per chunk (the deterministic kernel's unit)
         const dim3 grid(n_chunk, C / 64), blk(512);
         const size_t lds = (size_t)n_table * 64 * sizeof(float);
         float* part = (scratch && scratch_floats >= (int64_t)n_chunk * n_table * C && (((uintptr_t)scratch | (uintptr_t)dtable) & 15) == 0) ? scratch : nullptr;
+        if (part) {                                                       // deterministic: channel-split waves, rows in ascending order, chunk-order sum
+            static bool attr_det[MAGE_MAX_DEVICES][2] = {{false}};
+            const int dev_ = mage_device_index();
+            MAGE_CHECK_ARG(dev_ >= 0, "mage_embedding_bwd: no current device");
+            const int ti = dout_dtype == MAGE_F32 ? 0 : 1;
+            if (!attr_det[dev_][ti]) {
+                if (ti == 0) (void)hipFuncSetAttribute((const void*)embedding_bwd_det_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                else (void)hipFuncSetAttribute((const void*)embedding_bwd_det_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                attr_det[dev_][ti] = true;
+            }
+            if (ti == 0)
+                hipLaunchKernelGGL((embedding_bwd_det_kernel<float>), grid, blk, lds, s, ids, (const float*)dout, (long)n, C, n_table, (long)padding_idx,
+                                   (long)group, (long)group_stride, (long)off, rpc, part);
+            else
+                hipLaunchKernelGGL((embedding_bwd_det_kernel<unsigned short>), grid, blk, lds, s, ids, (const unsigned short*)dout, (long)n, C, n_table,
+                                   (long)padding_idx, (long)group, (long)group_stride, (long)off, rpc, part);
+            const long n_elem = (long)n_table * C;
+            hipLaunchKernelGGL(embedding_bwd_reduce_kernel, dim3((unsigned)((n_elem / 4 + 255) / 256)), dim3(256), 0, s, part, dtable, n_elem, n_chunk);
+            MAGE_CHECK_LAUNCH("mage_embedding_bwd");
+            return MAGE_OK;
+        }
         static bool attr_set[MAGE_MAX_DEVICES][2] = {{false}};
         const int dev = mage_device_index();
         MAGE_CHECK_ARG(dev >= 0, "mage_embedding_bwd: no current device");

@@ -893,8 +893,11 @@ def embedding_bwd(ids, dout, dtable, *, padding_idx: int = -1, group: Optional[i
     group = n if group is None else group
     group_stride = group if group_stride is None else group_stride
     scratch = None
-    if dtable.shape[0] <= 512 and dtable.shape[1] % 64 == 0 and n >= 8192:      # small hot table: partial tables instead of global atomics
-        scratch = torch.empty(64 * dtable.numel(), device=dtable.device, dtype=torch.float32)
+    if dtable.shape[0] <= 512 and dtable.shape[1] % 64 == 0:
+        # small table (the visual token table, the codebook, the caption vocabulary): per-chunk partial tables summed in chunk order, rows added
+        # in ascending order inside a chunk -- no atomics between waves, a fixed-order fp32 sum: bit-identical gradients from run to run
+        n_chunk = min(64, (n + 4095) // 4096)
+        scratch = torch.empty(n_chunk * dtable.numel(), device=dtable.device, dtype=torch.float32)
     _lib.check(l.mage_embedding_bwd(ids.data_ptr(), dout.data_ptr(), code(dout), dtable.data_ptr(), n, dtable.shape[1], dtable.shape[0],
                                     padding_idx, group, group_stride, off, _p(scratch), 0 if scratch is None else scratch.numel(), s), l)
     return dtable

@@ -128,14 +128,60 @@ def _sprite(g: np.random.Generator) -> np.ndarray:
     return img
 
 
+STROKE_CLASSES = 10
+
+
+def _stroke_template(cls: int) -> np.ndarray:
+    """Control points [n, 2] (y, x in a 28 x 28 box) of shape class `cls`: a fixed polyline per class (its own generator, independent of the
+    batch seed), 4-6 points -- the ten 'digits' of the strokes style."""
+    g = rng_for(0, f"stroke_class/{cls}")
+    n = 4 + cls % 3
+    pts = g.uniform(5.0, 23.0, size=(n, 2))
+    if cls % 2 == 0:                                            # even classes close the loop
+        pts = np.concatenate([pts, pts[:1]], 0)
+    return pts
+
+
+def _stroke_sprite(g: np.random.Generator, cls: int) -> np.ndarray:
+    """A 28x28 stroke drawing in [0, 1]: the class polyline under a small random affine map, with a random stroke width, a random peak
+    intensity and a sinusoidal shading along a random direction -- many distinct 4x4 patches (a VQ-VAE trained on these frames uses a
+    large part of its codebook; the Gaussian blobs of `_sprite` need 8 codes)."""
+    pts = _stroke_template(cls) + g.normal(0.0, 0.6, size=_stroke_template(cls).shape)
+    ang, sc = g.uniform(-0.25, 0.25), g.uniform(0.85, 1.15)
+    rot = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]]) * sc
+    pts = (pts - 14.0) @ rot.T + 14.0
+    thick, inten = g.uniform(1.0, 2.6), g.uniform(0.5, 1.0)
+    yy, xx = np.mgrid[0:28, 0:28].astype(np.float64)
+    p = np.stack([yy, xx], -1)                                   # [28, 28, 2]
+    d = np.full((28, 28), 1e9)
+    for a_, b_ in zip(pts[:-1], pts[1:]):
+        ab = b_ - a_
+        t_ = np.clip(((p - a_) @ ab) / max(float(ab @ ab), 1e-9), 0.0, 1.0)
+        d = np.minimum(d, np.linalg.norm(p - (a_ + t_[..., None] * ab), axis=-1))
+    img = np.clip((thick + 0.7 - d) / 1.4, 0.0, 1.0) * inten
+    fy, fx, ph = g.uniform(0.4, 1.4), g.uniform(0.4, 1.4), g.uniform(0, 2 * np.pi)
+    img *= 0.8 + 0.2 * np.sin(fy * yy + fx * xx + ph)
+    img[img < 0.04] = 0.0
+    return img
+
+
 def synth_batch_mnist(B: int, L: int, seed: int = 0, digits: int = 1, text_len: int = 11,
-                      vocab: int = 30, ragged_text: bool = False, caption_lengths: Optional[Iterable[int]] = None) -> Dict[str, torch.Tensor]:
+                      vocab: int = 30, ragged_text: bool = False, caption_lengths: Optional[Iterable[int]] = None,
+                      style: str = "blob") -> Dict[str, torch.Tensor]:
     """Moving-MNIST-like batch with the reference's batch contract
     (dataload.py:240-271): images f32 [B,L,1,64,64] in [-0.5, 0.5], text int64 [B,S]
     right-padded with 0, speed f32 [B].  Motion follows the bounce rule of
     data/mnist_caption_single.py:62-109.  ``caption_lengths`` (e.g. (16, 18, 20): the token counts of the double-digit captions
     of data/mnist_caption_double_modified.py:218-220, each motion phrase being 1 or 3 words) draws every caption's length from
-    that set and right-pads to its maximum."""
+    that set and right-pads to its maximum.
+
+    style 'blob' (default; what every golden fixture and test uses): Gaussian-blob sprites, random caption tokens.  style 'strokes' (the
+    trained-weights token task of bench.py): stroke drawings of STROKE_CLASSES shape classes with random width / intensity / shading, and a
+    caption that SAYS what moves how -- token 1 = 3 + class, token 2 = 13 + 2 * axis + (direction > 0), like the reference's captions
+    ('the digit 3 is moving up then down', data/mnist_caption_single.py:27-45) -- so that the next frame is predictable from frame 0 + text."""
+    if style == "strokes":
+        return _synth_batch_strokes(B, L, seed, text_len, vocab)
+    assert style == "blob", style
     g = rng_for(seed, f"batch_mnist/{B}/{L}/{digits}")
     imgs = np.zeros((B, L, 1, 64, 64), np.float32)
     lim = 64 - 28
@@ -174,6 +220,41 @@ def synth_batch_mnist(B: int, L: int, seed: int = 0, digits: int = 1, text_len: 
         text[b, 1:n - 1] = g.integers(3, vocab, size=n - 2)
         text[b, n - 1] = 2                                        # [SEP]
     speed = g.random(size=B).astype(np.float32)                    # dataload.py:246
+    return {"images": torch.from_numpy(imgs), "text": torch.from_numpy(text), "speed": torch.from_numpy(speed)}
+
+
+def _synth_batch_strokes(B: int, L: int, seed: int, text_len: int, vocab: int) -> Dict[str, torch.Tensor]:
+    assert text_len >= 5 and vocab >= 20
+    g = rng_for(seed, f"batch_strokes/{B}/{L}")
+    imgs = np.zeros((B, L, 1, 64, 64), np.float32)
+    text = np.zeros((B, text_len), np.int64)
+    lim = 64 - 28
+    step = 0.2 * lim
+    for b in range(B):
+        cls = int(g.integers(0, STROKE_CLASSES))
+        sp = _stroke_sprite(g, cls).astype(np.float32)
+        y, x = g.uniform(0, lim, size=2)
+        axis = int(g.integers(0, 2))
+        sign = 1.0 if g.random() < 0.5 else -1.0
+        text[b, 0], text[b, 1], text[b, 2] = 1, 3 + cls, 13 + 2 * axis + (1 if sign > 0 else 0)
+        text[b, 3:text_len - 1] = g.integers(17, vocab, size=text_len - 4)          # filler words
+        text[b, text_len - 1] = 2
+        for t in range(L):
+            iy, ix = int(round(y)), int(round(x))
+            canvas = imgs[b, t, 0]
+            canvas[iy:iy + 28, ix:ix + 28] = np.maximum(canvas[iy:iy + 28, ix:ix + 28], sp)
+            if axis == 0:
+                y += sign * step
+                if y < 0 or y > lim:
+                    sign = -sign
+                    y = min(max(y, 0), lim)
+            else:
+                x += sign * step
+                if x < 0 or x > lim:
+                    sign = -sign
+                    x = min(max(x, 0), lim)
+    imgs -= 0.5
+    speed = g.random(size=B).astype(np.float32)
     return {"images": torch.from_numpy(imgs), "text": torch.from_numpy(text), "speed": torch.from_numpy(speed)}
 
 

@@ -719,18 +719,29 @@ def test_f4_encoder_split_precision_path_against_exact_fp32_path():
     assert not (bad & (margin > TOK_TOL)).any()
 
 
-def test_bf16_tokens_on_trained_weights_follow_the_oracle_outside_the_error_margin():
-    """north_star: reference-matching token sequences.  On random-init weights the decoder's top-2 margins (1e-5 class) are below bf16's
-    logit error, so the bf16 mode cannot match there; this test gives a small model a trained model's margins -- stage 1 (VQ-VAE) and
-    stage 2 (MAGE) trained IN-TREE on the HIP training path (bench.py's trained_token_agreement leg at a reduced size) -- and compares
-    free-running tokens of held-out clips with the CPU oracle on the same weights: f16x3 identical; bf16 either identical or leaving the
-    oracle's sequence first at a decision the oracle took by less than twice the measured bf16 logit error (every later position of that
-    clip sees other inputs), and overall agreement high."""
+def test_tokens_on_trained_weights_follow_the_oracle_outside_the_error_margin():
+    """north_star: reference-matching token sequences.  On random-init weights the decoder's top-2 margins (1e-5 class) are below any 16-bit
+    mode's logit error, so those modes cannot match there; this test gives a small model a trained model's margins -- stage 1 (VQ-VAE) and
+    stage 2 (MAGE) trained IN-TREE on the HIP training path (bench.py's trained_token_agreement leg at a reduced size, the 'strokes' task) --
+    and compares held-out clips with the CPU oracle on the same weights:
+      f16x3: identical tokens;
+      f16 / bf16, teacher-forced on the oracle's sequence (per-decision, no compounding): every disagreement sits at a decision the oracle
+        took by less than twice the mode's measured logit error; f16's error is a fraction of bf16's and its per-decision agreement >= 0.999;
+      free-running: a clip leaves the oracle's sequence first at such a decision (every later position of that clip sees other inputs);
+        f16 keeps at least as many positions as bf16."""
     import bench
-    r = bench.trained_token_agreement(torch.device(DEV), 6, 200, 16, 2, 8, cfg_kw=dict(width=128, layers=3, vq_dim=64, K=64))
+    r = bench.trained_token_agreement(torch.device(DEV), 6, 200, 16, 4, 8, cfg_kw=dict(width=128, layers=3, vq_dim=64, K=64))
     print({k: v for k, v in r.items() if k != "note"})
-    assert r["stage1"]["distinct_tokens_in_the_oracle_sequences"] >= 3          # a non-degenerate token task
+    assert r["stage1"]["distinct_tokens_in_the_oracle_sequences"] >= 8          # a non-degenerate token task
     assert r["loss_trajectory"][-1] < 0.5 * r["loss_trajectory"][0]
     assert r["f16x3"]["all_positions"] == 1.0
-    assert r["bf16"]["first_divergences_inside_twice_the_bf16_logit_error"] is True
-    assert r["bf16"]["all_positions"] >= 0.9
+    for prec in ("bf16", "f16"):
+        assert r[prec]["first_divergences_inside_twice_the_modes_logit_error"] is True
+        assert r[prec]["teacher_forced"]["mismatches_where_oracle_margin_above_twice_the_error"] == 0
+    assert r["f16"]["teacher_forced_max_logit_error_vs_oracle"] < 0.3 * r["bf16"]["teacher_forced_max_logit_error_vs_oracle"]
+    assert r["f16"]["teacher_forced"]["token_agreement"] >= 0.999
+    assert r["f16"]["all_positions"] >= r["bf16"]["all_positions"] - 1e-9
+    # reproducible: seeded dropout, fixed-order gradient sums (mage_embedding_bwd's deterministic form) -> the same trained weights again
+    r2 = bench.trained_token_agreement(torch.device(DEV), 6, 200, 16, 4, 8, cfg_kw=dict(width=128, layers=3, vq_dim=64, K=64))
+    assert r2["trained_weights_sha256"] == r["trained_weights_sha256"]
+    assert r2["f16"]["all_positions"] == r["f16"]["all_positions"] and r2["bf16"]["all_positions"] == r["bf16"]["all_positions"]
