@@ -159,7 +159,9 @@ typedef struct mage_gemm_desc {
                                         * (scale_factor=2, nearest) in front of a convolution folded into its gather (vqvae_model.py:203-209) */
     float ln_eps;                      /* consumer with ln_stats null and ln_part set: the epilogue takes (mean, rstd) of its rows straight from
                                         * the producer's partial sums (mage_ln_stats' arithmetic, eps = ln_eps; K / 64 slices per row) -- no
-                                        * mage_ln_stats launch in between.  Few-rows GEMMs only: ask mage_gemm_is_small first */
+                                        * mage_ln_stats launch in between.  Few-rows GEMMs only: ask mage_gemm_is_small first.  (Built and measured
+                                        * for the tiled kernels at the incremental loop's 16 k rows, round 5: the in-tile reduction costs the
+                                        * consumers +5 .. +11 us per launch against the 7 us launch it removes -- not kept.) */
     const void* head_w;                /* bf16 padded-taps form with N == 256 (one column tile holds whole rows), bias, ReLU: a second, narrow Linear
                                         * taken on the tile before it leaves the CU.  head_w is bf16 [16][N]; the rows y = relu(acc + bias), rounded
                                         * to bf16 as a store would round them, are NOT written; Y (y_dtype MAGE_F32, ldy >= 16 floats) receives
@@ -240,6 +242,10 @@ typedef struct mage_attn_desc {
      * fp32 thread-per-query kernels only (drop_p = 0: off). */
     float drop_p;
     uint64_t drop_seed;
+    /* Row map of `out` when it differs from q's (both 0: out row of query i = q's row): query i of sequence s -> row
+     * outer*o_outer_stride + in + i*o_axis_stride.  The incremental loop's temporal blocks read q from the [q | k | v] cache slots
+     * (q_outer_stride = L*hw) and write the packed rows of the new positions (o_outer_stride = P*hw). */
+    int32_t o_outer_stride, o_axis_stride;
 } mage_attn_desc;
 
 int mage_attention(const mage_attn_desc* desc, void* stream);

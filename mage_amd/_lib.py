@@ -47,6 +47,7 @@ class AttnDesc(C.Structure):
         ("n_seq", i32), ("inner", i32), ("nq", i32), ("nk", i32), ("n_head", i32),
         ("q_outer_stride", i32), ("q_axis_stride", i32), ("kv_outer_stride", i32), ("kv_axis_stride", i32),
         ("causal", i32), ("kv_len", vp), ("kv_len_div", i32), ("scale", f32), ("out_split", i32), ("drop_p", f32), ("drop_seed", C.c_uint64),
+        ("o_outer_stride", i32), ("o_axis_stride", i32),
     ]
 
 

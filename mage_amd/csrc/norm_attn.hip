@@ -90,6 +90,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, 
     const int h0 = blockIdx.y * hg;
     const int outer = s / d.inner, in = s - outer * d.inner;
     const long q_base = (long)outer * d.q_outer_stride + in;
+    const long o_base = d.o_axis_stride ? (long)outer * d.o_outer_stride + in : q_base;      // out: q's row map unless the descriptor gives its own
+    const long o_step = d.o_axis_stride ? d.o_axis_stride : d.q_axis_stride;
     const long kv_base = (long)outer * d.kv_outer_stride + in;
     const T* kp = (const T*)d.k;
     const T* vp = (const T*)d.v;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const mage_attn_desc d, 
             }
         }
         const float inv = 1.0f / den;
-        OT* orow = op + row * ldo + (h0 + hl) * 32;
+        OT* orow = op + (o_base + (long)i * o_step) * ldo + (h0 + hl) * 32;
 #pragma unroll
         for (int c = 0; c < 4; ++c) store8(orow + c * 8, o[2 * c] * inv, o[2 * c + 1] * inv);
     }
@@ -220,6 +222,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const mage_attn_des
     const int s = blockIdx.x;
     const int outer = s / d.inner, in = s - outer * d.inner;
     const long q_base = (long)outer * d.q_outer_stride + in;
+    const long o_base = d.o_axis_stride ? (long)outer * d.o_outer_stride + in : q_base;      // out: q's row map unless the descriptor gives its own
+    const long o_step = d.o_axis_stride ? d.o_axis_stride : d.q_axis_stride;
     const long kv_base = (long)outer * d.kv_outer_stride + in;
     const unsigned short* qp = (const unsigned short*)d.q;
     const unsigned short* kp = (const unsigned short*)d.k;
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const mage_attn_des
             }
             if (qi < d.nq) {
                 const int col = h * 32 + 16 * (g & 1) + 8 * (g >> 1);
-                store8(op + (q_base + (long)qi * d.q_axis_stride) * d.ldo + col, v0, v1);
+                store8(op + (o_base + (long)qi * o_step) * d.ldo + col, v0, v1);
             }
         }
     }
@@ -355,6 +359,8 @@ __global__ __launch_bounds__(256) void attention_mfma_fewq_kernel(const mage_att
     if (s >= d.n_seq) return;
     const int outer = s / d.inner, in = s - outer * d.inner;
     const long q_base = (long)outer * d.q_outer_stride + in;
+    const long o_base = d.o_axis_stride ? (long)outer * d.o_outer_stride + in : q_base;      // out: q's row map unless the descriptor gives its own
+    const long o_step = d.o_axis_stride ? d.o_axis_stride : d.q_axis_stride;
     const long kv_base = (long)outer * d.kv_outer_stride + in;
     const unsigned short* qp = (const unsigned short*)d.q;
     const unsigned short* kp = (const unsigned short*)d.k;
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(256) void attention_mfma_fewq_kernel(const mage_att
             }
             if (qi < d.nq) {
                 const int col = h * 32 + 16 * (g & 1) + 8 * (g >> 1);
-                store8(op + (q_base + (long)qi * d.q_axis_stride) * d.ldo + col, v0, v1);
+                store8(op + (o_base + (long)qi * o_step) * d.ldo + col, v0, v1);
             }
         };
         finish(std::integral_constant<int, 0>{});
@@ -511,6 +517,8 @@ __global__ __launch_bounds__(256) void attention_mfma_split_kernel(const mage_at
     const int s = blockIdx.x;
     const int outer = s / d.inner, in = s - outer * d.inner;
     const long q_base = (long)outer * d.q_outer_stride + in;
+    const long o_base = d.o_axis_stride ? (long)outer * d.o_outer_stride + in : q_base;      // out: q's row map unless the descriptor gives its own
+    const long o_step = d.o_axis_stride ? d.o_axis_stride : d.q_axis_stride;
     const long kv_base = (long)outer * d.kv_outer_stride + in;
     const unsigned short* qp = (const unsigned short*)d.q;
     const unsigned short* kp = (const unsigned short*)d.k;
@@ -628,7 +636,7 @@ __global__ __launch_bounds__(256) void attention_mfma_split_kernel(const mage_at
             }
             if (qi < d.nq) {
                 const int col = h * 32 + 16 * (g & 1) + 8 * (g >> 1);
-                store8(op + (q_base + (long)qi * d.q_axis_stride) * ldo + col, v0, v1);
+                store8(op + (o_base + (long)qi * o_step) * ldo + col, v0, v1);
             }
         }
     }
@@ -646,6 +654,8 @@ __global__ __launch_bounds__(256) void attention_mfma_split_fewq_kernel(const ma
     if (s >= d.n_seq) return;
     const int outer = s / d.inner, in = s - outer * d.inner;
     const long q_base = (long)outer * d.q_outer_stride + in;
+    const long o_base = d.o_axis_stride ? (long)outer * d.o_outer_stride + in : q_base;      // out: q's row map unless the descriptor gives its own
+    const long o_step = d.o_axis_stride ? d.o_axis_stride : d.q_axis_stride;
     const long kv_base = (long)outer * d.kv_outer_stride + in;
     const unsigned short* qp = (const unsigned short*)d.q;
     const unsigned short* kp = (const unsigned short*)d.k;
@@ -766,7 +776,7 @@ __global__ __launch_bounds__(256) void attention_mfma_split_fewq_kernel(const ma
             }
             if (qi < d.nq) {
                 const int col = h * 32 + 16 * (g & 1) + 8 * (g >> 1);
-                store8(op + (q_base + (long)qi * d.q_axis_stride) * ldo + col, v0, v1);
+                store8(op + (o_base + (long)qi * o_step) * ldo + col, v0, v1);
             }
         };
         finish(std::integral_constant<int, 0>{});
@@ -1011,6 +1021,7 @@ extern "C" int mage_attention(const mage_attn_desc* d, void* stream) {
     MAGE_CHECK_ARG(d->nq >= 1 && d->n_seq >= 1 && d->n_head >= 1 && d->inner >= 1, "mage_attention: bad sizes");
     MAGE_CHECK_ARG((d->ldq | d->ldk | d->ldv | d->ldo) % 8 == 0, "mage_attention: leading dims must be multiples of 8");
     MAGE_CHECK_ARG(!d->kv_len || d->kv_len_div >= 1, "mage_attention: kv_len_div must be >= 1");
+    MAGE_CHECK_ARG((d->o_axis_stride == 0 && d->o_outer_stride == 0) || d->o_axis_stride > 0, "mage_attention: o_axis_stride must be > 0 when an output row map is given");
     MAGE_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f && (d->drop_p == 0.f || (d->dtype == MAGE_F32 && d->out_split == 0)),
                    "mage_attention: drop_p=%g needs fp32 q/k/v (the thread-per-query kernel) and 0 <= p < 1", (double)d->drop_p);
     MAGE_CHECK_ARG(d->out_split == 0 || ((d->out_split == MAGE_BF16X3 || d->out_split == MAGE_F16X3) && (d->dtype == MAGE_F32 || d->dtype == MAGE_F16X3) &&

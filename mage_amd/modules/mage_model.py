@@ -498,7 +498,8 @@ class FlatAxialDecoder(nn.Module):
 
     def _stats_inline(self, xb, M: int) -> bool:
         """One clip per call: every Linear that follows a LayerNorm (N = C .. 4C) runs on the few-rows kernel, which reduces the
-        producer's partial sums itself (same arithmetic as mage_ln_stats, mage_ln_stats_row in csrc/common.h)."""
+        producer's partial sums itself (same arithmetic as mage_ln_stats, mage_ln_stats_row in csrc/common.h).  (The tiled kernels doing the
+        same at the incremental loop's 16 k rows was measured in round 5: slower than the 7 us launch it removes.)"""
         Cc = self.model_channels
         return all(ops.gemm_is_small(xb, M, n, Cc) for n in (Cc, 2 * Cc, 3 * Cc, 4 * Cc))
 
@@ -611,7 +612,9 @@ class FlatAxialDecoder(nn.Module):
         if self._split_on() and self._attn_split():        # f16x3: K, V cached as split rows (what the attention kernel reads)
             caches = {i: ops.split_empty(B * L * hh * ww, 2 * Cc, self.split_kind, device) for i in range(self.layers) if i % 3 == 0}
             return {"B": B, "hh": hh, "ww": ww, "kv": caches, "p": 0}
-        caches = {i: torch.empty(B * L * hh * ww, 2 * Cc, device=device, dtype=dt) for i in range(self.layers) if i % 3 == 0}
+        # temporal blocks: one row [q | k | v] per (clip, slot, pixel) -- the new positions' QKV projection is ONE launch writing straight into
+        # the slots (q is read back from there by the attention of the same step; 1.5x the K,V bytes of a cache that is 0.8 GB at cfg2)
+        caches = {i: torch.empty(B * L * hh * ww, 3 * Cc, device=device, dtype=dt) for i in range(self.layers) if i % 3 == 0}
         return {"B": B, "hh": hh, "ww": ww, "kv": caches, "p": 0}
 
     @torch.no_grad()
@@ -663,18 +666,14 @@ class FlatAxialDecoder(nn.Module):
             w, b = _wdt(d, p + ".in_proj", dt), d[p + ".in_proj.b"]
             pin = part if (inl and not (fill_stats and i == 0)) else None        # block 0: the statistics of the fill, not partial sums
             if axis == 0:
-                kv = st["kv"][i]                                             # [B, L, hw, K|V]
-                if have_stats:
-                    self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=Cc, part=pin)                   # q, packed [M, C]
-                    self._ln_linear(d, p, "in_proj", xb, stats, kv, M=M, N=2 * Cc, lo=Cc, hi=3 * Cc, out_w=P * hw,
-                                    y_img_stride=L * hw, y_off=p0 * hw, part=pin)                           # k, v -> cache slots
+                kv = st["kv"][i]                                             # [B, L, hw, Q|K|V]
+                if have_stats:                                               # q, k, v of the new positions -> their cache slots, one launch
+                    self._ln_linear(d, p, "in_proj", xb, stats, kv, M=M, N=3 * Cc, out_w=P * hw, y_img_stride=L * hw, y_off=p0 * hw, part=pin)
                 else:
-                    ops.gemm(xn, w[:Cc], qkv, M=M, N=Cc, K=Cc, lda=Cc, ldy=Cc, bias=b[:Cc])
-                    ops.gemm(xn, w[Cc:], kv, M=M, N=2 * Cc, K=Cc, lda=Cc, ldy=2 * Cc, bias=b[Cc:], out_w=P * hw,
-                             y_img_stride=L * hw, y_off=p0 * hw)
-                ops.attention(qkv, kv, kv[:, Cc:], ao, ldq=Cc, ldk=2 * Cc, ldv=2 * Cc, ldo=Cc, n_seq=B * hw, inner=hw, nq=P,
-                              nk=p0 + P, n_head=H, q_outer_stride=P * hw, q_axis_stride=hw, kv_outer_stride=L * hw,
-                              kv_axis_stride=hw, causal=True)
+                    ops.gemm(xn, w, kv, M=M, N=3 * Cc, K=Cc, lda=Cc, ldy=3 * Cc, bias=b, out_w=P * hw, y_img_stride=L * hw, y_off=p0 * hw)
+                ops.attention(kv[p0 * hw:], kv[:, Cc:], kv[:, 2 * Cc:], ao, ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=Cc, n_seq=B * hw, inner=hw,
+                              nq=P, nk=p0 + P, n_head=H, q_outer_stride=L * hw, q_axis_stride=hw, kv_outer_stride=L * hw,
+                              kv_axis_stride=hw, causal=True, o_outer_stride=P * hw, o_axis_stride=hw)
             else:
                 if have_stats:
                     self._ln_linear(d, p, "in_proj", xb, stats, qkv, M=M, N=3 * Cc, part=pin)

@@ -428,7 +428,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch
 
 def attention(q, k, v, out, *, ldq, ldk, ldv, ldo, n_seq, inner, nq, nk, n_head, q_outer_stride, q_axis_stride,
               kv_outer_stride, kv_axis_stride, causal=False, kv_len=None, kv_len_div=1, scale=None, out_split: int = 0,
-              drop_p: float = 0.0, drop_seed: int = 0, split_kind: int = 0):
+              drop_p: float = 0.0, drop_seed: int = 0, split_kind: int = 0, o_outer_stride: int = 0, o_axis_stride: int = 0):
     """out_split BF16X3 / F16X3 (fp32 q, k, v): out is a split-precision tensor, ldo in 16-bit elements (2 * logical width).
     split_kind F16X3: q, k, v are split-precision tensors too (ld* in 16-bit elements; views start at 2 * the logical column)."""
     l, s = _dev(q)
@@ -444,6 +444,7 @@ def attention(q, k, v, out, *, ldq, ldk, ldv, ldo, n_seq, inner, nq, nk, n_head,
     d.scale = float(32 ** -0.5 if scale is None else scale)
     d.out_split = out_split
     d.drop_p, d.drop_seed = float(drop_p), int(drop_seed) & (2 ** 64 - 1)       # dropout on the probabilities (fp32 kernels; mage_hip.h)
+    d.o_outer_stride, d.o_axis_stride = o_outer_stride, o_axis_stride            # out's own row map (0, 0: q's)
     ev = PROFILE.begin() if PROFILE.wants("attention") else None
     _lib.check(l.mage_attention(C.byref(d), s), l)
     if ev is not None:
