@@ -66,6 +66,16 @@ int mage_init(int device);
  * (MAGE.forward, MAGE.autoregressive_generate, VectorQuantizedVAE.decode / forward). */
 int mage_check_device_errors(void* stream);
 
+/* Kernel-selection options (tuning, A/B tests, bisecting a regression): ONE table inside the library, filled once from the environment
+ * variables MAGE_<NAME IN CAPITALS> the first time any entry point needs it, changed afterwards only through mage_set_option (no dispatch
+ * function reads the environment; a change applies to every later call of the process).  Names:
+ *   gemm_no_4w, gemm4_train_forms, gemm_no_8phase, gemm_no_taps8, gemm_no_narrow, gemm_no_narrow_few, gemm_no_small, gemm_small_m,
+ *   gemm_res_mfma_layout, gemm_stagger_groups / _percent / _forced (MAGE_GEMM_STAGGER="G,percent"), gemm4_stagger_groups / _percent
+ *   (MAGE_GEMM4_STAGGER), attn_no_mfma, attn_no_fewq, vq_no_mfma          -- what each one does: struct MageOptions in csrc/common.h and
+ *   the table in INTEGRATION.md.  Unknown name: MAGE_EINVAL. */
+int mage_set_option(const char* name, int32_t value);
+int mage_get_option(const char* name, int32_t* value);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused GEMM / implicit-GEMM convolution on MFMA:   Y[yrow(m), n] = epi( sum_k A[arow(m,k), .] * W[n, k] )
  *
@@ -78,7 +88,7 @@ int mage_check_device_errors(void* stream);
  * Kernels behind this entry point (csrc/gemm.hip, csrc/gemm4.hip; chosen from the descriptor, same bits per output element from all of them for
  * bf16 plain GEMMs): the lockstep persistent kernel (any dtype / gather / epilogue), its 8-phase ping-pong variant (bf16, >= 2 tiles of 256x256
  * per CU), the one-wave-per-SIMD variant (bf16, bias or LayerNorm-consuming epilogue, K in [256, 1024], >= 4 tiles per CU: the decoder's QKV and
- * c_fc; MAGE_GEMM_NO_4W=1 disables it), the few-rows kernel (M <= 1024), the padded-taps forms and the split-precision forms.
+ * c_fc; option gemm_no_4w disables it), the few-rows kernel (M <= 1024), the padded-taps forms and the split-precision forms.
  *
  * Row geometry.  A GEMM row m in [0, M) is decoded as img = m / (out_h*out_w),
  * oy = (m / out_w) % out_h, ox = m % out_w.  K = taps_h*taps_w*cin; k -> (ky, kx, ci), ci fastest:
@@ -367,6 +377,14 @@ int mage_add_scaled_rowvec(float* x, const float* s, const float* vec, int32_t B
  * Text encoder: + positions (mage_model.py:227-228) and the padding-row zeroing (:233-235). */
 int mage_row_affine(float* x, const float* rs, const float* table, int64_t rows, int32_t C, int32_t div, int32_t mod,
                     void* stream);
+
+/* Caption bookkeeping of the text encoder (mage_model.py:233-239) in one launch: keep[b*S + s] = (ids[b][s] != padding_idx) as 1.0 / 0.0 (the row
+ * scale of mage_row_affine that zeroes padded rows), kv_len[b] = number of kept tokens (mage_attention's kv_len).  Either output may be null. */
+int mage_caption_mask(const int64_t* ids, int32_t B, int32_t S, int64_t padding_idx, int32_t* kv_len, float* keep, void* stream);
+/* Strided device-to-device block copy on the stream (hipMemcpy2DAsync): `height` rows of `width_bytes` bytes, pitches in bytes.  Assembles the
+ * [B, L, C, H, W] result of autoregressive_generate (mage_model.py:691: the passed-through first frame + the decoded frames) without a compute
+ * kernel. */
+int mage_copy2d(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t width_bytes, int64_t height, void* stream);
 
 /* MAGE+ head (mage_model.py:350-354,387-388): y = SiLU(GroupNorm(groups, C)(x)) with the statistics of each sample taken
  * over rows_per_sample rows x (C/groups) channels.  x fp32 rows; sample b uses rows [b*sample_stride_rows + row_off, +rows_per_sample)

@@ -57,6 +57,8 @@ SIGNATURES = {
     "mage_last_error": (C.c_char_p, []),
     "mage_init": (C.c_int, [C.c_int]),
     "mage_check_device_errors": (C.c_int, [vp]),
+    "mage_set_option": (C.c_int, [C.c_char_p, i32]),
+    "mage_get_option": (C.c_int, [C.c_char_p, C.POINTER(i32)]),
     "mage_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "mage_gemm_is_small": (C.c_int, [i32, i32, i32]),
     "mage_ln_stats": (C.c_int, [vp, i64, i32, i32, f32, vp, vp]),
@@ -90,6 +92,8 @@ SIGNATURES = {
     "mage_adain": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "mage_add_scaled_rowvec": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "mage_row_affine": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, vp]),
+    "mage_caption_mask": (C.c_int, [vp, i32, i32, i64, vp, vp, vp]),
+    "mage_copy2d": (C.c_int, [vp, i64, vp, i64, i64, i64, vp]),
     "mage_groupnorm_silu": (C.c_int, [vp, i64, i64, i32, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp]),
     "mage_groupnorm_act": (C.c_int, [vp, i64, i64, i32, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, i32, i64, i64, vp]),
     "mage_reparam_kl": (C.c_int, [vp, vp, vp, vp, vp, i32, i64, vp]),

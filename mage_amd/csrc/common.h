@@ -19,6 +19,26 @@ const void* mage_zero_page();          // device pointer, 16384 zero bytes (padd
                                        // columns); null before mage_init
 int* mage_error_word();                // device pointer to the deferred-error word of the current device (mage_check_device_errors)
 enum { MAGE_DEVERR_EMBEDDING_ID = 1, MAGE_DEVERR_CE_TARGET = 2 };
+// Kernel-selection switches (tuning, A/B tests, bisecting): ONE table, filled once from the MAGE_* environment variables of the same names
+// (upper-cased, "MAGE_" prefix) the first time it is asked for, changed at run time only through mage_set_option (include/mage_hip.h lists
+// them).  No dispatch function reads the environment.
+struct MageOptions {
+    int gemm_no_4w;              // 1: the one-wave-per-SIMD GEMM kernels (gemm4.hip) are not used
+    int gemm4_train_forms;       // 1: training's two c_fc forms on the one-wave-per-SIMD kernel (default: the 8-phase kernel, faster there)
+    int gemm_no_8phase;          // 1: the 8-phase ping-pong kernel is not used (lockstep kernel instead)
+    int gemm_no_taps8;           // 1: padded-taps convolutions take the generic gather kernel
+    int gemm_no_narrow;          // 1: no 256 x 64 narrow tiles
+    int gemm_no_narrow_few;      // 1: few-rows x + Linear(.) stays on the 128 x 256 tile
+    int gemm_no_small;           // 1: the few-rows kernel (gemm_small_kernel) is not used
+    int gemm_small_m;            // rows up to which the few-rows kernel is considered (default 1024)
+    int gemm_res_mfma_layout;    // 1: 16-bit residual tiles are fetched in the accumulator layout instead of as whole rows
+    int gemm_stagger_groups, gemm_stagger_percent, gemm_stagger_forced;      // staggered start of the 8-wave kernels (MAGE_GEMM_STAGGER="G,percent")
+    int gemm4_stagger_groups, gemm4_stagger_percent;                         // ... of the one-wave-per-SIMD kernel (MAGE_GEMM4_STAGGER)
+    int attn_no_mfma;            // 1: attention on the thread-per-query kernels only
+    int attn_no_fewq;            // 1: the few-query (incremental step) attention kernels are not used
+    int vq_no_mfma;              // 1: the quantiser's fp64-MFMA kernel is not used
+};
+const MageOptions& mage_options();
 // raise a deferred error from a kernel: the first one wins, the offending value and the bound are kept for the message
 __device__ __forceinline__ void mage_raise(int* word, int code, long value, int bound) {
     if (atomicCAS(word, 0, code) == 0) {

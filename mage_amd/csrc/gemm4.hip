@@ -469,14 +469,7 @@ int launch4(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     a.ntiles = (d->M / 256) * a.ntiles_n;
     // staggered start (gemm.hip, launch_tile): the workgroups of an XCD start in G groups spread over a fraction of one tile period, so that
     // the tiles' output bursts (128-256 KiB per CU at once: HBM-bound when all 256 CUs store together) fall under other groups' K loops
-    static int st_groups = -1, st_percent = 100;
-    if (st_groups < 0) {
-        st_groups = 8;
-        if (const char* e = getenv("MAGE_GEMM4_STAGGER")) {
-            if (sscanf(e, "%d,%d", &st_groups, &st_percent) < 2) st_percent = 100;
-            if (st_groups < 0) st_groups = 0;
-        }
-    }
+    const int st_groups = mage_options().gemm4_stagger_groups, st_percent = mage_options().gemm4_stagger_percent;
     a.stagger_groups = 0;
     a.stagger_sleeps = 0;
     const int grid = a.ntiles >= n_cu ? n_cu : ((a.ntiles + 7) & ~7);
@@ -721,7 +714,7 @@ __global__ __launch_bounds__(256) void gemm_tn4_kernel(const Tn4Args g) {
 int mage_gemm4_try(const mage_gemm_desc* d, hipStream_t s) {
     const bool hf = d->dtype == MAGE_F16;              // f16 operands: the bias and LayerNorm-consuming forms of the generation path
     if ((d->dtype != MAGE_BF16 && !hf) || d->n_split > 1) return 0;
-    if (getenv("MAGE_GEMM_NO_4W")) return 0;           // read on every call (not cached): tests run the same product on both kernels in one process
+    if (mage_options().gemm_no_4w) return 0;           // (mage_set_option: tests run the same product on both kernels in one process)
     if (d->M % 256 || d->N % 256 || d->K % 128 || d->K < 256 || d->K > 1024) return 0;
     if (d->taps_h * d->taps_w != 1 || d->stride != 1 || d->dy0 || d->dx0 || d->in_h != d->out_h || d->in_w != d->out_w || d->a_half) return 0;
     if (d->out_h != 1 || d->out_w < d->M || d->y_mul_x != 1) return 0;                     // plain rows in, plain rows out
@@ -736,8 +729,8 @@ int mage_gemm4_try(const mage_gemm_desc* d, hipStream_t s) {
     if (d->y2 && !dual && !gbwd) return 0;
     // measured in the training step (rocprofv3, same box): the data-gradient form 736 us per launch on the 8-phase kernel, 840 here (its saved
     // rows are requested inside the epilogue: two waves per SIMD hide that round trip, one does not); the two-output form 787 vs 794.  Both
-    // stay on the 8-phase kernel unless MAGE_GEMM4_TRAIN_FORMS=1 asks for them here (the instantiations are kept: tests compare the bits)
-    if ((dual || gbwd) && !getenv("MAGE_GEMM4_TRAIN_FORMS")) return 0;
+    // stay on the 8-phase kernel unless the option gemm4_train_forms asks for them here (the instantiations are kept: tests compare the bits)
+    if ((dual || gbwd) && !mage_options().gemm4_train_forms) return 0;
     if ((dual || gbwd) && (d->y_dtype != MAGE_BF16 || d->ldy2 % 8 || (((uintptr_t)d->y2) & 15))) return 0;
     if (!dual && !gbwd && d->act != MAGE_ACT_NONE && d->act != MAGE_ACT_QUICKGELU) return 0;
     if (d->y_dtype != MAGE_F32 && d->y_dtype != d->dtype) return 0;
@@ -777,7 +770,7 @@ int mage_gemm4_try(const mage_gemm_desc* d, hipStream_t s) {
 // mage_gemm_tn on the one-wave-per-SIMD schedule: 1 = launched, 0 = not eligible (gemm_tn.hip then runs its 8-wave kernel)
 int mage_gemm_tn4_try(const void* dY, int64_t lda, const void* X, int64_t ldb, int64_t T, int32_t N, int32_t K, int32_t n_split, int64_t tps,
                       float* partials, float* db_partials, hipStream_t stream) {
-    if (getenv("MAGE_GEMM_NO_4W")) return 0;
+    if (mage_options().gemm_no_4w) return 0;
     if (T % 64 || tps % 64 || tps < 128 || (T - (int64_t)(n_split - 1) * tps) < 128) return 0;          // whole slabs, at least two per slice
     if (lda * 2 * 64 + 16384 >= (1L << 31) || ldb * 2 * 64 + 16384 >= (1L << 31)) return 0;              // 32-bit lane offsets inside a slab
     const int dev = mage_device_index();

@@ -1365,21 +1365,11 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     // per 64-wide slab of a 256x256 tile, measured) + the tile's HBM burst at the all-at-once rate (~10.6 B per clock per CU,
     // measured).  Only when every workgroup has enough tiles for the idle start to pay.  MAGE_GEMM_STAGGER="G,percent"
     // overrides (tuning), "0" disables.  Measured on the decoder's 4-GEMM block: 775 -> 800 TFLOP/s with 8 groups over 60 %.
-    static int st_groups = -1, st_percent = 60, st_env = 0;
-    if (st_groups < 0) {
-        st_groups = 8;
-        if (const char* e = getenv("MAGE_GEMM_STAGGER")) {
-            st_env = 1;
-            if (sscanf(e, "%d,%d", &st_groups, &st_percent) < 2) st_percent = 60;
-            if (st_groups < 0) st_groups = 0;
-        }
-    }
+    const int st_groups = mage_options().gemm_stagger_groups, st_percent = mage_options().gemm_stagger_percent, st_env = mage_options().gemm_stagger_forced;
     a.stagger_groups = 0;
     a.stagger_sleeps = 0;
     {
-        static int res_rows_env = -1;
-        if (res_rows_env < 0) res_rows_env = getenv("MAGE_GEMM_RES_MFMA_LAYOUT") ? 0 : 1;
-        a.res_rows = res_rows_env && RB && d->residual && d->y_mul_x == 1 && d->out_h == 1 && d->out_w >= d->M && d->ldr % 8 == 0 &&
+        a.res_rows = !mage_options().gemm_res_mfma_layout && RB && d->residual && d->y_mul_x == 1 && d->out_h == 1 && d->out_w >= d->M && d->ldr % 8 == 0 &&
                      ((uintptr_t)d->residual & 15) == 0;
     }
     const int tiles_per_wg = a.ntiles / grid;
@@ -1398,8 +1388,7 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     }
     if constexpr (DT != MAGE_F32 && !GATHER && MT == 8 && EK != EK_GENERAL && NW == 4) {
         constexpr bool HF = DT == MAGE_F16;
-        static int use8 = -1;
-        if (use8 < 0) use8 = getenv("MAGE_GEMM_NO_8PHASE") ? 0 : 1;
+        const int use8 = !mage_options().gemm_no_8phase;
         const long a_rows = (long)((d->M + d->out_h * d->out_w - 1) / (d->out_h * d->out_w)) * d->a_img_stride + d->a_off + 1;
         const long a_span = a_rows * d->lda + (long)(d->n_split - 1) * d->a_split_stride;       // elements reachable from A / W
         const long w_span = (long)d->N * d->ldw + (long)(d->n_split - 1) * d->w_split_stride;
@@ -1450,8 +1439,7 @@ int launch_taps8(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
 
 template <int SPL = 0, bool HF = false>
 int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
-    static int use8 = -1;
-    if (use8 < 0) use8 = (getenv("MAGE_GEMM_NO_8PHASE") || getenv("MAGE_GEMM_NO_TAPS8")) ? 0 : 1;
+    const int use8 = !(mage_options().gemm_no_8phase || mage_options().gemm_no_taps8);
     if ((!use8 && SPL == 0) || d->dtype != (SPL == 0 ? (HF ? MAGE_F16 : MAGE_BF16) : SPL == 1 ? MAGE_BF16X3 : MAGE_F16X3) || d->n_split != 1) return 0;
     const bool table = d->rowadd && !d->residual;                                                         // y = table[row] + conv (+ bias)
     const bool plain = !d->rowadd && !d->residual;
@@ -1501,11 +1489,7 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
 
 // few rows: the 128-row tile list would cover less than half of the chip (one clip per call; see gemm_small_kernel)
 bool small_shape(int M, int N, int K, int n_cu) {
-    static int small = -1, small_m = 0;
-    if (small < 0) {
-        small = getenv("MAGE_GEMM_NO_SMALL") ? 0 : 1;
-        small_m = getenv("MAGE_GEMM_SMALL_M") ? atoi(getenv("MAGE_GEMM_SMALL_M")) : 1024;
-    }
+    const int small = !mage_options().gemm_no_small, small_m = mage_options().gemm_small_m;
     const long tiles4 = (long)((M + 127) / 128) * ((N + BN - 1) / BN);
     return small && 2 * tiles4 <= n_cu && K % 512 == 0 && N % 16 == 0 && M <= small_m;
 }
@@ -1573,16 +1557,14 @@ int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
     if constexpr (EK != EK_RES_INIT && LN == LN_NONE) {
         // narrow outputs (N <= 128) on the 256 x 64 tile: a 256-column tile would spend 3/4 (N = 64) or more of its matrix-core work on
         // columns that do not exist.  Only where a 256-row tile list still fills the chip.
-        static int narrow = -1;
-        if (narrow < 0) narrow = getenv("MAGE_GEMM_NO_NARROW") ? 0 : 1;
+        const int narrow = !mage_options().gemm_no_narrow;
         if (narrow && d->N <= 128 && d->n_split == 1 && (long)((d->M + 255) / 256) * ((d->N + 63) / 64) >= n_cu)
             return launch_tile<DT, GATHER, ACT, 2, EK, false, LN_NONE, 1>(d, s, n_cu);
     }
     if constexpr (DT != MAGE_F32 && !GATHER && ACT == MAGE_ACT_NONE && EK == EK_RES_INIT) {
         // few rows (the incremental AR loop's x + Linear(.) at 8 k rows x 512 columns: 128 tiles of 128 x 256 on 256 CUs): the narrow tile
         // cuts the same output into 256 x 64 pieces, one per CU.  Same K order per element: the tokens stay bit-identical to the full loop's.
-        static int few = -1;
-        if (few < 0) few = (getenv("MAGE_GEMM_NO_NARROW") || getenv("MAGE_GEMM_NO_NARROW_FEW")) ? 0 : 1;
+        const int few = !(mage_options().gemm_no_narrow || mage_options().gemm_no_narrow_few);
         const long tiles4 = (long)((d->M + 127) / 128) * ((d->N + BN - 1) / BN);
         // (tiles4 == n_cu, the B = 64 incremental step, measured on the narrow tile: 31.5 vs 28.2 ms per call -- the 128 x 256 tile stays)
         if (few && d->n_split == 1 && tiles4 < n_cu && d->N % 64 == 0) return launch_tile<DT, GATHER, ACT, 2, EK, false, LN, 1, 0, RB>(d, s, n_cu);

@@ -853,10 +853,10 @@ template <typename T>
 int attn_launch(const mage_attn_desc* d, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         // the axial attentions: short sequences on the matrix cores (16-byte aligned 64-byte head segments)
-        if (d->nq <= 32 && d->nk <= 32 && d->n_head <= 32 && !getenv("MAGE_ATTN_NO_MFMA") &&
+        if (d->nq <= 32 && d->nk <= 32 && d->n_head <= 32 && !mage_options().attn_no_mfma &&
             ((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->out) & 15) == 0)) {
             const int nkb = d->nk <= 16 ? 1 : 2;
-            if (d->nq <= 2 && d->n_seq >= 1024 && !getenv("MAGE_ATTN_NO_FEWQ")) {      // the incremental step's temporal attention
+            if (d->nq <= 2 && d->n_seq >= 1024 && !mage_options().attn_no_fewq) {      // the incremental step's temporal attention
                 const dim3 grid((unsigned)((d->n_seq + 3) / 4));
                 if (nkb == 1) hipLaunchKernelGGL((attention_mfma_fewq_kernel<1, T>), grid, dim3(256), 0, s, *d);
                 else hipLaunchKernelGGL((attention_mfma_fewq_kernel<2, T>), grid, dim3(256), 0, s, *d);
@@ -993,7 +993,7 @@ int attn_split_launch(const mage_attn_desc* d, hipStream_t s) {
     MAGE_CHECK_ARG((d->ldq | d->ldk | d->ldv | d->ldo) % 128 == 0 && ((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->out) & 255) == 0),
                    "mage_attention: split operands need leading dimensions that are multiples of 128 16-bit elements and 256-byte aligned bases");
     const int nkb = d->nk <= 16 ? 1 : 2;
-    if (d->nq <= 2 && d->n_seq >= 1024 && !getenv("MAGE_ATTN_NO_FEWQ")) {      // the incremental step's temporal attention
+    if (d->nq <= 2 && d->n_seq >= 1024 && !mage_options().attn_no_fewq) {      // the incremental step's temporal attention
         const dim3 grid((unsigned)((d->n_seq + 3) / 4));
         if (nkb == 1) hipLaunchKernelGGL((attention_mfma_split_fewq_kernel<1>), grid, dim3(256), 0, s, *d);
         else hipLaunchKernelGGL((attention_mfma_split_fewq_kernel<2>), grid, dim3(256), 0, s, *d);
@@ -1052,6 +1052,43 @@ extern "C" int mage_add_scaled_rowvec(float* x, const float* s, const float* vec
     hipLaunchKernelGGL(add_scaled_rowvec_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, x, s, vec, (long)P * C, C, total);
     MAGE_CHECK_LAUNCH("mage_add_scaled_rowvec");
+    return MAGE_OK;
+}
+
+// Caption bookkeeping of the text encoder in one launch (mage_model.py:233-239: `text != padding_idx`, its row sums): keep[b*S + s] = 1.0 where
+// ids[b][s] != padding_idx else 0.0 (the row scale that zeroes padded rows), kv_len[b] = number of kept tokens (the key-padding length).
+namespace {
+__global__ __launch_bounds__(64) void caption_mask_kernel(const int64_t* __restrict__ ids, int S, long padding_idx, int* __restrict__ kv_len,
+                                                          float* __restrict__ keep) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int cnt = 0;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
+        const bool k = s < S && ids[(long)b * S + s] != padding_idx;
+        if (s < S && keep) keep[(long)b * S + s] = k ? 1.0f : 0.0f;
+        cnt += __popcll(__ballot(k));
+    }
+    if (lane == 0 && kv_len) kv_len[b] = cnt;
+}
+}  // namespace
+
+extern "C" int mage_caption_mask(const int64_t* ids, int32_t B, int32_t S, int64_t padding_idx, int32_t* kv_len, float* keep, void* stream) {
+    MAGE_CHECK_ARG(ids && B > 0 && S > 0 && (kv_len || keep), "mage_caption_mask: bad arguments");
+    hipLaunchKernelGGL(caption_mask_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, ids, S, (long)padding_idx, kv_len, keep);
+    MAGE_CHECK_LAUNCH("mage_caption_mask");
+    return MAGE_OK;
+}
+
+// Strided block copy on the stream (hipMemcpy2DAsync, device to device): `height` rows of `width_bytes`, row pitches in bytes.  Output
+// assembly without a compute kernel: the passed-through first frame and the decoded frames into the [B, L, C, H, W] result (mage_model.py:691).
+extern "C" int mage_copy2d(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t width_bytes, int64_t height, void* stream) {
+    MAGE_CHECK_ARG(dst && src && width_bytes > 0 && height > 0 && dst_pitch >= width_bytes && src_pitch >= width_bytes, "mage_copy2d: bad arguments");
+    const hipError_t e = hipMemcpy2DAsync(dst, (size_t)dst_pitch, src, (size_t)src_pitch, (size_t)width_bytes, (size_t)height, hipMemcpyDeviceToDevice,
+                                          (hipStream_t)stream);
+    if (e != hipSuccess) {
+        mage_set_error("mage_copy2d: %s", hipGetErrorString(e));
+        return MAGE_EHIP;
+    }
     return MAGE_OK;
 }
 

@@ -2,6 +2,7 @@
 // deferred-error word that kernels raise when they meet an argument only visible on the device (an out-of-range id).
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 static void* g_zero[MAGE_MAX_DEVICES] = {nullptr};
@@ -28,6 +29,80 @@ const void* mage_zero_page() {
 int* mage_error_word() {
     const int dev = mage_device_index();
     return dev < 0 ? nullptr : g_flag[dev];
+}
+
+// ---- options: one table, read once from the environment, changed through mage_set_option
+static MageOptions g_opt;
+static bool g_opt_ready = false;
+struct OptField { const char* name; int MageOptions::*field; };
+static const OptField g_opt_fields[] = {
+    {"gemm_no_4w", &MageOptions::gemm_no_4w}, {"gemm4_train_forms", &MageOptions::gemm4_train_forms},
+    {"gemm_no_8phase", &MageOptions::gemm_no_8phase}, {"gemm_no_taps8", &MageOptions::gemm_no_taps8},
+    {"gemm_no_narrow", &MageOptions::gemm_no_narrow}, {"gemm_no_narrow_few", &MageOptions::gemm_no_narrow_few},
+    {"gemm_no_small", &MageOptions::gemm_no_small}, {"gemm_small_m", &MageOptions::gemm_small_m},
+    {"gemm_res_mfma_layout", &MageOptions::gemm_res_mfma_layout}, {"gemm_stagger_groups", &MageOptions::gemm_stagger_groups},
+    {"gemm_stagger_percent", &MageOptions::gemm_stagger_percent}, {"gemm_stagger_forced", &MageOptions::gemm_stagger_forced},
+    {"gemm4_stagger_groups", &MageOptions::gemm4_stagger_groups}, {"gemm4_stagger_percent", &MageOptions::gemm4_stagger_percent},
+    {"attn_no_mfma", &MageOptions::attn_no_mfma}, {"attn_no_fewq", &MageOptions::attn_no_fewq}, {"vq_no_mfma", &MageOptions::vq_no_mfma},
+};
+static int env_flag(const char* name) {
+    const char* e = getenv(name);
+    return (e && *e && strcmp(e, "0") != 0) ? 1 : 0;
+}
+const MageOptions& mage_options() {
+    if (!g_opt_ready) {
+        MageOptions o = {};
+        o.gemm_no_4w = env_flag("MAGE_GEMM_NO_4W");
+        o.gemm4_train_forms = env_flag("MAGE_GEMM4_TRAIN_FORMS");
+        o.gemm_no_8phase = env_flag("MAGE_GEMM_NO_8PHASE");
+        o.gemm_no_taps8 = env_flag("MAGE_GEMM_NO_TAPS8");
+        o.gemm_no_narrow = env_flag("MAGE_GEMM_NO_NARROW");
+        o.gemm_no_narrow_few = env_flag("MAGE_GEMM_NO_NARROW_FEW");
+        o.gemm_no_small = env_flag("MAGE_GEMM_NO_SMALL");
+        o.gemm_small_m = getenv("MAGE_GEMM_SMALL_M") ? atoi(getenv("MAGE_GEMM_SMALL_M")) : 1024;
+        o.gemm_res_mfma_layout = env_flag("MAGE_GEMM_RES_MFMA_LAYOUT");
+        o.gemm_stagger_groups = 8;
+        o.gemm_stagger_percent = 60;
+        if (const char* e = getenv("MAGE_GEMM_STAGGER")) {
+            o.gemm_stagger_forced = 1;
+            if (sscanf(e, "%d,%d", &o.gemm_stagger_groups, &o.gemm_stagger_percent) < 2) o.gemm_stagger_percent = 60;
+            if (o.gemm_stagger_groups < 0) o.gemm_stagger_groups = 0;
+        }
+        o.gemm4_stagger_groups = 8;
+        o.gemm4_stagger_percent = 100;
+        if (const char* e = getenv("MAGE_GEMM4_STAGGER")) {
+            if (sscanf(e, "%d,%d", &o.gemm4_stagger_groups, &o.gemm4_stagger_percent) < 2) o.gemm4_stagger_percent = 100;
+            if (o.gemm4_stagger_groups < 0) o.gemm4_stagger_groups = 0;
+        }
+        o.attn_no_mfma = env_flag("MAGE_ATTN_NO_MFMA");
+        o.attn_no_fewq = env_flag("MAGE_ATTN_NO_FEWQ");
+        o.vq_no_mfma = env_flag("MAGE_VQ_NO_MFMA");
+        g_opt = o;
+        g_opt_ready = true;
+    }
+    return g_opt;
+}
+extern "C" int mage_set_option(const char* name, int32_t value) {
+    MAGE_CHECK_ARG(name != nullptr, "mage_set_option: null name");
+    (void)mage_options();
+    for (const OptField& f : g_opt_fields)
+        if (strcmp(f.name, name) == 0) {
+            g_opt.*(f.field) = value;
+            return MAGE_OK;
+        }
+    mage_set_error("mage_set_option: unknown option '%s'", name);
+    return MAGE_EINVAL;
+}
+extern "C" int mage_get_option(const char* name, int32_t* value) {
+    MAGE_CHECK_ARG(name != nullptr && value != nullptr, "mage_get_option: null argument");
+    const MageOptions& o = mage_options();
+    for (const OptField& f : g_opt_fields)
+        if (strcmp(f.name, name) == 0) {
+            *value = o.*(f.field);
+            return MAGE_OK;
+        }
+    mage_set_error("mage_get_option: unknown option '%s'", name);
+    return MAGE_EINVAL;
 }
 
 extern "C" int mage_abi_version(void) { return MAGE_ABI_VERSION; }

@@ -1320,7 +1320,7 @@ extern "C" int mage_attention_bwd(const mage_attn_desc* d, const void* dout, voi
     MAGE_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f && (d->drop_p == 0.f || d->dtype == MAGE_F32),
                    "mage_attention_bwd: drop_p=%g needs the fp32 kernels and 0 <= p < 1", (double)d->drop_p);
     MAGE_CHECK_ARG(d->o_axis_stride == 0 && d->o_outer_stride == 0, "mage_attention_bwd: dout is addressed like q (no separate output row map)");
-    if (d->dtype == MAGE_BF16 && d->nq <= 32 && d->nk <= 32 && !getenv("MAGE_ATTN_NO_MFMA") && d->ldq % 8 == 0 && d->ldk % 8 == 0 &&
+    if (d->dtype == MAGE_BF16 && d->nq <= 32 && d->nk <= 32 && !mage_options().attn_no_mfma && d->ldq % 8 == 0 && d->ldk % 8 == 0 &&
         d->ldv % 8 == 0 && d->ldo % 8 == 0 && ld_dq % 8 == 0 && ld_dk % 8 == 0 && ld_dv % 8 == 0 &&
         ((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0)) {
         const dim3 grid(d->n_seq, (d->n_head + 3) / 4), blk(256);

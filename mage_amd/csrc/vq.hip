@@ -306,9 +306,7 @@ extern "C" int mage_vq_nearest(const float* z, const float* codebook_t, const fl
     MAGE_CHECK_ARG(z && codebook_t && c2 && idx, "mage_vq_nearest: null pointer");
     MAGE_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && K > 0 && K <= 1024, "mage_vq_nearest: M=%ld D=%d K=%d unsupported", (long)M, D, K);
     hipStream_t s = (hipStream_t)stream;
-    static int use_mfma = -1;
-    if (use_mfma < 0) use_mfma = getenv("MAGE_VQ_NO_MFMA") ? 0 : 1;
-    if (use_mfma) {                                       // the fp64 matrix-core kernel: any D % 4 == 0, K <= 1024
+    if (!mage_options().vq_no_mfma) {                                       // the fp64 matrix-core kernel: any D % 4 == 0, K <= 1024
         const dim3 g32((unsigned)((M + 31) / 32));        // 4 tiles of 16 codes per wave: 92 + 64 registers, 3 waves per SIMD
         if (K <= 256) hipLaunchKernelGGL((vq_nearest_mfma_kernel<4, 2, 4>), g32, dim3(256), 0, s, z, codebook_t, c2, (long)M, D, K, idx, margin);
         else if (K <= 512) hipLaunchKernelGGL((vq_nearest_mfma_kernel<4, 2, 8>), g32, dim3(512), 0, s, z, codebook_t, c2, (long)M, D, K, idx, margin);

@@ -17,7 +17,6 @@ products per K slab, fp32 accumulation -- include/mage_hip.h): fp32-class logits
 from __future__ import annotations
 
 import gc
-import os
 from collections import OrderedDict
 from math import exp
 from typing import Dict, Optional
@@ -25,7 +24,7 @@ from typing import Dict, Optional
 import torch
 from torch import nn
 
-from .. import ops
+from .. import config, ops
 from ..utils.util import default, instantiate_from_config, zero_module
 from .vqvae_model import VectorQuantizedVAE, _Derived, _conv_w, _no_torch_forward
 
@@ -91,6 +90,18 @@ def _lin_fp32(a, d, name, y, *, M, N, K, sk=0, lo=0, hi=None, a_split=None, **kw
         a_s = a_split if a_split is not None else ops.split(a, sk)
         return ops.gemm(a_s, _wsplit(d, name, sk)[lo:hi], y, M=M, N=N, K=K, lda=2 * K, ldy=kw.pop("ldy", N), bias=b, split_kind=sk, **kw)
     return ops.gemm(a, d[name + ".f32"][lo:hi], y, M=M, N=N, K=K, lda=K, ldy=kw.pop("ldy", N), bias=b, **kw)
+
+
+def _to_dt(x: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+    """fp32 rows in the decoder's compute dtype (mage_cast)."""
+    return x if dt == x.dtype else ops.cast(x.contiguous(), torch.empty(x.shape, device=x.device, dtype=dt))
+
+
+def _assemble(images: torch.Tensor, video: torch.Tensor) -> torch.Tensor:
+    """The result of autoregressive_generate (mage_model.py:691): the input's first frame followed by the decoded frames."""
+    if images.dtype == video.dtype and video.is_contiguous() and images[0, 0].is_contiguous():
+        return ops.assemble_video(images, video)
+    return torch.cat([images[:, 0:1].to(video.dtype), video], 1)
 
 
 def _need_gpu(t: torch.Tensor, who: str) -> None:
@@ -290,12 +301,11 @@ class TransformerTextEncoder(nn.Module):
             raise ValueError(f"caption length {S} exceeds context_length {self.context_length} (kernel limit 64)")
         Wd, dev, H = self.transformer_width, text.device, self.transformer_width // 32
         ids = text.to(torch.int64).contiguous()
-        keep = ids != self.padding_idx                                   # index plumbing (masks / lengths), not arithmetic
-        kv_len = keep.sum(-1).to(torch.int32).contiguous()
+        kv_len, keep = ops.caption_mask(ids, self.padding_idx)          # key-padding lengths, row scale of the padded rows (:233-239)
         x = ops.embedding(ids, d["tok"], torch.empty(B * S, Wd, device=dev, dtype=F32))
         ops.row_affine(x, None, d["pos"], div=1, mod=S)                  # + positions[0..S)       (:227-228)
         ops.layernorm(x, d["layer_norm.w"], d["layer_norm.b"], x, self.layer_norm.eps)
-        ops.row_affine(x, keep.reshape(-1).to(F32).contiguous(), None)   # zero padded rows          (:233-235)
+        ops.row_affine(x, keep, None)                                    # zero padded rows          (:233-235)
         sk = getattr(self, "split_kind", 0) if Wd % 64 == 0 else 0
         for i in range(self.transformer_layers):
             p = f"l{i}"
@@ -463,15 +473,15 @@ class FlatAxialDecoder(nn.Module):
         the x + Linear(.) GEMM also writes a bf16 copy of x and per-row partial (sum, sum of squares); the next Linear takes that
         copy with gamma folded into its weights and finishes the normalisation in its epilogue.  Needs whole 256-row tiles per
         frame slot (so that the full pass and the incremental loop take the same route: their tokens stay bit-identical)."""
-        return (dt in HALF_TYPES and (B * hw) % 256 == 0 and self.model_channels % 256 == 0 and not os.environ.get("MAGE_NO_LN_FOLD"))
+        return (dt in HALF_TYPES and (B * hw) % 256 == 0 and self.model_channels % 256 == 0 and config.get().ln_fold)
 
     def _stream_bf16(self) -> bool:
         """bf16 mode with the LayerNorm fold: x itself stays in bf16 between the blocks -- every x + Linear(.) reads the bf16 rows as its
         residual and writes bf16 rows (+ the LayerNorm partial sums of the fp32 values before rounding); no fp32 stream, no second copy:
         -0.8 GB of HBM traffic per x + Linear(.) launch at cfg2.  Measured against the fp32-stream form (`stream_bf16 = False` or
-        MAGE_STREAM_FP32=1): first-generated-frame token agreement with the fp32-class modes 0.956 vs 0.958 (16 clips), i.e. inside the
+        config stream_16bit = False (MAGE_STREAM_FP32=1)): first-generated-frame token agreement with the fp32-class modes 0.956 vs 0.958 (16 clips), i.e. inside the
         bf16 GEMM noise.  The incremental loop uses the same kernels on the same rows: still bit-identical to the full loop."""
-        return getattr(self, "stream_bf16", True) and not os.environ.get("MAGE_STREAM_FP32")
+        return getattr(self, "stream_bf16", True) and config.get().stream_16bit
 
     def _ln_linear(self, d, p, lin, xb, stats, y, *, M, N, lo=0, hi=None, part=None, **kw):
         """y = Linear(LN(x)) from the bf16 copy of x and its row statistics (rows lo:hi of the Linear's outputs).  part (instead of
@@ -739,7 +749,7 @@ class FlatAxialDecoder(nn.Module):
     def _attn_split(self) -> bool:
         """f16x3: the axial attentions read split q, k, v on the matrix cores (attention_mfma_split_kernel); sequences up to 32."""
         return (self.split_kind == ops.F16X3 and self.frames_length <= 32 and (self.model_channels // 32) % 2 == 0
-                and not os.environ.get("MAGE_ATTN_SPLIT_FP32"))
+                and config.get().attn_split)
 
     def _taps_ok(self, rows: int) -> bool:
         """in_linear / context_linear (+ T positions) and the frame convolution run as the padded-taps form of the split GEMM."""
@@ -1057,14 +1067,14 @@ class MAGE(nn.Module):
         Built once per weights on the fp32 MFMA kernels (a derived cache like the folded BatchNorm vectors); 9.4 MB each at the MNIST
         config: resident in L2 / Infinity Cache.  The per-call work becomes a gather-sum (mage_table_conv): 0 matrix-core FLOPs for
         the 2*9*C^2 + 2*C^2 per pixel the reference spends (11 % of a decoder iteration), fp32-exact sums in every precision mode.
-        Returns the cache dict with 'ft.T', 'ft.T2', 'ft.P2' (None when not applicable: use_cids=False, MAGE_NO_FRAME_TABLE=1); `self.frame_table = False`
+        Returns the cache dict with 'ft.T', 'ft.T2', 'ft.P2' (None when not applicable: use_cids=False, config frame_table = False); `self.frame_table = False`
         switches the callers back to the convolution GEMM + in_linear (the reference's operation order) at any time."""
         d = self._derived.get(self._build)
         if "ft.T" in d:
             return d
         R, Cc, Kc = self.image_resolution, self.vision_width, self.codebook_size
         gm = self.generate_model
-        ok = (self.use_cids and not os.environ.get("MAGE_NO_FRAME_TABLE") and Cc % 4 == 0
+        ok = (self.use_cids and config.get().frame_table and Cc % 4 == 0
               and 9 * Kc * max(Cc, getattr(gm, "model_channels", Cc)) * 4 <= (256 << 20) and "emb" in d and d["emb"].is_cuda
               and getattr(gm, "in_channels", None) == Cc and hasattr(gm, "_build"))
         if not ok:
@@ -1211,7 +1221,7 @@ class MAGE(nn.Module):
         external latent first stage is not ours to capture), and not while per-launch profiling is on."""
         images = batch["images"]
         return (self.use_cids and images.shape[0] * self.image_resolution ** 2 <= 1024 and not ops.PROFILE.enabled
-                and all(torch.is_tensor(v) for v in batch.values()) and not os.environ.get("MAGE_NO_AUTO_GRAPH"))
+                and all(torch.is_tensor(v) for v in batch.values()) and config.get().auto_graph)
 
     def _graph_fingerprint(self):
         """Everything besides shapes, precision, AR mode and weights that selects kernels: a captured graph replays only under the same."""
@@ -1219,7 +1229,7 @@ class MAGE(nn.Module):
         return (bool(getattr(self, "frame_table", True)), self.generate_model._stream_bf16(), bool(getattr(self.ma_encoder, "mage_plus", False)),
                 getattr(self.ma_encoder, "split_kind", 0), getattr(self.text_encoder, "split_kind", 0),
                 tuple(str(getattr(fs, a, None)) for a in ("decode_dtype", "encode_split", "decode_split")),
-                tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("MAGE_"))))
+                config.get(), tuple(sorted(config.lib_options().items())))
 
     def _generate_eager(self, batch):
         if not self.use_cids:
@@ -1360,7 +1370,7 @@ class MAGE(nn.Module):
         cur[..., :E] = lat0.permute(0, 2, 3, 1).reshape(B, 1, hw, E).float()                  # :670 every slot holds frame 0
         first = self._frame_features_latent(cur[:, 0].contiguous(), LD, F32)
         ma = self._motion_anchor(None, batch, batch.get("video_noise"), first=first)
-        ma_dt = ma if dt == F32 else ma.to(dt)
+        ma_dt = _to_dt(ma, dt)
         pred = None
         for i in range(Lm1):                                                                  # :673-684
             feats = self._frame_features_latent(cur.view(-1, LD), LD, dt)
@@ -1371,7 +1381,7 @@ class MAGE(nn.Module):
         gen = pred[..., :E].reshape(B * Lm1, R, R, E).permute(0, 3, 1, 2).contiguous()          # :689
         video = self.first_stage_model.decode(gen)
         video = video.view(B, Lm1, *video.shape[1:])
-        return torch.cat([images[:, 0:1].to(video.dtype), video], 1)
+        return _assemble(images, video)
 
     @torch.no_grad()
     def _generate_one(self, batch):
@@ -1382,7 +1392,7 @@ class MAGE(nn.Module):
         dt = self._dt()
         tok0 = self.first_stage_encode(images[:, 0:1])[:, 0].reshape(B, hw)                   # :642
         ma = self._motion_anchor(tok0, batch, batch.get("video_noise"))
-        ma_dt = ma if dt == F32 else ma.to(dt)                                                # dtype plumbing of a [B*hw, C] tensor
+        ma_dt = _to_dt(ma, dt)
         gen = torch.empty(B, Lm1, R, R, device=images.device, dtype=torch.int64)
         if self.ar_mode == "incremental":
             # each position once, temporal K,V cached; bit-identical tokens to the reference loop below
@@ -1397,7 +1407,7 @@ class MAGE(nn.Module):
             gen = gen_t.permute(1, 0, 2).reshape(B, Lm1, R, R) if B == 1 else gen_t.permute(1, 0, 2).contiguous().view(B, Lm1, R, R)   # index plumbing, once
             self.last_tokens, self.last_logits = gen, None
             video = self.first_stage_decode(gen)
-            return torch.cat([images[:, 0:1].to(video.dtype), video], 1)
+            return _assemble(images, video)
         cur = tok0[:, None, :].repeat(1, Lm1, 1).contiguous()                                 # :670 future slots hold frame 0
         logits = None
         for i in range(Lm1):                                                                  # :673-684
@@ -1412,7 +1422,7 @@ class MAGE(nn.Module):
         ops.argmax(logits, gen, rows=B * Lm1 * hw, K=K)                                       # :687
         self.last_tokens, self.last_logits = gen, logits.view(B, Lm1, R, R, K)
         video = self.first_stage_decode(gen)                                                  # :690
-        return torch.cat([images[:, 0:1].to(video.dtype), video], 1)                         # :691
+        return _assemble(images, video)                         # :691
 
     # ------------------------------------------------------------------ teacher-forced pass (mage_model.py:575-639)
     @torch.no_grad()
@@ -1509,7 +1519,7 @@ class MAGE(nn.Module):
         video_rows = self._reparam_video_rows(batch, B, extras, tok=tok) if self.randomness else None
         ma = self._motion_anchor(tok[:, 0].contiguous(), batch, None, video_rows=video_rows)
         feats = self._frame_source(tok[:, :L - 1].contiguous(), dt)
-        logits = self.generate_model._run(ma if dt == F32 else ma.to(dt), feats, B=B, hh=R, ww=R)
+        logits = self.generate_model._run(_to_dt(ma, dt), feats, B=B, hh=R, ww=R)
         return tok.view(B, -1, R, R), logits.view(B, L - 1, R, R, self.codebook_size)
 
     def _reparam_video_rows(self, batch, B: int, extras: Optional[dict], tok=None, lat_rows=None, L: int = 0) -> torch.Tensor:
@@ -1560,7 +1570,7 @@ class MAGE(nn.Module):
         first = self._frame_features_latent(rows[:, 0].contiguous().view(-1, LD), LD, F32)
         ma = self._motion_anchor(None, batch, None, first=first, video_rows=video_rows)
         feats = self._frame_features_latent(rows[:, :L - 1].contiguous().view(-1, LD), LD, dt)
-        pred = self.generate_model._run(ma if dt == F32 else ma.to(dt), feats, B=B, hh=R, ww=R)      # [B*(L-1)*hw, 8]
+        pred = self.generate_model._run(_to_dt(ma, dt), feats, B=B, hh=R, ww=R)      # [B*(L-1)*hw, 8]
         tgt = rows[:, 1:L].contiguous().view(-1, LD)
         return ops.mse(pred, tgt, rows=B * (L - 1) * hw, cols=E, lda=pred.shape[1], ldb=LD), pred
 

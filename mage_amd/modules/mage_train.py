@@ -20,12 +20,11 @@ backward pass from a per-call seed.
 """
 from __future__ import annotations
 
-import os
 from typing import Dict, Optional
 
 import torch
 
-from .. import ops
+from .. import config, ops
 from .vqvae_model import VectorQuantizedVAE
 
 F32 = torch.float32
@@ -69,7 +68,9 @@ class _Run:
 # exact-fp32 MFMA chain, 3x its rate -- as in generation (mage_model._lin_fp32); precision 'fp32' keeps the exact chain, which is what the
 # 1e-4 gradient gates against the oracle are stated for.  _SPLIT32 is set by train_forward / train_backward.
 _SPLIT32 = {"sk": 0, "w": {}}
-_F32_BRANCH = bool(os.environ.get("MAGE_TRAIN_F32_BRANCH"))     # fp32 branch rows / LayerNorm-output gradients in bf16 mode too (the round-2 form)
+def _f32_branch() -> bool:
+    """fp32 branch rows / LayerNorm-output gradients in bf16 mode too (the round-2 form; config.train_f32_branch)."""
+    return config.get().train_f32_branch
 
 
 def _gemm32(a, w, y, *, M, N, K, lda=None, **kw):
@@ -108,7 +109,7 @@ def _wgrad(dy, x, *, M: int, N: int, K: int, ld_dy: int, ld_x: int, dy_geo: Opti
     assert dy.dtype == x.dtype
     dev, dt = dy.device, dy.dtype
     if (dt == BF16 and dy_geo is None and x_geo is None and N % 256 == 0 and K % 256 == 0 and M >= 4096 and ld_dy % 8 == 0 and ld_x % 8 == 0
-            and not os.environ.get("MAGE_WGRAD_TRANSPOSE")):
+            and not config.get().train_wgrad_transpose):
         # the decoder stack's Linear layers: dW = dY^T X straight from the row-major operands (mage_gemm_tn: transposing LDS loads),
         # no dY^T / X^T copies (they were 11.8 ms of a 92 ms step at cfg2)
         return ops.gemm_tn(dy, x, T=M, N=N, K=K, ld_dy=ld_dy, ld_x=ld_x, want_bias=want_bias)
@@ -154,14 +155,14 @@ def _res_linear(run: _Run, a, d, name, x_old, dt, *, M, N, K, seed, ln=None, cas
             return x_new if cast_to is None else (x_new, ops.cast(x_new, torch.empty(M, N, device=a.device, dtype=cast_to)))
         return x_new, ops.layernorm(x_new, ln[0], ln[1], torch.empty(M, N, device=a.device, dtype=ln[2]), 1e-5)
     # the branch rows leave the GEMM in the compute dtype (bf16 mode: half the bytes written here and read by the mask-and-add pass;
-    # the stream x itself stays fp32).  MAGE_TRAIN_F32_BRANCH=1 keeps fp32 branch rows.
-    br = _gemm32(a, w, torch.empty(M, N, device=a.device, dtype=F32 if _F32_BRANCH else a.dtype), M=M, N=N, K=K, lda=K, ldy=N, bias=b)
+    # the stream x itself stays fp32).  MAGE_TRAIN_f32_branch()=1 keeps fp32 branch rows.
+    br = _gemm32(a, w, torch.empty(M, N, device=a.device, dtype=F32 if _f32_branch() else a.dtype), M=M, N=N, K=K, lda=K, ldy=N, bias=b)
     if ln is None:
         if cast_to is not None:                      # the last block: its rows also as the head GEMM's bf16 operand
             xb = torch.empty(M, N, device=a.device, dtype=cast_to)
             return ops.dropout_add(br, x_old, torch.empty_like(x_old), run.p, seed, y_bf16=xb), xb
         return ops.dropout_add(br, x_old, torch.empty_like(x_old), run.p, seed)
-    if os.environ.get("MAGE_TRAIN_NO_EMIT"):
+    if not config.get().train_emit:
         x_new = ops.dropout_add(br, x_old, torch.empty_like(x_old), run.p, seed)
         return x_new, ops.layernorm(x_new, ln[0], ln[1], torch.empty(M, N, device=a.device, dtype=ln[2]), 1e-5)
     return ops.dropout_add_layernorm(br, x_old, torch.empty_like(x_old), ln[0], ln[1], torch.empty(M, N, device=a.device, dtype=ln[2]), 1e-5,
@@ -199,7 +200,7 @@ def _dec_forward(gm, run: _Run, motion, feats, B: int, hh: int, ww: int):
         ops.attention(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], ao, ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=Cc, **geo)
         s_attn, s_mlp = run.next_seed(), run.next_seed()
         x1, xn2 = _res_linear(run, ao, d, p + ".out_proj", x, dt, M=M, N=Cc, K=Cc, seed=s_attn, ln=(d[p + ".ln_2.w"], d[p + ".ln_2.b"], dt))
-        if dt != F32 and M % 256 == 0 and Cc % 64 == 0 and not os.environ.get("MAGE_TRAIN_NO_DUAL"):
+        if dt != F32 and M % 256 == 0 and Cc % 64 == 0 and config.get().train_dual:
             # one launch writes the pre-activation rows (kept for the backward pass) and QuickGELU of them (the next Linear's operand)
             hdn = torch.empty(M, 4 * Cc, device=dev, dtype=dt)
             hpre = ops.gemm(xn2, d[p + ".c_fc" + _sfx(dt)], torch.empty(M, 4 * Cc, device=dev, dtype=dt), M=M, N=4 * Cc, K=Cc, lda=Cc,
@@ -245,7 +246,7 @@ def _dec_forward(gm, run: _Run, motion, feats, B: int, hh: int, ww: int):
 def _emit_next(run, dx, emit):
     """layernorm_bwd's extra output for `emit` = (seed of the branch the updated dx enters next, or None for a plain cast): bf16 mode
     only (the masked / cast copy _to_dt would make in a separate pass); None otherwise."""
-    if emit is None or run.dt != BF16 or os.environ.get("MAGE_TRAIN_NO_EMIT"):
+    if emit is None or run.dt != BF16 or not config.get().train_emit:
         return None, {}
     seed = emit[0]
     dxb = torch.empty(dx.shape, device=dx.device, dtype=BF16)
@@ -265,7 +266,7 @@ def _block_mlp_bwd(run, d, p, pre, grads, dx, x1, xn2, hpre, M, Cc, seed, ln_key
         hdn = ops.act(hpre, torch.empty_like(hpre), act)
     grads[names["proj_w"]], grads[names["proj_b"]] = _wgrad(dxb, hdn, M=M, N=Cc, K=4 * Cc, ld_dy=Cc, ld_x=4 * Cc)
     del hdn
-    if dt != F32 and act == ops.ACT_QUICKGELU and M % 256 == 0 and Cc % 64 == 0 and not os.environ.get("MAGE_TRAIN_NO_DUAL"):
+    if dt != F32 and act == ops.ACT_QUICKGELU and M % 256 == 0 and Cc % 64 == 0 and config.get().train_dual:
         # d/d(pre-activation) straight from the data-gradient GEMM: its epilogue multiplies the accumulators by QuickGELU'(hpre)
         dh = ops.gemm(dxb, _wt(d, f"{p}.{proj}", dt), torch.empty(M, 4 * Cc, device=dev, dtype=dt), M=M, N=4 * Cc, K=Cc, lda=Cc, ldy=4 * Cc,
                       act=ops.ACT_QUICKGELU_GRAD, y2=hpre, ldy2=4 * Cc)
@@ -274,7 +275,7 @@ def _block_mlp_bwd(run, d, p, pre, grads, dx, x1, xn2, hpre, M, Cc, seed, ln_key
         ops.act_bwd(hpre, dh, dh, act)
     grads[names["fc_w"]], grads[names["fc_b"]] = _wgrad(dh, xn2, M=M, N=4 * Cc, K=Cc, ld_dy=4 * Cc, ld_x=Cc)
     # d/d(LayerNorm output) in the compute dtype: layernorm_bwd reads it once (its dx stream stays fp32)
-    dxn = _gemm_x(dh, _wt(d, f"{p}.{fc}", dt), torch.empty(M, Cc, device=dev, dtype=F32 if _F32_BRANCH else dt), M=M, N=Cc, K=4 * Cc)
+    dxn = _gemm_x(dh, _wt(d, f"{p}.{fc}", dt), torch.empty(M, Cc, device=dev, dtype=F32 if _f32_branch() else dt), M=M, N=Cc, K=4 * Cc)
     del dh, dxb
     nxt, kw = _emit_next(run, dx, emit)
     grads[names["ln_w"]], grads[names["ln_b"]] = ops.layernorm_bwd(x1, d[f"{p}.{ln_key}.w"], dxn, dx, eps=1e-5, accumulate=True, **kw)
@@ -316,7 +317,7 @@ def _dec_backward(gm, run: _Run, tape, dlogits, grads: Dict[str, torch.Tensor], 
                           ldo=Cc, ld_dq=3 * Cc, ld_dk=3 * Cc, ld_dv=3 * Cc, **t["geo"])
         grads[bp + ".attn.in_proj_weight"], grads[bp + ".attn.in_proj_bias"] = _wgrad(dqkv, t["xn1"], M=M, N=3 * Cc, K=Cc, ld_dy=3 * Cc,
                                                                                      ld_x=Cc)
-        dxn = _gemm_x(dqkv, _wt(d, p + ".in_proj", dt), torch.empty(M, Cc, device=dev, dtype=F32 if _F32_BRANCH else dt), M=M, N=Cc, K=3 * Cc)
+        dxn = _gemm_x(dqkv, _wt(d, p + ".in_proj", dt), torch.empty(M, Cc, device=dev, dtype=F32 if _f32_branch() else dt), M=M, N=Cc, K=3 * Cc)
         del dxb, dao, dqkv
         dxb, kw = _emit_next(run, dx, (tape["blocks"][i - 1]["s_mlp"] if i > 0 else None,))
         grads[bp + ".ln_1.weight"], grads[bp + ".ln_1.bias"] = ops.layernorm_bwd(t["x0"], d[p + ".ln_1.w"], dxn, dx, eps=1e-5, accumulate=True, **kw)
@@ -363,7 +364,7 @@ def _frame_backward(model, run_dt, tok_rows, emb, dfeats, grads, acc, lat_rows=N
     hp = ops.group_rowsum(dfeats, torch.empty(hw, Cc, device=dev, dtype=F32), rows=rows, C=Cc, div=1, mod=hw)
     acc["hwpos"] = hp if acc.get("hwpos") is None else acc["hwpos"] + hp
     P = R + 2
-    taps = run_dt == BF16 and Cc % 256 == 0 and rows % 256 == 0 and not os.environ.get("MAGE_TRAIN_NO_TAPS")
+    taps = run_dt == BF16 and Cc % 256 == 0 and rows % 256 == 0 and config.get().train_taps
     if taps:
         # dfeats as bf16 rows in the interior of a zero-padded (R+2) x (R+2) frame buffer (border written once): its transposed
         # convolution below is then the padded-taps form of mage_gemm (8-phase kernel, 1.4 -> 0.9 ms at cfg2), as in _frame_features
@@ -596,7 +597,7 @@ def train_forward(model, batch):
     run32 = _Run(F32, model.dropout, model.training)
     run32.seed, run32.p = run.seed, run.p
     run32.site = 1 << 20            # its own stream of dropout sites: the decoder's and the encoders' layers never share a seed
-    run32.sk = ops.F16X3 if (dt != F32 and not os.environ.get("MAGE_TRAIN_ENC_FP32")) else 0
+    run32.sk = ops.F16X3 if (dt != F32 and config.get().train_enc_split) else 0
     _SPLIT32["sk"], _SPLIT32["w"] = run32.sk, {}
     d = model._derived.get(model._build)
     dev = images.device
@@ -621,7 +622,7 @@ def train_forward(model, batch):
         lin = dict(N=Cc, K=E, lda=LD, ldy=Cc, bias=d["emb_lin.b"])
         emb = ops.gemm(lat_in, d["emb_lin.w"], torch.empty(B * (L - 1) * hw, Cc, device=dev, dtype=dt), M=B * (L - 1) * hw, **lin)
         emb0 = ops.gemm(lat0, d["emb_lin.w"], torch.empty(B * hw, Cc, device=dev, dtype=F32), M=B * hw, **lin)
-    if model.use_cids and dt == BF16 and Cc % 64 == 0 and not os.environ.get("MAGE_TRAIN_NO_TAPS"):
+    if model.use_cids and dt == BF16 and Cc % 64 == 0 and config.get().train_taps:
         # the generation path's padded-taps convolution (embedding rows written into a zero-padded frame buffer: the 8-phase kernel
         # instead of the per-lane gather, 1.45 -> 0.9 ms at cfg2); emb (plain rows) stays the backward pass's operand
         feats = model._frame_features(tok_in, dt)

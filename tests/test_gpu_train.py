@@ -6,6 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from mage_amd import config
 from mage_amd.utils import synth
 from oracle import mage_oracle as O
 from tests.helpers import build_mage, cpu_sd
@@ -276,11 +277,8 @@ def test_attention_backward_on_the_matrix_cores(axis, L, hh, ww, H):
     assert torch.isfinite(got.float()).all()
     for j, nm in enumerate(("dq", "dk", "dv")):
         assert rel(got[:, j * Cc:(j + 1) * Cc], want[:, j * Cc:(j + 1) * Cc]) < 1e-2, nm
-    os.environ["MAGE_ATTN_NO_MFMA"] = "1"
-    try:
+    with config.lib_option("attn_no_mfma", 1):
         old = run()
-    finally:
-        del os.environ["MAGE_ATTN_NO_MFMA"]
     assert rel(got, old.float()) < 1e-2
 
 
@@ -523,9 +521,9 @@ def test_dropout_training_mode_is_consistent_between_forward_and_backward():
     assert abs(fd - an) < 0.05 * max(abs(an), 1e-3) + 2e-4
 
 
-def test_bf16_training_folds_equal_the_separate_passes(monkeypatch):
+def test_bf16_training_folds_equal_the_separate_passes():
     """bf16 train(): the folded passes (residual add + dropout + next LayerNorm in one launch, layernorm_bwd writing the next branch's
-    masked operand, padded-taps frame convolutions) against the separate launches they replace (MAGE_TRAIN_NO_EMIT / MAGE_TRAIN_NO_TAPS),
+    masked operand, padded-taps frame convolutions) against the separate launches they replace (config train_emit / train_taps off),
     same dropout seed: same masks, same loss and gradients up to bf16 rounding of one intermediate."""
     cfg = synth.mnist_model_config(frames_length=4, width=256, layers=3, vq_dim=32, K=64)
     m = build_mage(cfg, 41, DEV).train()
@@ -540,9 +538,8 @@ def test_bf16_training_folds_equal_the_separate_passes(monkeypatch):
         loss.backward()
         return loss.item(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
     l1, g1 = run()
-    monkeypatch.setenv("MAGE_TRAIN_NO_EMIT", "1")
-    monkeypatch.setenv("MAGE_TRAIN_NO_TAPS", "1")
-    l0, g0 = run()
+    with config.override(train_emit=False, train_taps=False):
+        l0, g0 = run()
     assert abs(l1 - l0) < 2e-3 * max(1.0, abs(l0))
     cos = {n: F.cosine_similarity(g1[n].flatten().double(), g0[n].flatten().double(), dim=0).item() for n in g0 if g0[n].abs().max() > 0}
     print(f"folded vs separate passes: loss {l1:.6f} / {l0:.6f}, min gradient cosine {min(cos.values()):.6f}")
@@ -570,14 +567,10 @@ def test_gemm_tn_weight_gradient_against_fp64(T, N, K, ld_dy, ld_x):
     dW2, db2 = o.gemm_tn(dy, x_full, T=T, N=N, K=K, ld_dy=ld_dy, ld_x=ld_x)
     assert torch.equal(dW, dW2) and torch.equal(db, db2)
     # whole 64-token slabs run on the one-wave-per-SIMD form (csrc/gemm4.hip, gemm_tn4_kernel): same LDS image, same MFMA order per
-    # accumulator, same dot2 order for the bias gradient -> the same bits as the 8-wave kernel (MAGE_GEMM_NO_4W is read on every call)
-    import os
-    os.environ["MAGE_GEMM_NO_4W"] = "1"
-    try:
+    # accumulator, same dot2 order for the bias gradient -> the same bits as the 8-wave kernel (library option gemm_no_4w)
+    with config.lib_option("gemm_no_4w", 1):
         dW8, db8 = o.gemm_tn(dy, x_full, T=T, N=N, K=K, ld_dy=ld_dy, ld_x=ld_x)
         dW8n, _ = o.gemm_tn(dy, x_full, T=T, N=N, K=K, ld_dy=ld_dy, ld_x=ld_x, want_bias=False)
-    finally:
-        os.environ.pop("MAGE_GEMM_NO_4W", None)
     dWn, _ = o.gemm_tn(dy, x_full, T=T, N=N, K=K, ld_dy=ld_dy, ld_x=ld_x, want_bias=False)
     assert torch.equal(dW, dW8) and torch.equal(db, db8) and torch.equal(dWn, dW8n) and torch.equal(dWn, dW)
     cs = o.colsum(dy, T=T, C_=N, ld=ld_dy)

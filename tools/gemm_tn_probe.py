@@ -3,7 +3,7 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mage_amd import ops
+from mage_amd import config, ops
 from mage_amd.modules import mage_train as T
 
 DEV = "cuda:0"
@@ -29,7 +29,6 @@ for N, K, tag in ((1536, 512, "in_proj"), (512, 512, "out_proj"), (2048, 512, "c
     fl = 2.0 * M * N * K
     t_tn = timeit(lambda: ops.gemm_tn(dy, x, T=M, N=N, K=K, ld_dy=N, ld_x=K, want_bias=False))
     t_tnb = timeit(lambda: ops.gemm_tn(dy, x, T=M, N=N, K=K, ld_dy=N, ld_x=K, want_bias=True))
-    os.environ["MAGE_WGRAD_TRANSPOSE"] = "1"
-    t_old = timeit(lambda: T._wgrad(dy, x, M=M, N=N, K=K, ld_dy=N, ld_x=K))
-    os.environ.pop("MAGE_WGRAD_TRANSPOSE")
+    with config.override(train_wgrad_transpose=True):
+        t_old = timeit(lambda: T._wgrad(dy, x, M=M, N=N, K=K, ld_dy=N, ld_x=K))
     print(f"{tag:9s} N={N:5d} K={K:5d}: gemm_tn {t_tn:6.3f} ms ({fl / t_tn / 1e9:6.0f} TF/s)  + colsum {t_tnb:6.3f} ms   transposes + split-K gemm8 + db {t_old:6.3f} ms", flush=True)

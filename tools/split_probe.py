@@ -11,7 +11,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from mage_amd import ops  # noqa: E402
+from mage_amd import config, ops  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -66,9 +66,9 @@ def main():
             f = lambda: ops.gemm(a_s, w_s, y, M=M, N=N, K=K, lda=2 * K, ldy=N, bias=b, residual=r, ldr=N, split_kind=kind)
             ms = timeit(f)
             err = (y[rows].double() - want).abs().max().item()
-            os.environ["MAGE_GEMM_NO_8PHASE"] = "1"
             y2 = torch.empty_like(y)
-            ops.gemm(a_s, w_s, y2, M=M, N=N, K=K, lda=2 * K, ldy=N, bias=b, residual=r, ldr=N, split_kind=kind)
+            with config.lib_option("gemm_no_8phase", 1):
+                ops.gemm(a_s, w_s, y2, M=M, N=N, K=K, lda=2 * K, ldy=N, bias=b, residual=r, ldr=N, split_kind=kind)
             print(f"{'':16s} {'':28s} {nm:8s} err {err:.3e}  {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TF/s (x3 = {3 * fl / ms / 1e9:7.1f} MFMA TF/s)", flush=True)
             # split output with QuickGELU (no residual)
             ys = ops.split_empty(M, N, kind, DEV)
