@@ -119,6 +119,19 @@ __device__ __forceinline__ void g4_mfma(const u32x4& w, const u32x4& x) {
     if constexpr (HF) G4_MFMA_STMT("v_mfma_f32_16x16x32_f16");
     else G4_MFMA_STMT("v_mfma_f32_16x16x32_bf16");
 }
+#ifdef MAGE4_MFMA32
+// Tuning build (tools/probes/gemm4_probe.hip -DMAGE4_MFMA32 -DMAGE4_ABL=1): the K loop on v_mfma_f32_32x32x16_bf16 -- 16 blocks of 32 x 32 outputs
+// (16 accumulator registers each) instead of 64 of 16 x 16: half the MFMA issues and half the operand-register reads per FLOP.  K loop only:
+// the epilogue is written for the 16 x 16 accumulator layout, so this build answers one question -- does the same slab of work draw less
+// power (hold a higher clock) in the other MFMA shape -- and nothing else.
+template <int B, bool ZERO, bool CLOB>
+__device__ __forceinline__ void g4_mfma32(const u32x4& w, const u32x4& x) {
+    if constexpr (ZERO && CLOB) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(w), "v"(x), "i"(16 * B), "i"(16 * B + 15) : G4_ALL_ACC);
+    else if constexpr (ZERO) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(w), "v"(x), "i"(16 * B), "i"(16 * B + 15));
+    else if constexpr (CLOB) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(x), "i"(16 * B), "i"(16 * B + 15) : G4_ALL_ACC);
+    else asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(x), "i"(16 * B), "i"(16 * B + 15));
+}
+#endif
 template <int I, bool CLOB = false>
 __device__ __forceinline__ f32x4 g4_acc_read() {
     f32x4 v;
@@ -212,6 +225,20 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
         xf[buf][mt & 3] = *(const u32x4*)(smem + stage * G4_STAGE + x_off + mt * 2048 + pc[t]);
     };
 
+#ifdef MAGE4_MFMA32
+    // 32 x 32 x 16: lane (l31 = lane & 31, hi = lane >> 5) holds 8 consecutive k (16 bytes) of fragment row l31: k-step s of a slab is logical
+    // chunks 2s + hi of the 128-byte row
+    const int l31 = lane & 31, hi5 = lane >> 5;
+    const int rsw32 = (l31 >> 1) & 7;
+    const int x32_off = (wm * 128 + l31) * 128, w32_off = G4_WOFF + (wn * 128 + l31) * 128;
+    u32x4 wq[2][4], xq[2][4];
+    auto rd_w32 = [&](int buf, int stage, int ks, int nb) __attribute__((always_inline)) {
+        wq[buf][nb] = *(const u32x4*)(smem + stage * G4_STAGE + w32_off + nb * 4096 + (((2 * ks + hi5) ^ rsw32) << 4));
+    };
+    auto rd_x32 = [&](int buf, int stage, int ks, int mb) __attribute__((always_inline)) {
+        xq[buf][mb] = *(const u32x4*)(smem + stage * G4_STAGE + x32_off + mb * 4096 + (((2 * ks + hi5) ^ rsw32) << 4));
+    };
+#endif
     if (g.stagger_groups > 1) {
         for (int w = (li % g.stagger_groups) * g.stagger_sleeps; w > 0; --w) __builtin_amdgcn_s_sleep(16);
     }
@@ -231,10 +258,15 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): slabs 0 AND 1 (a tile's first slab waits with a count that assumes the previous
                                                        // tile's epilogue traffic behind slab 1's pieces; there is none in front of the first tile)
     ring_barrier();
+#ifdef MAGE4_MFMA32
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { rd_w32(0, 0, 0, b); rd_x32(0, 0, 0, b); }
+#else
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) rd_w1(0, 0, 0, nt);
 #pragma unroll
     for (int m = 0; m < 4; ++m) rd_x1(0, 0, 0, m);
+#endif
 
     [[maybe_unused]] int it = 0;
     for (; c_tile < chunk1; c_tile += nwg8, ++it) {
@@ -353,6 +385,56 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
             if constexpr (!(MAGE4_ABL & 8)) a_src = (j == nk - 3) ? a_next : a_src + 128;
             if constexpr (!(MAGE4_ABL & 8) && LAST) w_src += 128;
         };
+#ifdef MAGE4_MFMA32
+        // the same slab on 32 x 32 x 16 MFMAs: quarter q = k-step q (16 of the slab's 64 k), 16 MFMAs over the 4 x 4 blocks; the next k-step's 8
+        // fragments are read during the quarter, the DMA issue points, the barrier and the waits are the 16 x 16 schedule's
+        auto slab32 = [&](auto S_, auto FIRST_, auto LAST_, int j) __attribute__((always_inline)) {
+            constexpr int S = decltype(S_)::value;
+            constexpr bool FIRST = decltype(FIRST_)::value, LAST = decltype(LAST_)::value;
+            auto quarter = [&](auto Q_) __attribute__((always_inline)) {
+                constexpr int Q = decltype(Q_)::value, buf = Q & 1;
+                g4_for<16>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value, mb = i >> 2, nb = i & 3;
+                    g4_mfma32<mb * 4 + nb, FIRST && Q == 0, i == 0>(wq[buf][nb], xq[buf][mb]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!(MAGE4_ABL & 4) && i < 8 && !(Q == 3 && LAST)) {        // next k-step's fragments (Q3: the next slab's first, other stage)
+                        constexpr int st = Q == 3 ? (S ^ 1) : S, ks = (Q + 1) & 3;
+                        if constexpr (i < 4) rd_x32(buf ^ 1, st, ks, i);
+                        else rd_w32(buf ^ 1, st, ks, i - 4);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (Q == 0 && !(MAGE4_ABL & 2) && !FIRST) {                  // W(j+1): 8 pieces
+                        if constexpr (i == 4) dma_m0((S ^ 1) * G4_STAGE + G4_WOFF);
+                        if constexpr (i >= 5 && i < 13) g4_dma<i - 5>(voffW[i - 5], w_src);
+                        if constexpr (i >= 4 && i < 13) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (Q == 3 && !(MAGE4_ABL & 2) && !LAST) {                   // A(j+2): 8 pieces
+                        if constexpr (i == 1) dma_m0(S * G4_STAGE);
+                        if constexpr (i >= 2 && i < 10) g4_dma<i - 2>(voffA[i - 2], a_src);
+                        if constexpr (i >= 1 && i < 10) __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+            };
+            quarter(std::integral_constant<int, 0>{});
+            if constexpr (!(MAGE4_ABL & 8) && !FIRST) w_src = (j == nk - 2) ? w_next : w_src + 128;
+            quarter(std::integral_constant<int, 1>{});
+            quarter(std::integral_constant<int, 2>{});
+            if constexpr (FIRST) __builtin_amdgcn_s_waitcnt(0x8070);
+            else __builtin_amdgcn_s_waitcnt(0x0070);
+            ring_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            quarter(std::integral_constant<int, 3>{});
+            if constexpr (LAST && !(MAGE4_ABL & 2)) {                                       // the next tile's slab 1 (A and W), as the 16 x 16 schedule sends it
+                dma_m0(S * G4_STAGE);
+                g4_for<8>([&](auto u_) { g4_dma<decltype(u_)::value>(voffA[decltype(u_)::value], a_src); });
+                dma_m0(S * G4_STAGE + G4_WOFF);
+                g4_for<8>([&](auto u_) { g4_dma<decltype(u_)::value>(voffW[decltype(u_)::value], w_src); });
+            }
+            if constexpr (!(MAGE4_ABL & 8)) a_src = (j == nk - 3) ? a_next : a_src + 128;
+            if constexpr (!(MAGE4_ABL & 8) && LAST) w_src += 128;
+        };
+#define slab slab32
+#endif
         typedef std::integral_constant<int, 0> S0;
         typedef std::integral_constant<int, 1> S1;
         slab(S0{}, std::true_type{}, std::false_type{}, 0);
@@ -363,6 +445,9 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
         }
         slab(S0{}, std::false_type{}, std::false_type{}, nk - 2);
         slab(S1{}, std::false_type{}, std::true_type{}, nk - 1);
+#ifdef MAGE4_MFMA32
+#undef slab
+#endif
         // the last MFMAs' results must have left the matrix pipe before an accumulator is read (an asm statement gets no hazard padding)
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
         G4_STAMP(it, 1);
@@ -427,10 +512,15 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
         // the next tile's first fragments (its slab 0 has been in stage 0 since the last slab's barrier)
         __builtin_amdgcn_sched_barrier(0);
         if (c_tile + nwg8 < chunk1) {
+#ifdef MAGE4_MFMA32
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { rd_w32(0, 0, 0, b); rd_x32(0, 0, 0, b); }
+#else
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) rd_w1(0, 0, 0, nt);
 #pragma unroll
             for (int m = 0; m < 4; ++m) rd_x1(0, 0, 0, m);
+#endif
         }
     }
 }

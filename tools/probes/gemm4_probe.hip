@@ -62,9 +62,9 @@ int main(int argc, char** argv) {
         mage_gemm_desc d0 = d, d1 = d;
         d0.Y = Y0;
         d1.Y = Y1;
-        setenv("MAGE_GEMM_NO_4W", "1", 1);           // the library's own dispatch stays on the 8-wave kernels (it reads the variable once)
-        if (mage_gemm(&d0, nullptr) != MAGE_OK) { printf("mage_gemm: %s\n", mage_last_error()); return 1; }
-        unsetenv("MAGE_GEMM_NO_4W");
+        // the library's own dispatch stays on the 8-wave kernels (option gemm_no_4w = 1); this file's copy of the kernel runs with it cleared
+        auto run8 = [&]() { mage_set_option("gemm_no_4w", 1); const int r_ = mage_gemm(&d0, nullptr); mage_set_option("gemm_no_4w", 0); return r_; };
+        if (run8() != MAGE_OK) { printf("mage_gemm: %s\n", mage_last_error()); return 1; }
         const int r = mage_gemm4_try(&d1, nullptr);
         if (r != 1) { printf("%s: gemm4 not eligible (%d) %s\n", sh.name, r, mage_last_error()); continue; }
         if (hipDeviceSynchronize() != hipSuccess) { printf("sync failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
@@ -101,7 +101,9 @@ int main(int argc, char** argv) {
         for (int rd = 0; rd < rounds; ++rd) {
             float ms;
             hipEventRecord(e0);
+            mage_set_option("gemm_no_4w", 1);
             for (int i = 0; i < 4; ++i) mage_gemm(&d0, nullptr);
+            mage_set_option("gemm_no_4w", 0);
             hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
             t8 += ms / 4;
             hipEventRecord(e0);
