@@ -47,6 +47,16 @@ __device__ __forceinline__ void mage_raise(int* word, int code, long value, int 
     }
 }
 
+// Debug build (`make debug`: -DMAGE_DEBUG=1, host code under AddressSanitizer): device-side invariants -- LDS offsets inside their rings and
+// windows, tile indices inside the tile list, table rows inside their tables -- as device asserts (a failed one aborts the kernel and the
+// next synchronisation reports it with file and line).  Compiled out of the release library.
+#if defined(MAGE_DEBUG) && MAGE_DEBUG
+#include <cassert>
+#define MAGE_DASSERT(cond) assert(cond)
+#else
+#define MAGE_DASSERT(cond) ((void)0)
+#endif
+
 #define MAGE_CHECK_ARG(cond, ...)                                   \
     do {                                                            \
         if (!(cond)) {                                              \

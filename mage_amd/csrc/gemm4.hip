@@ -272,6 +272,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
     for (; c_tile < chunk1; c_tile += nwg8, ++it) {
         G4_STAMP(it, 0);
         const int tm = c_tile / g.ntiles_n, tn = c_tile - tm * g.ntiles_n;
+        MAGE_DASSERT(c_tile >= 0 && c_tile < g.ntiles && tm * 256 < g.M && tn * 256 < g.N);
         const int m0 = ((MAGE4_ABL & 32) ? (int)blockIdx.x : tm) * 256 + wm * 128, n0 = ((MAGE4_ABL & 32) ? 0 : tn) * 256 + wn * 128;
         {
             const int nt_tile = c_tile + nwg8 > last_tile ? last_tile : c_tile + nwg8;     // past the end: re-fetch the last tile (never read)

@@ -380,11 +380,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
             } else {
                 src = (live && (SPL || kc < d.K) && a_row[i]) ? a_row[i] + (long)kc * ES : g.zero;
             }
+            MAGE_DASSERT(ld_stage >= 0 && ld_stage < NST && (wave * AU + i) * 1024 + 1024 <= A_BYTES);
             glds16(src, sa + (wave * AU + i) * 1024);
         } else {
             const int i = u - AU;
             const int kc = ktw * BK + wcs[i] * CH;
             const char* wsrc = (live && (SPL || kc < d.K) && w_row[i]) ? w_row[i] + (long)kc * ES : g.zero;
+            MAGE_DASSERT(A_BYTES + (wave * WU + i) * 1024 + 1024 <= STAGE_BYTES);
             glds16(wsrc, sa + A_BYTES + (wave * WU + i) * 1024);
         }
     };
@@ -432,6 +434,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     for (int it = 0; c_tile < chunk1; c_tile += nwg8, ++it) {
         const int ts = SPLIT ? c_tile / g.tiles_per_split : 0, trem = SPLIT ? c_tile - ts * g.tiles_per_split : c_tile;
         const int tm = trem / g.ntiles_n, tn = trem - tm * g.ntiles_n;
+        MAGE_DASSERT(c_tile >= 0 && c_tile < g.ntiles && tm * BM < d.M && tn * BNT < d.N);
         const long ysplit = SPLIT ? (long)ts * d.y_split_stride : 0;
         const int m0 = tm * BM + wm * MT * 16, n0 = tn * BNT + wn * 64;
         [[maybe_unused]] bool res_rows = false;
@@ -838,6 +841,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     [[maybe_unused]] int w_tap[2] = {0, 0}, w_c[2] = {0, 0}, w_slab[2] = {0, 0};
     [[maybe_unused]] const int ntaps_k = TAPS ? d.taps_h * d.taps_w : 1;
     auto issue = [&](int P) {
+        MAGE_DASSERT((cur_buf[P] == 0 || cur_buf[P] == 1) && cur_kt[P] >= 0 && cur_kt[P] < nk);
         char* dst = smem + cur_buf[P] * KBUF + P * PIECE + (2 * wave) * 1024;
         const bool isA = P == P_A0 || P == P_A1;
         const char* sbase;
@@ -939,6 +943,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
         const int ts = SPLIT ? c_tile / g.tiles_per_split : 0, trem = SPLIT ? c_tile - ts * g.tiles_per_split : c_tile;
         const int tm = trem / g.ntiles_n, tn = trem - tm * g.ntiles_n;
         const long ysplit = SPLIT ? (long)ts * d.y_split_stride : 0;
+        MAGE_DASSERT(c_tile >= 0 && c_tile < g.ntiles && tm * BM < d.M && tn * BN < d.N);
         const int m0 = tm * BM + wr * 128, n0 = tn * BN + wc * 64;
         [[maybe_unused]] bool res_rows = false;
         if constexpr (EK == EK_RES_INIT && RB && !TAPS && SPL == 0) {

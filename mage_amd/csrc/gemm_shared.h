@@ -96,6 +96,11 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
         roff[i] = F32 ? r * RB + ((cc ^ r) << 4) : r * RB + ((cc ^ ((r >> 1) & 7)) << 4);
     }
     const int col = n0 + cc * CPC;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)                  // the wave's private 4 KiB staging window (split rows: two 8-byte pieces 128 bytes apart)
+        MAGE_DASSERT(woff[nt] >= 0 && (OSPL ? (woff[nt] | 128) + 8 : woff[nt] + (F32 ? 16 : 8)) <= 4096);
+#pragma unroll
+    for (int i = 0; i < NST; ++i) MAGE_DASSERT(roff[i] >= 0 && roff[i] + 16 <= 4096);
     const bool simple_rows = d.out_h == 1 && d.out_w >= d.M;
     const bool affine_rows = AFFINE && d.out_h == 1 && d.y_mul_x == 1 && d.out_w % 256 == 0;
     const bool interior = (simple_rows || affine_rows) && m0 + MT * 16 <= d.M && n0 + 64 <= d.N;     // wave-uniform

@@ -474,6 +474,7 @@ __global__ __launch_bounds__(512) void embedding_bwd_det_kernel(const int64_t* _
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {                                  // the instruction's 8 rows, ascending: one exec-masked LDS add each
+                MAGE_DASSERT(id[u] < n_table && ch < 64);
                 if (rs == r && id[u] >= 0) atomicAdd(&tab[id[u] * 64 + ch], v[u]);
                 __builtin_amdgcn_wave_barrier();                           // keeps the eight adds eight instructions, in this order
             }

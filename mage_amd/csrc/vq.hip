@@ -373,6 +373,7 @@ __global__ __launch_bounds__(256) void table_conv_kernel(const int64_t* __restri
                 if (lane == 0) mage_raise(err, MAGE_DEVERR_EMBEDDING_ID, id, n_codes);
                 id = id < 0 ? 0 : n_codes - 1;
             }
+            MAGE_DASSERT(id >= 0 && id < n_codes);
             const TT_* row = table + ((long)(ky * tw + kx) * n_codes + id) * C;
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
