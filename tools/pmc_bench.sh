@@ -5,7 +5,7 @@ TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-mode --no-parity-mode --no-decode-roofline --no-train-step --no-latency-b1 --streams 1 > /tmp/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-mode --no-parity-mode --no-decode-roofline --no-train-step --no-latency-b1 --no-cfg4 --streams 1 > /tmp/pmc_$c.log 2>&1
 done
 python - <<PY
 import csv, collections, json, re

@@ -3,7 +3,7 @@
 # tools/bench_vqvae.py (FETCH_SIZE and WRITE_SIZE do not fit one pass), kernel-trace only; corrected as MI355X_MICROARCH.md prescribes
 # (gfx950: FETCH_SIZE reports half of wide streaming reads).  Output: gpurun_out/pmc_decode_<tag>.json (copy to profiles/<tag>_pmc_decode.json:
 # bench.py reads it for roofline_decode.traffic).  usage: tools/pmc_decode.sh r04
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcd_$c
@@ -12,8 +12,8 @@ done
 python - <<PY
 import csv, collections, json, re
 # launches of one decode call (mage_amd/modules/vqvae_model.py: _decode_chunk, bf16, 16x16 latents, dim 256)
-per_call = {"resblock_table_kernel": 1, "gemm8_kernel<1, 0, false, true, 0, 0, false>": 1, "resblock_rows_kernel": 1,
-            "gemm8_kernel<1, 0, false, true, 5, 0, false>": 1, "convt_fold_tanh_img_kernel": 1}
+per_call = {"resblock_table_kernel": 1, "gemm8_kernel<1, 0, false, true, 0, 0, false, false>": 1, "resblock_rows_kernel": 1,
+            "gemm8_kernel<1, 0, false, true, 5, 0, false, false>": 1, "convt_fold_tanh_img_kernel": 1}
 out = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(list)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call that regenerates everything under profiles/ for the committed code:
 #   bench line (with cpu_baseline), bench line under rocprofv3 + kernel stats, PMC traffic.  usage: tools/refresh_profiles.sh r01
-TAG=${1:-r03}
+TAG=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 # PMC first: bench.py reads the committed summary for roofline.traffic, so refresh it on the box before the bench line
@@ -11,7 +11,7 @@ cd $GRAFT_REPO_ROOT
 python bench.py 2> $OUT/bench_$TAG.err | tail -1 > $OUT/${TAG}_bench_cfg2_bf16.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o k -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-mode --no-parity-mode --no-decode-roofline --no-train-step --no-latency-b1 2> /dev/null | tail -1 > $OUT/${TAG}_bench_cfg2_bf16_under_rocprof.json
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o k -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-mode --no-parity-mode --no-decode-roofline --no-train-step --no-latency-b1 --no-cfg4 2> /dev/null | tail -1 > $OUT/${TAG}_bench_cfg2_bf16_under_rocprof.json
 cp /tmp/kt/k_kernel_stats.csv $OUT/${TAG}_bench_cfg2_bf16_kernel_stats.csv
 # GPU busy vs span of the timed step (last generate call): sum of kernel durations / (last end - first start) over the second half
 python - <<PY > $OUT/${TAG}_gpu_busy.txt
