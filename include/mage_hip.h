@@ -70,7 +70,7 @@ int mage_check_device_errors(void* stream);
  * variables MAGE_<NAME IN CAPITALS> the first time any entry point needs it, changed afterwards only through mage_set_option (no dispatch
  * function reads the environment; a change applies to every later call of the process).  Names:
  *   gemm_no_4w, gemm4_train_forms, gemm_no_8phase, gemm_no_taps8, gemm_no_narrow, gemm_no_narrow_few, gemm_no_small, gemm_small_m,
- *   gemm_res_mfma_layout, gemm_stagger_groups / _percent / _forced (MAGE_GEMM_STAGGER="G,percent"), gemm4_stagger_groups / _percent
+ *   gemm_stagger_groups / _percent / _forced (MAGE_GEMM_STAGGER="G,percent"), gemm4_stagger_groups / _percent
  *   (MAGE_GEMM4_STAGGER), attn_no_mfma, attn_no_fewq, vq_no_mfma          -- what each one does: struct MageOptions in csrc/common.h and
  *   the table in INTEGRATION.md.  Unknown name: MAGE_EINVAL. */
 int mage_set_option(const char* name, int32_t value);

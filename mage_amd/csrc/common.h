@@ -31,7 +31,6 @@ struct MageOptions {
     int gemm_no_narrow_few;      // 1: few-rows x + Linear(.) stays on the 128 x 256 tile
     int gemm_no_small;           // 1: the few-rows kernel (gemm_small_kernel) is not used
     int gemm_small_m;            // rows up to which the few-rows kernel is considered (default 1024)
-    int gemm_res_mfma_layout;    // 1: 16-bit residual tiles are fetched in the accumulator layout instead of as whole rows
     int gemm_stagger_groups, gemm_stagger_percent, gemm_stagger_forced;      // staggered start of the 8-wave kernels (MAGE_GEMM_STAGGER="G,percent")
     int gemm4_stagger_groups, gemm4_stagger_percent;                         // ... of the one-wave-per-SIMD kernel (MAGE_GEMM4_STAGGER)
     int attn_no_mfma;            // 1: attention on the thread-per-query kernels only

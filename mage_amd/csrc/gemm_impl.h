@@ -88,7 +88,6 @@ struct GemmArgs {
     int ntiles_n, ntiles;
     int tiles_per_split;                   // tiles_m * ntiles_n: tile index = split * tiles_per_split + tm * ntiles_n + tn
     int stagger_groups, stagger_sleeps;    // start group (li % groups) of an XCD's workgroups after group * sleeps s_sleep(16)
-    int res_rows;                          // gemm8, bf16 residual stream: the residual tile may be fetched as whole rows (see the kernel)
 };
 
 template <int DT> struct TT;
@@ -437,51 +436,29 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
         MAGE_DASSERT(c_tile >= 0 && c_tile < g.ntiles && tm * BM < d.M && tn * BNT < d.N);
         const long ysplit = SPLIT ? (long)ts * d.y_split_stride : 0;
         const int m0 = tm * BM + wm * MT * 16, n0 = tn * BNT + wn * 64;
-        [[maybe_unused]] bool res_rows = false;
-        if constexpr (EK == EK_RES_INIT && RB && MT == 4 && NW == 4 && NST == 3 && SPL == 0) {
-            // bf16 residual stream on the 128 x 256 tile (the incremental AR step): the wave's 64 x 64 residual block as 8 loads of 8 rows x
-            // 128 B (whole lines) and through a private 2 KiB window into the accumulator layout, as in the 8-phase kernel (finding 47)
-            res_rows = g.res_rows && m0 + 64 <= d.M && n0 + 64 <= d.N;                                       // wave-uniform
-            if (res_rows) {
-                const int rr = lane >> 3, cc = lane & 7;
-                const unsigned short* rp = (const unsigned short*)d.residual + ((long)(m0 + rr) + d.y_off) * d.ldr + n0 + cc * 8;
-                const long step8 = 8L * d.ldr;
-                u32x4 land[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) land[j] = *(const u32x4*)(rp + j * step8);
-                char* blk = smem + TL::RING_BYTES + wave * 2048;
-#pragma unroll
-                for (int a = 0; a < MT; ++a) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int r = rr + 8 * i;
-                        *(u32x4*)(blk + r * 128 + ((cc ^ ((r >> 1) & 7)) << 4)) = land[2 * a + i];
-                    }
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const uint2 t = *(const uint2*)(blk + l15 * 128 + (((b * 2 + (grp >> 1)) ^ ((l15 >> 1) & 7)) << 4) + (grp & 1) * 8);
-                        acc[a][b] = widen4<H16>(t);
-                    }
-                }
-            }
-        }
+        // RB (16-bit residual stream, 16-bit rows out: host check): the residual is added in the epilogue (epilogue_lean RESE) and the
+        // accumulators start at 0; an fp32 residual seeds the accumulators before the K loop
+        constexpr bool res_epi = RB;
         if constexpr (EK == EK_RES_INIT) {
             // y = x + (A W^T + b): start the accumulators from the fp32 residual.  32 independent 16-byte loads per lane,
             // straight into the MFMA layout (row mt*16 + l15, columns nt*16 + grp*4 + {0..3}), no register cost, one
             // round trip per tile that the first slab's vmcnt(0) below absorbs together with the previous tile's store acks.
-            if (!res_rows) {
+            if constexpr (res_epi) {
 #pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                const int m = min(m0 + a * 16 + l15, d.M - 1);
-                const float* rp = (const float*)d.residual + (long)(m * d.y_mul_x + d.y_off) * d.ldr;
-                [[maybe_unused]] const unsigned short* rpb = (const unsigned short*)d.residual + (long)(m * d.y_mul_x + d.y_off) * d.ldr;
+                for (int a = 0; a < MT; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int n = n0 + b * 16 + grp * 4;
-                    if constexpr (RB) res_bf16_request(acc[a][b], rpb + (n < d.N ? n : 0));
-                    else acc[a][b] = *(const f32x4*)(rp + (n < d.N ? n : 0));
+                    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int a = 0; a < MT; ++a) {
+                    const int m = min(m0 + a * 16 + l15, d.M - 1);
+                    const float* rp = (const float*)d.residual + (long)(m * d.y_mul_x + d.y_off) * d.ldr;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int n = n0 + b * 16 + grp * 4;
+                        acc[a][b] = *(const f32x4*)(rp + (n < d.N ? n : 0));
+                    }
                 }
-            }
             }
         } else {
 #pragma unroll
@@ -527,14 +504,6 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
         // one slab, after the wait for its DMAs
         auto slab = [&](int kt) __attribute__((always_inline)) {
             asm volatile("" ::: "memory");
-            if constexpr (RB) {
-                if (kt == 0 && !res_rows) {            // the residual rows have landed: widen them in place
-#pragma unroll
-                    for (int a = 0; a < MT; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) res_bf16_widen<H16>(acc[a][b]);
-                }
-            }
             if constexpr (SPL == 2 && EK == EK_RES_INIT) {
                 if (kt == 0) {                         // the residual has landed: give it the lo pieces' scale (exact), undone at kt == nk2
 #pragma unroll
@@ -666,7 +635,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
             } else if constexpr (LN == LN_PRODUCE) {
                 // fp32 stream + 16-bit copy, or (16-bit y_dtype) the 16-bit stream alone
                 if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, false, LN, 0, H16>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
-                else epilogue_lean<ACT, H16, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
+                else epilogue_lean<ACT, H16, MT, false, LN, 0, H16, RB>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
             } else if constexpr (LN == LN_DUAL || LN == LN_GELUBWD) {
                 epilogue_lean<ACT, unsigned short, MT, false, LN>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);           // bf16 rows (host check)
             } else if constexpr (SPL != 0) {
@@ -674,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                 else epilogue_lean<ACT, float, MT, false, LN_NONE, SPL>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);   // split rows out
             } else {
                 if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
-                else epilogue_lean<ACT, H16, MT>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
+                else epilogue_lean<ACT, H16, MT, false, LN_NONE, 0, H16, RB>(d, biasm, acc, m0, n0, lane, plane, stg, ysplit);
             }
         }
         MAGE_STAMP(it, 1);
@@ -945,43 +914,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
         const long ysplit = SPLIT ? (long)ts * d.y_split_stride : 0;
         MAGE_DASSERT(c_tile >= 0 && c_tile < g.ntiles && tm * BM < d.M && tn * BN < d.N);
         const int m0 = tm * BM + wr * 128, n0 = tn * BN + wc * 64;
-        [[maybe_unused]] bool res_rows = false;
-        if constexpr (EK == EK_RES_INIT && RB && !TAPS && SPL == 0) {
-            // bf16 residual stream, interior tile, plain rows: the wave's 128 x 64 residual block as 16 loads of 8 rows x 128 B (whole
-            // lines) instead of 32 loads in the accumulator layout (16 rows x 32 B each: the request count, not the byte count, is
-            // what a CU's address path pays for -- the same rule as the epilogue's stores), then through the wave's private staging
-            // window into the accumulator layout: the epilogue's row transposition backwards (same swizzle, DS operations of a wave
-            // execute in order: no barrier).  Pure data movement: the accumulators start from the same bits.
-            res_rows = g.res_rows && m0 + 128 <= d.M && n0 + 64 <= d.N;                                      // wave-uniform
-            if (res_rows) {
-                const int rr = lane >> 3, cc = lane & 7;
-                const unsigned short* rp = (const unsigned short*)d.residual + ((long)(m0 + rr) + d.y_off) * d.ldr + n0 + cc * 8;
-                const long step8 = 8L * d.ldr;
-                u32x4 land[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) land[j] = *(const u32x4*)(rp + j * step8);
-                char* stg_r = smem + 2 * KBUF + wave * 4096;
-#pragma unroll
-                for (int a = 0; a < MT; ++a) {
-                    char* blk = stg_r + (a & 1) * 2048;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int r = rr + 8 * i;
-                        *(u32x4*)(blk + r * 128 + ((cc ^ ((r >> 1) & 7)) << 4)) = land[2 * a + i];
-                    }
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const uint2 t = *(const uint2*)(blk + l15 * 128 + (((b * 2 + (grp >> 1)) ^ ((l15 >> 1) & 7)) << 4) + (grp & 1) * 8);
-                        acc[a][b] = widen4<H16>(t);
-                    }
-                }
-            }
-        }
+        constexpr bool res_epi = RB && !TAPS;         // 16-bit stream, 16-bit rows out (host check): residual added in the epilogue (RESE), acc from 0
         if constexpr (EK == EK_RES_INIT) {
             // y = r + (A W^T + b): the accumulators start from r.  r is the fp32 residual stream, or (rowadd set, residual null) a
             // broadcast row table: r[m] = rowadd[(yrow / div) % mod] -- the H/W positional table of the frame convolution
             // (the table form exists in the TAPS instantiation only: the Linear layers' kernel keeps its exact code)
-            if (!res_rows) {
+            if constexpr (res_epi) {
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int m = min(m0 + a * 16 + l15, d.M - 1);
@@ -994,12 +937,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
                 } else {
                     rp = (const float*)d.residual + (long)(m * d.y_mul_x + d.y_off) * d.ldr;
                 }
-                [[maybe_unused]] const unsigned short* rpb = (const unsigned short*)d.residual + (long)(m * d.y_mul_x + d.y_off) * d.ldr;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int n = n0 + b * 16 + grp * 4;
-                    if constexpr (RB) res_bf16_request(acc[a][b], rpb + (n < d.N ? n : 0));
-                    else acc[a][b] = *(const f32x4*)(rp + (n < d.N ? n : 0));
+                    acc[a][b] = *(const f32x4*)(rp + (n < d.N ? n : 0));
                 }
             }
             }
@@ -1074,7 +1015,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             read_a(0);
             issue(P_A1);
-            if (EK == EK_RES_INIT && kt == 0 && !res_rows) {
+            if (EK == EK_RES_INIT && !res_epi && kt == 0) {
                 // the residual tile (requested before this slab's two DMA instructions) is in the accumulators: loads return in
                 // order, so "at most 2 outstanding" proves it whatever the previous epilogue's stores are doing
                 __builtin_amdgcn_s_waitcnt(0x0F72);
@@ -1084,12 +1025,6 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
                     for (int a = 0; a < MT; ++a)
 #pragma unroll
                         for (int b = 0; b < 4; ++b) acc[a][b] *= MAGE_F16_LO_SCALE;
-                }
-                if constexpr (RB) {                    // bf16 residual rows: widen in place
-#pragma unroll
-                    for (int a = 0; a < MT; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) res_bf16_widen<H16>(acc[a][b]);
                 }
             }
             mfma_quadrant(0, 0);
@@ -1162,7 +1097,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             else epilogue_lean<ACT, H16, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit, &lnc);
         } else if constexpr (LN == LN_PRODUCE) {
             // fp32 stream + 16-bit copy, or (16-bit y_dtype; always with RB: host check) the 16-bit stream alone
-            if (RB || d.y_dtype != MAGE_F32) epilogue_lean<ACT, H16, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
+            if (RB || d.y_dtype != MAGE_F32) epilogue_lean<ACT, H16, MT, TAPS, LN, 0, H16, RB && !TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
             else epilogue_lean<ACT, float, MT, TAPS, LN, 0, H16>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
         } else if constexpr (LN == LN_DUAL || LN == LN_GELUBWD) {
             epilogue_lean<ACT, unsigned short, MT, TAPS, LN>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);               // bf16 rows (host check)
@@ -1171,7 +1106,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             else epilogue_lean<ACT, float, MT, TAPS, LN_NONE, SPL>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);   // split rows out
         } else {
             if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
-            else epilogue_lean<ACT, H16, MT, TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
+            else epilogue_lean<ACT, H16, MT, TAPS, LN_NONE, 0, H16, RB && !TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
         }
         MAGE_STAMP(it, 1);                             // probe: epilogue issued
     }
@@ -1217,17 +1152,16 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const mage_gemm_desc d)
     const unsigned short* wp = (const unsigned short*)d.W + (long)min(n0 + w * 16 + l15, d.N - 1) * (SPL ? d.ldw : d.K) + grp * 8;
     [[maybe_unused]] const int nk2s = SPL ? (d.K >> 6) * 4 : 0;      // SPL: k-steps of the two small-term passes
     f32x4 acc[RW];
-    if constexpr (EK == EK_RES_INIT) {
+    constexpr bool res_epi = RB;                       // 16-bit stream, 16-bit rows out (host check): residual added in the epilogue (RESE)
+    if constexpr (EK == EK_RES_INIT && res_epi) {
+#pragma unroll
+        for (int a = 0; a < RW; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if constexpr (EK == EK_RES_INIT) {
         const int nn = n0 + w * 16 + grp * 4;
 #pragma unroll
         for (int a = 0; a < RW; ++a) {
             const long row = (long)min(m0 + a * 16 + l15, d.M - 1) * d.y_mul_x + d.y_off;
-            if constexpr (RB) res_bf16_request(acc[a], (const unsigned short*)d.residual + row * d.ldr + (nn < d.N ? nn : 0));
-            else acc[a] = *(const f32x4*)((const float*)d.residual + row * d.ldr + (nn < d.N ? nn : 0));
-        }
-        if constexpr (RB) {
-#pragma unroll
-            for (int a = 0; a < RW; ++a) res_bf16_widen<H16>(acc[a]);
+            acc[a] = *(const f32x4*)((const float*)d.residual + row * d.ldr + (nn < d.N ? nn : 0));
         }
         if constexpr (SPL == 2) {                      // the residual gets the lo pieces' scale (exact), undone at k-step nk2s
 #pragma unroll
@@ -1328,7 +1262,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const mage_gemm_desc d)
         else epilogue_lean<ACT, H16, RW, false, LN>(d, biasm, accf, m0, n0, lane, plane, sm, 0, &lnc);
     } else {
         if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, RW, false, LN, 0, H16>(d, biasm, accf, m0, n0, lane, plane, sm, 0);
-        else epilogue_lean<ACT, H16, RW, false, LN>(d, biasm, accf, m0, n0, lane, plane, sm, 0);
+        else epilogue_lean<ACT, H16, RW, false, LN, 0, H16, RB>(d, biasm, accf, m0, n0, lane, plane, sm, 0);
     }
 }
 
@@ -1373,10 +1307,6 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     const int st_groups = mage_options().gemm_stagger_groups, st_percent = mage_options().gemm_stagger_percent, st_env = mage_options().gemm_stagger_forced;
     a.stagger_groups = 0;
     a.stagger_sleeps = 0;
-    {
-        a.res_rows = !mage_options().gemm_res_mfma_layout && RB && d->residual && d->y_mul_x == 1 && d->out_h == 1 && d->out_w >= d->M && d->ldr % 8 == 0 &&
-                     ((uintptr_t)d->residual & 15) == 0;
-    }
     const int tiles_per_wg = a.ntiles / grid;
     // Only the residual kind by default: its tile ends in a 512 KB read + write burst per CU that the stagger spreads (out_proj
     // 0.307 -> 0.276 ms, c_proj 0.567 -> 0.542 ms).  The bias kinds (QKV, c_fc) have no drain stall to hide (round-2 tile probe); an
@@ -1435,7 +1365,6 @@ int launch_taps8(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     a.ntiles = a.tiles_per_split;
     a.stagger_groups = 0;
     a.stagger_sleeps = 0;
-    a.res_rows = 0;
     const int grid = a.ntiles >= n_cu ? n_cu : ((a.ntiles + 7) & ~7);
     hipLaunchKernelGGL((gemm8_kernel<ACT, EK, false, true, LN, SPL, false, HF>), dim3(grid), dim3(512), 160 * 1024, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
@@ -1620,7 +1549,10 @@ int launch_act(const mage_gemm_desc* d, hipStream_t s) {
                                "mage_gemm: ln_part goes with the residual form x + Linear(.)");
                 MAGE_CHECK_ARG(d->y_dtype == MAGE_F32 ? (d->y2 && d->ldy2 % 8 == 0 && d->res_dtype == MAGE_F32) : !d->y2,
                                "mage_gemm: ln_part: fp32 stream out + 16-bit copy y2 (fp32 residual), or 16-bit stream out alone");
-                if (d->res_dtype == DT) return launch_ek<DT, GATHER, ACT, EK_RES_INIT, LN_PRODUCE, true>(d, s);
+                if (d->res_dtype == DT) {
+                    MAGE_CHECK_ARG(d->y_dtype == DT && d->ldr % 8 == 0, "mage_gemm: a 16-bit residual stream with ln_part writes 16-bit rows (ldr %% 8 == 0)");
+                    return launch_ek<DT, GATHER, ACT, EK_RES_INIT, LN_PRODUCE, true>(d, s);
+                }
                 return launch_ek<DT, GATHER, ACT, EK_RES_INIT, LN_PRODUCE>(d, s);
             }
         }
@@ -1633,8 +1565,8 @@ int launch_act(const mage_gemm_desc* d, hipStream_t s) {
             d->out_w >= d->M && (((uintptr_t)d->residual) & 15) == 0)
             return launch_ek<DT, GATHER, ACT, EK_RES_INIT>(d, s);
         if constexpr (DT != MAGE_F32) {            // the same on a 16-bit residual stream
-            if (d->residual && d->res_dtype == DT && !d->scale && !d->rowadd && !d->post_relu && d->out_h == 1 &&
-                d->out_w >= d->M && (((uintptr_t)d->residual) & 15) == 0 && d->y_mul_x == 1)
+            if (d->residual && d->res_dtype == DT && d->y_dtype == DT && !d->scale && !d->rowadd && !d->post_relu && d->out_h == 1 &&
+                d->out_w >= d->M && (((uintptr_t)d->residual) & 15) == 0 && d->y_mul_x == 1 && d->ldr % 8 == 0)
                 return launch_ek<DT, GATHER, ACT, EK_RES_INIT, LN_NONE, true>(d, s);
         }
     }

@@ -68,12 +68,21 @@ enum { LN_NONE = 0, LN_PRODUCE = 1, LN_CONSUME = 2, LN_DUAL = 3, LN_GELUBWD = 4,
 // K slab of the consumer, [hi(64) | lo(64)] = the same 256 contiguous bytes per row as 64 fp32 values, so only the staging write differs.
 // HT: the kernel's 16-bit element type (unsigned short = bf16, f16_t = f16): the type of the LN_PRODUCE copy y2 when OT is float, and of
 // 16-bit rows OT themselves.
+// RESE (16-bit rows out, LN_NONE / LN_PRODUCE; plain rows: host check): y = x + (A W^T + b) with the 16-bit residual rows x ADDED HERE instead
+// of seeding the accumulators before the K loop (EK_RES_INIT).  The wave's residual block is requested in the epilogue itself, 16-row tile by
+// 16-row tile (2 loads of 8 rows x 128 B: whole lines), three tiles ahead of the tile being finished, and goes through the upper half of the
+// staging window into the accumulator layout.  Why: loads that seed the accumulators must be complete before a
+// tile's first MFMA, and memory operations retire in order, so the tile start waited for the previous tile's store acknowledgements and
+// for its own 128 KB of rows -- 13-17 k of a 55 k-cycle tile period at N = K = 512 (profiles/r04_clock_probe.txt; a residual-free GEMM of
+// that size runs 121 us against 188, profiles/r05_residual_form_probe.txt).  Here nothing waits at the tile start, and the rows' latency
+// hides behind the epilogue's own arithmetic.  The sum is (acc + bias) + x, the reference's own order (x + Linear(.), mage_model.py:48,52).
 template <int ACT, typename OT, int MT, bool AFFINE = false, int LN = LN_NONE, int OSPL = 0,
-          typename HT = std::conditional_t<sizeof(OT) == 2, OT, unsigned short>>
+          typename HT = std::conditional_t<sizeof(OT) == 2, OT, unsigned short>, bool RESE = false>
 __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32x4 (&bias)[4], f32x4 (&acc)[MT][4], int m0, int n0,
                                               int lane, int plane, char* stg, long ysplit, const LnConsume* lnc = nullptr) {
     constexpr bool F32 = sizeof(OT) == 4;
     static_assert((LN != LN_DUAL && LN != LN_GELUBWD) || std::is_same<HT, unsigned short>::value, "training forms: bf16 rows");
+    static_assert(!RESE || (sizeof(OT) == 2 && OSPL == 0 && (LN == LN_NONE || LN == LN_PRODUCE)), "residual in the epilogue: 16-bit rows out");
     constexpr int RB = F32 ? 256 : 128;            // bytes of one staged row (64 columns)
     constexpr int NCH = RB / 16;                   // 16-byte chunks per row: 16 | 8
     constexpr int RPI = 64 / NCH;                  // rows per store instruction: 4 | 8
@@ -127,9 +136,39 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
         for (int i = 0; i < 2; ++i) auxr[mt & 1][i] = *(const u32x4*)(ap + (long)(8 * i) * d.y_mul_x * d.ldy2);
     };
     if constexpr (LN == LN_GELUBWD) aux_request(0);
+    // RESE: the residual rows of 16-row tile t (2 loads of 8 rows x 128 B: whole lines), kept RD tiles ahead of the tile being finished in a
+    // ring of RD register pairs (the whole block at once -- 64 registers at MT = 8 -- spilled the 8-phase kernel: 145 VGPRs to scratch);
+    // rows clamped to the problem (edge tiles store predicated)
+    constexpr int RD = 3;
+    [[maybe_unused]] u32x4 rland[RESE ? RD : 1][2];
+    [[maybe_unused]] const HT* rbase = nullptr;
+    [[maybe_unused]] auto res_request = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = min(m0 + t * 16 + (lane >> 3) + 8 * i, d.M - 1);
+            rland[t % RD][i] = *(const u32x4*)(rbase + (long)(m * d.y_mul_x + d.y_off) * d.ldr);
+        }
+    };
+    if constexpr (RESE) {
+        const int rcol = n0 + (lane & 7) * 8;
+        rbase = (const HT*)d.residual + (rcol < d.N ? rcol : 0);
+#pragma unroll
+        for (int t = 0; t < RD && t < MT; ++t) res_request(t);
+    }
     auto stage = [&](int mt, u32x4 (&o)[NST], auto apply_act) {     // math + transpose of 16-row tile mt: results land in o[] (row-contiguous)
         [[maybe_unused]] float s1 = 0.f, s2 = 0.f;
         [[maybe_unused]] uint2 auxb[4];
+        if constexpr (RESE) {                          // this tile's 16 residual rows into the accumulator layout (upper half of the window)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = (lane >> 3) + 8 * i;
+                *(u32x4*)(stg + 2048 + r * 128 + (((lane & 7) ^ ((r >> 1) & 7)) << 4)) = rland[mt % RD][i];
+            }
+            if (mt + RD < MT) res_request(mt + RD);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                auxb[nt] = *(const uint2*)(stg + 2048 + l15 * 128 + (((nt * 2 + (grp >> 1)) ^ ((l15 >> 1) & 7)) << 4) + (grp & 1) * 8);
+        }
         if constexpr (LN == LN_GELUBWD) {
             if (mt + 1 < MT) aux_request(mt + 1);
 #pragma unroll
@@ -146,6 +185,7 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
             f32x4 v;
             if constexpr (LN == LN_CONSUME) v = (acc[mt][nt] - lnc->s[nt] * lnc->mean[mt]) * lnc->rstd[mt] + bias[nt];
             else v = acc[mt][nt] + bias[nt];
+            if constexpr (RESE) v = v + widen4<HT>(auxb[nt]);
             if constexpr (LN == LN_PRODUCE) {
                 s1 += (v[0] + v[1]) + (v[2] + v[3]);
                 s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
@@ -273,18 +313,9 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
     }
 }
 
-// RB (template parameter of both kernels): the residual of EK_RES_INIT is a BF16 stream (the decoder's bf16 mode keeps x in bf16 between
-// its blocks: half the residual bytes in, and LN_PRODUCE then writes the bf16 rows as its ONLY output).  The 8 bytes of a lane's 4 columns
-// land in the first two registers of the accumulator they seed and are widened in place once the tile's first wait has passed: no staging
-// registers, all 32 loads of a tile in flight at once, as in the fp32 form.
-__device__ __forceinline__ void res_bf16_request(f32x4& a, const void* p) {
-    const uint2 t = *(const uint2*)p;
-    a = f32x4{__uint_as_float(t.x), __uint_as_float(t.y), 0.f, 0.f};
-}
-template <typename HT = unsigned short>
-__device__ __forceinline__ void res_bf16_widen(f32x4& a) {
-    a = widen4<HT>(uint2{__float_as_uint(a[0]), __float_as_uint(a[1])});
-}
+// RB (template parameter of the kernels): the residual of x + Linear(.) is the 16-bit stream (the decoder's bf16 / f16 modes keep x in that type
+// between its blocks) and the rows leave in that type too: the residual is added in the epilogue (RESE above), LN_PRODUCE writes the 16-bit rows
+// as its ONLY output.
 
 // raw barrier that LDS-DMA may stay in flight across (a __syncthreads() would drain vmcnt to 0); the empty asm
 // statements keep the compiler from moving LDS accesses over it

@@ -40,7 +40,7 @@ static const OptField g_opt_fields[] = {
     {"gemm_no_8phase", &MageOptions::gemm_no_8phase}, {"gemm_no_taps8", &MageOptions::gemm_no_taps8},
     {"gemm_no_narrow", &MageOptions::gemm_no_narrow}, {"gemm_no_narrow_few", &MageOptions::gemm_no_narrow_few},
     {"gemm_no_small", &MageOptions::gemm_no_small}, {"gemm_small_m", &MageOptions::gemm_small_m},
-    {"gemm_res_mfma_layout", &MageOptions::gemm_res_mfma_layout}, {"gemm_stagger_groups", &MageOptions::gemm_stagger_groups},
+    {"gemm_stagger_groups", &MageOptions::gemm_stagger_groups},
     {"gemm_stagger_percent", &MageOptions::gemm_stagger_percent}, {"gemm_stagger_forced", &MageOptions::gemm_stagger_forced},
     {"gemm4_stagger_groups", &MageOptions::gemm4_stagger_groups}, {"gemm4_stagger_percent", &MageOptions::gemm4_stagger_percent},
     {"attn_no_mfma", &MageOptions::attn_no_mfma}, {"attn_no_fewq", &MageOptions::attn_no_fewq}, {"vq_no_mfma", &MageOptions::vq_no_mfma},
@@ -60,7 +60,6 @@ const MageOptions& mage_options() {
         o.gemm_no_narrow_few = env_flag("MAGE_GEMM_NO_NARROW_FEW");
         o.gemm_no_small = env_flag("MAGE_GEMM_NO_SMALL");
         o.gemm_small_m = getenv("MAGE_GEMM_SMALL_M") ? atoi(getenv("MAGE_GEMM_SMALL_M")) : 1024;
-        o.gemm_res_mfma_layout = env_flag("MAGE_GEMM_RES_MFMA_LAYOUT");
         o.gemm_stagger_groups = 8;
         o.gemm_stagger_percent = 60;
         if (const char* e = getenv("MAGE_GEMM_STAGGER")) {

@@ -630,44 +630,51 @@ def test_row_stats_of_bf16_rows(ht):
 @pytest.mark.parametrize("ht", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M", [512, 2048, 65536])
 def test_x_plus_linear_on_a_bf16_residual_stream(M, ht):
-    """The producer forms of the bf16 mode's bf16 stream (mage_hip.h, ln_part without y2): the residual x is read as bf16 rows, the new
-    rows leave as bf16 only, the LayerNorm partial sums are those of the fp32 values before rounding.  Against the fp32-residual form
-    fed the SAME (bf16-representable) residual: identical sums, and rows = its fp32 stream rounded -- bit for bit; all three kernels
-    (M = 512 few-rows, M = 2048 lockstep, M = 65536 8-phase) and the same rows through another one."""
+    """The producer forms of the 16-bit modes' residual stream (mage_hip.h, ln_part without y2): the residual x is read as 16-bit rows, the new
+    rows leave as 16-bit rows only, the LayerNorm partial sums are those of the fp32 values before rounding.  The residual is added in the
+    epilogue: y = (A W^T + b) + x in fp32, the reference's own order.  Checked against fp64 on the same operands (one rounding of the fp32
+    sum), against the general epilogue's fp32 rows (same sum: equal after rounding), on all three kernels (M = 512 few-rows, M = 2048
+    lockstep, M = 65536 8-phase) and the same rows through another kernel (bitwise)."""
     o = ops()
     C_ = 512
     xb0 = (rnd(M, C_, seed=11) + 0.3).to(ht).to(DEV)
     ao = rnd(M, C_, seed=12).to(ht).to(DEV)
     wo, bo = rnd(C_, C_, seed=13, scale=C_ ** -0.5).to(ht).to(DEV), rnd(C_, seed=14, scale=0.1).to(DEV)
-    # reference: the fp32-stream producer on float(xb0)
-    x32 = xb0.float()
-    xb_ref = torch.empty(M, C_, device=DEV, dtype=ht)
-    part_ref = torch.empty(M, C_ // 64, 2, device=DEV, dtype=torch.float32)
-    o.gemm(ao, wo, x32, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=x32, ldr=C_, y2=xb_ref, ldy2=C_, ln_part=part_ref)
-    # bf16 residual in, bf16 rows out, in place
+    want = xb0.double().cpu() + ao.double().cpu() @ wo.double().cpu().t() + bo.double().cpu()
+    # 16-bit residual in, 16-bit rows out, in place, with the partial sums
     xb = xb0.clone()
-    part = torch.empty_like(part_ref)
+    part = torch.empty(M, C_ // 64, 2, device=DEV, dtype=torch.float32)
     o.gemm(ao, wo, xb, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xb, ldr=C_, ln_part=part)
-    assert torch.equal(xb, xb_ref) and torch.equal(part, part_ref)
-    # fp32 residual in, bf16 rows out (the first producer of a pass reads the fp32 rows the frame fill wrote)
-    xb1 = torch.empty_like(xb0)
-    part1 = torch.empty_like(part_ref)
-    o.gemm(ao, wo, xb1, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xb0.float(), ldr=C_, ln_part=part1)
-    assert torch.equal(xb1, xb_ref) and torch.equal(part1, part_ref)
-    # no LayerNorm after it (the last block): bf16 residual, bf16 or fp32 rows out
-    y16 = torch.empty_like(xb0)
-    o.gemm(ao, wo, y16, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xb0, ldr=C_)
+    # fp32 rows of the same sum from the general epilogue (a 16-bit residual with fp32 rows out): (acc + b) + x
     y32 = torch.empty(M, C_, device=DEV, dtype=torch.float32)
     o.gemm(ao, wo, y32, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xb0, ldr=C_)
-    assert torch.equal(y32, x32) and torch.equal(y16, xb_ref)
-    want = xb0.double().cpu() + ao.double().cpu() @ wo.double().cpu().t() + bo.double().cpu()
     torch.testing.assert_close(y32.double().cpu(), want, atol=2e-3, rtol=1e-3)
-    # the same rows through the other kernel
+    assert torch.equal(xb, y32.to(ht))                                  # the stream rows = that fp32 sum, rounded once
+    ys = y32.double().view(M, C_ // 64, 64)
+    torch.testing.assert_close(part[..., 0].double(), ys.sum(-1), atol=2e-4, rtol=1e-5)
+    torch.testing.assert_close(part[..., 1].double(), (ys * ys).sum(-1), atol=2e-3, rtol=1e-5)
+    # out of place, and without the LayerNorm after it (the last block): the same rows
+    y16 = torch.empty_like(xb0)
+    o.gemm(ao, wo, y16, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xb0, ldr=C_)
+    assert torch.equal(y16, xb)
+    # fp32 residual in, 16-bit rows out (accumulators seeded with x: another order of the same sum)
+    xb1 = torch.empty_like(xb0)
+    part1 = torch.empty_like(part)
+    o.gemm(ao, wo, xb1, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xb0.float(), ldr=C_, ln_part=part1)
+    torch.testing.assert_close(xb1.float(), xb.float(), **HTOL[ht])
+    torch.testing.assert_close(part1, part, atol=2e-3, rtol=1e-4)
+    # the same rows through the other kernel: bitwise
     xs = xb0[:256].clone()
     ps = torch.empty(256, C_ // 64, 2, device=DEV, dtype=torch.float32)
     o.gemm(ao[:256], wo, xs, M=256, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xs, ldr=C_, ln_part=ps)
-    assert torch.equal(xs, xb_ref[:256]) and torch.equal(ps, part_ref[:256])
-    with pytest.raises(Exception):             # fp32 rows out need the bf16 copy y2
+    assert torch.equal(xs, xb[:256]) and torch.equal(ps, part[:256])
+    # ragged row count (edge tiles: clamped residual rows, predicated stores), no partial sums
+    Mr = M - 24
+    yr = torch.full((M, C_), 7.0, device=DEV, dtype=ht)
+    o.gemm(ao, wo, yr, M=Mr, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xb0, ldr=C_)
+    assert torch.equal(yr[:Mr], xb[:Mr]) and (yr[Mr:] == 7.0).all()
+    x32 = xb0.float()
+    with pytest.raises(Exception):             # fp32 rows out of the partial-sum form need the 16-bit copy y2
         o.gemm(ao, wo, x32, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=x32, ldr=C_, ln_part=part)
 
 
