@@ -177,7 +177,12 @@ typedef struct mage_gemm_desc {
                                         * to bf16 as a store would round them, are NOT written; Y (y_dtype MAGE_F32, ldy >= 16 floats) receives
                                         *     Y[yrow][t] = sum_n y[n] * head_w[t][n],  t = 0..15      (fp32 sums, fixed order)
                                         * -- the 4 x 4 taps of the VQ-VAE's last ConvTranspose2d (vqvae_model.py:187) computed inside the
-                                        * sub-pixel GEMMs of the one before it (:184), whose 4x-resolution activation is then never stored */
+                                        * sub-pixel GEMMs of the one before it (:184), whose 4x-resolution activation is then never stored.
+                                        * With `residual` (bf16 rows [.., N]; res_half allowed; head_phases 0) the rows are
+                                        *     y = relu((acc + bias) + residual)
+                                        * -- the last DecoderBlock's closing 3x3 convolution + identity path + the decoder's ReLU with the 1x1 RGB
+                                        * head taken on the tile (f8 VQ-VAE, vqvae_model.py:147-166,209-213): the 128 x 128 x 256 activation
+                                        * (8 MB per frame) is never stored */
     int32_t head_phases;               /* with head_w: 0, or 4 = the four sub-pixel phases of that ConvTranspose2d(., ., 4, 2, 1) in ONE launch:
                                         * N = 4 * 256, W and bias hold the phases' [256][K] / [256] blocks in the order (py, px) = (0,0) (0,1)
                                         * (1,0) (1,1); column tile p reads its 2 x 2 window at a_off + py*in_w + px and writes the rows

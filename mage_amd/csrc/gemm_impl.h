@@ -59,7 +59,9 @@ template <int DT, bool GATHER, int MT, int EK, bool SPLIT, int NW> constexpr int
 #ifdef MAGE_GEMM_RING2
     return 2;
 #else
-    return (DT != MAGE_F32 && !GATHER && MT == 4 && NW == 4 && !SPLIT) ? 3 : 2;
+    // (round 5: the NARROW tile -- MT = 2, NW = 1: 40 KiB per stage, 16 MFMAs per wave and slab -- takes the 3-stage ring too, gather form
+    // included: the f8 VQ-VAE's 64-channel 3x3 convolutions ran one slab per L2 round trip, 14.5 us per 256 x 64 tile of 9 slabs)
+    return (DT != MAGE_F32 && !SPLIT && ((!GATHER && MT == 4 && NW == 4) || (MT == 2 && NW == 1))) ? 3 : 2;
 #endif
 }
 // NW = waves side by side along n (each owns 64 columns): 4 -> the 256-column tile; 1 -> the NARROW tile of the lockstep kernel
@@ -317,6 +319,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     const char* w_row[WU];
     int acs[AU], wcs[WU];                // logical chunk this lane fetches for each unit
     int ld_tile = chunk0 + li, ld_kt = 0, ld_stage = 0;
+    // GATHER with cin a multiple of the slab width (every 64-channel convolution): a slab lies in ONE tap, so the tap of the loader's slab is a
+    // wave-uniform cursor (ky, kx, first channel) stepped once per slab -- no per-lane divisions in the load path (two integer divisions per
+    // DMA unit and lane made the f8 VQ-VAE's narrow 3x3 convolutions loader-bound: 16 MFMAs of work per ~250 VALU instructions)
+    [[maybe_unused]] const bool tap_uniform = GATHER && d.cin % BK == 0;
+    [[maybe_unused]] int ld_ky = 0, ld_kx = 0, ld_c0 = 0;
 
     auto loader_set_tile = [&](int tile) {
         const int ts = SPLIT ? tile / g.tiles_per_split : 0, trem = SPLIT ? tile - ts * g.tiles_per_split : tile;   // split-K slice
@@ -367,10 +374,17 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
             const char* src = g.zero;
             if (GATHER) {
                 if (live && kc < d.K && a_img[i] >= 0) {
-                    const int tap = kc / d.cin;
-                    const int ci = kc - tap * d.cin;
-                    const int ky = tap / d.taps_w;
-                    const int kx = tap - ky * d.taps_w;
+                    int ci, ky, kx;
+                    if (tap_uniform) {
+                        ci = ld_c0 + acs[i] * CH;
+                        ky = ld_ky;
+                        kx = ld_kx;
+                    } else {
+                        const int tap = kc / d.cin;
+                        ci = kc - tap * d.cin;
+                        ky = tap / d.taps_w;
+                        kx = tap - ky * d.taps_w;
+                    }
                     const int iy = a_iy[i] + ky * d.dys;
                     const int ix = a_ix[i] + kx * d.dxs;
                     if ((unsigned)iy < (unsigned)d.in_h && (unsigned)ix < (unsigned)d.in_w)
@@ -395,8 +409,19 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     };
     auto loader_advance = [&]() {
         ld_stage = ld_stage + 1 == NST ? 0 : ld_stage + 1;
+        if constexpr (GATHER) {                        // the uniform tap cursor: next 64 channels, then the next tap
+            ld_c0 += BK;
+            if (ld_c0 >= d.cin) {
+                ld_c0 = 0;
+                if (++ld_kx == d.taps_w) {
+                    ld_kx = 0;
+                    ++ld_ky;
+                }
+            }
+        }
         if (++ld_kt == nk) {
             ld_kt = 0;
+            if constexpr (GATHER) ld_ky = ld_kx = ld_c0 = 0;
             ld_tile += nwg8;
             if (ld_tile < chunk1) loader_set_tile(ld_tile);
         }
@@ -541,12 +566,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
 #if MAGE_ABL != 5
                     // Plain GEMM: ALWAYS issue (the zero page, into the stage nobody reads, once the tile list is exhausted) so
                     // the slab body is one basic block and hipcc counts lgkmcnt exactly instead of draining it at every join.
-                    if (GATHER) {
+                    if (GATHER && NST == 2) {
                         if (more) {
 #pragma unroll
                             for (int u = MAGE_U0(ph); u < MAGE_U0(ph + 1); ++u) issue_one(u);
                         }
-                    } else {
+                    } else {                           // (3-stage ring: counted waits need every slab to issue its full set of loads)
 #pragma unroll
                         for (int u = MAGE_U0(ph); u < MAGE_U0(ph + 1); ++u) issue_one(u, more);
                     }
@@ -659,17 +684,37 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
 // channels n0 + 32t + {grp*4 + 0..3, 16 + grp*4 + 0..3}).  16 MFMAs per wave and tile give the wave's 64-channel partial sums; the four
 // wave columns are added in the fixed order wc = 0..3 through the staging windows (4 KiB per wave = 64 rows x 16 taps: two halves), each
 // wave finishing 16 of the 64 rows.  All eight waves run this in step (the K loop's half-offset is closed before the epilogue).
+// With d.residual (bf16 rows [.., N], optionally at half resolution: res_half) the rows are y = act((acc + bias) + residual) -- a bottleneck
+// block's last convolution + its identity path + the ReLU that follows the block (vqvae_model.py:147-166,210), fetched in the accumulator
+// layout one 16-row tile ahead (8 bytes per lane and 16-column block: the identity path is a quarter-resolution tensor that lives in L2).
 template <int ACT>
 __device__ __forceinline__ void epilogue_head(const mage_gemm_desc& d, const f32x4 (&bias)[4], f32x4 (&acc)[8][4], const u32x4 (&hw)[2],
                                               int tile_m0, int lane, int wave, int plane, char* stg_all, long phase_rows) {
     const int l15 = lane & 15, grp = lane >> 4, wr = wave >> 2, wc = wave & 3;
     f32x4 h[8];
+    const bool has_res = d.residual != nullptr;        // uniform
+    uint2 rres[2][4];
+    auto res_request = [&](int a) {
+        const int m = tile_m0 + wr * 128 + a * 16 + l15;
+        const int img = m / plane, rem = m - img * plane;
+        const int oy = rem / d.out_w, ox = rem - oy * d.out_w;
+        const long rrow = d.res_half ? (long)img * (plane >> 2) + (long)(oy >> 1) * (d.out_w >> 1) + (ox >> 1) : (long)m;
+        const unsigned short* rp = (const unsigned short*)d.residual + rrow * d.ldr + wc * 64 + grp * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rres[a & 1][q] = *(const uint2*)(rp + q * 16);
+    };
+    if (has_res) res_request(0);
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
         h[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has_res && a + 1 < 8) res_request(a + 1);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 v0 = acc[a][2 * t] + bias[2 * t], v1 = acc[a][2 * t + 1] + bias[2 * t + 1];
+            if (has_res) {
+                v0 += widen4<unsigned short>(rres[a & 1][2 * t]);
+                v1 += widen4<unsigned short>(rres[a & 1][2 * t + 1]);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 v0[e] = act_apply<ACT>(v0[e]);
@@ -1403,9 +1448,12 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
         // the narrow Linear on the tile's rows (LN_HEAD): one column tile must hold whole rows; refused loudly, the caller asked for a fusion
         MAGE_CHECK_ARG(d->head_phases == 0 || (d->head_phases == 4 && d->taps_h == 2 && d->taps_w == 2 && d->y_mul_x == 2 && d->y_mul_y % 2 == 0),
                        "mage_gemm: head_phases is 0 or 4 (the sub-pixel phases of a 4 x 4 / stride 2 transposed convolution: 2 x 2 taps, y_mul_x = 2)");
-        MAGE_CHECK_ARG(SPL == 0 && plain && d->act == MAGE_ACT_RELU && d->N == (d->head_phases ? 1024 : 256) && d->y_dtype == MAGE_F32 && d->ldy >= 16 && d->ldy % 4 == 0
-                           && d->bias && (((uintptr_t)d->head_w) & 7) == 0 && (((uintptr_t)d->Y) & 15) == 0,
-                       "mage_gemm: head_w takes the bf16 padded-taps form with N = 256 (1024 with head_phases), bias, ReLU, fp32 [row][ldy >= 16] output");
+        const bool head_res = !d->rowadd && d->residual && d->res_dtype == MAGE_BF16 && d->head_phases == 0 && d->ldr % 4 == 0 && d->ldr >= d->N &&
+                              (((uintptr_t)d->residual) & 7) == 0 && (d->res_half || (d->out_h * d->out_w == d->y_img_stride && d->y_off == 0));
+        MAGE_CHECK_ARG(SPL == 0 && (plain || head_res) && d->act == MAGE_ACT_RELU && d->N == (d->head_phases ? 1024 : 256) && d->y_dtype == MAGE_F32 && d->ldy >= 16 &&
+                           d->ldy % 4 == 0 && d->bias && (((uintptr_t)d->head_w) & 7) == 0 && (((uintptr_t)d->Y) & 15) == 0,
+                       "mage_gemm: head_w takes the bf16 padded-taps form with N = 256 (1024 with head_phases), bias, ReLU, fp32 [row][ldy >= 16] output, "
+                       "optionally a bf16 residual (N = 256 form; res_half or packed rows)");
         if constexpr (SPL == 0 && !HF) return launch_taps8<MAGE_ACT_RELU, EK_BIAS, 0, LN_HEAD>(d, s, n_cu);
     }
     if (table && d->act == MAGE_ACT_NONE && (((uintptr_t)d->rowadd) & 15) == 0) return launch_taps8<MAGE_ACT_NONE, EK_RES_INIT, SPL, LN_NONE, HF>(d, s, n_cu);

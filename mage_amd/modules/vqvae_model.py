@@ -271,6 +271,12 @@ class VectorQuantizedVAE(nn.Module):
                 bott(f"d{i}", dec[i])
             d["d8.wt"] = dec[8].weight.float().reshape(dec[8].weight.shape[0], -1).contiguous()   # [cout, cin]
             d["d8.b"] = dec[8].bias.float().contiguous()
+            # the 1x1 RGB head taken on the tiles of the last block's closing convolution (mage_gemm_desc::head_w): 16 head rows, the first
+            # input_dim of them the head's weights; the [row][16] sums then go through tanh(. + bias) by an identity 1x1
+            h16 = torch.zeros(16, d["d8.wt"].shape[1], device=d["d8.wt"].device)
+            h16[:self.input_dim] = d["d8.wt"]
+            d["d8.w16.bf16"] = h16.to(torch.bfloat16).contiguous()
+            d["d8.eye"] = torch.eye(self.input_dim, 16, device=d["d8.wt"].device).contiguous()
         return d
 
     def _weights(self) -> Dict[str, torch.Tensor]:
@@ -308,12 +314,15 @@ class VectorQuantizedVAE(nn.Module):
                    scale=w[p + ".s1"], shift=w[p + ".t1"], residual=r, ldr=dim, post_relu=post_relu)
         return out
 
-    def _bottleneck(self, w, p, x, dt, n_img, H, W, cin, cout, first_k, last_k, post_relu, up_first=False):
+    def _bottleneck(self, w, p, x, dt, n_img, H, W, cin, cout, first_k, last_k, post_relu, up_first=False, head=None):
         """up_first (decoder blocks behind an nn.Upsample, first_k = 1): x is the LOW-resolution input [n_img, H/2, W/2, cin].  A 1x1
         convolution and a ReLU act per pixel, so they commute with nearest-neighbour upsampling: the block's first convolution and its
         identity path run on a quarter of the pixels and nothing is upsampled at all: the second convolution gathers the first one's
         output at half resolution (mage_gemm a_half), the block's last convolution reads the identity path there (res_half) -- the
-        same arithmetic per output pixel, bit-identical results."""
+        same arithmetic per output pixel, bit-identical results.
+        head (bf16 [16, cout], the decoder's last block): the block's closing 3x3 convolution runs in the padded-taps form on the 8-phase kernel
+        (its input is written into a zero-padded frame buffer by the convolution before it) with the identity path, the ReLU that follows the
+        block and the 1x1 head taken on the tile: returns the head's sums [n_img*H*W, 16] fp32; the block's output is never stored."""
         s = "." + ("f32" if dt == torch.float32 else "bf16")
         hid = cout // 4
         dev = x.device
@@ -334,12 +343,28 @@ class VectorQuantizedVAE(nn.Module):
             self._conv(xr, w[f"{p}.w1{s}"], h1, n_img=n_img, H=Hi, W=Wi, cin=cin, cout=hid, k=1, bias=w[f"{p}.b1"], act=ops.ACT_RELU)
             h = h1                                  # stays at low resolution too: the next convolution gathers it there (a_half);
             j0 = 1                                  # the identity path is read there by the last convolution (res_half)
+        Pw, PP = W + 2, (H + 2) * (W + 2)
         for j in range(j0, 3):
-            nh = torch.empty(n_img * H * W, chans[j + 1], device=dev, dtype=dt)
             half = dict(a_half=True, a_img_stride=Hi * Wi) if (up_first and j == 1) else {}
+            if head is not None and j == 2:             # the closing convolution's input: the interior of a zero-padded frame buffer
+                key = ("f8tail", n_img, H, W, hid, str(dev), torch.cuda.current_stream(dev).cuda_stream)
+                nh = self._pad_bufs.get(key)
+                if nh is None:
+                    if len(self._pad_bufs) > 6:
+                        self._pad_bufs.clear()
+                    nh = self._pad_bufs[key] = torch.zeros(n_img * PP + 1, hid, device=dev, dtype=dt)
+                half = dict(half, y_img_stride=PP, y_mul_y=Pw, y_off=Pw + 1)
+            else:
+                nh = torch.empty(n_img * H * W, chans[j + 1], device=dev, dtype=dt)
             self._conv(h, w[f"{p}.w{2 * j + 1}{s}"], nh, n_img=n_img, H=H, W=W, cin=chans[j], cout=chans[j + 1], k=ks[j],
                        bias=w[f"{p}.b{2 * j + 1}"], act=ops.ACT_RELU, **half)
             h = nh
+        if head is not None:
+            sums = torch.empty(n_img * H * W, 16, device=dev, dtype=torch.float32)
+            ops.gemm(h, w[p + ".w7" + s], sums, M=n_img * H * W, N=cout, K=9 * hid, lda=hid, ldy=16, out_h=H, out_w=W, in_h=H + 2, in_w=Pw,
+                     a_img_stride=PP, taps_h=3, taps_w=3, cin=hid, stride=1, dy0=0, dx0=0, bias=w[p + ".b7"], act=ops.ACT_RELU,
+                     residual=idp, ldr=cout, res_half=up_first, head_w=head)
+            return sums
         out = torch.empty(n_img * H * W, cout, device=dev, dtype=dt)
         self._conv(h, w[p + ".w7" + s], out, n_img=n_img, H=H, W=W, cin=hid, cout=cout, k=ks[3], bias=w[p + ".b7"],
                    residual=idp, ldr=cout, post_relu=post_relu, res_half=up_first)
@@ -569,18 +594,19 @@ class VectorQuantizedVAE(nn.Module):
             # activation that a windowed layer reads lives in a zero-padded frame buffer, written there by its producer
             hw, Pw = h * wd, wd + 2
             PP = (h + 2) * Pw                                         # rows per padded image
-            key = (N, h, wd, str(dev), torch.cuda.current_stream(dev).cuda_stream)
-            pads = self._pad_bufs.get(key)
-            if pads is None:
-                if len(self._pad_bufs) > 4:
-                    self._pad_bufs.clear()
-                pads = self._pad_bufs[key] = [torch.zeros(N * PP + 1, dim, device=dev, dtype=dt) for _ in range(3)]
-            inner = dict(out_h=h, out_w=wd, y_img_stride=PP, y_mul_y=Pw, y_off=Pw + 1)      # a producer's rows inside the padding
-            win = dict(out_h=h, out_w=wd, in_h=h + 2, in_w=Pw, a_img_stride=PP, cin=dim, stride=1, dy0=0, dx0=0)
             # the first ResBlock reads relu(codebook[ids]): its 3x3 convolution is a table sum, and with 16-wide frames and dim == 256 the
             # whole block is ONE launch (mage_resblock_table): neither the embedded frames nor t ever reach HBM
             fused0 = (self._d0_table(w) is not None and wd == 16 and h % 2 == 0 and dim == 256
                       and config.get().decode_resblock_fusion)
+            key = (N, h, wd, str(dev), torch.cuda.current_stream(dev).cuda_stream, fused0)
+            pads = self._pad_bufs.get(key)
+            if pads is None:
+                if len(self._pad_bufs) > 4:
+                    self._pad_bufs.clear()
+                # (pads[0] holds the embedded frames: nobody writes or reads it when the first block is the fused kernel)
+                pads = self._pad_bufs[key] = [None if (fused0 and i == 0) else torch.zeros(N * PP + 1, dim, device=dev, dtype=dt) for i in range(3)]
+            inner = dict(out_h=h, out_w=wd, y_img_stride=PP, y_mul_y=Pw, y_off=Pw + 1)      # a producer's rows inside the padding
+            win = dict(out_h=h, out_w=wd, in_h=h + 2, in_w=Pw, a_img_stride=PP, cin=dim, stride=1, dy0=0, dx0=0)
             if not fused0:
                 ops.embedding(ids, w["cb"], pads[0], relu=True, group=hw, group_stride=PP, off=Pw + 1, inner=wd, inner_stride=Pw)
             t = torch.empty(N * hw, dim, device=dev, dtype=dt)
@@ -652,11 +678,20 @@ class VectorQuantizedVAE(nn.Module):
         chans = [(4 * dim, 2 * dim), (2 * dim, dim), (dim, dim), (dim, dim)]
         for bi, (ci, co) in zip((0, 2, 4, 6), chans):
             last = bi == 6
+            # the last block's closing convolution + identity path + decoder[7] ReLU + the 1x1 head (decoder[8]) in one launch: the
+            # block's [N, H, W, dim] output (8 MB per 128 x 128 frame) is neither written nor read
+            fuse_tail = (last and dt == torch.bfloat16 and co == 256 and (co // 4) % 64 == 0 and (N * H * W) % 256 == 0
+                         and (N * (H + 2) * (W + 2) + (H + 2) * (W + 2)) * (co // 4) * 2 < 2 ** 32 and config.get().decode_head_fusion
+                         and not config.lib_flag("gemm_no_8phase") and not config.lib_flag("gemm_no_taps8"))
             # the nn.Upsample in front of blocks 2, 4, 6 is folded into the block (see _bottleneck up_first)
-            x = self._bottleneck(w, f"d{bi}", x, dt, N, H, W, ci, co, 1, 3, post_relu=last, up_first=bi != 0)    # decoder[7] ReLU folded
+            x = self._bottleneck(w, f"d{bi}", x, dt, N, H, W, ci, co, 1, 3, post_relu=last, up_first=bi != 0,      # decoder[7] ReLU folded
+                                 head=w["d8.w16.bf16"] if fuse_tail else None)
             if not last:
                 H, W = H * 2, W * 2
-        ops.conv_out(x, w["d8.wt"], w["d8.b"], out, N=N, IH=H, IW=W, cin=dim, cout=self.input_dim, transposed=False)
+        if fuse_tail:
+            ops.conv_out(x, w["d8.eye"], w["d8.b"], out, N=N, IH=H, IW=W, cin=16, cout=self.input_dim, transposed=False)   # tanh(sums + bias) -> NCHW
+        else:
+            ops.conv_out(x, w["d8.wt"], w["d8.b"], out, N=N, IH=H, IW=W, cin=dim, cout=self.input_dim, transposed=False)
 
     # ------------------------------------------------------------------ forward (values only)
     def forward(self, x: torch.Tensor):

@@ -318,7 +318,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
                 and not lo["gemm_no_8phase"] and not lo["gemm_no_taps8"]):
             if table and act == ACT_NONE:
                 key = f"gemm8_kernel<0, 1, false, true, 0, 0, false, {hf}>"
-            elif plain and act in (ACT_NONE, ACT_RELU) and d.dtype == BF16:
+            elif (plain or (head_w is not None and rowadd is None)) and act in (ACT_NONE, ACT_RELU) and d.dtype == BF16:
                 key = f"gemm8_kernel<{act}, 0, false, true, {5 if head_w is not None else 0}, 0, false, false>"
         # the one-wave-per-SIMD kernel (mage_gemm4_try in csrc/gemm4.hip): QKV / c_fc at full-loop sizes
         if (h16 and not gather and n_split <= 1 and M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and 256 <= K <= 1024
