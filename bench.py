@@ -682,11 +682,11 @@ def main():
                   "mfma": {"achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)},
                   "note": "VectorQuantizedVAE.decode of the call's generated frames (median of 10, HIP events); bytes = SURVEY 8d's "
                           "layer-materialised model (sum over the 6 conv layers of input+output activations at the storage dtype); "
-                          "the same stack is 1.216 GFLOP/frame, so the MFMA fraction is reported beside it.  The bf16 path is 9 launches "
-                          "(first ResBlock as one table-sum + MFMA kernel, 3x3 GEMM, the second block's tail as a row kernel, four sub-pixel GEMMs "
-                          "with the last transposed convolution's taps taken in their epilogue, fold + tanh): the 4x-resolution activation, t and "
-                          "the embedded frames of the byte model never reach HBM, so the HBM fraction UNDERSTATES nothing and overstates the "
-                          "bytes actually moved; the MFMA fraction is the one to read"}
+                          "the same stack is 1.216 GFLOP/frame, so the MFMA fraction is reported beside it.  The bf16 path is 5 launches "
+                          "(first ResBlock as one table-sum + MFMA kernel, the second block's 3x3 GEMM, its tail as a row kernel, ONE launch for the four "
+                          "sub-pixel phases of the transposed convolution with the last transposed convolution's taps taken in its epilogue, fold + tanh): "
+                          "the 4x-resolution activation, t and the embedded frames of the byte model never reach HBM, so the byte model counts more than is "
+                          "moved (traffic = the measured bytes) and the HBM fraction is an upper bound; the MFMA fraction is the one to read"}
 
     # one more object, never the metric: the reference's training step (main_mage.py:139-154: forward, loss.backward(), Adam) on the same
     # model family and batch shape, per rank, with the gradient exchange of the data-parallel path -- reduce-scatter of the flat gradient

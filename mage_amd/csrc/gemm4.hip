@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const Gemm4Args g) {
     const char* w_next = w_src;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 8192 + 4096;     // (8 units of 1 KiB per wave and operand)
     auto dma_m0 = [&](unsigned lds_group) __attribute__((always_inline)) {       // lds_group: stage * G4_STAGE (+ G4_WOFF)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds0 + lds_group) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds0 + lds_group) : "memory");      // (m0 cannot be named as a clobber: the compiler treats it as reserved and warns; check4 audits its writers)
     };
 
     // ---- compute state: wave (wm, wn) owns rows [wm*128, +128) x columns [wn*128, +128) of the tile

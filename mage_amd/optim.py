@@ -185,13 +185,18 @@ class FlatAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, sd):
         """Accepts torch.optim.Adam's per-parameter layout (written by this class at ANY world size, or by the reference's optim.Adam over
-        model.parameters()): entries are matched by their index in the full parameter list; a parameter without an entry (one that never
+        model.parameters()): entries are matched by their index in the full parameter list (a checkpoint numbered over the TRAINABLE
+        parameters only -- this class's layout before it counted frozen ones -- is recognised by its length and re-indexed); a parameter without an entry (one that never
         received a gradient, e.g. ln_q / ln_kv under find_unused_parameters=True) starts from zero moments; an entry for a frozen parameter
         or with a different shape is an error, never a silent reassignment."""
         st = {int(k): e for k, e in sd["state"].items()}
         groups = sd.get("param_groups") or []
-        if groups and "params" in groups[0] and len(groups[0]["params"]) != len(self.all_params):
-            raise ValueError(f"FlatAdam.load_state_dict: the checkpoint's optimizer was built over {len(groups[0]['params'])} parameters, "
+        n_ckpt = len(groups[0]["params"]) if groups and "params" in groups[0] else None
+        if n_ckpt is not None and n_ckpt == len(self.index) and n_ckpt != len(self.all_params):
+            # the layout this class wrote before it numbered frozen parameters too: entry j belongs to the j-th TRAINABLE parameter
+            st = {self.index[j]: e for j, e in st.items() if 0 <= j < len(self.index)}
+        elif n_ckpt is not None and n_ckpt != len(self.all_params):
+            raise ValueError(f"FlatAdam.load_state_dict: the checkpoint's optimizer was built over {n_ckpt} parameters, "
                              f"this one over {len(self.all_params)} (pass the same model.parameters())")
         trainable = set(self.index)
         for i in st:

@@ -80,6 +80,34 @@ def test_flat_adam_matches_torch_adam_single_process(monkeypatch):
     torch.optim.Adam(_net(1).parameters(), lr=1e-2).load_state_dict(sd)     # and the other way round
 
 
+def test_flat_adam_accepts_the_layout_numbered_over_trainable_parameters(monkeypatch):
+    """Checkpoints this class wrote before it counted frozen parameters (entry j = the j-th TRAINABLE parameter, param_groups.params of that
+    length) load into the right slots; a length that is neither layout is still an error."""
+    from mage_amd.optim import FlatAdam
+    monkeypatch.setattr(FlatAdam, "_adam", _adam_double)
+
+    def frozen_first(seed):
+        net = _net(seed)
+        net[0].weight.requires_grad_(False)                  # parameter 0 frozen: trainable indices are 1..5
+        return net
+    a = frozen_first(3)
+    opt = FlatAdam(a.parameters(), lr=1e-2)
+    for i in range(2):
+        opt.zero_grad()
+        a(torch.randn(4, 7, generator=torch.Generator().manual_seed(i))).pow(2).mean().backward()
+        opt.step()
+    sd = opt.state_dict()
+    assert sorted(sd["state"]) == opt.index == [1, 2, 3, 4, 5] and len(sd["param_groups"][0]["params"]) == 6
+    legacy = {"state": {j: sd["state"][i] for j, i in enumerate(opt.index)},
+              "param_groups": [dict(sd["param_groups"][0], params=list(range(len(opt.index))))]}
+    opt2 = FlatAdam(frozen_first(3).parameters(), lr=1e-2)
+    opt2.load_state_dict(legacy)
+    assert opt2.steps == 2 and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
+    bad = {"state": {}, "param_groups": [dict(sd["param_groups"][0], params=list(range(4)))]}
+    with pytest.raises(ValueError, match="built over 4 parameters"):
+        FlatAdam(frozen_first(3).parameters(), lr=1e-2).load_state_dict(bad)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
