@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MAGE_ABI_VERSION 7
+#define MAGE_ABI_VERSION 8
 
 /* MAGE_BF16X3 / MAGE_F16X3: SPLIT-PRECISION operands -- the fast parity mode.  A logical fp32 matrix [rows, C] (C % 64 == 0, base
  * 256-byte aligned) is stored as two 16-bit pieces per element, x ~ hi + lo, per row as 64-column slabs [hi(64) | lo(64)] (so a row
@@ -176,6 +176,7 @@ typedef struct mage_gemm_desc {
                                         * taken on the tile before it leaves the CU.  head_w is bf16 [16][N]; the rows y = relu(acc + bias), rounded
                                         * to bf16 as a store would round them, are NOT written; Y (y_dtype MAGE_F32, ldy >= 16 floats) receives
                                         *     Y[yrow][t] = sum_n y[n] * head_w[t][n],  t = 0..15      (fp32 sums, fixed order)
+                                        * (ldy == 4 with head_phases 0: only t = 0..3 are written, 16 bytes per row -- a head with <= 4 outputs)
                                         * -- the 4 x 4 taps of the VQ-VAE's last ConvTranspose2d (vqvae_model.py:187) computed inside the
                                         * sub-pixel GEMMs of the one before it (:184), whose 4x-resolution activation is then never stored.
                                         * With `residual` (bf16 rows [.., N]; res_half allowed; head_phases 0) the rows are
@@ -188,6 +189,10 @@ typedef struct mage_gemm_desc {
                                         * (1,0) (1,1); column tile p reads its 2 x 2 window at a_off + py*in_w + px and writes the rows
                                         * y_off + py*(y_mul_y/2) + px*(y_mul_x/2) (y_mul_x == 2): four launches' tiles, bit for bit, from one tile
                                         * list in which a frame's four phases are neighbours (its padded rows are fetched once) */
+    int32_t a_relu;                    /* 16-bit plain GEMM with N <= 128 (the 256 x 64 tile): the product is taken over relu(A) -- the ReLU in front of a
+                                        * bottleneck block's first 1x1 convolution (vqvae_model.py:147-166: Sequential(ReLU, Conv2d 1x1, ...)) applied to
+                                        * the operand fragments, so that relu(x) is never stored next to x (which the identity path reads).  Refused
+                                        * on every other form */
 } mage_gemm_desc;
 
 int mage_gemm(const mage_gemm_desc* desc, void* stream);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MAGE_HIP_LIB", os.path.join(_HERE, "lib", "libmage_hi
 
 F32, BF16, BF16X3, F16X3, F16 = 0, 1, 2, 3, 4  # BF16X3 / F16X3: split-precision operands; F16: single-pass half operands (include/mage_hip.h)
 ACT_NONE, ACT_RELU, ACT_QUICKGELU, ACT_GELU_ERF, ACT_TANH, ACT_QUICKGELU_GRAD = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -36,7 +36,7 @@ class GemmDesc(C.Structure):
         ("post_relu", i32), ("ldw", i32), ("n_split", i32),
         ("a_split_stride", i64), ("w_split_stride", i64), ("y_split_stride", i64),
         ("y2", vp), ("ldy2", i32), ("res_half", i32), ("ln_part", vp), ("ln_stats", vp), ("ln_colsum", vp), ("a_half", i32), ("ln_eps", C.c_float),
-        ("head_w", vp), ("head_phases", i32),
+        ("head_w", vp), ("head_phases", i32), ("a_relu", i32),
     ]
 
 

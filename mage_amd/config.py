@@ -38,6 +38,7 @@ class Config:
     decode_resblock_fusion: bool = True
     decode_head_fusion: bool = True
     decode_phase_merge: bool = True
+    decode_relu_fold: bool = True     # f8 decode: a block's leading ReLU taken on the operand fragments of its first 1x1 convolution
     # ---- training path (modules/mage_train*.py)
     train_f32_branch: bool = False    # fp32 branch rows / LayerNorm-output gradients in bf16 training (the round-2 form)
     train_wgrad_transpose: bool = False   # weight gradients through transposed copies + split-K (False: mage_gemm_tn)
@@ -61,6 +62,7 @@ ENV = {
     "decode_resblock_fusion": ("MAGE_DECODE_NO_RESBLOCK_FUSION", False),
     "decode_head_fusion": ("MAGE_DECODE_NO_HEAD_FUSION", False),
     "decode_phase_merge": ("MAGE_DECODE_NO_PHASE_MERGE", False),
+    "decode_relu_fold": ("MAGE_DECODE_NO_RELU_FOLD", False),
     "train_f32_branch": ("MAGE_TRAIN_F32_BRANCH", True),
     "train_wgrad_transpose": ("MAGE_WGRAD_TRANSPOSE", True),
     "train_emit": ("MAGE_TRAIN_NO_EMIT", False),

@@ -195,6 +195,13 @@ __device__ __forceinline__ void store8(f16_t* p, f32x4 a, f32x4 b) {
 // One logical element occupies 4 bytes, so `T* row = base + r * C` is the row start for T = split_bf16 / split_f16 as it is for
 // float, and the slab-relative address of column c follows from the byte address alone when the base is 256-byte aligned:
 // that is what store4 / store8 below use, so every kernel templated on its output type writes split rows unchanged.
+// max(x, 0) on two packed 16-bit floats (bf16 or f16: a negative value is a negative int16, -0 included)
+typedef short mage_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned relu16x2(unsigned v) {
+    const mage_s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(mage_s16x2, v), z));
+}
+
 struct split_bf16 { unsigned int pair; };
 struct split_f16 { unsigned int pair; };
 #define MAGE_F16_LO_SCALE 2048.0f

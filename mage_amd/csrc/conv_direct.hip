@@ -160,6 +160,22 @@ __global__ __launch_bounds__(256) void conv_out_1x1_kernel(const IT* __restrict_
     }
 }
 
+// The same head over FOUR fp32 input channels (the f8 decoder's RGB head already taken on the last convolution's tile, mage_gemm_desc::head_w
+// with ldy == 4: x holds the head's sums): a thread per pixel, one 16-byte load, cout <= 4 coalesced plane stores.
+__global__ __launch_bounds__(256) void conv_out_1x1_c4_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                              float* __restrict__ y, long npix, long plane, int cout) {
+    const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= npix) return;
+    const f32x4 v = __builtin_nontemporal_load((const f32x4*)(x + pix * 4));
+    const long n = pix / plane, p = pix - n * plane;
+    for (int co = 0; co < cout; ++co) {
+        const f32x4 w = *(const f32x4*)(wt + co * 4);
+        // (the 16-lane kernel's order for cin = 4: one lane holds the pixel, its four products added left to right)
+        const float a = v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+        y[(n * cout + co) * plane + p] = tanhf(a + (bias ? bias[co] : 0.f));
+    }
+}
+
 // One wave per output pixel, lanes split the input channels, shuffle reduction, tanh, NCHW fp32 store.
 template <typename IT, bool TRANSPOSED>
 __global__ __launch_bounds__(256) void conv_out_kernel(const IT* __restrict__ x, const float* __restrict__ wt,
@@ -394,6 +410,11 @@ extern "C" int mage_conv_out(const void* x, int32_t x_dtype, const float* weight
     if (!transposed && (x_dtype == MAGE_F32 || x_dtype == MAGE_BF16) && cin % (x_dtype == MAGE_BF16 ? 8 : 4) == 0 &&
         (((uintptr_t)x | (uintptr_t)weight_t) & 15) == 0) {
         const long npix = (long)N * IH * IW;
+        if (x_dtype == MAGE_F32 && cin == 4) {
+            hipLaunchKernelGGL(conv_out_1x1_c4_kernel, dim3((unsigned)((npix + 255) / 256)), blk, 0, s, (const float*)x, weight_t, bias, y, npix, (long)IH * IW, cout);
+            MAGE_CHECK_LAUNCH("mage_conv_out");
+            return MAGE_OK;
+        }
         const dim3 g1((unsigned)((npix * 16 + 255) / 256));
         if (x_dtype == MAGE_F32)
             hipLaunchKernelGGL((conv_out_1x1_kernel<float>), g1, blk, 0, s, (const float*)x, weight_t, bias, y, npix, (long)IH * IW, cin, cout);

@@ -293,6 +293,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int ES = sizeof(E);
     const mage_gemm_desc& d = g.d;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // mage_gemm_desc::a_relu: the 256 x 64 tile's plain bf16 form only (host: launch_ek)
+    constexpr bool ARELU = DT == MAGE_BF16 && !GATHER && MT == 2 && NW == 1 && EK == EK_BIAS && LN == LN_NONE && !SPLIT && SPL == 0;
+    [[maybe_unused]] const bool a_relu = ARELU && d.a_relu != 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -586,6 +589,14 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
                         xf[1][0] = *(const u32x4*)(xs + pcs[1]);
                         xf[1][1] = *(const u32x4*)(xs + 2048 + pcs[1]);
                     }
+                    if constexpr (ARELU) {             // the product over relu(A): max(., 0) on the fragments' 16-bit lanes as integers
+                        if (a_relu) {
+#pragma unroll
+                            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) xf[t][2 * gq + mm][q] = relu16x2(xf[t][2 * gq + mm][q]);
+                        }
+                    }
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -741,7 +752,8 @@ __device__ __forceinline__ void epilogue_head(const mage_gemm_desc& d, const f32
         const int img = m / plane, rem = m - img * plane;
         const int oy = rem / d.out_w, ox = rem - oy * d.out_w;
         const long yrow = (long)img * d.y_img_stride + (long)oy * d.y_mul_y + (long)ox * d.y_mul_x + d.y_off + phase_rows;
-        __builtin_nontemporal_store(s, (f32x4*)((float*)d.Y + yrow * d.ldy + grp * 4));
+        // (ldy == 4: a head with at most 4 outputs -- the f8 decoder's RGB head: only taps 0..3 leave the CU, 16 bytes per row)
+        if (d.ldy >= 16 || grp == 0) __builtin_nontemporal_store(s, (f32x4*)((float*)d.Y + yrow * d.ldy + grp * 4));
         if (half == 0) {
             __builtin_amdgcn_s_waitcnt(0xC07F);        // the reads of half 0 are done before anyone overwrites a window
             ring_barrier();
@@ -1450,9 +1462,9 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
                        "mage_gemm: head_phases is 0 or 4 (the sub-pixel phases of a 4 x 4 / stride 2 transposed convolution: 2 x 2 taps, y_mul_x = 2)");
         const bool head_res = !d->rowadd && d->residual && d->res_dtype == MAGE_BF16 && d->head_phases == 0 && d->ldr % 4 == 0 && d->ldr >= d->N &&
                               (((uintptr_t)d->residual) & 7) == 0 && (d->res_half || (d->out_h * d->out_w == d->y_img_stride && d->y_off == 0));
-        MAGE_CHECK_ARG(SPL == 0 && (plain || head_res) && d->act == MAGE_ACT_RELU && d->N == (d->head_phases ? 1024 : 256) && d->y_dtype == MAGE_F32 && d->ldy >= 16 &&
+        MAGE_CHECK_ARG(SPL == 0 && (plain || head_res) && d->act == MAGE_ACT_RELU && d->N == (d->head_phases ? 1024 : 256) && d->y_dtype == MAGE_F32 && (d->ldy >= 16 || (d->ldy == 4 && d->head_phases == 0)) &&
                            d->ldy % 4 == 0 && d->bias && (((uintptr_t)d->head_w) & 7) == 0 && (((uintptr_t)d->Y) & 15) == 0,
-                       "mage_gemm: head_w takes the bf16 padded-taps form with N = 256 (1024 with head_phases), bias, ReLU, fp32 [row][ldy >= 16] output, "
+                       "mage_gemm: head_w takes the bf16 padded-taps form with N = 256 (1024 with head_phases), bias, ReLU, fp32 [row][ldy >= 16] output (ldy == 4: taps 0..3 only), "
                        "optionally a bf16 residual (N = 256 form; res_half or packed rows)");
         if constexpr (SPL == 0 && !HF) return launch_taps8<MAGE_ACT_RELU, EK_BIAS, 0, LN_HEAD>(d, s, n_cu);
     }
@@ -1532,7 +1544,7 @@ int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
     }
     const int n_cu = n_cu_dev[dev];
     if constexpr (DT != MAGE_F32 && !GATHER && EK != EK_GENERAL && LN != LN_DUAL && LN != LN_GELUBWD && (ACT == MAGE_ACT_NONE || ACT == MAGE_ACT_QUICKGELU)) {
-        if (d->n_split == 1 && small_shape(d->M, d->N, d->K, n_cu)) return launch_small<ACT, EK, LN, RB, 0, DT == MAGE_F16>(d, s, n_cu);
+        if (d->n_split == 1 && !d->a_relu && small_shape(d->M, d->N, d->K, n_cu)) return launch_small<ACT, EK, LN, RB, 0, DT == MAGE_F16>(d, s, n_cu);
     }
     // 256-row tiles only where there are enough of them to give every CU at least two (bf16; the fp32 8x4-accumulator
     // variant does not fit the register file)
@@ -1543,6 +1555,8 @@ int launch_ek(const mage_gemm_desc* d, hipStream_t s) {
         if (narrow && d->N <= 128 && d->n_split == 1 && (long)((d->M + 255) / 256) * ((d->N + 63) / 64) >= n_cu)
             return launch_tile<DT, GATHER, ACT, 2, EK, false, LN_NONE, 1>(d, s, n_cu);
     }
+    // (a_relu is applied to the operand fragments of that tile's K loop only: refused, not dropped, when the shape does not run there)
+    MAGE_CHECK_ARG(!d->a_relu, "mage_gemm: a_relu runs on the 256 x 64 tile: N <= 128, at least one tile per CU, option gemm_no_narrow off");
     if constexpr (DT != MAGE_F32 && !GATHER && ACT == MAGE_ACT_NONE && EK == EK_RES_INIT) {
         // few rows (the incremental AR loop's x + Linear(.) at 8 k rows x 512 columns: 128 tiles of 128 x 256 on 256 CUs): the narrow tile
         // cuts the same output into 256 x 64 pieces, one per CU.  Same K order per element: the tokens stay bit-identical to the full loop's.

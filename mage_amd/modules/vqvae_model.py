@@ -272,11 +272,11 @@ class VectorQuantizedVAE(nn.Module):
             d["d8.wt"] = dec[8].weight.float().reshape(dec[8].weight.shape[0], -1).contiguous()   # [cout, cin]
             d["d8.b"] = dec[8].bias.float().contiguous()
             # the 1x1 RGB head taken on the tiles of the last block's closing convolution (mage_gemm_desc::head_w): 16 head rows, the first
-            # input_dim of them the head's weights; the [row][16] sums then go through tanh(. + bias) by an identity 1x1
+            # input_dim of them the head's weights; the first four sums of a row ([row][4] fp32) then go through tanh(. + bias) by an identity 1x1
             h16 = torch.zeros(16, d["d8.wt"].shape[1], device=d["d8.wt"].device)
             h16[:self.input_dim] = d["d8.wt"]
             d["d8.w16.bf16"] = h16.to(torch.bfloat16).contiguous()
-            d["d8.eye"] = torch.eye(self.input_dim, 16, device=d["d8.wt"].device).contiguous()
+            d["d8.eye"] = torch.eye(self.input_dim, 4, device=d["d8.wt"].device).contiguous()      # the head's first 4 sums -> RGB (input_dim <= 4)
         return d
 
     def _weights(self) -> Dict[str, torch.Tensor]:
@@ -322,12 +322,18 @@ class VectorQuantizedVAE(nn.Module):
         same arithmetic per output pixel, bit-identical results.
         head (bf16 [16, cout], the decoder's last block): the block's closing 3x3 convolution runs in the padded-taps form on the 8-phase kernel
         (its input is written into a zero-padded frame buffer by the convolution before it) with the identity path, the ReLU that follows the
-        block and the 1x1 head taken on the tile: returns the head's sums [n_img*H*W, 16] fp32; the block's output is never stored."""
+        block and the 1x1 head taken on the tile: returns the head's first four sums [n_img*H*W, 4] fp32; the block's output is never stored."""
         s = "." + ("f32" if dt == torch.float32 else "bf16")
         hid = cout // 4
         dev = x.device
-        xr = ops.relu(x, torch.empty_like(x))
         Hi, Wi = (H // 2, W // 2) if up_first else (H, W)
+        # the block's leading ReLU: only its first convolution reads relu(x) (the identity path reads x).  A 1x1 first convolution with a
+        # narrow hidden width takes it on its operand fragments (mage_gemm_desc::a_relu: the 256 x 64 tile) -- relu(x) is never stored
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count & ~7
+        fold_relu = (dt == torch.bfloat16 and first_k == 1 and hid <= 128 and config.get().decode_relu_fold and not config.lib_flag("gemm_no_narrow")
+                     and ((n_img * Hi * Wi + 255) // 256) * ((hid + 63) // 64) >= n_cu)
+        xr = x if fold_relu else ops.relu(x, torch.empty_like(x))
+        relu_kw = dict(a_relu=True) if fold_relu else {}
         if (p + ".wid" + s) in w:
             idp = torch.empty(n_img * Hi * Wi, cout, device=dev, dtype=dt)
             self._conv(x, w[p + ".wid" + s], idp, n_img=n_img, H=Hi, W=Wi, cin=cin, cout=cout, k=1, bias=w[p + ".bid"])
@@ -340,7 +346,7 @@ class VectorQuantizedVAE(nn.Module):
         if up_first:
             assert first_k == 1
             h1 = torch.empty(n_img * Hi * Wi, hid, device=dev, dtype=dt)
-            self._conv(xr, w[f"{p}.w1{s}"], h1, n_img=n_img, H=Hi, W=Wi, cin=cin, cout=hid, k=1, bias=w[f"{p}.b1"], act=ops.ACT_RELU)
+            self._conv(xr, w[f"{p}.w1{s}"], h1, n_img=n_img, H=Hi, W=Wi, cin=cin, cout=hid, k=1, bias=w[f"{p}.b1"], act=ops.ACT_RELU, **relu_kw)
             h = h1                                  # stays at low resolution too: the next convolution gathers it there (a_half);
             j0 = 1                                  # the identity path is read there by the last convolution (res_half)
         Pw, PP = W + 2, (H + 2) * (W + 2)
@@ -357,11 +363,11 @@ class VectorQuantizedVAE(nn.Module):
             else:
                 nh = torch.empty(n_img * H * W, chans[j + 1], device=dev, dtype=dt)
             self._conv(h, w[f"{p}.w{2 * j + 1}{s}"], nh, n_img=n_img, H=H, W=W, cin=chans[j], cout=chans[j + 1], k=ks[j],
-                       bias=w[f"{p}.b{2 * j + 1}"], act=ops.ACT_RELU, **half)
+                       bias=w[f"{p}.b{2 * j + 1}"], act=ops.ACT_RELU, **half, **(relu_kw if j == 0 else {}))
             h = nh
         if head is not None:
-            sums = torch.empty(n_img * H * W, 16, device=dev, dtype=torch.float32)
-            ops.gemm(h, w[p + ".w7" + s], sums, M=n_img * H * W, N=cout, K=9 * hid, lda=hid, ldy=16, out_h=H, out_w=W, in_h=H + 2, in_w=Pw,
+            sums = torch.empty(n_img * H * W, 4, device=dev, dtype=torch.float32)            # (ldy == 4: the head's first four outputs only)
+            ops.gemm(h, w[p + ".w7" + s], sums, M=n_img * H * W, N=cout, K=9 * hid, lda=hid, ldy=4, out_h=H, out_w=W, in_h=H + 2, in_w=Pw,
                      a_img_stride=PP, taps_h=3, taps_w=3, cin=hid, stride=1, dy0=0, dx0=0, bias=w[p + ".b7"], act=ops.ACT_RELU,
                      residual=idp, ldr=cout, res_half=up_first, head_w=head)
             return sums
@@ -680,7 +686,7 @@ class VectorQuantizedVAE(nn.Module):
             last = bi == 6
             # the last block's closing convolution + identity path + decoder[7] ReLU + the 1x1 head (decoder[8]) in one launch: the
             # block's [N, H, W, dim] output (8 MB per 128 x 128 frame) is neither written nor read
-            fuse_tail = (last and dt == torch.bfloat16 and co == 256 and (co // 4) % 64 == 0 and (N * H * W) % 256 == 0
+            fuse_tail = (last and dt == torch.bfloat16 and co == 256 and (co // 4) % 64 == 0 and (N * H * W) % 256 == 0 and self.input_dim <= 4
                          and (N * (H + 2) * (W + 2) + (H + 2) * (W + 2)) * (co // 4) * 2 < 2 ** 32 and config.get().decode_head_fusion
                          and not config.lib_flag("gemm_no_8phase") and not config.lib_flag("gemm_no_taps8"))
             # the nn.Upsample in front of blocks 2, 4, 6 is folded into the block (see _bottleneck up_first)
@@ -689,7 +695,7 @@ class VectorQuantizedVAE(nn.Module):
             if not last:
                 H, W = H * 2, W * 2
         if fuse_tail:
-            ops.conv_out(x, w["d8.eye"], w["d8.b"], out, N=N, IH=H, IW=W, cin=16, cout=self.input_dim, transposed=False)   # tanh(sums + bias) -> NCHW
+            ops.conv_out(x, w["d8.eye"], w["d8.b"], out, N=N, IH=H, IW=W, cin=4, cout=self.input_dim, transposed=False)   # tanh(sums + bias) -> NCHW
         else:
             ops.conv_out(x, w["d8.wt"], w["d8.b"], out, N=N, IH=H, IW=W, cin=dim, cout=self.input_dim, transposed=False)
 

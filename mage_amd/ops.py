@@ -214,12 +214,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
          residual=None, ldr: int = 0, post_relu: bool = False, ldw: int = 0, n_split: int = 1, a_split_stride: int = 0,
          w_split_stride: int = 0, y_split_stride: int = 0, y2=None, ldy2: int = 0, ln_part=None, ln_stats=None,
          ln_colsum=None, res_half: bool = False, a_half: bool = False, split_kind: int = 0, y_split: bool = False,
-         ln_eps: float = 0.0, head_w=None, head_phases: int = 0) -> torch.Tensor:
+         ln_eps: float = 0.0, head_w=None, head_phases: int = 0, a_relu: bool = False) -> torch.Tensor:
     """Y = epilogue(A (*) W^T); see mage_gemm in include/mage_hip.h for the geometry fields.
     split_kind BF16X3 / F16X3: a and w are split-precision tensors (lda / ldw in 16-bit elements); y_split: so is y (ldy likewise).
     head_w (bf16 [16, N], padded-taps form with N == 256, bias, ReLU): y (fp32, ldy >= 16) receives the narrow Linear head_w on the
-    bf16-rounded rows relu(acc + bias), which are not stored (mage_gemm_desc::head_w)."""
+    bf16-rounded rows relu(acc + bias), which are not stored (mage_gemm_desc::head_w).
+    a_relu (16-bit plain GEMM, N <= 128): the product over relu(a) (mage_gemm_desc::a_relu)."""
     l, s = _dev(a)
+    if split_kind and a_relu:
+        raise ValueError("ops.gemm: split-precision operands (split_kind) do not take a_relu")
     if split_kind:
         # the split-precision form takes a subset of the arguments (launch_spl / try_taps8 in csrc/gemm.hip): refuse the rest loudly
         # instead of dropping them
@@ -271,6 +274,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     d.head_phases = head_phases if head_w is not None else 0
     d.res_half = int(res_half)
     d.a_half = int(a_half)
+    d.a_relu = int(a_relu)
     ln = 2 if (ln_stats is not None or ln_colsum is not None) else (1 if (y2 is not None or ln_part is not None) else 0)      # LN_CONSUME / LN_PRODUCE
     h16 = d.dtype in (BF16, F16)                                                             # 16-bit operands: the same kernels, bf16 or f16 MFMA
     hf = "true" if d.dtype == F16 else "false"                                               # HF, the kernels' last template argument

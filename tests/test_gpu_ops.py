@@ -444,6 +444,29 @@ def test_out_of_range_ids_and_targets_are_reported():
         o.check_device_errors(DEV)
 
 
+def test_gemm_over_relu_of_the_operand_rows():
+    """mage_gemm_desc::a_relu (the 256 x 64 tile, bf16): A W^T over relu(A) == the product over a stored relu(A), bit for bit; refused
+    where the shape does not run on that tile."""
+    o = ops()
+    M, K = 256 * 256, 256
+    for N in (64, 128):
+        a = rnd(M, K, seed=120).bfloat16().to(DEV)
+        w = rnd(N, K, seed=121, scale=K ** -0.5).bfloat16().to(DEV)
+        bias = rnd(N, seed=122, scale=0.1).to(DEV)
+        y0 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        y1 = torch.empty_like(y0)
+        o.gemm(torch.relu(a), w, y0, M=M, N=N, K=K, lda=K, ldy=N, bias=bias, act=o.ACT_RELU)
+        o.gemm(a, w, y1, M=M, N=N, K=K, lda=K, ldy=N, bias=bias, act=o.ACT_RELU, a_relu=True)
+        assert torch.equal(y0, y1)
+        ref = torch.relu(torch.relu(a.float()) @ w.float().t() + bias)
+        torch.testing.assert_close(y1.float(), ref, atol=3e-2, rtol=2e-2)
+    with pytest.raises(Exception, match="a_relu"):             # 256 columns: not the narrow tile
+        w2 = rnd(256, K, seed=123).bfloat16().to(DEV)
+        o.gemm(a, w2, torch.empty(M, 256, device=DEV, dtype=torch.bfloat16), M=M, N=256, K=K, lda=K, ldy=256, a_relu=True)
+    with pytest.raises(Exception, match="a_relu"):             # too few rows for a tile per CU
+        o.gemm(a, w, y1, M=4096, N=N, K=K, lda=K, ldy=N, bias=bias, a_relu=True)
+
+
 @pytest.mark.parametrize("ht", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("n_img,Cc,mode", [(8, 256, "table"), (3, 512, "table"), (6, 256, "relu_bias"), (5, 256, "plain")])
 def test_padded_taps_conv_on_the_8phase_kernel(n_img, Cc, mode, ht):

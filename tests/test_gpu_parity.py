@@ -82,6 +82,31 @@ def test_vqvae_f8_golden_tokens_and_frames():
     np.testing.assert_allclose(chk(rec.cpu()), g["rec_chk"], rtol=1e-4)
 
 
+def test_vqvae_f8_bf16_decode_fusions_keep_the_frames():
+    """The f8 decoder's bf16 path at a batch every fusion engages at (256 frames: the 256 x 64 tile list fills the chip in every block):
+    a block's leading ReLU on the operand fragments of its first 1x1 convolution (mage_gemm_desc::a_relu) gives the bits of the separate
+    ReLU pass; the last block's closing convolution + identity path + ReLU + RGB head in one launch (head_w with a residual, four sums per
+    row) gives the unfused frames to bf16 summation-order error; both stay within bf16-class error of the exact decode."""
+    g = golden("vqvae_f8")
+    m = build_vqvae(3, 8, int(g["dim"]), int(g["K"]), int(g["seed"]), DEV)
+    ids = torch.randint(0, int(g["K"]), (256, 16, 16), generator=torch.Generator().manual_seed(11)).to(DEV)
+    ids[:2] = t(g["ids"]).long().to(DEV)
+    rec32 = m.decode(ids[:8])
+    torch.testing.assert_close(rec32[:2, :, ::4, ::4].cpu(), t(g["rec_sub"]), atol=LOGIT_TOL, rtol=0)
+    m.set_precision("bf16")
+    rec = m.decode(ids)
+    assert torch.isfinite(rec).all() and (rec[:8] - rec32).abs().max().item() < 5e-2
+    with config.override(decode_relu_fold=False):
+        rec_relu_pass = m.decode(ids)
+    assert torch.equal(rec, rec_relu_pass)
+    with config.override(decode_head_fusion=False):
+        rec_unfused = m.decode(ids)
+    print(f"f8 bf16 decode: fused tail vs separate launches max |d| {(rec - rec_unfused).abs().max().item():.2e}, "
+          f"vs exact decode {(rec[:8] - rec32).abs().max().item():.2e}")
+    assert (rec - rec_unfused).abs().max().item() < 2e-3
+    assert torch.equal(m.decode(ids[:8]), rec[:8])              # few frames (no fold: the tile list would not fill the chip): the same frames
+
+
 @pytest.mark.parametrize("tag", ["mage_mnist_L4", "mage_mnist_L6_ragged"])
 def test_mage_stages_against_reference_goldens(tag):
     g = golden(tag)
