@@ -324,6 +324,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
                 key = f"gemm8_kernel<0, 1, false, true, 0, 0, false, {hf}>"
             elif (plain or (head_w is not None and rowadd is None)) and act in (ACT_NONE, ACT_RELU) and d.dtype == BF16:
                 key = f"gemm8_kernel<{act}, 0, false, true, {5 if head_w is not None else 0}, 0, false, false>"
+        # 64 -> 64 channel 3x3 convolutions over whole 16 x 16 pixel tiles (mage_conv3x3_c64_try in csrc/conv_tile.hip)
+        tile_conv = (d.dtype == BF16 and y.dtype == torch.bfloat16 and N == 64 and d.cin == 64 and taps_h == 3 and taps_w == 3 and stride == 1 and dy0 == -1
+                     and dx0 == -1 and dys == 1 and dxs == 1 and d.in_h == out_h and d.in_w == out_w and out_h % 16 == 0 and out_w % 16 == 0 and ek == 0
+                     and act in (ACT_NONE, ACT_RELU) and y_mul_x == 1 and a_off == 0 and n_split == 1 and M % (out_h * out_w) == 0
+                     and (M // 256) >= n_cu and not lo["conv_no_tile"])
+        if tile_conv:
+            key = "conv3x3_c64_kernel"
         # the one-wave-per-SIMD kernel (mage_gemm4_try in csrc/gemm4.hip): QKV / c_fc at full-loop sizes
         if (h16 and not gather and n_split <= 1 and M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and 256 <= K <= 1024
                 and out_h == 1 and out_w >= M and y_mul_x == 1 and ek == 0 and not res_half and ln_part is None
@@ -339,6 +346,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
             # copy and the LayerNorm partial sums of the producer form)
             es, ys = a.element_size(), y.element_size()
             nb = float(M) * K * es + float(N) * K * es + float(M) * N * ys
+            if key == "conv3x3_c64_kernel":                  # the input once (a quarter of it with a_half), not once per tap
+                nb = float(M) * 64 * es * (0.25 if a_half else 1.0) + float(N) * K * es + float(M) * N * ys
             if residual is not None:
                 nb += float(M) * N * residual.element_size()
             if y2 is not None:

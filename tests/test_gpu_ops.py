@@ -444,6 +444,47 @@ def test_out_of_range_ids_and_targets_are_reported():
         o.check_device_errors(DEV)
 
 
+@pytest.mark.parametrize("n_img,R,half,padded,relu", [(64, 32, False, False, True), (64, 32, True, False, True), (16, 64, True, True, True),
+                                                      (16, 128, False, True, False), (300, 16, False, False, True)])
+def test_tile_convolution_64_channels_equals_the_implicit_gemm(n_img, R, half, padded, relu):
+    """conv3x3 64 -> 64 channels over whole 16 x 16 pixel tiles (conv_tile.hip: the 18 x 18 input window and the weights resident in LDS) against
+    the implicit-GEMM kernel on the same descriptor (library option conv_no_tile): the same accumulation chains, bit for bit; and against
+    torch's conv2d on the bf16-rounded operands.  half: the input at half resolution (nn.Upsample folded into the fetch); padded: the rows
+    written into the interior of a zero-padded frame buffer (the next padded-taps convolution's input)."""
+    import torch.nn.functional as F
+    from mage_amd import config
+    o = ops()
+    Ri = R // 2 if half else R
+    x = rnd(n_img, Ri, Ri, 64, seed=130).bfloat16()
+    w = rnd(64, 3, 3, 64, seed=131, scale=(9 * 64) ** -0.5).bfloat16()                  # [co, ky, kx, ci]
+    bias = rnd(64, seed=132, scale=0.1)
+    xin = x.float().permute(0, 3, 1, 2)
+    if half:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, w.float().permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1)
+    if relu:
+        ref = torch.relu(ref)
+    P = R + 2
+    geo = dict(y_img_stride=P * P, y_mul_y=P, y_off=P + 1) if padded else {}
+    kw = dict(M=n_img * R * R, N=64, K=576, lda=64, ldy=64, out_h=R, out_w=R, in_h=R, in_w=R, taps_h=3, taps_w=3, cin=64, stride=1, dy0=-1, dx0=-1,
+              bias=bias.to(DEV), act=o.ACT_RELU if relu else o.ACT_NONE, **geo)
+    if half:
+        kw.update(a_half=True, a_img_stride=Ri * Ri)
+    xd, wd = x.view(-1, 64).to(DEV), w.reshape(64, 576).to(DEV)
+    rows = n_img * P * P + 1 if padded else n_img * R * R
+    y_tile = torch.zeros(rows, 64, device=DEV, dtype=torch.bfloat16)
+    y_gemm = torch.zeros_like(y_tile)
+    o.gemm(xd, wd, y_tile, **kw)
+    with config.lib_option("conv_no_tile", 1):
+        o.gemm(xd, wd, y_gemm, **kw)
+    assert torch.equal(y_tile, y_gemm)
+    got = y_tile[:n_img * P * P].view(n_img, P, P, 64)[:, 1:-1, 1:-1] if padded else y_tile.view(n_img, R, R, 64)
+    torch.testing.assert_close(got.float().cpu(), ref, atol=3e-2, rtol=2e-2)
+    if padded:                                                  # the padding ring stays zero
+        full = y_tile[:n_img * P * P].view(n_img, P, P, 64)
+        assert full[:, 0].abs().max().item() == 0 and full[:, :, 0].abs().max().item() == 0 and full[:, -1].abs().max().item() == 0
+
+
 def test_gemm_over_relu_of_the_operand_rows():
     """mage_gemm_desc::a_relu (the 256 x 64 tile, bf16): A W^T over relu(A) == the product over a stored relu(A), bit for bit; refused
     where the shape does not run on that tile."""
