@@ -122,7 +122,7 @@ def _lib_opts(l) -> dict:
     """The library's kernel-selection options that the profile keys mirror (mage_get_option; read only while profiling)."""
     out = {}
     v = C.c_int32(0)
-    for name in ("gemm_no_narrow", "gemm_no_narrow_few", "gemm_no_8phase", "gemm_no_taps8", "gemm4_train_forms", "gemm_no_4w"):
+    for name in ("gemm_no_narrow", "gemm_no_narrow_few", "gemm_no_8phase", "gemm_no_taps8", "gemm4_train_forms", "gemm_no_4w", "conv_no_tile"):
         _lib.check(l.mage_get_option(name.encode(), C.byref(v)), l)
         out[name] = int(v.value)
     return out
