@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
             else epilogue_lean<ACT, float, MT, TAPS, LN_NONE, SPL>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);   // split rows out
         } else {
             if (d.y_dtype == MAGE_F32) epilogue_lean<ACT, float, MT, TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
-            else epilogue_lean<ACT, H16, MT, TAPS, LN_NONE, 0, H16, RB && !TAPS>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
+            else epilogue_lean<ACT, H16, MT, TAPS, LN_NONE, 0, H16, RB && (!TAPS || EK == EK_BIAS)>(d, biasm, acc, m0, n0, lane_e, plane, stg, ysplit);
         }
         MAGE_STAMP(it, 1);                             // probe: epilogue issued
     }
@@ -1405,13 +1405,13 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
 
 // Padded-taps convolutions on the 8-phase kernel (gemm8_kernel TAPS): eligible shapes only; returns 1 if launched, 0 if not
 // eligible (the caller falls through to the generic gather kernel), < 0 on error.
-template <int ACT, int EK, int SPL = 0, int LN = LN_NONE, bool HF = false>
+template <int ACT, int EK, int SPL = 0, int LN = LN_NONE, bool HF = false, bool RB = false>
 int launch_taps8(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     const int dev = mage_device_index();
     MAGE_CHECK_ARG(dev >= 0, "mage_gemm: no current device");
     static bool attr[MAGE_MAX_DEVICES] = {false};
     if (!attr[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK, false, true, LN, SPL, false, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm8_kernel<ACT, EK, false, true, LN, SPL, RB, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr[dev] = true;
     }
     GemmArgs a;
@@ -1424,7 +1424,7 @@ int launch_taps8(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     a.stagger_groups = 0;
     a.stagger_sleeps = 0;
     const int grid = a.ntiles >= n_cu ? n_cu : ((a.ntiles + 7) & ~7);
-    hipLaunchKernelGGL((gemm8_kernel<ACT, EK, false, true, LN, SPL, false, HF>), dim3(grid), dim3(512), 160 * 1024, s, a);
+    hipLaunchKernelGGL((gemm8_kernel<ACT, EK, false, true, LN, SPL, RB, HF>), dim3(grid), dim3(512), 160 * 1024, s, a);
     MAGE_CHECK_LAUNCH("mage_gemm");
     return 1;
 }
@@ -1470,6 +1470,13 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
         if constexpr (SPL == 0 && !HF) return launch_taps8<MAGE_ACT_RELU, EK_BIAS, 0, LN_HEAD>(d, s, n_cu);
     }
     if (table && d->act == MAGE_ACT_NONE && (((uintptr_t)d->rowadd) & 15) == 0) return launch_taps8<MAGE_ACT_NONE, EK_RES_INIT, SPL, LN_NONE, HF>(d, s, n_cu);
+    if constexpr (SPL == 0 && !HF) {
+        // a convolution that adds a bf16 residual tensor of its own (optionally at half resolution) and writes bf16 rows: a bottleneck block's
+        // closing convolution + identity path (vqvae_model.py:147-166); the residual rows are fetched in the epilogue (epilogue_lean RESE)
+        if (!d->rowadd && d->residual && d->res_dtype == MAGE_BF16 && d->y_dtype == MAGE_BF16 && d->act == MAGE_ACT_NONE && d->bias && d->ldr % 8 == 0 &&
+            d->ldr >= d->N && (((uintptr_t)d->residual) & 15) == 0 && d->y_mul_x == 1)
+            return launch_taps8<MAGE_ACT_NONE, EK_BIAS, 0, LN_NONE, false, true>(d, s, n_cu);
+    }
     if constexpr (HF) return 0;                        // f16: the row-table forms only (context_linear / in_linear / the frame convolution + positions)
     if constexpr (SPL == 0) {
         if (plain && d->act == MAGE_ACT_NONE) return launch_taps8<MAGE_ACT_NONE, EK_BIAS>(d, s, n_cu);

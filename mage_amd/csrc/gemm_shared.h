@@ -76,6 +76,7 @@ enum { LN_NONE = 0, LN_PRODUCE = 1, LN_CONSUME = 2, LN_DUAL = 3, LN_GELUBWD = 4,
 // for its own 128 KB of rows -- 13-17 k of a 55 k-cycle tile period at N = K = 512 (profiles/r04_clock_probe.txt; a residual-free GEMM of
 // that size runs 121 us against 188, profiles/r05_residual_form_probe.txt).  Here nothing waits at the tile start, and the rows' latency
 // hides behind the epilogue's own arithmetic.  The sum is (acc + bias) + x, the reference's own order (x + Linear(.), mage_model.py:48,52).
+// With AFFINE (the padded-taps convolutions) the residual rows follow the convolution's own row map (optionally at half resolution, res_half).
 template <int ACT, typename OT, int MT, bool AFFINE = false, int LN = LN_NONE, int OSPL = 0,
           typename HT = std::conditional_t<sizeof(OT) == 2, OT, unsigned short>, bool RESE = false>
 __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32x4 (&bias)[4], f32x4 (&acc)[MT][4], int m0, int n0,
@@ -146,7 +147,16 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = min(m0 + t * 16 + (lane >> 3) + 8 * i, d.M - 1);
-            rland[t % RD][i] = *(const u32x4*)(rbase + (long)(m * d.y_mul_x + d.y_off) * d.ldr);
+            if constexpr (AFFINE) {
+                // convolution rows (padded-taps form): the residual is a [img, out_h, out_w, N] tensor of its own -- or, res_half, that tensor at
+                // half resolution (nn.Upsample of a bottleneck block's identity path folded into the convolution that adds it)
+                const int img = m / plane, rem = m - img * plane;
+                const int oy = rem / d.out_w, ox = rem - oy * d.out_w;
+                const long rrow = d.res_half ? (long)img * (plane >> 2) + (long)(oy >> 1) * (d.out_w >> 1) + (ox >> 1) : (long)m;
+                rland[t % RD][i] = *(const u32x4*)(rbase + rrow * d.ldr);
+            } else {
+                rland[t % RD][i] = *(const u32x4*)(rbase + (long)(m * d.y_mul_x + d.y_off) * d.ldr);
+            }
         }
     };
     if constexpr (RESE) {

@@ -350,9 +350,14 @@ class VectorQuantizedVAE(nn.Module):
             h = h1                                  # stays at low resolution too: the next convolution gathers it there (a_half);
             j0 = 1                                  # the identity path is read there by the last convolution (res_half)
         Pw, PP = W + 2, (H + 2) * (W + 2)
+        # the closing 3x3 convolution (hid -> cout, + identity path) in the padded-taps form on the 8-phase kernel, the identity rows fetched in
+        # its epilogue (at half resolution behind an Upsample); with 64 hidden channels a K slab is one tap, so the sums keep the gather kernel's order
+        taps_close = (head is None and last_k == 3 and not post_relu and dt == torch.bfloat16 and hid % 64 == 0 and cout % 256 == 0
+                      and (n_img * H * W) % 256 == 0 and (n_img * PP + PP) * hid * 2 < 2 ** 32 and config.get().decode_taps8
+                      and not config.lib_flag("gemm_no_8phase") and not config.lib_flag("gemm_no_taps8"))
         for j in range(j0, 3):
             half = dict(a_half=True, a_img_stride=Hi * Wi) if (up_first and j == 1) else {}
-            if head is not None and j == 2:             # the closing convolution's input: the interior of a zero-padded frame buffer
+            if (head is not None or taps_close) and j == 2:             # the closing convolution's input: the interior of a zero-padded frame buffer
                 key = ("f8tail", n_img, H, W, hid, str(dev), torch.cuda.current_stream(dev).cuda_stream)
                 nh = self._pad_bufs.get(key)
                 if nh is None:
@@ -372,6 +377,10 @@ class VectorQuantizedVAE(nn.Module):
                      residual=idp, ldr=cout, res_half=up_first, head_w=head)
             return sums
         out = torch.empty(n_img * H * W, cout, device=dev, dtype=dt)
+        if taps_close:
+            ops.gemm(h, w[p + ".w7" + s], out, M=n_img * H * W, N=cout, K=9 * hid, lda=hid, ldy=cout, out_h=H, out_w=W, in_h=H + 2, in_w=Pw,
+                     a_img_stride=PP, taps_h=3, taps_w=3, cin=hid, stride=1, dy0=0, dx0=0, bias=w[p + ".b7"], residual=idp, ldr=cout, res_half=up_first)
+            return out
         self._conv(h, w[p + ".w7" + s], out, n_img=n_img, H=H, W=W, cin=hid, cout=cout, k=ks[3], bias=w[p + ".b7"],
                    residual=idp, ldr=cout, post_relu=post_relu, res_half=up_first)
         return out

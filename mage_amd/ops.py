@@ -324,6 +324,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
                 key = f"gemm8_kernel<0, 1, false, true, 0, 0, false, {hf}>"
             elif (plain or (head_w is not None and rowadd is None)) and act in (ACT_NONE, ACT_RELU) and d.dtype == BF16:
                 key = f"gemm8_kernel<{act}, 0, false, true, {5 if head_w is not None else 0}, 0, false, false>"
+            elif (rowadd is None and residual is not None and residual.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and act == ACT_NONE
+                  and d.dtype == BF16 and bias is not None and y_mul_x == 1):
+                key = "gemm8_kernel<0, 0, false, true, 0, 0, true, false>"       # the convolution adds a residual tensor in its epilogue
         # 64 -> 64 channel 3x3 convolutions over whole 16 x 16 pixel tiles (mage_conv3x3_c64_try in csrc/conv_tile.hip)
         tile_conv = (d.dtype == BF16 and y.dtype == torch.bfloat16 and N == 64 and d.cin == 64 and taps_h == 3 and taps_w == 3 and stride == 1 and dy0 == -1
                      and dx0 == -1 and dys == 1 and dxs == 1 and d.in_h == out_h and d.in_w == out_w and out_h % 16 == 0 and out_w % 16 == 0 and ek == 0

@@ -485,6 +485,41 @@ def test_tile_convolution_64_channels_equals_the_implicit_gemm(n_img, R, half, p
         assert full[:, 0].abs().max().item() == 0 and full[:, :, 0].abs().max().item() == 0 and full[:, -1].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("n_img,R,hid,cout,half", [(32, 32, 64, 256, True), (16, 64, 64, 256, False), (64, 16, 128, 512, False)])
+def test_padded_taps_conv_adds_a_residual_tensor_in_its_epilogue(n_img, R, hid, cout, half):
+    """A bottleneck block's closing convolution (3x3, hid -> cout) + identity path in the padded-taps form of the 8-phase kernel: the bf16 identity
+    rows -- at half resolution behind an Upsample (res_half) -- are fetched in the epilogue.  Against the implicit-GEMM kernel's general
+    epilogue on the unpadded input: with 64 hidden channels (a K slab is one tap) the same bits; with 128 the same sums in another order."""
+    o = ops()
+    P = R + 2
+    x = rnd(n_img, R, R, hid, seed=140).bfloat16()
+    w = rnd(cout, 3, 3, hid, seed=141, scale=(9 * hid) ** -0.5).bfloat16()
+    bias = rnd(cout, seed=142, scale=0.1).to(DEV)
+    Rr = R // 2 if half else R
+    res = rnd(n_img * Rr * Rr, cout, seed=143).bfloat16().to(DEV)
+    pad = torch.zeros(n_img, P, P, hid, dtype=torch.bfloat16)
+    pad[:, 1:-1, 1:-1] = x
+    pad = torch.cat([pad.view(-1, hid), torch.zeros(1, hid, dtype=torch.bfloat16)]).to(DEV)
+    wd = w.reshape(cout, 9 * hid).to(DEV)
+    M = n_img * R * R
+    y_taps = torch.empty(M, cout, device=DEV, dtype=torch.bfloat16)
+    y_gen = torch.empty_like(y_taps)
+    o.gemm(pad, wd, y_taps, M=M, N=cout, K=9 * hid, lda=hid, ldy=cout, out_h=R, out_w=R, in_h=P, in_w=P, a_img_stride=P * P, taps_h=3, taps_w=3,
+           cin=hid, stride=1, dy0=0, dx0=0, bias=bias, residual=res, ldr=cout, res_half=half)
+    o.gemm(x.view(-1, hid).to(DEV), wd, y_gen, M=M, N=cout, K=9 * hid, lda=hid, ldy=cout, out_h=R, out_w=R, in_h=R, in_w=R, taps_h=3, taps_w=3,
+           cin=hid, stride=1, dy0=-1, dx0=-1, bias=bias, residual=res, ldr=cout, res_half=half)
+    if hid == 64:
+        assert torch.equal(y_taps, y_gen)
+    else:
+        assert (y_taps.float() - y_gen.float()).abs().max().item() <= 2 ** -6 * max(1.0, y_gen.float().abs().max().item())
+    import torch.nn.functional as F
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1) + bias.cpu()
+    r4 = res.float().cpu().view(n_img, Rr, Rr, cout)
+    if half:
+        r4 = r4.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    torch.testing.assert_close(y_taps.float().cpu().view(n_img, R, R, cout), ref + r4, atol=4e-2, rtol=2e-2)
+
+
 def test_gemm_over_relu_of_the_operand_rows():
     """mage_gemm_desc::a_relu (the 256 x 64 tile, bf16): A W^T over relu(A) == the product over a stored relu(A), bit for bit; refused
     where the shape does not run on that tile."""
