@@ -332,9 +332,12 @@ def cfg4_probe(m4, dev, B=32, L=32):
                                  "hbm_model": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                                                "bytes_model_per_frame": F8_DEC_BYTES_PER_FRAME["bf16"]},
                                  "flop_per_frame": F8_DEC_FLOP_PER_FRAME,
-                                 "note": "VectorQuantizedVAE.decode (f8: 1024-wide codebook rows -> 3 DecoderBlocks with nearest upsampling -> 1x1 head) of "
-                                         "the call's generated frames; 221 FLOP per byte of the layer-materialised model: MFMA-bound, the HBM figure "
-                                         "is SURVEY 8d's bf16 byte model over the same time"}
+                                 "note": "VectorQuantizedVAE.decode (f8: 1024-wide codebook rows -> 4 bottleneck DecoderBlocks, 3 of them behind a nearest upsampling "
+                                         "that is folded into the block's gathers -> 1x1 RGB head + tanh) of the call's generated frames; 221 FLOP per byte of the "
+                                         "layer-materialised model: MFMA-bound, the HBM figure is SURVEY 8d's bf16 byte model over the same time.  Launches per "
+                                         "block: 1x1 (leading ReLU on its operand fragments), two 3x3 64 -> 64 tile convolutions (csrc/conv_tile.hip: input window "
+                                         "and weights resident in LDS), closing 3x3 in the padded-taps form with the identity path added in its epilogue; the last "
+                                         "block's closing convolution also takes the decoder's ReLU and the RGB head on its tile (its 8 MB-per-frame output never stored)"}
     imgs = batch["images"].reshape(-1, 3, 128, 128)[:frames // 4].contiguous()      # a quarter of the frames (the exact-fp32 encoder: 16x the MFMA time)
     ms_e = timed(lambda: m4.first_stage_model.encode(imgs), 2)
     tfe = F8_ENC_FLOP_PER_FRAME * imgs.shape[0] / (ms_e * 1e-3) / 1e12
