@@ -126,7 +126,10 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const Conv64Args g) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) wf[slot][nt] = *(const u32x4*)(smem + tap * 8192 + nt * 2048 + woff[t]);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) xf[slot][mt] = *(const u32x4*)(win + (mt + ky) * (18 * 128) + xoff[kx][t]);
+            for (int mt = 0; mt < 4; ++mt) {
+                MAGE_DASSERT((wave * 4 + mt + ky) * (18 * 128) + xoff[kx][t] + 16 <= C64_HALO_PIX * 128 && tap * 8192 + 3 * 2048 + woff[t] + 16 <= C64_W_BYTES);
+                xf[slot][mt] = *(const u32x4*)(win + (mt + ky) * (18 * 128) + xoff[kx][t]);
+            }
         };
         fetch(0, 0);
 #pragma unroll
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const Conv64Args g) {
         char* stg = smem + C64_W_BYTES + buf * C64_HALO_BYTES + wave * 2048;
         const int img = tile / g.tiles_per_img, rem = tile - img * g.tiles_per_img;
         const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+        MAGE_DASSERT(tile >= 0 && tile < g.ntiles && ty * 16 < g.H && tx * 16 < g.Wd && 4 * 2048 <= C64_HALO_BYTES);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
