@@ -641,8 +641,9 @@ def main():
                     "free_running_token_agreement_with_f16x3": (agreement(tok16, tok3) if parity is not None else None),
                     "note": "set_precision('f16'): every kernel, schedule and buffer of the bf16 mode with IEEE half operands and rows "
                             "(v_mfma_f32_16x16x32_f16: the bf16 opcode's rate; 11 significand bits instead of 8).  Teacher-forced logits against "
-                            "the reference's goldens: 0.002 (bf16: 0.016, tests/test_gpu_f16.py); on trained weights 13 of 16 held-out clips keep "
-                            "the CPU oracle's exact token sequence where bf16 keeps 1 (cpu_baseline.gpu_tokens_vs_oracle_trained_weights).  "
+                            "the reference's goldens: 0.002 (bf16: 0.016, tests/test_gpu_f16.py); on trained weights most held-out clips keep "
+                            "the CPU oracle's exact token sequence where bf16 keeps hardly any (this line's cpu_baseline.gpu_tokens_vs_oracle_trained_weights: "
+                            "clips_identical_count per mode).  "
                             "Which mode to run: 'f16x3' when the reference's tokens are wanted bit for bit (parity_mode); 'f16' for throughput "
                             "-- it costs nothing against 'bf16' and is 8x closer to the reference; 'bf16' only if activations could leave "
                             "f16's range (+-65504)"}

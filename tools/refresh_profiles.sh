@@ -4,9 +4,8 @@
 TAG=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
-# PMC first: bench.py reads the committed summary for roofline.traffic, so refresh it on the box before the bench line
-bash $GRAFT_REPO_ROOT/tools/pmc_bench.sh $TAG > $OUT/pmc_$TAG.txt 2>&1
-cp $OUT/pmc_$TAG.json $GRAFT_REPO_ROOT/profiles/${TAG}_pmc_traffic.json
+# the bench line first, on a rested chip (the PMC passes before it cost the line 3-6 % on some boxes); roofline.traffic comes from the
+# committed PMC summary (profiles/<tag>_pmc_traffic.json), refreshed by the passes at the end of this script for the next commit
 cd $GRAFT_REPO_ROOT
 python bench.py 2> $OUT/bench_$TAG.err | tail -1 > $OUT/${TAG}_bench_cfg2_bf16.json
 cd /tmp && export TMPDIR=/tmp
@@ -28,4 +27,5 @@ rm -rf /tmp/kd
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kd -o k -- python $GRAFT_REPO_ROOT/tools/bench_vqvae.py > $OUT/${TAG}_decode_bench.txt 2>&1
 cp /tmp/kd/k_kernel_stats.csv $OUT/${TAG}_decode_kernel_stats.csv
 python $GRAFT_REPO_ROOT/tools/decode_timeline.py /tmp/kd > $OUT/${TAG}_decode_timeline.txt 2>&1      # one decode call, launch by launch, with the gaps
+bash $GRAFT_REPO_ROOT/tools/pmc_bench.sh $TAG > $OUT/pmc_$TAG.txt 2>&1
 cat $OUT/${TAG}_gpu_busy.txt; head -c 600 $OUT/${TAG}_bench_cfg2_bf16.json; echo; tail -9 $OUT/pmc_$TAG.txt
