@@ -833,12 +833,14 @@ def test_vq_nearest_on_the_fp64_matrix_cores(M, D, K):
     torch.testing.assert_close(mg, srt.values[:, 1] - srt.values[:, 0], atol=0, rtol=0)
 
 
-def test_table_conv_equals_convolution_of_embeddings_and_folded_linear():
+@pytest.mark.parametrize("Cd", [128, 512])
+def test_table_conv_equals_convolution_of_embeddings_and_folded_linear(Cd):
     """mage_table_conv: conv3x3(embedding(ids)) + positions (+ a Linear folded into the table) as a gather-sum, against torch's conv2d
-    on the embedded image (fp64), incl. border pixels, regrouped output rows and the broadcast row table."""
+    on the embedded image (fp64), incl. border pixels, regrouped output rows and the broadcast row table.  Cd = 512 with 16-bit tables and
+    rows runs the 8-channels-per-lane kernel (table_conv512_kernel): the same bits as the generic one on the fp32 copy of the table."""
     from mage_amd import ops as o
     g = torch.Generator().manual_seed(8)
-    Kc, C, Cd, R, B, Lm1, L = 48, 64, 128, 6, 2, 3, 4
+    Kc, C, R, B, Lm1, L = 48, 64, 6, 2, 3, 4
     emb = torch.randn(Kc, C, generator=g).to(DEV)
     cw = (torch.randn(C, C, 3, 3, generator=g) * 0.1).to(DEV)                      # [Cout, Cin, kh, kw]
     w_in = (torch.randn(Cd, C, generator=g) * 0.1).to(DEV)
