@@ -1474,7 +1474,9 @@ int try_taps8(const mage_gemm_desc* d, hipStream_t s) {
         // a convolution that adds a bf16 residual tensor of its own (optionally at half resolution) and writes bf16 rows: a bottleneck block's
         // closing convolution + identity path (vqvae_model.py:147-166); the residual rows are fetched in the epilogue (epilogue_lean RESE)
         if (!d->rowadd && d->residual && d->res_dtype == MAGE_BF16 && d->y_dtype == MAGE_BF16 && d->act == MAGE_ACT_NONE && d->bias && d->ldr % 8 == 0 &&
-            d->ldr >= d->N && (((uintptr_t)d->residual) & 15) == 0 && d->y_mul_x == 1)
+            d->ldr >= d->N && (((uintptr_t)d->residual) & 15) == 0 && d->y_mul_x == 1 &&
+            // (without res_half the residual is indexed like the OUTPUT rows, as in the general epilogue: here only where that is the plain row m)
+            (d->res_half || (d->out_h * d->out_w == d->y_img_stride && d->y_mul_y == d->out_w && d->y_off == 0)))
             return launch_taps8<MAGE_ACT_NONE, EK_BIAS, 0, LN_NONE, false, true>(d, s, n_cu);
     }
     if constexpr (HF) return 0;                        // f16: the row-table forms only (context_linear / in_linear / the frame convolution + positions)
