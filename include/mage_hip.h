@@ -149,7 +149,7 @@ typedef struct mage_gemm_desc {
     int64_t a_split_stride, w_split_stride, y_split_stride;
     /* LayerNorm folded around the decoder's GEMMs (bf16, plain rows, M and N multiples of 256; mage_model.py:35-53: the
      * x + dropout(attn(ln_1(x))) / x + mlp(ln_2(x)) chain).  Producer -- the x + Linear(.) GEMM that writes the fp32 stream: with y2
-     * set it also writes a bf16 copy of the new rows (ldy2 elements per row) and ln_part[row][N/64][2] = (sum, sum of squares) of each
+     * set it also writes a bf16 copy of the new rows (ldy2 elements per row) and ln_part[N/64][ln_part_rows][2] = (sum, sum of squares) of each
      * 64-column slice; mage_ln_stats reduces those to ln_stats[row][2] = (mean, rstd).  Consumer -- the Linear that follows the norm:
      * A = that bf16 copy, W = gamma * W (per input channel), bias = W beta + b, ln_colsum[n] = sum_k W'[n, k]; with ln_stats set the
      * epilogue computes rstd_m (acc - mean_m ln_colsum[n]) + bias[n] before the activation: LN(x) W^T + b without the LayerNorm pass.
@@ -193,14 +193,17 @@ typedef struct mage_gemm_desc {
                                         * bottleneck block's first 1x1 convolution (vqvae_model.py:147-166: Sequential(ReLU, Conv2d 1x1, ...)) applied to
                                         * the operand fragments, so that relu(x) is never stored next to x (which the identity path reads).  Refused
                                         * on every other form */
+    int64_t ln_part_rows;              /* rows of the ln_part buffer = the stride (in float2) between two 64-column slices: slice-major, so that the 16
+                                        * rows of an accumulator tile leave as ONE 128-byte store (row-major partial sums left as 16 scattered 8-byte
+                                        * pieces per store) and mage_ln_stats reads them coalesced.  Required (> the largest output row) with ln_part */
 } mage_gemm_desc;
 
 int mage_gemm(const mage_gemm_desc* desc, void* stream);
 /* 1 if a bf16 plain GEMM of this size (lean epilogue: bias / x + Linear(.) / the LayerNorm-folded forms) runs on the few-rows kernel
  * on the current device (one clip per call), 0 if on the tiled kernels, < 0 on error */
 int mage_gemm_is_small(int32_t M, int32_t N, int32_t K);
-/* stats[row] = (mean, rstd) from the producer GEMM's partial sums: mean = sum_s part[row][s][0] / C,
- * var = sum_s part[row][s][1] / C - mean^2, rstd = 1 / sqrt(max(var, 0) + eps); fixed order. */
+/* stats[row] = (mean, rstd) from the producer GEMM's partial sums part[n_slices][rows][2] (slice-major: mage_gemm_desc::ln_part_rows = rows):
+ * mean = sum_s part[s][row][0] / C, var = sum_s part[s][row][1] / C - mean^2, rstd = 1 / sqrt(max(var, 0) + eps); fixed order (s ascending). */
 int mage_ln_stats(const float* part, int64_t rows, int32_t n_slices, int32_t C, float eps, float* stats, void* stream);
 /* stats[row] = (mean, rstd) of bf16 rows x[row][0..C) (fp32 sums): the LayerNorm in front of the decoder's first Linear when the residual
  * stream starts in bf16 (mage_model.py:35-36,47 on the rows mage_model.py:375-378 assembles); consumed like mage_ln_stats' output */

@@ -36,7 +36,7 @@ class GemmDesc(C.Structure):
         ("post_relu", i32), ("ldw", i32), ("n_split", i32),
         ("a_split_stride", i64), ("w_split_stride", i64), ("y_split_stride", i64),
         ("y2", vp), ("ldy2", i32), ("res_half", i32), ("ln_part", vp), ("ln_stats", vp), ("ln_colsum", vp), ("a_half", i32), ("ln_eps", C.c_float),
-        ("head_w", vp), ("head_phases", i32), ("a_relu", i32),
+        ("head_w", vp), ("head_phases", i32), ("a_relu", i32), ("ln_part_rows", i64),
     ]
 
 

@@ -114,10 +114,11 @@ __device__ __forceinline__ void store4(float* p, f32x4 v) { *(f32x4*)p = v; }
 // two fp32 -> packed bf16x2 with the hardware converter (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN-safe)
 // (mean, rstd) of a row from the producer GEMM's per-slice partial sums (sum, sum of squares): ONE definition for mage_ln_stats and for the
 // few-rows GEMM that folds it into its prologue, explicit roundings: the same bits from both.
-__device__ __forceinline__ void mage_ln_stats_row(const float2* __restrict__ p, int n_slices, float inv_c, float eps, float& mean, float& rstd) {
+// (p: the row's first partial sum; consecutive slices are `stride` float2 apart: slice-major ln_part, mage_gemm_desc::ln_part_rows)
+__device__ __forceinline__ void mage_ln_stats_row(const float2* __restrict__ p, long stride, int n_slices, float inv_c, float eps, float& mean, float& rstd) {
     float s1 = 0.f, s2 = 0.f;
     for (int i = 0; i < n_slices; ++i) {
-        const float2 v = p[i];
+        const float2 v = p[(long)i * stride];
         s1 = __fadd_rn(s1, v.x);
         s2 = __fadd_rn(s2, v.y);
     }

@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const mage_gemm_desc d)
             const int ns = d.K >> 6;
 #pragma unroll
             for (int a = 0; a < RW; ++a)
-                mage_ln_stats_row((const float2*)d.ln_part + (long)min(m0 + a * 16 + l15, d.M - 1) * ns, ns, 1.0f / (float)d.K, d.ln_eps,
+                mage_ln_stats_row((const float2*)d.ln_part + (long)min(m0 + a * 16 + l15, d.M - 1), d.ln_part_rows, ns, 1.0f / (float)d.K, d.ln_eps,
                                   lnc.mean[a], lnc.rstd[a]);
         }
     }

@@ -45,7 +45,7 @@ enum { EK_BIAS = 0, EK_RES_INIT = 1, EK_GENERAL = 2 };
 // yrow = m + group*(y_img_stride - P) + y_off.  A template parameter so that the Linear layers' kernels keep their exact code.
 // LN: LayerNorm folded around the GEMMs (bf16 mode of the decoder stack; interior tiles and simple rows only -- the host checks).
 //   LN_PRODUCE (x + Linear(.), fp32 stream out): the epilogue also writes a bf16 copy of the new x (y2) and, per row and per
-//     64-column wave slice, the partial sums (sum x, sum x^2) of the fp32 values it holds anyway (ln_part[row][N/64][2]):
+//     64-column wave slice, the partial sums (sum x, sum x^2) of the fp32 values it holds anyway (ln_part[N/64][rows][2]):
 //     mage_ln_stats turns them into (mean, rstd) per row.  The standalone LayerNorm pass (read 4 B + write 2 B per element) is gone.
 //   LN_CONSUME (the Linear that follows the norm): A is that bf16 copy of x, W carries gamma (W' = gamma * W, rounded to bf16),
 //     and the epilogue finishes the norm algebraically:   LN(x) W^T + b = rstd_m (x W'^T - mean_m s_n) + c_n,
@@ -247,7 +247,7 @@ __device__ __forceinline__ void epilogue_lean(const mage_gemm_desc& d, const f32
             s2 += __shfl_xor(s2, 32);
             if (grp == 0) {
                 const long row = (long)(m0 + mt * 16 + l15) * d.y_mul_x + d.y_off;
-                float* pp = d.ln_part + (row * (d.N >> 6) + (n0 >> 6)) * 2;
+                float* pp = d.ln_part + ((long)(n0 >> 6) * d.ln_part_rows + row) * 2;       // slice-major: the tile's 16 rows = 128 contiguous bytes
                 *(float2*)pp = float2{s1, s2};
             }
         }

@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
     const long r = (long)blockIdx.x * 256 + threadIdx.x;
     if (r >= rows) return;
     float mean, rstd;
-    mage_ln_stats_row((const float2*)part + r * n_slices, n_slices, inv_c, eps, mean, rstd);
+    mage_ln_stats_row((const float2*)part + r, rows, n_slices, inv_c, eps, mean, rstd);          // slice-major: each slice's loads are coalesced
     *(float2*)(stats + 2 * r) = float2{mean, rstd};
 }
 }  // namespace

@@ -529,7 +529,7 @@ class FlatAxialDecoder(nn.Module):
         inl = fill_stats = False
         if fold:
             xb = torch.empty(M, Cc, device=dev, dtype=dt)                          # the bf16 stream (or the bf16 copy of the fp32 one)
-            part = torch.empty(M, Cc // 64, 2, device=dev, dtype=F32)
+            part = torch.empty(Cc // 64, M, 2, device=dev, dtype=F32)       # slice-major (mage_gemm_desc::ln_part_rows)
             stats = torch.empty(M, 2, device=dev, dtype=F32)
             inl = self._stats_inline(xb, M)
         # the stream starts in bf16 too: context_linear and the frame fill write bf16 rows, their LayerNorm statistics come from one pass
@@ -647,7 +647,7 @@ class FlatAxialDecoder(nn.Module):
         inl = fill_stats = False
         if fold:                                                             # see _run
             xb = torch.empty(M, Cc, device=dev, dtype=dt)
-            part = torch.empty(M, Cc // 64, 2, device=dev, dtype=F32)
+            part = torch.empty(Cc // 64, M, 2, device=dev, dtype=F32)       # slice-major (mage_gemm_desc::ln_part_rows)
             stats = torch.empty(M, 2, device=dev, dtype=F32)
             inl = self._stats_inline(xb, M)
         x0 = xb if sb else torch.empty(M, Cc, device=dev, dtype=F32)

@@ -267,6 +267,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
     d.a_split_stride, d.w_split_stride, d.y_split_stride = a_split_stride, w_split_stride, y_split_stride
     d.y2, d.ldy2, d.ln_part, d.ln_stats, d.ln_colsum = _p(y2), ldy2, _p(ln_part), _p(ln_stats), _p(ln_colsum)
     d.ln_eps = float(ln_eps)
+    if ln_part is not None:                                 # slice-major partial sums [n_slices, rows, 2] (mage_gemm_desc::ln_part_rows)
+        assert ln_part.dtype == torch.float32 and ln_part.dim() == 3 and ln_part.shape[2] == 2 and ln_part.is_contiguous(), tuple(ln_part.shape)
+        d.ln_part_rows = ln_part.shape[1]
     if head_w is not None:
         assert head_w.dtype == torch.bfloat16 and head_w.is_contiguous() and tuple(head_w.shape) == (16, N // (head_phases or 1)) \
             and y.dtype == torch.float32, (head_w.dtype, tuple(head_w.shape), y.dtype)
@@ -425,9 +428,9 @@ def row_stats(x: torch.Tensor, eps: float, stats: torch.Tensor) -> torch.Tensor:
 
 
 def ln_stats(part: torch.Tensor, C_: int, eps: float, stats: torch.Tensor) -> torch.Tensor:
-    """(mean, rstd) per row from a producer GEMM's partial sums ``part[rows, n_slices, 2]`` (mage_ln_stats)."""
+    """(mean, rstd) per row from a producer GEMM's partial sums ``part[n_slices, rows, 2]`` (slice-major; mage_ln_stats)."""
     l, s = _dev(part)
-    rows, n_slices = part.shape[0], part.shape[1]
+    n_slices, rows = part.shape[0], part.shape[1]
     assert part.dtype == torch.float32 and part.is_contiguous() and stats.is_contiguous() and stats.numel() >= 2 * rows
     if PROFILE.wants("ln_stats_kernel"):
         ev = PROFILE.begin()

@@ -663,13 +663,13 @@ def test_layernorm_folded_around_the_gemms(M, ht):
     o.gemm(aod, wod, x_plain, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bod, residual=x_plain, ldr=C_)
     x_new = xd.clone()
     xb = torch.empty(M, C_, device=DEV, dtype=ht)
-    part = torch.empty(M, C_ // 64, 2, device=DEV, dtype=torch.float32)
+    part = torch.empty(C_ // 64, M, 2, device=DEV, dtype=torch.float32)             # slice-major (mage_gemm_desc::ln_part_rows)
     o.gemm(aod, wod, x_new, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bod, residual=x_new, ldr=C_, y2=xb, ldy2=C_, ln_part=part)
     assert torch.equal(x_new, x_plain)
     assert torch.equal(xb, x_new.to(ht))
     xs = x_new.double().view(M, C_ // 64, 64)
-    torch.testing.assert_close(part[..., 0].double(), xs.sum(-1), atol=1e-4, rtol=1e-5)
-    torch.testing.assert_close(part[..., 1].double(), (xs * xs).sum(-1), atol=1e-3, rtol=1e-5)
+    torch.testing.assert_close(part[..., 0].t().double(), xs.sum(-1), atol=1e-4, rtol=1e-5)
+    torch.testing.assert_close(part[..., 1].t().double(), (xs * xs).sum(-1), atol=1e-3, rtol=1e-5)
     stats = torch.empty(M, 2, device=DEV, dtype=torch.float32)
     o.ln_stats(part, C_, eps, stats)
     mean = x_new.double().mean(-1)
@@ -695,15 +695,15 @@ def test_layernorm_folded_around_the_gemms(M, ht):
         # ... and with (mean, rstd) taken from the partial sums inside the few-rows kernel (no mage_ln_stats launch): the same bits
         assert o.gemm_is_small(xb, 256, 4 * C_, C_)
         y_p = torch.empty(256, 4 * C_, device=DEV, dtype=ht)
-        o.gemm(xb[:256], wq.to(DEV), y_p, M=256, N=4 * C_, K=C_, lda=C_, ldy=4 * C_, bias=c.to(DEV), act=act, ln_part=part[:256],
-               ln_eps=eps, ln_colsum=s.to(DEV))
+        o.gemm(xb[:256], wq.to(DEV), y_p, M=256, N=4 * C_, K=C_, lda=C_, ldy=4 * C_, bias=c.to(DEV), act=act, ln_part=part,
+               ln_eps=eps, ln_colsum=s.to(DEV))             # (rows 0..255 of the slice-major buffer: its row stride is ln_part_rows = M)
         assert torch.equal(y_p, y[:256])
     # ... and the producer's extra outputs do not depend on the kernel either
     x_s = xd[:256].clone()
     xb_s = torch.empty(256, C_, device=DEV, dtype=ht)
-    part_s = torch.empty(256, C_ // 64, 2, device=DEV, dtype=torch.float32)
+    part_s = torch.empty(C_ // 64, 256, 2, device=DEV, dtype=torch.float32)
     o.gemm(aod[:256], wod, x_s, M=256, N=C_, K=C_, lda=C_, ldy=C_, bias=bod, residual=x_s, ldr=C_, y2=xb_s, ldy2=C_, ln_part=part_s)
-    assert torch.equal(x_s, x_new[:256]) and torch.equal(xb_s, xb[:256]) and torch.equal(part_s, part[:256])
+    assert torch.equal(x_s, x_new[:256]) and torch.equal(xb_s, xb[:256]) and torch.equal(part_s, part[:, :256])
     # loud on shapes the folded forms do not take (the partial-sum form exists in the few-rows kernel only)
     if M > 1024:
         with pytest.raises(Exception):
@@ -742,7 +742,7 @@ def test_x_plus_linear_on_a_bf16_residual_stream(M, ht):
     want = xb0.double().cpu() + ao.double().cpu() @ wo.double().cpu().t() + bo.double().cpu()
     # 16-bit residual in, 16-bit rows out, in place, with the partial sums
     xb = xb0.clone()
-    part = torch.empty(M, C_ // 64, 2, device=DEV, dtype=torch.float32)
+    part = torch.empty(C_ // 64, M, 2, device=DEV, dtype=torch.float32)
     o.gemm(ao, wo, xb, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xb, ldr=C_, ln_part=part)
     # fp32 rows of the same sum from the general epilogue (a 16-bit residual with fp32 rows out): (acc + b) + x
     y32 = torch.empty(M, C_, device=DEV, dtype=torch.float32)
@@ -750,8 +750,8 @@ def test_x_plus_linear_on_a_bf16_residual_stream(M, ht):
     torch.testing.assert_close(y32.double().cpu(), want, atol=2e-3, rtol=1e-3)
     assert torch.equal(xb, y32.to(ht))                                  # the stream rows = that fp32 sum, rounded once
     ys = y32.double().view(M, C_ // 64, 64)
-    torch.testing.assert_close(part[..., 0].double(), ys.sum(-1), atol=2e-4, rtol=1e-5)
-    torch.testing.assert_close(part[..., 1].double(), (ys * ys).sum(-1), atol=2e-3, rtol=1e-5)
+    torch.testing.assert_close(part[..., 0].t().double(), ys.sum(-1), atol=2e-4, rtol=1e-5)
+    torch.testing.assert_close(part[..., 1].t().double(), (ys * ys).sum(-1), atol=2e-3, rtol=1e-5)
     # out of place, and without the LayerNorm after it (the last block): the same rows
     y16 = torch.empty_like(xb0)
     o.gemm(ao, wo, y16, M=M, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xb0, ldr=C_)
@@ -764,9 +764,9 @@ def test_x_plus_linear_on_a_bf16_residual_stream(M, ht):
     torch.testing.assert_close(part1, part, atol=2e-3, rtol=1e-4)
     # the same rows through the other kernel: bitwise
     xs = xb0[:256].clone()
-    ps = torch.empty(256, C_ // 64, 2, device=DEV, dtype=torch.float32)
+    ps = torch.empty(C_ // 64, 256, 2, device=DEV, dtype=torch.float32)
     o.gemm(ao[:256], wo, xs, M=256, N=C_, K=C_, lda=C_, ldy=C_, bias=bo, residual=xs, ldr=C_, ln_part=ps)
-    assert torch.equal(xs, xb[:256]) and torch.equal(ps, part[:256])
+    assert torch.equal(xs, xb[:256]) and torch.equal(ps, part[:, :256])
     # ragged row count (edge tiles: clamped residual rows, predicated stores), no partial sums
     Mr = M - 24
     yr = torch.full((M, C_), 7.0, device=DEV, dtype=ht)

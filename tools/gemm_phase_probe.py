@@ -12,7 +12,7 @@ a = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev)
 y = torch.randn(M, N, device=dev) if res == 1 else torch.randn(M, N, device=dev).bfloat16()
 kw = dict(M=M, N=N, K=K, lda=K, ldy=N, bias=b, act=act)
 if res: kw.update(residual=y, ldr=N)
-if res == 2: kw.update(ln_part=torch.empty(M, N // 64, 2, device=dev))
+if res == 2: kw.update(ln_part=torch.empty(N // 64, M, 2, device=dev))
 for _ in range(3): ops.gemm(a, w, y, **kw)
 torch.cuda.synchronize()
 l = _lib.load()

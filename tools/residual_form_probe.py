@@ -14,7 +14,7 @@ for N, K in ((512, 512), (512, 2048)):
     b = torch.randn(N, device=dev, generator=g)
     x = torch.randn(M, N, device=dev, generator=g).bfloat16()
     y = torch.empty_like(x)
-    part = torch.empty(M, N // 64, 2, device=dev)
+    part = torch.empty(N // 64, M, 2, device=dev)
     row = torch.randn(8, N, device=dev, generator=g).bfloat16()
     def timeit(f, n=10):
         f(); f(); torch.cuda.synchronize()

@@ -29,7 +29,7 @@ for K in (64, 128, 256, 512, 1024, 2048):
     x = torch.randn(M, N, device=DEV)
     y16 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
     xb = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
-    part = torch.empty(M, N // 64, 2, device=DEV)
+    part = torch.empty(N // 64, M, 2, device=DEV)
     t_plain = timeit(lambda: ops.gemm(a, w, y16, M=M, N=N, K=K, lda=K, ldy=N, bias=bias))
     t_res = timeit(lambda: ops.gemm(a, w, x, M=M, N=N, K=K, lda=K, ldy=N, bias=bias, residual=x, ldr=N))
     t_ln = timeit(lambda: ops.gemm(a, w, x, M=M, N=N, K=K, lda=K, ldy=N, bias=bias, residual=x, ldr=N, y2=xb, ldy2=N, ln_part=part))
