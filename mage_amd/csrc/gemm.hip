@@ -83,8 +83,9 @@ extern "C" int mage_gemm(const mage_gemm_desc* d_in, void* stream) {
     MAGE_CHECK_ARG(!d->a_half || (d->in_h % 2 == 0 && d->in_w % 2 == 0 && d->n_split == 1), "mage_gemm: a_half needs an even in_h x in_w grid");
     MAGE_CHECK_ARG(!d->res_half || (d->residual && d->out_h > 1 && d->out_h % 2 == 0 && d->out_w % 2 == 0 && d->n_split == 1),
                    "mage_gemm: res_half needs a residual and an even out_h x out_w output plane");
-    MAGE_CHECK_ARG(!d->ln_part || d->ln_part_rows > (int64_t)(d->M - 1) * d->y_mul_x + d->y_off,
-                   "mage_gemm: ln_part needs ln_part_rows (rows of the slice-major partial-sum buffer) > the largest output row");
+    // producer: the partial sums of OUTPUT row r go to ln_part[slice][r]; consumer (ln_colsum set): it reads those of its INPUT rows 0..M-1
+    MAGE_CHECK_ARG(!d->ln_part || d->ln_part_rows > (d->ln_colsum ? (int64_t)d->M - 1 : (int64_t)(d->M - 1) * d->y_mul_x + d->y_off),
+                   "mage_gemm: ln_part needs ln_part_rows (rows of the slice-major partial-sum buffer) > the largest row it is indexed with");
     MAGE_CHECK_ARG(!d->a_relu || (d->dtype == MAGE_BF16 && !gather_ && !d->a_half && d->N <= 128 && d->n_split == 1 && !d->residual && !d->rowadd && !d->scale &&
                                   !d->post_relu && !d->y2 && !d->ln_part && !d->ln_stats && !d->ln_colsum && !d->head_w),
                    "mage_gemm: a_relu is a form of the bf16 plain GEMM with N <= 128 (epilogue act(acc + bias) only)");
