@@ -26,7 +26,7 @@ from torch import nn
 
 from .. import config, ops
 from ..utils.util import default, instantiate_from_config, zero_module
-from .vqvae_model import VectorQuantizedVAE, _Derived, _conv_w, _no_torch_forward
+from .vqvae_model import VectorQuantizedVAE, _Derived, _conv_w, _no_torch_forward, weights_frozen
 
 __all__ = ["QuickGELU", "AxialAttentionBlock", "TransformerBlock", "MAEncoder", "TransformerTextEncoder", "BasicBlock",
            "ADAIN2D", "FlatAxialDecoder", "PIDControl", "MAGE"]
@@ -1205,7 +1205,8 @@ class MAGE(nn.Module):
         run under the MFMA-bound GEMMs of the other instead of in front of them."""
         images = batch["images"]
         _need_gpu(images, "MAGE.autoregressive_generate")
-        with torch.cuda.device(images.device):
+        # (weights_frozen: no parameter changes during one inference call -- the derived caches validate once, not at each of their ~40 fetches)
+        with torch.cuda.device(images.device), weights_frozen():
             ug = self._graph_auto(batch) if self.use_graph is None else bool(self.use_graph)
             if ug and int(getattr(self, "streams", 1)) == 1 and not torch.cuda.is_current_stream_capturing():
                 out = self._generate_graphed(batch)
