@@ -37,7 +37,6 @@ struct MageOptions {
     int attn_no_fewq;            // 1: the few-query (incremental step) attention kernels are not used
     int vq_no_mfma;              // 1: the quantiser's fp64-MFMA kernel is not used
     int conv_no_tile;            // 1: the 64-channel 3x3 tile convolution (conv_tile.hip) is not used (the implicit-GEMM kernels run)
-    int gemm_2wg;                // 1: the two-workgroups-per-CU experiment (gemm2.hip) takes the bias / LayerNorm-consuming GEMMs it is eligible for
 };
 const MageOptions& mage_options();
 // raise a deferred error from a kernel: the first one wins, the offending value and the bound are kept for the message

@@ -108,7 +108,6 @@ extern "C" int mage_gemm(const mage_gemm_desc* d_in, void* stream) {
     if (const int r = try_taps8(d, s)) return r < 0 ? r : MAGE_OK;
     MAGE_CHECK_ARG(!d->head_w, "mage_gemm: head_w is a fusion of the bf16 padded-taps form; this geometry does not run there");
     if (const int r = mage_conv3x3_c64_try(d, s)) return r < 0 ? r : MAGE_OK;    // 64 -> 64 channel 3x3 convolutions over whole 16 x 16 tiles (conv_tile.hip)
-    if (const int r = mage_gemm2_try(d, s)) return r < 0 ? r : MAGE_OK;          // (experiment, off by default: two workgroups per CU, gemm2.hip)
     if (const int r = mage_gemm4_try(d, s)) return r < 0 ? r : MAGE_OK;          // the one-wave-per-SIMD kernel (gemm4.hip): QKV / c_fc at full-loop sizes
     const bool gather = d->taps_h * d->taps_w > 1 || d->stride != 1 || d->dy0 != 0 || d->dx0 != 0 || d->in_h != d->out_h ||
                         d->in_w != d->out_w || d->a_half;

@@ -50,7 +50,6 @@
 
 int mage_gemm4_try(const mage_gemm_desc* d, hipStream_t s);    // gemm4.hip: 1 = launched, 0 = not eligible, < 0 = error
 int mage_conv3x3_c64_try(const mage_gemm_desc* d, hipStream_t s);    // conv_tile.hip: likewise
-int mage_gemm2_try(const mage_gemm_desc* d, hipStream_t s);          // gemm2.hip (experiment, option gemm_2wg): likewise
 
 namespace {
 

@@ -43,7 +43,7 @@ static const OptField g_opt_fields[] = {
     {"gemm_stagger_groups", &MageOptions::gemm_stagger_groups},
     {"gemm_stagger_percent", &MageOptions::gemm_stagger_percent}, {"gemm_stagger_forced", &MageOptions::gemm_stagger_forced},
     {"gemm4_stagger_groups", &MageOptions::gemm4_stagger_groups}, {"gemm4_stagger_percent", &MageOptions::gemm4_stagger_percent},
-    {"attn_no_mfma", &MageOptions::attn_no_mfma}, {"attn_no_fewq", &MageOptions::attn_no_fewq}, {"vq_no_mfma", &MageOptions::vq_no_mfma}, {"conv_no_tile", &MageOptions::conv_no_tile}, {"gemm_2wg", &MageOptions::gemm_2wg},
+    {"attn_no_mfma", &MageOptions::attn_no_mfma}, {"attn_no_fewq", &MageOptions::attn_no_fewq}, {"vq_no_mfma", &MageOptions::vq_no_mfma}, {"conv_no_tile", &MageOptions::conv_no_tile},
 };
 static int env_flag(const char* name) {
     const char* e = getenv(name);
@@ -77,7 +77,6 @@ const MageOptions& mage_options() {
         o.attn_no_fewq = env_flag("MAGE_ATTN_NO_FEWQ");
         o.vq_no_mfma = env_flag("MAGE_VQ_NO_MFMA");
         o.conv_no_tile = env_flag("MAGE_CONV_NO_TILE");
-        o.gemm_2wg = env_flag("MAGE_GEMM_2WG");
         g_opt = o;
         g_opt_ready = true;
     }

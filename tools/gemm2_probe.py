@@ -1,4 +1,5 @@
-"""The two-workgroups-per-CU GEMM experiment (csrc/gemm2.hip, library option gemm_2wg) against the shipped kernels on the decoder's LayerNorm-consuming
+"""(Runs only on a library built WITH the experiment: see the header of tools/probes/gemm2_experiment.hip.)
+The two-workgroups-per-CU GEMM experiment (library option gemm_2wg) against the shipped kernels on the decoder's LayerNorm-consuming
 GEMMs at full-loop size: bitwise comparison and interleaved timing.  Tuning only."""
 import os, sys
 import torch

@@ -6,7 +6,10 @@
 // half as wide) and 1.5x the fragment reads per MFMA.
 // Same bits as the other GEMM kernels: per output element the K chain is v_mfma_f32_16x16x32 over k ascending in steps of 32 from 0, and
 // the epilogue is epilogue_lean (gemm_shared.h).
-// Off by default (library option gemm_2wg): see profiles/r05_gemm2_experiment.txt for what it measured.
+// NOT part of libmage_hip.so: it was built into the library for one commit ("gemm2 experiment ...") to be measured through the C ABI
+// (tools/gemm2_probe.py at that commit; results: profiles/r05_gemm2_experiment.txt: bit-identical, 17-28 % slower) and then moved here.
+// To re-run: copy to mage_amd/csrc/gemm2.hip, add it to SRCS in the Makefile, an `int gemm_2wg` option (common.h / runtime.hip / config.py)
+// and `if (const int r = mage_gemm2_try(d, s)) return r < 0 ? r : MAGE_OK;` in front of mage_gemm4_try in gemm.hip.
 //
 // LDS: 3-stage ring of K slabs of 32 (A 256 rows x 64 B + W 128 rows x 64 B = 24 KB per stage, 72 KB per workgroup); 16-byte chunk c of
 // row r sits at chunk c ^ h[(r >> 2) & 3], h = {0, 3, 2, 1}: conflict-free for the ds_read_b128 lane groups.  The ring's first 16 KB are
