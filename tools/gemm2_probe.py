@@ -6,6 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mage_amd import ops, config
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+OPT = sys.argv[2] if len(sys.argv) > 2 else "gemm_2wg"
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
 def timeit(f, n=10):
@@ -28,13 +29,13 @@ for name, N, K, act, ln in (("c_fc", 2048, 512, ops.ACT_QUICKGELU, True), ("QKV"
     y0 = torch.empty(m, N, device=dev, dtype=torch.bfloat16)
     y1 = torch.empty_like(y0)
     ops.gemm(a, w, y0, **kw)
-    with config.lib_option("gemm_2wg", 1):
+    with config.lib_option(OPT, 1):
         ops.gemm(a, w, y1, **kw)
     same = torch.equal(y0, y1)
     res = []
     for rep in range(3):
         t0 = timeit(lambda: ops.gemm(a, w, y0, **kw))
-        with config.lib_option("gemm_2wg", 1):
+        with config.lib_option(OPT, 1):
             t1 = timeit(lambda: ops.gemm(a, w, y1, **kw))
         res.append((t0, t1))
     fl = 2.0 * m * N * K
