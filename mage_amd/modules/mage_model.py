@@ -995,6 +995,10 @@ class MAGE(nn.Module):
     def set_precision(self, precision: str) -> "MAGE":
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        if precision == "f16" and not self.use_cids:
+            # the latent path's fp32-operand embedding Linear and its GroupNorm + SiLU + Conv3d head have bf16 and fp32 / split outputs only
+            raise ValueError("precision 'f16' covers the VQ-token path (use_cids=True); the latent first-stage path (use_cids=False, MAGE+) runs "
+                             "'bf16', 'f16x3' or 'fp32'")
         self.precision = precision
         self.generate_model.compute_dtype, self.generate_model.split_kind = PRECISIONS[precision]
         # the once-per-clip prologue: exact-fp32 MFMA chains only in 'fp32' mode, f16x3 split operands otherwise (_lin_fp32)

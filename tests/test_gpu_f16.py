@@ -153,6 +153,8 @@ def test_f16_refusals_are_loud():
     m.first_stage_model.requires_grad_(False)
     with pytest.raises(ValueError, match="generation mode"):
         m(dev_batch(synth.synth_batch_mnist(2, 4, seed=1)))
+    with pytest.raises(ValueError, match="use_cids"):            # the latent (MAGE+) path has no f16 forms: refused when the mode is chosen
+        build_mage(synth.magep_model_config(frames_length=4, width=64, layers=3), 1, DEV).set_precision("f16")
     a = torch.randn(256, 64, device=DEV).half()
     w = torch.randn(256, 64, device=DEV).half()
     y = torch.empty(256, 256, device=DEV, dtype=torch.float16)
