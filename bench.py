@@ -446,6 +446,13 @@ def parse():
 
 def main():
     args = parse()
+    _t = {"last": time.perf_counter(), "sec": {}}
+
+    def tick(name):
+        """wall seconds since the previous tick, kept per section (bench_sections_s of the line: where a default run's minutes go)"""
+        now = time.perf_counter()
+        _t["sec"][name] = round(_t["sec"].get(name, 0.0) + now - _t["last"], 1)
+        _t["last"] = now
     from mage_amd.utils import dist as D
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under a launcher: start the N ranks ourselves (one process per GPU) and relay the exit code
@@ -530,6 +537,7 @@ def main():
     # the other AR mode, same batch, reported next to the headline (identical tokens: tests/test_gpu_parity.py)
     other_mode = "incremental" if args.ar_mode == "full" else "full"
     other = None
+    tick("build_warmup_and_timed_headline")
     if not args.no_other_mode:
         model.ar_mode = other_mode
         model.streams = 1 if other_mode == "incremental" else args.streams     # small launches: concurrency only adds gaps
@@ -654,6 +662,7 @@ def main():
 
     # VQ-VAE decode of this call's B*(L-1) generated frames on its own: HBM roofline under SURVEY 8d's traffic model + MFMA fraction
     decode = None
+    tick("other_ar_mode_parity_mode_f16_mode")
     if not args.no_decode_roofline:
         gen = tok_main.view(B, L - 1, 16, 16)
         model.first_stage_decode(gen)
@@ -697,6 +706,7 @@ def main():
     # arena, Adam on this rank's shard, all-gather of the parameters, over RCCL when there is more than one rank (mage_amd.optim.FlatAdam).
     # This is the only place of the path with a real exchange step, so it is what an N > 1 run of this script measures RCCL with.
     train = None
+    tick("decode_roofline")
     if args.precision == "bf16" and not args.no_train_step:
         try:
             train = train_step_probe(args, dev, rank, world, B, L, wl_kw, D)
@@ -704,6 +714,7 @@ def main():
             train = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     lat = cfg4 = None
+    tick("train_step")
     if rank == 0 and world == 1 and args.precision == "bf16" and not (args.no_latency_b1 and args.no_cfg4):
         m4 = None
         try:
@@ -835,8 +846,10 @@ def main():
         if replayed:
             res["config"]["graph_replay_note"] = ("the timed calls replay ONE captured HIP graph of the whole autoregressive_generate call "
                                                   "(same kernels, same order, bit-identical results; tests/test_gpu_parity.py)")
+        tick("cfg4_and_latency_b1")
         if cpu_sd is not None:
             res["cpu_baseline"], oracle_tok, oracle_margin = cpu_baseline(cpu_sd, L, args.cpu_clips)
+            tick("cpu_baseline")
             # the same clips through the HIP path: do the GPU token sequences equal the CPU oracle's (= the reference's algorithm, pinned
             # by the goldens)?  north_star: "reference-matching VQ token sequences on Single Moving MNIST"
             try:
@@ -860,12 +873,15 @@ def main():
                                                                         "baseline sample's clips (same weights, same inputs)")
             except Exception as e:
                 res["cpu_baseline"]["gpu_tokens_vs_oracle"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            tick("gpu_tokens_vs_oracle")
             if args.trained_steps > 0 and world == 1 and args.workload == "cfg2":
                 try:
                     res["cpu_baseline"]["gpu_tokens_vs_oracle_trained_weights"] = trained_token_agreement(
                         dev, L, args.trained_steps, 64, args.trained_clips, res["cpu_baseline"]["cores"])
                 except Exception as e:
                     res["cpu_baseline"]["gpu_tokens_vs_oracle_trained_weights"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        tick("trained_weights_token_leg")
+        res["bench_sections_s"] = dict(_t["sec"], note="wall seconds of this run per section (model builds, warm-ups and CPU work included)")
         # the headline secondary numbers once more as flat scalars (tools that keep only top-level scalars of this line still see them)
         res["parity_mode_frames_per_s"] = parity["value"] if parity else None
         res["parity_mode_dtype"] = parity["dtype"] if parity else None
@@ -920,7 +936,10 @@ def cpu_baseline(sd, L, clips):
             O.flat_axial_decoder(sd, "generate_model.", ma, imgs)
             t0 = time.perf_counter()
             O.flat_axial_decoder(sd, "generate_model.", ma, imgs)
-            best = min(best, (time.perf_counter() - t0, th))
+            t_th = time.perf_counter() - t0
+            best = min(best, (t_th, th))
+            if t_th > 1.5 * best[0]:                    # past the optimum (oversubscription only gets worse): stop calibrating
+                break
         torch.set_num_threads(best[1])
         t0 = time.perf_counter()
         _, o_tok, _, o_trace = O.mage_generate(sd, batch, L, return_trace=True)
