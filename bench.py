@@ -104,23 +104,10 @@ def train_step_probe(args, dev, rank, world, B, L, wl_kw, D):
     return out
 
 
-def trained_token_agreement(dev, L, train_steps, B, clips, threads, cfg_kw=None, style="strokes", s1_steps=None):
-    """north_star asks for reference-matching VQ token sequences; with RANDOM-INIT weights the decoder's top-2 logit margins (6e-6 .. 3e-4)
-    sit below any 16-bit mode's logit error, so those modes must diverge there whatever the kernels do.  This leg gives the weights a trained
-    model's margins: stage 1 (VQ-VAE, train_vqvae.py:13-35) and stage 2 (MAGE, main_mage.py:139-154) are trained with the in-tree HIP
-    training path on synthetic clips, then HELD-OUT clips are generated free-running by the HIP path in bf16, f16 and f16x3 and by the CPU
-    oracle (fp32, the reference's algorithm) from the same weights.
-
-    The task (style 'strokes', mage_amd.utils.synth): stroke drawings of ten shape classes with random width, intensity and shading, moved by
-    the reference's bounce rule, the caption naming the class and the motion (so the next frame is predictable); the codebook is re-seeded
-    from encoder outputs early in stage 1 (a data-dependent initialisation: a random-init codebook collapses onto a handful of codes, which
-    made round 4's task trivial -- 8 codes, median margin 12).  Everything is seeded (torch.manual_seed for the dropout seeds; the embedding
-    gradients are fixed-order sums): the same weights, hence the same figures, from run to run on one box.
-
-    Reported per mode: free-running token agreement with the oracle, clips identical, where each clip first leaves the oracle's sequence and
-    the oracle's margin there, the teacher-forced max |d logit| against the oracle's own per-step logits; and the oracle's margin
-    distribution."""
-    import gc
+def train_strokes_model(dev, L, train_steps, B, cfg_kw=None, style="strokes", s1_steps=None):
+    """The in-tree trained model of the token-agreement legs (trained_token_agreement below, tools/f16_attribution.py): stage 1 (VQ-VAE) and
+    stage 2 (MAGE) trained with the HIP training path on synthetic 'strokes' clips, everything seeded.  Returns (model in eval mode on dev,
+    CPU fp32 state_dict, info dict: loss trajectories, the weights' sha256, stage-1 facts)."""
     from mage_amd.optim import FlatAdam
     from mage_amd.utils import synth
     from mage_amd.utils.util import instantiate_from_config
@@ -186,6 +173,34 @@ def trained_token_agreement(dev, L, train_steps, B, clips, threads, cfg_kw=None,
     h = hashlib.sha256()
     for k in sorted(sd):
         h.update(sd[k].numpy().tobytes())
+    info = dict(train_seconds=round(t_train, 1), loss_trajectory=losses, trained_weights_sha256=h.hexdigest()[:16], s1_steps=s1_steps,
+                s1_losses=s1_losses, reseed_at=reseed_at)
+    del opt, pool
+    return tm, sd, info
+
+
+def trained_token_agreement(dev, L, train_steps, B, clips, threads, cfg_kw=None, style="strokes", s1_steps=None):
+    """north_star asks for reference-matching VQ token sequences; with RANDOM-INIT weights the decoder's top-2 logit margins (6e-6 .. 3e-4)
+    sit below any 16-bit mode's logit error, so those modes must diverge there whatever the kernels do.  This leg gives the weights a trained
+    model's margins: stage 1 (VQ-VAE, train_vqvae.py:13-35) and stage 2 (MAGE, main_mage.py:139-154) are trained with the in-tree HIP
+    training path on synthetic clips, then HELD-OUT clips are generated free-running by the HIP path in bf16, f16 and f16x3 and by the CPU
+    oracle (fp32, the reference's algorithm) from the same weights.
+
+    The task (style 'strokes', mage_amd.utils.synth): stroke drawings of ten shape classes with random width, intensity and shading, moved by
+    the reference's bounce rule, the caption naming the class and the motion (so the next frame is predictable); the codebook is re-seeded
+    from encoder outputs early in stage 1 (a data-dependent initialisation: a random-init codebook collapses onto a handful of codes, which
+    made round 4's task trivial -- 8 codes, median margin 12).  Everything is seeded (torch.manual_seed for the dropout seeds; the embedding
+    gradients are fixed-order sums): the same weights, hence the same figures, from run to run on one box.
+
+    Reported per mode: free-running token agreement with the oracle, clips identical, where each clip first leaves the oracle's sequence and
+    the oracle's margin there, the teacher-forced max |d logit| against the oracle's own per-step logits; and the oracle's margin
+    distribution."""
+    import gc
+    from mage_amd.utils import synth
+    from oracle import mage_oracle as O
+    tm, sd, tinfo = train_strokes_model(dev, L, train_steps, B, cfg_kw=cfg_kw, style=style, s1_steps=s1_steps)
+    losses, t_train, s1_losses, s1_steps, reseed_at = (tinfo["loss_trajectory"], tinfo["train_seconds"], tinfo["s1_losses"], tinfo["s1_steps"],
+                                                       tinfo["reseed_at"])
     held = synth.synth_batch_mnist(clips, L, seed=5000, style=style)
     torch.set_num_threads(threads)
     t0 = time.perf_counter()
@@ -254,8 +269,8 @@ def trained_token_agreement(dev, L, train_steps, B, clips, threads, cfg_kw=None,
           if fgm.numel() else [None] * 5)
     with torch.no_grad():
         codes_used = int(torch.unique(tm.first_stage_encode(hb["images"])).numel())
-    res = dict(out, task=style, train_steps=train_steps, train_batch=B, train_seconds=round(t_train, 1), loss_trajectory=losses,
-               trained_weights_sha256=h.hexdigest()[:16],
+    res = dict(out, task=style, train_steps=train_steps, train_batch=B, train_seconds=t_train, loss_trajectory=losses,
+               trained_weights_sha256=tinfo["trained_weights_sha256"],
                stage1={"steps": s1_steps, "batch_frames": 256, "loss_trajectory": s1_losses, "codes_used_on_the_held_out_clips": codes_used,
                        "distinct_tokens_in_the_oracle_sequences": int(torch.unique(o_tok).numel()),
                        "codebook_reseeded_from_encoder_outputs_at_step": reseed_at if reseed_at >= 0 else None},
@@ -270,7 +285,7 @@ def trained_token_agreement(dev, L, train_steps, B, clips, threads, cfg_kw=None,
                     "the CPU oracle on the same trained weights.  A free-running sequence can only stay identical while every decision's margin "
                     "exceeds the mode's logit error (teacher_forced_max_logit_error_vs_oracle); the margin quantiles say how many decisions of this "
                     "trained model sit below that")
-    del tm, opt, pool
+    del tm
     gc.collect()
     torch.cuda.empty_cache()
     return res

@@ -278,13 +278,13 @@ def synth_batch_cater(B: int, L: int, seed: int = 0, text_len: int = 20, vocab: 
 
 # ----------------------------------------------------------------------------- configs
 def mnist_model_config(frames_length: int = 16, width: int = 512, layers: int = 6, vq_dim: int = 256,
-                       K: int = 512, vocab: int = 30, context_length: int = 32, text_layers: int = 2) -> dict:
+                       K: int = 512, vocab: int = 30, context_length: int = 32, text_layers: int = 2, image_resolution: int = 16) -> dict:
     """BASELINE cfg1/cfg2/cfg3 model: MNIST f4 VQ-VAE + MAGE, assembled the
     way config/mage_caterv1.yaml:10-53 assembles the CATER one."""
     return {
         "target": "modules.mage_model.MAGE",
         "params": {
-            "codebook_size": K, "frames_length": frames_length, "image_resolution": 16,
+            "codebook_size": K, "frames_length": frames_length, "image_resolution": image_resolution,
             "vision_width": width, "dropout": 0.1, "use_cids": True, "randomness": False,
             "first_stage_config": {"target": "modules.vqvae_model.VectorQuantizedVAE",
                                    "params": {"input_dim": 1, "down_ratio": 4, "dim": vq_dim, "K": K}},
