@@ -108,39 +108,61 @@ def override(**kw) -> Iterator[Config]:
         _CONFIG = saved
 
 
+# Python-side mirror of the library's option table: read through mage_get_option ONCE, refreshed by every change made through this module
+# (lib_option / set_lib_option) -- MAGE._graph_fingerprint and VectorQuantizedVAE._bottleneck ask per call / per block, on the host-bound path
+# (ADVICE r5).  Code that calls mage_set_option directly (C hosts) must call invalidate_lib_options() if it shares the process with this package.
+_LIB_CACHE = None
+
+
+def invalidate_lib_options() -> None:
+    global _LIB_CACHE
+    _LIB_CACHE = None
+
+
+def _lib_cache() -> dict:
+    global _LIB_CACHE
+    if _LIB_CACHE is None:
+        import ctypes as C
+        from . import _lib
+        l = _lib.load()
+        out = {}
+        for name in LIB_OPTIONS:
+            v = C.c_int32(0)
+            _lib.check(l.mage_get_option(name.encode(), C.byref(v)), l)
+            out[name] = int(v.value)
+        _LIB_CACHE = out
+    return _LIB_CACHE
+
+
 def lib_options() -> dict:
     """Current values of the library-side options (mage_get_option)."""
-    import ctypes as C
-    from . import _lib
-    l = _lib.load()
-    out = {}
-    for name in LIB_OPTIONS:
-        v = C.c_int32(0)
-        _lib.check(l.mage_get_option(name.encode(), C.byref(v)), l)
-        out[name] = int(v.value)
-    return out
+    return dict(_lib_cache())
 
 
 def lib_flag(name: str) -> int:
     """One library-side option (mage_get_option)."""
-    import ctypes as C
+    c = _lib_cache()
+    if name not in c:
+        raise KeyError(f"unknown library option '{name}' (mage_amd.config.LIB_OPTIONS)")
+    return c[name]
+
+
+def set_lib_option(name: str, value: int) -> None:
+    """mage_set_option + refresh of the mirror (the library validates the name and the value)."""
     from . import _lib
     l = _lib.load()
-    v = C.c_int32(0)
-    _lib.check(l.mage_get_option(name.encode(), C.byref(v)), l)
-    return int(v.value)
+    try:
+        _lib.check(l.mage_set_option(name.encode(), int(value)), l)
+    finally:
+        invalidate_lib_options()
 
 
 @contextlib.contextmanager
 def lib_option(name: str, value: int) -> Iterator[None]:
     """Set one library-side option inside a ``with`` block (mage_set_option), restoring the previous value afterwards."""
-    import ctypes as C
-    from . import _lib
-    l = _lib.load()
-    old = C.c_int32(0)
-    _lib.check(l.mage_get_option(name.encode(), C.byref(old)), l)
-    _lib.check(l.mage_set_option(name.encode(), int(value)), l)
+    old = lib_flag(name)
+    set_lib_option(name, value)
     try:
         yield
     finally:
-        _lib.check(l.mage_set_option(name.encode(), int(old.value)), l)
+        set_lib_option(name, old)

@@ -1,5 +1,6 @@
 // Library state: thread-local error string, the per-device zero page used for padded gather loads, and the per-device
 // deferred-error word that kernels raise when they meet an argument only visible on the device (an out-of-range id).
+#include <mutex>
 #include "common.h"
 #include <string.h>
 #include <stdlib.h>
@@ -33,7 +34,7 @@ int* mage_error_word() {
 
 // ---- options: one table, read once from the environment, changed through mage_set_option
 static MageOptions g_opt;
-static bool g_opt_ready = false;
+static std::once_flag g_opt_once;             // the first mage_gemm calls of several host threads race for the table otherwise
 struct OptField { const char* name; int MageOptions::*field; };
 static const OptField g_opt_fields[] = {
     {"gemm_no_4w", &MageOptions::gemm_no_4w}, {"gemm4_train_forms", &MageOptions::gemm4_train_forms},
@@ -50,7 +51,7 @@ static int env_flag(const char* name) {
     return (e && *e && strcmp(e, "0") != 0) ? 1 : 0;
 }
 const MageOptions& mage_options() {
-    if (!g_opt_ready) {
+    std::call_once(g_opt_once, [] {
         MageOptions o = {};
         o.gemm_no_4w = env_flag("MAGE_GEMM_NO_4W");
         o.gemm4_train_forms = env_flag("MAGE_GEMM4_TRAIN_FORMS");
@@ -77,16 +78,24 @@ const MageOptions& mage_options() {
         o.attn_no_fewq = env_flag("MAGE_ATTN_NO_FEWQ");
         o.vq_no_mfma = env_flag("MAGE_VQ_NO_MFMA");
         o.conv_no_tile = env_flag("MAGE_CONV_NO_TILE");
+        if (o.gemm_small_m < 0) o.gemm_small_m = 0;
         g_opt = o;
-        g_opt_ready = true;
-    }
+    });
     return g_opt;
 }
 extern "C" int mage_set_option(const char* name, int32_t value) {
     MAGE_CHECK_ARG(name != nullptr, "mage_set_option: null name");
     (void)mage_options();
+    // values: switches are 0 / 1, counts and percentages have ranges (a negative row bound or group count would index nothing sensible).
+    // Changing an option while another host thread is inside a dispatch function is the caller's race: set options before the threads start.
+    const bool is_count = strstr(name, "stagger_groups") != nullptr, is_percent = strstr(name, "stagger_percent") != nullptr;
+    const bool is_rows = strcmp(name, "gemm_small_m") == 0;
     for (const OptField& f : g_opt_fields)
         if (strcmp(f.name, name) == 0) {
+            MAGE_CHECK_ARG(is_count ? (value >= 0 && value <= 64) : is_percent ? (value >= 0 && value <= 400) : is_rows ? (value >= 0 && value <= (1 << 20))
+                                                                                                                    : (value == 0 || value == 1),
+                           "mage_set_option: value %d out of range for '%s' (switches: 0 | 1; stagger groups 0..64, percent 0..400; gemm_small_m 0..2^20)",
+                           (int)value, name);
             g_opt.*(f.field) = value;
             return MAGE_OK;
         }

@@ -622,6 +622,9 @@ class FlatAxialDecoder(nn.Module):
         if self._split_on() and self._attn_split():        # f16x3: K, V cached as split rows (what the attention kernel reads)
             caches = {i: ops.split_empty(B * L * hh * ww, 2 * Cc, self.split_kind, device) for i in range(self.layers) if i % 3 == 0}
             return {"B": B, "hh": hh, "ww": ww, "kv": caches, "p": 0}
+        if self._split_on():                                # the other split forms (_inc_step_split with fp32 rows): [K | V] only, q stays in qkv
+            caches = {i: torch.empty(B * L * hh * ww, 2 * Cc, device=device, dtype=dt) for i in range(self.layers) if i % 3 == 0}
+            return {"B": B, "hh": hh, "ww": ww, "kv": caches, "p": 0}
         # temporal blocks: one row [q | k | v] per (clip, slot, pixel) -- the new positions' QKV projection is ONE launch writing straight into
         # the slots (q is read back from there by the attention of the same step; 1.5x the K,V bytes of a cache that is 0.8 GB at cfg2)
         caches = {i: torch.empty(B * L * hh * ww, 3 * Cc, device=device, dtype=dt) for i in range(self.layers) if i % 3 == 0}
@@ -1074,14 +1077,18 @@ class MAGE(nn.Module):
         Returns the cache dict with 'ft.T', 'ft.T2', 'ft.P2' (None when not applicable: use_cids=False, config frame_table = False); `self.frame_table = False`
         switches the callers back to the convolution GEMM + in_linear (the reference's operation order) at any time."""
         d = self._derived.get(self._build)
+        if not config.get().frame_table:
+            # switched off for this call only: the decision is NOT cached (a `config.override(frame_table=False)` block must not leave the tables
+            # off behind it -- ADVICE r5), tables built earlier stay in the cache for when the switch is back on
+            return {**d, "ft.T": None, "ft.T2": None, "ft.P2": None}
         if "ft.T" in d:
             return d
         R, Cc, Kc = self.image_resolution, self.vision_width, self.codebook_size
         gm = self.generate_model
-        ok = (self.use_cids and config.get().frame_table and Cc % 4 == 0
+        ok = (self.use_cids and Cc % 4 == 0
               and 9 * Kc * max(Cc, getattr(gm, "model_channels", Cc)) * 4 <= (256 << 20) and "emb" in d and d["emb"].is_cuda
               and getattr(gm, "in_channels", None) == Cc and hasattr(gm, "_build"))
-        if not ok:
+        if not ok:                                  # structural: cached with the weights
             d["ft.T"] = d["ft.T2"] = d["ft.P2"] = None
             return d
         gd = gm._derived.get(gm._build)

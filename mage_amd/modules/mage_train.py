@@ -155,7 +155,7 @@ def _res_linear(run: _Run, a, d, name, x_old, dt, *, M, N, K, seed, ln=None, cas
             return x_new if cast_to is None else (x_new, ops.cast(x_new, torch.empty(M, N, device=a.device, dtype=cast_to)))
         return x_new, ops.layernorm(x_new, ln[0], ln[1], torch.empty(M, N, device=a.device, dtype=ln[2]), 1e-5)
     # the branch rows leave the GEMM in the compute dtype (bf16 mode: half the bytes written here and read by the mask-and-add pass;
-    # the stream x itself stays fp32).  MAGE_TRAIN_f32_branch()=1 keeps fp32 branch rows.
+    # the stream x itself stays fp32).  MAGE_TRAIN_F32_BRANCH=1 keeps fp32 branch rows.
     br = _gemm32(a, w, torch.empty(M, N, device=a.device, dtype=F32 if _f32_branch() else a.dtype), M=M, N=N, K=K, lda=K, ldy=N, bias=b)
     if ln is None:
         if cast_to is not None:                      # the last block: its rows also as the head GEMM's bf16 operand

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 
 import contextlib
+import itertools
+import threading
 from itertools import chain
 from typing import Dict, List, Optional
 
@@ -106,8 +108,15 @@ def bump_weights_epoch() -> None:
     _WEIGHTS_EPOCH += 1
 
 
-_FROZEN_DEPTH = 0      # > 0: inside weights_frozen(): one signature check per cache and region
-_FROZEN_EPOCH = 0
+# weights_frozen() regions are PER THREAD: a thread that has left its own region must not inherit another thread's promise (nn.DataParallel
+# replicas, inference in one thread and an optimizer step in another); each region gets a process-unique token
+_FROZEN = threading.local()
+_FROZEN_TOKENS = itertools.count(1)
+
+
+def _frozen_token() -> int:
+    """0 outside a weights_frozen() region of THIS thread, else the region's token."""
+    return getattr(_FROZEN, "token", 0) if getattr(_FROZEN, "depth", 0) else 0
 
 
 @contextlib.contextmanager
@@ -115,15 +124,16 @@ def weights_frozen():
     """The caller promises that no parameter or buffer changes inside the block (one inference call: MAGE.autoregressive_generate).  Every
     derived cache then validates its signature ONCE per block instead of at every fetch -- the walk over all parameters and buffers
     (data_ptr, version, device: ~0.2 ms per fetch, ~40 fetches per incremental call) was half of the host's enqueue time of an
-    incremental call, enough to make the call host-bound on a slow box."""
-    global _FROZEN_DEPTH, _FROZEN_EPOCH
-    if _FROZEN_DEPTH == 0:
-        _FROZEN_EPOCH += 1
-    _FROZEN_DEPTH += 1
+    incremental call, enough to make the call host-bound on a slow box.  The promise is the calling thread's; bump_weights_epoch()
+    (FlatAdam.step) is honoured inside a region too: the fast path compares the epoch."""
+    depth = getattr(_FROZEN, "depth", 0)
+    if depth == 0:
+        _FROZEN.token = next(_FROZEN_TOKENS)
+    _FROZEN.depth = depth + 1
     try:
         yield
     finally:
-        _FROZEN_DEPTH -= 1
+        _FROZEN.depth -= 1
 
 
 class _Derived:
@@ -134,11 +144,12 @@ class _Derived:
         self._m = module
         self._sig = None
         self._store: Dict[str, torch.Tensor] = {}
-        self._checked = -1             # the weights_frozen() region this cache was last validated in
+        self._checked = (-1, -1)       # (weights_frozen() region token, weights epoch) this cache was last validated in
         self.gen = 0                   # bumped at every rebuild: captured HIP graphs that reference the old copies are stale
 
     def get(self, builder) -> Dict[str, torch.Tensor]:
-        if _FROZEN_DEPTH and self._checked == _FROZEN_EPOCH:
+        tok = _frozen_token()
+        if tok and self._checked == (tok, _WEIGHTS_EPOCH):
             return self._store
         sig = (_WEIGHTS_EPOCH,) + tuple((t.data_ptr(), t._version, t.device) for t in chain(self._m.parameters(), self._m.buffers()))
         if sig != self._sig:
@@ -146,8 +157,8 @@ class _Derived:
                 self._store = builder()
             self._sig = sig
             self.gen += 1
-        if _FROZEN_DEPTH:
-            self._checked = _FROZEN_EPOCH
+        if tok:
+            self._checked = (tok, _WEIGHTS_EPOCH)
         return self._store
 
 
@@ -547,8 +558,10 @@ class VectorQuantizedVAE(nn.Module):
     def _d0_table(self, w):
         """T[tap][code] = (BatchNorm-folded) W3_tap relu(codebook[code]) of the decoder's first ResBlock (vqvae_model.py:111-124,180),
         bf16 [9, K, dim]; built once per weights on the fp32 MFMA kernel.  None when switched off (MAGE_NO_DECODE_TABLE=1)."""
+        if not config.get().decode_table:             # switched off for this call: not cached (ADVICE r5: a config.override block must not stick)
+            return None
         if "d0.tab" not in w:
-            if not config.get().decode_table or 9 * self.K * self.dim * 2 > (64 << 20):
+            if 9 * self.K * self.dim * 2 > (64 << 20):
                 w["d0.tab"] = None
             else:
                 dim, Kc, dev = self.dim, self.K, w["cb"].device

@@ -180,7 +180,9 @@ class FlatAdam(torch.optim.Optimizer):
             k = p.numel()
             state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": m[off:off + k].view(p.shape).clone(),
                         "exp_avg_sq": v[off:off + k].view(p.shape).clone()}
-        groups = [dict({k: v_ for k, v_ in g.items() if k != "params"}, params=list(range(len(self.all_params)))) for g in self.param_groups]
+        # 'flat_adam_numbering': an explicit marker of the index space; torch.optim.Adam ignores unknown group keys on load
+        groups = [dict({k: v_ for k, v_ in g.items() if k != "params"}, params=list(range(len(self.all_params))), flat_adam_numbering="all")
+                  for g in self.param_groups]
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
@@ -192,9 +194,24 @@ class FlatAdam(torch.optim.Optimizer):
         st = {int(k): e for k, e in sd["state"].items()}
         groups = sd.get("param_groups") or []
         n_ckpt = len(groups[0]["params"]) if groups and "params" in groups[0] else None
-        if n_ckpt is not None and n_ckpt == len(self.index) and n_ckpt != len(self.all_params):
-            # the layout this class wrote before it numbered frozen parameters too: entry j belongs to the j-th TRAINABLE parameter
-            st = {self.index[j]: e for j, e in st.items() if 0 <= j < len(self.index)}
+        numbering = groups[0].get("flat_adam_numbering") if groups else None
+        if numbering not in (None, "all", "trainable"):
+            raise ValueError(f"FlatAdam.load_state_dict: unknown flat_adam_numbering {numbering!r}")
+        legacy = numbering == "trainable" or (numbering is None and n_ckpt is not None and n_ckpt == len(self.index) and n_ckpt != len(self.all_params))
+        if legacy:
+            # the layout this class wrote before it numbered frozen parameters too: entry j belongs to the j-th TRAINABLE parameter.  Recognised
+            # by the marker, or (checkpoints older than the marker) by its length -- then EVERY entry must be in range and match its
+            # parameter's shape, so that a foreign checkpoint of the same length is refused instead of remapped
+            bad = [j for j in st if not 0 <= j < len(self.index)]
+            if bad:
+                raise ValueError(f"FlatAdam.load_state_dict: state entries {bad[:5]} are outside the {len(self.index)} trainable parameters of the "
+                                 f"legacy (trainable-only) numbering this checkpoint appears to use")
+            for j, e in st.items():
+                pj = self.params[j]
+                if tuple(e["exp_avg"].shape) != tuple(pj.shape):
+                    raise ValueError(f"FlatAdam.load_state_dict: legacy-numbered state {j} has shape {tuple(e['exp_avg'].shape)}, trainable parameter {j} "
+                                     f"{tuple(pj.shape)}: not a checkpoint of this parameter list")
+            st = {self.index[j]: e for j, e in st.items()}
         elif n_ckpt is not None and n_ckpt != len(self.all_params):
             raise ValueError(f"FlatAdam.load_state_dict: the checkpoint's optimizer was built over {n_ckpt} parameters, "
                              f"this one over {len(self.all_params)} (pass the same model.parameters())")
@@ -220,4 +237,4 @@ class FlatAdam(torch.optim.Optimizer):
         self.m.copy_(m[self.shard_off:self.shard_off + self.shard_n])
         self.v.copy_(v[self.shard_off:self.shard_off + self.shard_n])
         for g, sg in zip(self.param_groups, groups):
-            g.update({k: v_ for k, v_ in sg.items() if k != "params"})
+            g.update({k: v_ for k, v_ in sg.items() if k not in ("params", "flat_adam_numbering")})

@@ -98,12 +98,22 @@ def test_flat_adam_accepts_the_layout_numbered_over_trainable_parameters(monkeyp
         opt.step()
     sd = opt.state_dict()
     assert sorted(sd["state"]) == opt.index == [1, 2, 3, 4, 5] and len(sd["param_groups"][0]["params"]) == 6
-    legacy = {"state": {j: sd["state"][i] for j, i in enumerate(opt.index)},
-              "param_groups": [dict(sd["param_groups"][0], params=list(range(len(opt.index))))]}
-    opt2 = FlatAdam(frozen_first(3).parameters(), lr=1e-2)
-    opt2.load_state_dict(legacy)
-    assert opt2.steps == 2 and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
-    bad = {"state": {}, "param_groups": [dict(sd["param_groups"][0], params=list(range(4)))]}
+    assert sd["param_groups"][0]["flat_adam_numbering"] == "all"                  # the explicit marker of the index space
+    g_old = {k: v for k, v in sd["param_groups"][0].items() if k != "flat_adam_numbering"}      # a checkpoint older than the marker
+    legacy = {"state": {j: sd["state"][i] for j, i in enumerate(opt.index)}, "param_groups": [dict(g_old, params=list(range(len(opt.index))))]}
+    for ck in (legacy, {"state": legacy["state"], "param_groups": [dict(legacy["param_groups"][0], flat_adam_numbering="trainable")]}):
+        opt2 = FlatAdam(frozen_first(3).parameters(), lr=1e-2)
+        opt2.load_state_dict(ck)
+        assert opt2.steps == 2 and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
+    # a foreign checkpoint that merely has the legacy LENGTH is refused, not remapped: an out-of-range key, a shape that does not fit
+    foreign = {"state": {**legacy["state"], 7: legacy["state"][0]}, "param_groups": legacy["param_groups"]}
+    with pytest.raises(ValueError, match="outside the 5 trainable"):
+        FlatAdam(frozen_first(3).parameters(), lr=1e-2).load_state_dict(foreign)
+    swapped = {"state": {0: legacy["state"][2], **{j: legacy["state"][j] for j in (1, 2, 3, 4)}}, "param_groups": legacy["param_groups"]}
+    if tuple(legacy["state"][0]["exp_avg"].shape) != tuple(legacy["state"][2]["exp_avg"].shape):
+        with pytest.raises(ValueError, match="not a checkpoint of this parameter list"):
+            FlatAdam(frozen_first(3).parameters(), lr=1e-2).load_state_dict(swapped)
+    bad = {"state": {}, "param_groups": [dict(g_old, params=list(range(4)))]}
     with pytest.raises(ValueError, match="built over 4 parameters"):
         FlatAdam(frozen_first(3).parameters(), lr=1e-2).load_state_dict(bad)
 
