@@ -528,7 +528,7 @@ def main():
     ops.PROFILE.reset(enabled=True)
     model.autoregressive_generate(batch)
     warm_prof = ops.PROFILE.summary()
-    warm_gemms = {k: v for k, v in warm_prof.items() if k.startswith(("gemm_kernel", "gemm8_kernel", "gemm4_kernel", "gemm_split"))}
+    warm_gemms = {k: v for k, v in warm_prof.items() if k.startswith(("gemm_kernel", "gemm8_kernel", "gemm4_kernel", "gemm4h_kernel", "gemm_split"))}
     dom_warm = max(warm_gemms, key=lambda k: warm_gemms[k]["ms"]) if warm_gemms else None
     sync_all()
     # timed region: HIP events on the launch stream around the dominant symbol's launches (--events all: around all).  With
@@ -751,7 +751,7 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * B * L * args.steps / dt
-        gemms = {k: v for k, v in prof.items() if k.startswith(("gemm_kernel", "gemm8_kernel", "gemm4_kernel", "gemm_split"))}
+        gemms = {k: v for k, v in prof.items() if k.startswith(("gemm_kernel", "gemm8_kernel", "gemm4_kernel", "gemm4h_kernel", "gemm_split"))}
         dom_key = max(gemms, key=lambda k: gemms[k]["ms"]) if gemms else None
         all_src, all_div = (gemms, args.steps) if args.events == "all" else (warm_gemms, 1)
         peak = PEAK_BF16_TFLOPS if args.precision in ("bf16", "f16") else PEAK_F32_TFLOPS
@@ -760,7 +760,7 @@ def main():
         # only rocprofv3 can read: tools/pmc_bench.sh collects them on this same command in two separate --pmc passes
         # and the summary is committed under profiles/; bench.py reports it only for the matching workload and says where from.
         traffic, traffic_source = None, None
-        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             pmc_path = os.path.join(ROOT, "profiles", name)
             if dom_key and os.path.exists(pmc_path) and (B, L, args.precision, args.ar_mode, args.workload) == (64, 16, "bf16", "full", "cfg2"):
                 traffic = json.load(open(pmc_path)).get(dom_key, {}).get("hbm_bytes_per_launch")
@@ -772,7 +772,8 @@ def main():
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             allf, allms = sum(v["flops"] for v in all_src.values()), sum(v["ms"] for v in all_src.values())
             legend = ("  [gemm4_kernel<act, epilogue kind, LayerNorm fold, bf16 residual stream>: the one-wave-per-SIMD bf16 256x256 GEMM (4 waves of "
-                      "128x128 outputs, all 256 accumulator registers: QKV and c_fc at full-loop sizes, csrc/gemm4.hip); "
+                      "128x128 outputs, all 256 accumulator registers: QKV at full-loop sizes, csrc/gemm4.hip); gemm4h_kernel<act, LayerNorm fold, f16>: its "
+                      "split-half form with the epilogue under the K loop (c_fc at full-loop sizes, csrc/gemm4h.hip); "
                       "gemm8_kernel<act, epilogue kind, split-K, padded taps, LayerNorm fold, split precision(, bf16 residual stream)>: the 8-phase "
                       "ping-pong bf16 256x256 GEMM; gemm_kernel<dtype, gather, act, m-tiles/wave, epilogue kind, split-K, LayerNorm fold, n-waves, "
                       "split precision(, bf16 residual stream)>: the lockstep one.  act 2 = QuickGELU (c_fc).  Epilogue kind 1 = x + Linear(.): "

@@ -69,7 +69,7 @@ int mage_check_device_errors(void* stream);
 /* Kernel-selection options (tuning, A/B tests, bisecting a regression): ONE table inside the library, filled once from the environment
  * variables MAGE_<NAME IN CAPITALS> the first time any entry point needs it, changed afterwards only through mage_set_option (no dispatch
  * function reads the environment; a change applies to every later call of the process).  Names:
- *   gemm_no_4w, gemm4_train_forms, gemm_no_8phase, gemm_no_taps8, gemm_no_narrow, gemm_no_narrow_few, gemm_no_small, gemm_small_m,
+ *   gemm_no_4w, gemm_no_4h, gemm_4h_plain, gemm4_train_forms, gemm_no_8phase, gemm_no_taps8, gemm_no_narrow, gemm_no_narrow_few, gemm_no_small, gemm_small_m,
  *   gemm_stagger_groups / _percent / _forced (MAGE_GEMM_STAGGER="G,percent"), gemm4_stagger_groups / _percent
  *   (MAGE_GEMM4_STAGGER), attn_no_mfma, attn_no_fewq, vq_no_mfma          -- what each one does: struct MageOptions in csrc/common.h and
  *   the table in INTEGRATION.md.  Unknown name: MAGE_EINVAL. */
@@ -88,7 +88,8 @@ int mage_get_option(const char* name, int32_t* value);
  * Kernels behind this entry point (csrc/gemm.hip, csrc/gemm4.hip; chosen from the descriptor, same bits per output element from all of them for
  * bf16 plain GEMMs): the lockstep persistent kernel (any dtype / gather / epilogue), its 8-phase ping-pong variant (bf16, >= 2 tiles of 256x256
  * per CU), the one-wave-per-SIMD variant (bf16, bias or LayerNorm-consuming epilogue, K in [256, 1024], >= 4 tiles per CU: the decoder's QKV and
- * c_fc; option gemm_no_4w disables it), the few-rows kernel (M <= 1024), the padded-taps forms and the split-precision forms.
+ * c_fc; option gemm_no_4w disables it) and its split-half form with the epilogue under the K loop (csrc/gemm4h.hip: K = 512, 16-bit rows out;
+ * by default the QuickGELU forms = c_fc; gemm_no_4h disables it, gemm_4h_plain sends QKV there too), the few-rows kernel (M <= 1024), the padded-taps forms and the split-precision forms.
  *
  * Row geometry.  A GEMM row m in [0, M) is decoded as img = m / (out_h*out_w),
  * oy = (m / out_w) % out_h, ox = m % out_w.  K = taps_h*taps_w*cin; k -> (ky, kx, ci), ci fastest:

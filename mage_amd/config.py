@@ -72,7 +72,7 @@ ENV = {
 }
 
 # the library-side options (mage_set_option; struct MageOptions in csrc/common.h); each is read by the library from MAGE_<NAME> once
-LIB_OPTIONS = ("gemm_no_4w", "gemm4_train_forms", "gemm_no_8phase", "gemm_no_taps8", "gemm_no_narrow", "gemm_no_narrow_few", "gemm_no_small",
+LIB_OPTIONS = ("gemm_no_4w", "gemm_no_4h", "gemm_4h_plain", "gemm4_train_forms", "gemm_no_8phase", "gemm_no_taps8", "gemm_no_narrow", "gemm_no_narrow_few", "gemm_no_small",
                "gemm_small_m", "gemm_stagger_groups", "gemm_stagger_percent", "gemm_stagger_forced",
                "gemm4_stagger_groups", "gemm4_stagger_percent", "attn_no_mfma", "attn_no_fewq", "vq_no_mfma", "conv_no_tile")
 

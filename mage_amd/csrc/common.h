@@ -24,6 +24,8 @@ enum { MAGE_DEVERR_EMBEDDING_ID = 1, MAGE_DEVERR_CE_TARGET = 2 };
 // them).  No dispatch function reads the environment.
 struct MageOptions {
     int gemm_no_4w;              // 1: the one-wave-per-SIMD GEMM kernels (gemm4.hip) are not used
+    int gemm_no_4h;              // 1: the split-half form of that kernel (gemm4h.hip: epilogue under the K loop) is not used (gemm4_kernel runs)
+    int gemm_4h_plain;           // 1: gemm4h_kernel also takes the forms without QuickGELU (QKV); default: the QuickGELU forms (c_fc) only
     int gemm4_train_forms;       // 1: training's two c_fc forms on the one-wave-per-SIMD kernel (default: the 8-phase kernel, faster there)
     int gemm_no_8phase;          // 1: the 8-phase ping-pong kernel is not used (lockstep kernel instead)
     int gemm_no_taps8;           // 1: padded-taps convolutions take the generic gather kernel

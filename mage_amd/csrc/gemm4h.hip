@@ -1,30 +1,36 @@
-// gemm4h_kernel: gemm4_kernel's 256 x 256 tile with the epilogue HIDDEN under the K loop (round 6; DESIGN.md section 9 item 0 of round 5).
+// gemm4h_kernel: gemm4_kernel's 256 x 256 tile with the epilogue UNDER the K loop (round 6; DESIGN.md section 9 item 0 of round 5).
 //
 // gemm4_kernel (gemm4.hip) gives each of its four waves 128 x 128 outputs = the whole accumulator file, so a tile's epilogue (LayerNorm fold,
-// QuickGELU, pack, LDS transposition, stores: 36 % of a c_fc tile) runs with the matrix pipe idle -- nothing else is resident on the SIMD.
+// QuickGELU, pack, stores: 36 % of a c_fc tile) runs with the matrix pipe idle -- nothing else is resident on the SIMD.
 // Here the wave's block is two HALVES of 64 rows (128 accumulator registers each) that alternate:
 //     pass (tile t, half 0): K loop into a[..] of half 0   ||  the finished half 1 of tile t-1 leaves through the epilogue
 //     pass (tile t, half 1): K loop into a[..] of half 1   ||  half 0 of tile t leaves
 // One pass = 8 steps (K = 512: 8 slabs of 64) of 64 MFMAs; one epilogue PIECE (16 rows x 64 columns = 4 accumulator blocks) per step, cut into
-// single instructions ("ops") that are placed BETWEEN the step's MFMAs in source order and pinned there (sched_barrier): 2-3 vector
-// instructions per 16-cycle MFMA slot, which one wave per SIMD can issue beside its MFMAs (MI355X_MICROARCH.md).  The arithmetic is
-// epilogue_lean's, operation for operation (fma(-mean, s, acc), fma(rstd, ., c), the QuickGELU chain, v_cvt_pk): the same bits as every
-// other GEMM kernel of the library (tests/test_gpu_ops.py compares them).
+// single instructions ("ops", asm statements: hipcc keeps those in source order, plain arithmetic it sinks to the consumer) that are placed
+// BETWEEN the step's MFMAs by issue cost (profiles/r06_mfma_valu_coissue.txt: beside a 16-cycle MFMA one wave issues two plain VALU
+// instructions or one of exp / rcp / cvt_pk / accvgpr_read for free).  The arithmetic is epilogue_lean's, operation for operation
+// (fma(-mean, s, acc), fma(rstd, ., c), the QuickGELU chain, v_cvt_pk): the same bits as every other GEMM kernel of the library.
+//
+// No LDS transposition: the MFMA operand roles are swapped against gemm4_kernel (A-operand = activation rows; same products, same k order,
+// same bits) and the W rows are gathered into a permuted LDS order, so that a lane holds 4 CONSECUTIVE output columns of 4 rows and the 16
+// lanes of a group one whole 128-byte row: rows are stored straight from registers (global_store_dwordx2, scalar base + one per-lane offset).
+// (A ds_write between the fragment reads cost 100 cycles in this loop: LDS operations of a wave execute in order.)
 //
 // Cost of the split: a 64 x 128 half reads 12 operand fragments per 32 MFMAs (gemm4: 16 per 64) and the W slab is fetched once per half
-// (1.5x the LDS-DMA bytes per MFMA, from L2).  LDS: A ring 4 stages x 16 KB (the pass's 128 A rows x 64 k), W ring 2 stages x 32 KB,
-// 2 KB of row staging per wave, 2 x 2 KB per wave of epilogue constants (the tile's (mean, rstd) rows, bias and LayerNorm column sums,
-// brought in by LDS-DMA one pass ahead): 152 KB.
+// (1.5x the LDS-DMA bytes per MFMA, from L2): the K loop alone runs 20.3 cycles per MFMA against gemm4's 17.7.  What it buys (measured,
+// profiles/r06_gemm4h_split_half.txt): c_fc (LayerNorm fold + QuickGELU) +9 %; QKV (LayerNorm fold only) +0..5 %.  LDS: A ring 4 x 16 KB (the
+// pass's 128 A rows x 64 k), W ring 2 x 32 KB, 2 x 2 KB per wave of epilogue constants (the tile's (mean, rstd) rows, bias and LayerNorm
+// column sums, brought in by LDS-DMA one pass ahead, read one piece ahead of their use): 144 KB.
 //
 // Step q (stage indices are compile time: a pass has 8 steps, the rings 4 and 2 stages):
-//     t0: 32 MFMAs from fragment buffer 0;  reads: fragments (q, t1) -> buffer 1;  the previous piece's two row stores
+//     t0: 32 MFMAs from fragment buffer 0;  reads: fragments (q, t1) -> buffer 1
 //     s_waitcnt vmcnt(N) lgkmcnt(0);  s_barrier          -- W(q+1) and A(q+1) of every wave have landed, stages of step q are free
 //     t1: 32 MFMAs from buffer 1;  reads: fragments (q+1, t0) -> buffer 0 (other stages);  LDS-DMA: W(q+2) x 8, then A(q+4) x 4
 // Memory operations retire in order, so the wait is COUNTED: N = the operations issued after the W pieces it needs (the four A pieces, the
-// two stores of the piece in flight, the constants' pieces) -- they stay in flight across the barrier; the A pieces (HBM) are forced home
-// one barrier later, two steps after their issue.
-#include "../../mage_amd/csrc/gemm_shared.h"
-#include "../../mage_amd/csrc/gemm4_regs.h"
+// row stores behind them, the constants' pieces) -- they stay in flight across the barrier; the A pieces (HBM) are forced home one barrier
+// later, two steps after their issue.
+#include "gemm_shared.h"
+#include "gemm4_regs.h"
 
 namespace {
 
@@ -56,9 +62,8 @@ __device__ unsigned long long h_stamps[256 * 4];
 #endif
 
 constexpr int H_ASTG = 16384, H_WSTG = 32768, H_WOFF = 4 * H_ASTG, H_RING = H_WOFF + 2 * H_WSTG;      // 128 KB of operand rings
-constexpr int H_STG_OFF = H_RING;                       // 4 waves x 2 KB: row staging (16 rows x 128 B)
-constexpr int H_CONST_OFF = H_RING + 4 * 2048;          // 4 waves x 2 sets x 2 KB: [stats 128 rows x 8 B | bias 128 x 4 B | colsum 128 x 4 B]
-constexpr int H_LDS = H_CONST_OFF + 4 * 4096;           // 152 KB
+constexpr int H_CONST_OFF = H_RING;                     // 4 waves x 2 sets x 2 KB: [stats 128 rows x 8 B | bias 128 x 4 B | colsum 128 x 4 B]
+constexpr int H_LDS = H_CONST_OFF + 4 * 4096;           // 144 KB (no row staging: the rows leave the accumulator layout directly, see below)
 constexpr int H_CSTEP = 2;                              // the step of a tile's half-0 pass that requests the tile's epilogue constants
 
 template <int R, bool CLOB>
@@ -68,6 +73,12 @@ __device__ __forceinline__ float h_acc1() {
     else asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(v) : "i"(R));
     return v;
 }
+typedef unsigned h_u32x2 __attribute__((ext_vector_type(2)));
+// streaming store of 8 bytes per lane at (scalar base + per-lane 32-bit offset)
+__device__ __forceinline__ void h_store2(unsigned voff, h_u32x2 d, const char* base) {
+    asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(voff), "v"(d), "s"(base) : "memory");
+}
+__device__ __forceinline__ void h_sink(unsigned a, unsigned b, const void* p) { asm volatile("" ::"v"(a), "v"(b), "v"(p)); }
 // s_waitcnt immediate of gfx9: vmcnt(vm) lgkmcnt(0), expcnt untouched
 constexpr int h_wait_imm(int vm) { return (((vm >> 4) & 3) << 14) | (vm & 15) | 0x70; }
 
@@ -76,38 +87,36 @@ constexpr int h_wait_imm(int vm) { return (((vm >> 4) & 3) << 14) | (vm & 15) | 
 // beside back-to-back 16-cycle MFMAs one wave issues ~8 more cycles per MFMA for free -- two plain VALU instructions (4 cycles each) or ONE of
 // v_exp / v_rcp / v_cvt_pk / v_accvgpr_read (8 each); past that every instruction delays the next MFMA by its full issue time).
 // Unit = 4 cycles.  A slot holds 2 units; 1 if it already carries a fragment read, an LDS-DMA piece or a store.
-struct HPlan { int lo[65]; };
+struct HPlan { int lo[65]; int st[4]; };           // op range per slot; the slot of each of the piece's four row stores
+// A piece = 4 GROUPS (one per accumulator register e = the row 4g + e of the lane group's four) of OPG ops over the piece's 4 blocks j:
+//   0-3 accumulator reads, 4 the NEXT piece's constants (group 3 only), LN ops, activation, pack (2 converts) + the group's row store
 template <bool CONS, bool GELU>
 constexpr int h_op_cost(int K) {
-    constexpr int LNOPS = CONS ? 8 : 4, ACTOPS = GELU ? 20 : 0, LNB = 5, GB = LNB + LNOPS, PK = GB + ACTOPS, OPB = PK + 2;
-    if (K >= 4 * OPB) return 2;
-    const int o = K % OPB;
+    constexpr int LNOPS = CONS ? 8 : 4, ACTOPS = GELU ? 20 : 0, LNB = 5, GB = LNB + LNOPS, PK = GB + ACTOPS, OPG = PK + 2;
+    const int e = K / OPG, o = K % OPG;
     if (o < 4) return 2;
-    if (o == 4) return CONS ? 2 : 1;
+    if (o == 4) return e == 3 ? (CONS ? 4 : 1) : 0;
     if (o < GB) return 1;
     if (o < PK) { const int a = (o - GB) >> 2; return (a == 1 || a == 3) ? 2 : 1; }
     return o == PK ? 2 : 4;
 }
 template <bool CONS, bool GELU>
-constexpr HPlan h_make_plan(int S, int R0, int CS, bool consts_step) {
-    constexpr int LNOPS = CONS ? 8 : 4, ACTOPS = GELU ? 20 : 0, OPB = 4 + LNOPS + 1 + ACTOPS + 2, NOPS = 4 * OPB + 2;
-    const int L = S == 7 ? 57 : 63;
+constexpr HPlan h_make_plan(int S, int R0, bool consts_step) {
+    constexpr int LNOPS = CONS ? 8 : 4, ACTOPS = GELU ? 20 : 0, OPG = 5 + LNOPS + ACTOPS + 2, NOPS = 4 * OPG;
     HPlan p = {};
     int k = 0, rem = 0;
     for (int i = 0; i < NOPS; ++i) rem += h_op_cost<CONS, GELU>(i);
     for (int sl = 0; sl < 64; ++sl) {
         p.lo[sl] = k;
-        if (sl > L) continue;
         int cap = 2;
         if (sl < 32) {
             if (sl >= R0 && sl < R0 + 12) cap = 1;
-            if (S >= 1 && (sl == CS || sl == CS + 1)) cap = 1;
         } else {
             const int i = sl - 32;
             if (i < 24) cap = 1;
             if (i == 24 && consts_step) cap = 0;
         }
-        const int slots_left = L - sl + 1;
+        const int slots_left = 64 - sl;
         const int need = (rem + slots_left - 1) / slots_left;          // what this slot must take for the rest to fit evenly
         const int target = need > cap ? need : cap;
         int used = 0;
@@ -115,22 +124,23 @@ constexpr HPlan h_make_plan(int S, int R0, int CS, bool consts_step) {
             const int c = h_op_cost<CONS, GELU>(k);
             if (used > 0 && used + c > target) break;
             if (used == 0 && cap == 0 && need <= 2) break;
+            if (k % OPG == OPG - 1) p.st[k / OPG] = sl;
             used += c;
             rem -= c;
             ++k;
         }
     }
-    p.lo[64] = NOPS;
-    // anything left (cannot happen: the last slot's target is the whole remainder) would be dropped: checked by the static_assert at the use
-    if (k != NOPS) p.lo[64] = -1;
+    p.lo[64] = k == NOPS ? NOPS : -1;
     return p;
 }
+// stores of a step that are younger than its last W piece (issued at or after slot 46) / issued before its barrier (slots 0..31)
+constexpr int h_st_after_w(const HPlan& p) { int n = 0; for (int e = 0; e < 4; ++e) n += p.st[e] >= 46; return n; }
+constexpr int h_st_t0(const HPlan& p) { int n = 0; for (int e = 0; e < 4; ++e) n += p.st[e] < 32; return n; }
 
 template <int ACT, int LN, bool HF>
 __global__ __launch_bounds__(256) void gemm4h_kernel(const Gemm4hArgs g) {
     static_assert(LN == LN_NONE || LN == LN_CONSUME, "the generation path's epilogues");
     static_assert(ACT == MAGE_ACT_NONE || ACT == MAGE_ACT_QUICKGELU, "act none | QuickGELU");
-    typedef std::conditional_t<HF, f16_t, unsigned short> H16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     g4_claim_accumulators();
     const int tid = threadIdx.x;
@@ -158,8 +168,10 @@ __global__ __launch_bounds__(256) void gemm4h_kernel(const Gemm4hArgs g) {
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int r = u * 8 + lr;
-        voffW[u] = (unsigned)(r * g.ldw * 2 + ((lp ^ ((r >> 1) & 7)) << 4) + 8192 - u * 1024);
+        // LDS row slot r of the wave's 64-row strip (fragment j = r >> 4, lane row r & 15) holds W row 4 (r & 15) + j of the strip: with the MFMA
+        // operand roles of this kernel (below) lane l15 then owns the 4 CONSECUTIVE output columns 4 l15 + j of a 64-column piece
+        const int r = u * 8 + lr, rs = 4 * (r & 15) + (r >> 4);
+        voffW[u] = (unsigned)(rs * g.ldw * 2 + ((lp ^ ((r >> 1) & 7)) << 4) + 8192 - u * 1024);
     }
     auto a_base = [&](int tile, int half) {
         return (const char*)g.A + ((long)((tile / g.ntiles_n) * 256 + (wave >> 1) * 128 + half * 64 + (wave & 1) * 32) + g.a_off) * g.lda * 2 - 4096;
@@ -193,99 +205,88 @@ __global__ __launch_bounds__(256) void gemm4h_kernel(const Gemm4hArgs g) {
     constexpr bool CONS = LN == LN_CONSUME;
     constexpr bool GELU = ACT == MAGE_ACT_QUICKGELU;
     constexpr int LNOPS = CONS ? 8 : 4, ACTOPS = GELU ? 20 : 0;
-    constexpr int LNB = 5;                            // block-local op list: 0-3 accumulator reads, 4 the NEXT block's constants, LN ops, activation, pack + write
-    constexpr int GB = LNB + LNOPS, PK = GB + ACTOPS, OPB = PK + 2;
-    constexpr int NOPS = 4 * OPB + 2;
+    constexpr int LNB = 5, GB = LNB + LNOPS, PK = GB + ACTOPS, OPG = PK + 2;
+    constexpr int NOPS = 4 * OPG;
     constexpr int NC = CONS ? 2 : 1;                  // LDS-DMA pieces of a tile's epilogue constants
-    char* const stg = smem + H_STG_OFF + wave * 2048;
-    const int rr = lane >> 3, cc = lane & 7;
-    int woff[4], roff[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) woff[j] = l15 * 128 + (((j * 2 + (grp >> 1)) ^ ((l15 >> 1) & 7)) << 4) + (grp & 1) * 8;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = rr + 8 * i;
-        roff[i] = r * 128 + ((cc ^ ((r >> 1) & 7)) << 4);
-    }
-    // The constants are read from LDS ONE BLOCK AHEAD of their use (a block's first LN op comes 5 ops after its read otherwise: the wave sat in
-    // s_waitcnt lgkmcnt for the LDS latency once per block): bias / column sums of block j + 1 during block j into the other of two buffers, the
-    // next piece's (mean, rstd) and first block during this piece's last block -- across a pass boundary from the next pass's half and set.
+    // MFMA operand roles: A-operand = the activation fragment, B-operand = the W fragment (gemm4_kernel: the other way round; the products and
+    // their k order are the same, so are the bits).  The accumulator block (16-row tile mt, fragment nt = 4 ch + j) then holds, in lane (l15, g)
+    // and register e, the output of ROW mt*16 + 4g + e and COLUMN ch*64 + 4 l15 + j: a lane's four blocks j are 4 consecutive columns, the 16
+    // lanes of a group one whole 128-byte row -- the rows are stored straight from the registers (global_store_dwordx2, 4 rows x 128 B per
+    // instruction), no LDS transposition (a ds_write beside the fragment reads cost 100 cycles: profiles/r06_gemm4h_split_half.txt).
     [[maybe_unused]] float ea[4], eu[4];
-    [[maybe_unused]] f32x4 esb[2], ebb[2];
-    [[maybe_unused]] float2 est[2];
-    [[maybe_unused]] u32x4 eo[2];
+    [[maybe_unused]] f32x4 esb[2], ebb[2], em[2][2];   // by piece parity: column sums / bias of the lane's 4 columns, (mean, rstd) of its 4 rows
     [[maybe_unused]] unsigned epk0 = 0;
-    [[maybe_unused]] H16* eyp = (H16*)g.Y;
-    [[maybe_unused]] H16* eybase = (H16*)g.Y;          // row rr, column cc*8 of the drained half's 64 x 128 block
+    // row stores: global_store_dwordx2 voff, data, s[base]: ONE per-lane byte offset for the whole kernel (row 4g, column 4 l15 of a 16 x 64 piece),
+    // the piece's / row's position in the SCALAR base (s_add: free beside the MFMAs; 64-bit vector address arithmetic per store is not)
+    const unsigned evoff = (unsigned)(((long)4 * grp * g.ldy + 4 * l15) * 2);
+    [[maybe_unused]] const char* eyp = (const char*)g.Y;         // scalar: the piece's block
+    [[maybe_unused]] const char* eybase = (const char*)g.Y;      // scalar: the drained half's 64 x 128 block of this wave
     [[maybe_unused]] const char* ecb = smem + H_CONST_OFF + wave * 4096;      // the drained tile's constants
     [[maybe_unused]] const char* ecbn = ecb;                                  // ... of the NEXT pass's drained tile
-    const long ldy16 = (long)16 * g.ldy, ldy8 = (long)8 * g.ldy;
+    const long ldyb = (long)g.ldy * 2;                 // bytes per output row
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
-    // the constants of block J of piece P of half DH from set cb into buffer B (and the piece's (mean, rstd) with its first block)
-    auto epi_consts = [&](auto DH_, auto P_, auto J_, const char* cb) __attribute__((always_inline)) {
-        constexpr int DH = decltype(DH_)::value, P = decltype(P_)::value, J = decltype(J_)::value, mt = P & 3, ch = P >> 2;
+    // the constants of piece P of half DH from set cb, read ONE PIECE AHEAD of their use (the wave would sit in s_waitcnt lgkmcnt otherwise)
+    auto epi_consts = [&](auto DH_, auto P_, const char* cb) __attribute__((always_inline)) {
+        constexpr int DH = decltype(DH_)::value, P = decltype(P_)::value, mt = P & 3, ch = P >> 2;
         if constexpr (!(MAGE4H_OPMASK & 4)) return;
-        const char* cp = cb + 1024 + (ch * 64 + J * 16 + grp * 4) * 4;
-        ebb[J & 1] = *(const f32x4*)cp;
-        if constexpr (CONS) esb[J & 1] = *(const f32x4*)(cp + 512);
-        if constexpr (CONS && J == 0) est[P & 1] = *(const float2*)(cb + (DH * 64 + mt * 16 + l15) * 8);
-    };
-    // op K of piece P of the drained half DH (its 16-row tile mt = P & 3, 64-column half ch = P >> 2)
-    auto epi_op = [&](auto DH_, auto P_, auto K_) __attribute__((always_inline)) {
-        constexpr int DH = decltype(DH_)::value, P = decltype(P_)::value, K = decltype(K_)::value;
-        constexpr int mt = P & 3, ch = P >> 2;
-        if constexpr (K >= 4 * OPB) {
-            if constexpr (MAGE4H_OPMASK & 16) eo[K - 4 * OPB] = *(const u32x4*)(stg + roff[K - 4 * OPB]);
-        } else {
-            constexpr int j = K / OPB, o = K % OPB;
-            constexpr int blk = (ch * 8 + DH * 4 + mt) * 4 + j;
-            // every arithmetic op is ONE instruction as an asm statement: hipcc keeps asm volatile statements in source order, whereas plain
-            // arithmetic written between the MFMAs sinks to its consumer (measured: the whole block's chain landed in one MFMA slot).
-            // Hazards are this code's business: a transcendental's result is read >= 3 instructions later (gfx950 needs one wait state).
-            if constexpr (o < 4) {
-                if constexpr (MAGE4H_OPMASK & 1) ea[o] = h_acc1<4 * blk + o, o == 0>();
-            } else if constexpr (o == 4) {
-                if constexpr (j < 3) epi_consts(DH_, P_, std::integral_constant<int, j + 1>{}, ecb);
-                else if constexpr (P < 7) epi_consts(DH_, std::integral_constant<int, P + 1>{}, std::integral_constant<int, 0>{}, ecb);
-                else epi_consts(std::integral_constant<int, 1 - DH>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ecbn);
-            } else if constexpr (!(MAGE4H_OPMASK & 2) && o < PK + 1) {
-            } else if constexpr (o < LNB + 4) {
-                constexpr int e = o - LNB;
-                if constexpr (CONS) asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(ea[e]) : "v"(est[P & 1].x), "v"(esb[j & 1][e]));
-                else asm volatile("v_add_f32 %0, %0, %1" : "+v"(ea[e]) : "v"(ebb[j & 1][e]));
-            } else if constexpr (CONS && o < LNB + 8) {
-                constexpr int e = o - LNB - 4;
-                asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(ea[e]) : "v"(est[P & 1].y), "v"(ebb[j & 1][e]));
-            } else if constexpr (o < PK) {
-                constexpr int a = (o - GB) >> 2, e = (o - GB) & 3;
-                if constexpr (a == 0) asm volatile("v_mul_f32 %0, 0xc01d265f, %1" : "=v"(eu[e]) : "v"(ea[e]));        // -1.702 log2(e) x
-                else if constexpr (a == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(eu[e]));
-                else if constexpr (a == 2) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(eu[e]));
-                else if constexpr (a == 3) asm volatile("v_rcp_f32 %0, %0" : "+v"(eu[e]));
-                else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(ea[e]) : "v"(eu[e]));
-            } else if constexpr (o == PK) {
-                if constexpr (HF) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(epk0) : "v"(ea[0]), "v"(ea[1]));
-                else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(epk0) : "v"(ea[0]), "v"(ea[1]));
-            } else if constexpr (o == PK + 1) {
-                unsigned pk1 = 0;
-                if constexpr (!(MAGE4H_OPMASK & 2)) {
-                } else if constexpr (HF) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk1) : "v"(ea[2]), "v"(ea[3]));
-                else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk1) : "v"(ea[2]), "v"(ea[3]));
-                if constexpr (MAGE4H_OPMASK & 8) *(uint2*)(stg + woff[j]) = uint2{epk0, pk1};
-            }
+        const char* cp = cb + 1024 + (ch * 64 + 4 * l15) * 4;
+        ebb[P & 1] = *(const f32x4*)cp;
+        if constexpr (CONS) {
+            esb[P & 1] = *(const f32x4*)(cp + 512);
+            const char* mp = cb + (DH * 64 + mt * 16 + 4 * grp) * 8;
+            em[P & 1][0] = *(const f32x4*)mp;
+            em[P & 1][1] = *(const f32x4*)(mp + 16);
         }
     };
-    // the piece's store pointer (after the previous piece's stores have been issued off the old one)
     auto epi_ptr = [&](auto P_) __attribute__((always_inline)) {
         constexpr int P = decltype(P_)::value;
-        eyp = eybase + (P & 3) * ldy16 + (P >> 2) * 64;
+        eyp = eybase + (P & 3) * 16 * ldyb + (P >> 2) * 128;
     };
-    auto epi_store = [&](int i) __attribute__((always_inline)) {
+    // op K of piece P of the drained half DH (its 16-row tile mt = P & 3, 64-column half ch = P >> 2): group e = K / OPG
+    auto epi_op = [&](auto DH_, auto P_, auto K_) __attribute__((always_inline)) {
+        constexpr int DH = decltype(DH_)::value, P = decltype(P_)::value, K = decltype(K_)::value;
+        constexpr int mt = P & 3, ch = P >> 2, e = K / OPG, o = K % OPG;
+        // every arithmetic op is ONE instruction as an asm statement: hipcc keeps asm volatile statements in source order, whereas plain
+        // arithmetic written between the MFMAs sinks to its consumer (measured: the whole block's chain landed in one MFMA slot).
+        // Hazards are this code's business: a transcendental's result is read >= 3 instructions later (gfx950 needs one wait state).
+        if constexpr (o < 4) {
+            constexpr int blk = (ch * 8 + DH * 4 + mt) * 4 + o;
+            if constexpr (MAGE4H_OPMASK & 1) ea[o] = h_acc1<4 * blk + e, o == 0>();
+        } else if constexpr (o == 4) {
+            if constexpr (e == 3) {
+                if constexpr (P < 7) epi_consts(DH_, std::integral_constant<int, P + 1>{}, ecb);
+                else epi_consts(std::integral_constant<int, 1 - DH>{}, std::integral_constant<int, 0>{}, ecbn);
+            }
+        } else if constexpr (!(MAGE4H_OPMASK & 2) && o < PK + 1) {
+        } else if constexpr (o < LNB + 4) {
+            constexpr int j = o - LNB;
+            if constexpr (CONS) asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(ea[j]) : "v"(em[P & 1][e >> 1][(e & 1) * 2]), "v"(esb[P & 1][j]));
+            else asm volatile("v_add_f32 %0, %0, %1" : "+v"(ea[j]) : "v"(ebb[P & 1][j]));
+        } else if constexpr (CONS && o < LNB + 8) {
+            constexpr int j = o - LNB - 4;
+            asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(ea[j]) : "v"(em[P & 1][e >> 1][(e & 1) * 2 + 1]), "v"(ebb[P & 1][j]));
+        } else if constexpr (o < PK) {
+            constexpr int a = (o - GB) >> 2, j = (o - GB) & 3;
+            if constexpr (a == 0) asm volatile("v_mul_f32 %0, 0xc01d265f, %1" : "=v"(eu[j]) : "v"(ea[j]));        // -1.702 log2(e) x
+            else if constexpr (a == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(eu[j]));
+            else if constexpr (a == 2) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(eu[j]));
+            else if constexpr (a == 3) asm volatile("v_rcp_f32 %0, %0" : "+v"(eu[j]));
+            else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(ea[j]) : "v"(eu[j]));
+        } else if constexpr (o == PK) {
+            if constexpr (HF) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(epk0) : "v"(ea[0]), "v"(ea[1]));
+            else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(epk0) : "v"(ea[0]), "v"(ea[1]));
+        } else {
+            unsigned pk1 = 0;
+            if constexpr (!(MAGE4H_OPMASK & 2)) {
+            } else if constexpr (HF) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk1) : "v"(ea[2]), "v"(ea[3]));
+            else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk1) : "v"(ea[2]), "v"(ea[3]));
 #if !(MAGE4H_ABL & 2)
-        __builtin_nontemporal_store(eo[i], (u32x4*)(eyp + (i ? ldy8 : 0)));
+            h_store2(evoff, u32x2_t{epk0, pk1}, eyp + e * ldyb);                                       // row mt*16 + 4g + e: 16 lanes x 8 B = its 128 bytes
 #else
-        asm volatile("" ::"v"(eo[i]), "v"(eyp));
+            h_sink(epk0, pk1, eyp);
 #endif
+        }
     };
 
     // ---- prologue: W(0), W(1), A(0..3) of the first pass; everything home; slab 0's first fragments in registers
@@ -315,44 +316,30 @@ __global__ __launch_bounds__(256) void gemm4h_kernel(const Gemm4hArgs g) {
         constexpr bool EPI = decltype(EPI_)::value && !(MAGE4H_ABL & 1), CONSTS = decltype(CONSTS_)::value && !(MAGE4H_ABL & 1);
         constexpr int SA = S & 3, SW = S & 1, SA1 = (S + 1) & 3, SW1 = (S + 1) & 1;
         constexpr int R0 = MAGE4H_R0;
-        // the piece's ops go to slots [F, L]; the previous piece's two row stores to slots CS, CS + 1 (their LDS reads were the previous step's
-        // last ops); the LAST piece of a pass stores inside its own step (slots 62, 63): nothing of a pass is carried into the next one
-        constexpr int F = 0, L = S == 7 ? 57 : 63, CS = 6;
+        [[maybe_unused]] constexpr HPlan plan = h_make_plan<CONS, GELU>(S, R0, CONSTS && S == H_CSTEP);
+        static_assert(plan.lo[64] == NOPS, "every op of the piece has a slot");
         auto ops_at = [&](auto SL_) __attribute__((always_inline)) {
             constexpr int sl = decltype(SL_)::value;
             if constexpr (!EPI && !(MAGE4H_ABL & 1) && S == 7 && sl == 44) {        // the workgroup's first pass: what the first piece of the next one finds prefetched
-                epi_consts(std::integral_constant<int, H>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ecbn);
+                epi_consts(std::integral_constant<int, H>{}, std::integral_constant<int, 0>{}, ecbn);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (EPI) {
-                if constexpr (S >= 1 && (sl == CS || sl == CS + 1)) {
-                    epi_store(sl - CS);
-                    if constexpr (sl == CS + 1) epi_ptr(S_);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (S == 0 && sl == 0) {
+                if constexpr (sl == 0) {
                     epi_ptr(S_);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (S == 7 && sl >= 62) {
-                    epi_store(sl - 62);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (sl >= F && sl <= L) {
-                    constexpr HPlan plan = h_make_plan<CONS, GELU>(S, R0, CS, CONSTS && S == H_CSTEP);
-                    static_assert(plan.lo[64] == NOPS && plan.lo[L + 1] == NOPS, "every op of the piece has a slot");
-                    constexpr int lo = plan.lo[sl], hi = plan.lo[sl + 1];
-                    g4_for<hi - lo>([&](auto k_) {
-                        epi_op(std::integral_constant<int, 1 - H>{}, S_, std::integral_constant<int, lo + decltype(k_)::value>{});
-                    });
-                    if constexpr (hi > lo) __builtin_amdgcn_sched_barrier(0);
-                }
+                constexpr int lo = plan.lo[sl], hi = plan.lo[sl + 1];
+                g4_for<hi - lo>([&](auto k_) {
+                    epi_op(std::integral_constant<int, 1 - H>{}, S_, std::integral_constant<int, lo + decltype(k_)::value>{});
+                });
+                if constexpr (hi > lo) __builtin_amdgcn_sched_barrier(0);
             }
         };
         // ---- t0
         g4_for<32>([&](auto i_) {
             constexpr int i = decltype(i_)::value, m = i >> 3, nt = i & 7;
-            g4_mfma<((nt >> 2) * 8 + 4 * H + m) * 4 + (nt & 3), S == 0, i == 0, HF>(wf[0][nt], xf[0][m]);
+            g4_mfma<((nt >> 2) * 8 + 4 * H + m) * 4 + (nt & 3), S == 0, i == 0, HF>(xf[0][m], wf[0][nt]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (i >= R0 && i < R0 + 12) {
                 if constexpr (i - R0 < 4) rd_x(1, SA, 1, i - R0);
@@ -362,14 +349,17 @@ __global__ __launch_bounds__(256) void gemm4h_kernel(const Gemm4hArgs g) {
             ops_at(i_);
         });
         // W(q+1) (and everything older: A(q+1), the stores before it) home; in flight behind it: A(q+3)'s 4 pieces, the constants' pieces if the
-        // previous step sent them, the previous pass's closing stores (S == 0), this step's two stores
+        // previous step sent them, the previous step's stores issued after its last W piece, this step's stores so far
         {
-            constexpr int n_base = 4 + ((S >= 1 && (S - 1) == H_CSTEP && CONSTS) ? NC : 0) + ((EPI && S >= 1) ? 2 : 0);
+            constexpr bool prev_consts = S >= 1 && (S - 1) == H_CSTEP && CONSTS;
+            constexpr HPlan prev = h_make_plan<CONS, GELU>(S >= 1 ? S - 1 : 7, R0, prev_consts);
+            constexpr int n_base = 4 + (prev_consts ? NC : 0) + (EPI ? h_st_t0(plan) : 0);
+            constexpr int n_prev = h_st_after_w(prev);
             if constexpr (S == 0) {
-                if (prev_stores) __builtin_amdgcn_s_waitcnt(h_wait_imm(n_base + 2));
+                if (prev_stores) __builtin_amdgcn_s_waitcnt(h_wait_imm(n_base + n_prev));
                 else __builtin_amdgcn_s_waitcnt(h_wait_imm(n_base));
             } else {
-                __builtin_amdgcn_s_waitcnt(h_wait_imm(n_base));
+                __builtin_amdgcn_s_waitcnt(h_wait_imm(n_base + (EPI ? n_prev : 0)));
             }
         }
         ring_barrier();
@@ -377,7 +367,7 @@ __global__ __launch_bounds__(256) void gemm4h_kernel(const Gemm4hArgs g) {
         // ---- t1
         g4_for<32>([&](auto i_) {
             constexpr int i = decltype(i_)::value, m = i >> 3, nt = i & 7;
-            g4_mfma<((nt >> 2) * 8 + 4 * H + m) * 4 + (nt & 3), false, i == 0, HF>(wf[1][nt], xf[1][m]);
+            g4_mfma<((nt >> 2) * 8 + 4 * H + m) * 4 + (nt & 3), false, i == 0, HF>(xf[1][m], wf[1][nt]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr ((i & 1) == 1 && i < 24) {                 // fragments (q+1, t0): the next step's stages
                 constexpr int k = i >> 1;
@@ -426,7 +416,7 @@ __global__ __launch_bounds__(256) void gemm4h_kernel(const Gemm4hArgs g) {
     auto drain_of = [&](int dtm, int dtn, int dh, int dpar, int npar) __attribute__((always_inline)) {
         ecb = smem + H_CONST_OFF + wave * 4096 + dpar * 2048;
         ecbn = smem + H_CONST_OFF + wave * 4096 + npar * 2048;
-        eybase = (H16*)g.Y + ((long)(dtm * 256 + wm * 128 + dh * 64 + rr) + g.y_off) * g.ldy + dtn * 256 + wn * 128 + cc * 8;
+        eybase = (const char*)g.Y + (((long)(dtm * 256 + wm * 128 + dh * 64) + g.y_off) * g.ldy + dtn * 256 + wn * 128) * 2;
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
@@ -474,8 +464,6 @@ __global__ __launch_bounds__(256) void gemm4h_kernel(const Gemm4hArgs g) {
     g4_for<8>([&](auto p_) {
         epi_ptr(p_);
         g4_for<NOPS>([&](auto k_) { epi_op(I1{}, p_, k_); });
-        epi_store(0);
-        epi_store(1);
     });
 #endif
 }
@@ -513,10 +501,14 @@ int launch4h(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
 
 }  // namespace
 
-// 1 = launched, 0 = not this kernel's form: K = 512 (one epilogue piece per K slab), 16-bit rows out, the epilogues act(acc + bias) and its
-// LayerNorm-consuming form -- the decoder's QKV and c_fc in the 16-bit modes; the caller has checked gemm4_kernel's own eligibility
-// (M, N multiples of 256, plain rows, 32-bit lane offsets).
+// Called by mage_gemm4_try (gemm4.hip) once a product has passed gemm4_kernel's eligibility checks (M, N multiples of 256, plain rows, 32-bit
+// lane offsets, at least 4 tiles per CU): 1 = launched, 0 = not this kernel's form.  Its form: K = 512 (one epilogue piece per K slab), 16-bit
+// rows out, the epilogues act(acc + bias) and its LayerNorm-consuming form -- the decoder's QKV and c_fc in the 16-bit modes.
+// Options (mage_set_option): gemm_no_4h = 1: gemm4_kernel runs instead (tests compare the two bitwise); gemm_4h_plain = 1: also the forms
+// without QuickGELU (default: only the QuickGELU forms come here -- the others gain 0..5 %, inside the box-to-box spread).
 int mage_gemm4h_try(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
+    if (mage_options().gemm_no_4h) return 0;
+    if (d->act != MAGE_ACT_QUICKGELU && !mage_options().gemm_4h_plain) return 0;
     if (d->K != 512 || d->y_dtype != d->dtype || d->y2 || (d->act != MAGE_ACT_NONE && d->act != MAGE_ACT_QUICKGELU)) return 0;
     if (d->ln_stats && (((uintptr_t)d->ln_stats) & 15)) return 0;
     const bool hf = d->dtype == MAGE_F16;

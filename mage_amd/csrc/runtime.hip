@@ -37,7 +37,7 @@ static MageOptions g_opt;
 static std::once_flag g_opt_once;             // the first mage_gemm calls of several host threads race for the table otherwise
 struct OptField { const char* name; int MageOptions::*field; };
 static const OptField g_opt_fields[] = {
-    {"gemm_no_4w", &MageOptions::gemm_no_4w}, {"gemm4_train_forms", &MageOptions::gemm4_train_forms},
+    {"gemm_no_4w", &MageOptions::gemm_no_4w}, {"gemm_no_4h", &MageOptions::gemm_no_4h}, {"gemm_4h_plain", &MageOptions::gemm_4h_plain}, {"gemm4_train_forms", &MageOptions::gemm4_train_forms},
     {"gemm_no_8phase", &MageOptions::gemm_no_8phase}, {"gemm_no_taps8", &MageOptions::gemm_no_taps8},
     {"gemm_no_narrow", &MageOptions::gemm_no_narrow}, {"gemm_no_narrow_few", &MageOptions::gemm_no_narrow_few},
     {"gemm_no_small", &MageOptions::gemm_no_small}, {"gemm_small_m", &MageOptions::gemm_small_m},
@@ -54,6 +54,8 @@ const MageOptions& mage_options() {
     std::call_once(g_opt_once, [] {
         MageOptions o = {};
         o.gemm_no_4w = env_flag("MAGE_GEMM_NO_4W");
+        o.gemm_no_4h = env_flag("MAGE_GEMM_NO_4H");
+        o.gemm_4h_plain = env_flag("MAGE_GEMM_4H_PLAIN");
         o.gemm4_train_forms = env_flag("MAGE_GEMM4_TRAIN_FORMS");
         o.gemm_no_8phase = env_flag("MAGE_GEMM_NO_8PHASE");
         o.gemm_no_taps8 = env_flag("MAGE_GEMM_NO_TAPS8");

@@ -122,7 +122,8 @@ def _lib_opts(l) -> dict:
     """The library's kernel-selection options that the profile keys mirror (mage_get_option; read only while profiling)."""
     out = {}
     v = C.c_int32(0)
-    for name in ("gemm_no_narrow", "gemm_no_narrow_few", "gemm_no_8phase", "gemm_no_taps8", "gemm4_train_forms", "gemm_no_4w", "conv_no_tile"):
+    for name in ("gemm_no_narrow", "gemm_no_narrow_few", "gemm_no_8phase", "gemm_no_taps8", "gemm4_train_forms", "gemm_no_4w", "gemm_no_4h", "gemm_4h_plain",
+                 "conv_no_tile"):
         _lib.check(l.mage_get_option(name.encode(), C.byref(v)), l)
         out[name] = int(v.value)
     return out
@@ -345,6 +346,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
                                                                           and bool(lo["gemm4_train_forms"])))
                 and lda % 8 == 0 and ldy % 8 == 0 and (M // 256) * (N // 256) >= 4 * n_cu and not lo["gemm_no_4w"]):
             key = f"gemm4_kernel<{act_k}, 0, {ln}, false, {hf}>"
+            # its split-half form (mage_gemm4h_try in csrc/gemm4h.hip): K = 512, 16-bit rows out, by default the QuickGELU forms (c_fc)
+            if (K == 512 and y.dtype == a.dtype and y2 is None and ln in (0, 2) and not lo["gemm_no_4h"]
+                    and (act == ACT_QUICKGELU or lo["gemm_4h_plain"]) and (ln_stats is None or ln_stats.data_ptr() % 16 == 0)):
+                key = f"gemm4h_kernel<{act_k}, {ln}, {hf}>"
         if PROFILE.wants(key):
             ev = PROFILE.begin()
             _lib.check(l.mage_gemm(C.byref(d), s), l)

@@ -1074,3 +1074,81 @@ def test_gemm_one_wave_per_simd_training_forms_equal_the_8phase_kernel():
         torch.cuda.synchronize()
         for r, g_ in zip(ref, got):
             assert not torch.isnan(g_.float()).any() and torch.equal(r, g_), form
+
+
+@pytest.mark.parametrize("ht", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,act,ln", [(65536, 2048, 2, True), (65792, 2048, 2, True), (262144, 512, 2, False), (65536, 1536, 0, True),
+                                        (33024, 1536, 0, True), (65536, 1024, 0, False)])
+def test_gemm_split_half_kernel_equals_gemm4_and_the_8phase_kernel(M, N, act, ln, ht):
+    """csrc/gemm4h.hip (round 6: the wave's 128 x 128 block as two 64-row halves, the finished half's epilogue between the other half's MFMAs, rows
+    stored straight from the swapped-role accumulator layout) against gemm4_kernel and the 8-phase kernel on the same product: bit-identical
+    outputs in bf16 and f16, the LayerNorm-consuming and plain forms, with and without QuickGELU, whole and ragged tile counts per workgroup
+    (257 and 129 row tiles: the last pass of some workgroups drains alone); repeated launches agree."""
+    o = ops()
+    K = 512
+    a = rnd(M, K, seed=41).to(ht)
+    w, b = rnd(N, K, seed=42, scale=K ** -0.5).to(ht), rnd(N, seed=43, scale=0.1)
+    ad, wd, bd = a.to(DEV), w.to(DEV), b.to(DEV)
+    kw = dict(M=M, N=N, K=K, lda=K, ldy=N, bias=bd, act=act)
+    if ln:
+        st = torch.stack([0.05 * rnd(M, seed=44), 1.0 + 0.2 * rnd(M, seed=45).abs()], 1).contiguous()
+        cs = 0.3 * rnd(N, seed=46)
+        kw.update(ln_stats=st.to(DEV), ln_colsum=cs.to(DEV))
+
+    def run(**opts):
+        import contextlib
+        with contextlib.ExitStack() as es:
+            for k_, v_ in opts.items():
+                es.enter_context(config.lib_option(k_, v_))
+            y = torch.full((M, N), float("nan"), device=DEV, dtype=ht)
+            o.gemm(ad, wd, y, **kw)
+            return y
+    y8 = run(gemm_no_4w=1)
+    y4 = run(gemm_no_4h=1)
+    yh = [run(gemm_4h_plain=1) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert not torch.isnan(yh[0].float()).any()
+    assert torch.equal(y4, y8)
+    for y in yh:
+        assert torch.equal(y, y4), f"{int((y != y4).sum())} of {y.numel()} outputs differ from gemm4_kernel's"
+    rows = torch.arange(0, M, M // 64) + 5
+    acc = a[rows].double() @ w.double().t()
+    want = ((acc - st[rows, 0:1].double() * cs.double()) * st[rows, 1:2].double() if ln else acc) + b.double()
+    if act == o.ACT_QUICKGELU:
+        want = want * torch.sigmoid(1.702 * want)
+    torch.testing.assert_close(yh[0][rows.to(DEV)].cpu().double(), want, **HTOL[ht])
+
+
+def test_gemm_split_half_kernel_race_screen_under_memory_load():
+    """gemm4h_kernel orders its LDS-DMA writes, fragment reads, constants and row stores by COUNTED vmcnt waits + one barrier per step (the count
+    leaves the A pieces, the constants' pieces and the stores in flight): a wrong count would still pass whenever the pieces happen to land in
+    time.  24 launches of the c_fc- and QKV-shaped products while a second stream keeps the HBM busy, every output compared bit for bit with
+    gemm4_kernel's."""
+    o = ops()
+    K = 512
+    for M, N, act in ((65536, 2048, o.ACT_QUICKGELU), (65536, 1536, 0)):
+        a = rnd(M, K, seed=51).bfloat16().to(DEV)
+        w, b = rnd(N, K, seed=52, scale=K ** -0.5).bfloat16().to(DEV), rnd(N, seed=53, scale=0.1).to(DEV)
+        st = torch.stack([0.05 * rnd(M, seed=54), 1.0 + 0.2 * rnd(M, seed=55).abs()], 1).contiguous().to(DEV)
+        cs = (0.3 * rnd(N, seed=56)).to(DEV)
+        kw = dict(M=M, N=N, K=K, lda=K, ldy=N, bias=b, ln_stats=st, ln_colsum=cs, act=act)
+        with config.lib_option("gemm_no_4h", 1):
+            ref = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            o.gemm(a, w, ref, **kw)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        big = torch.empty(1 << 28, device=DEV, dtype=torch.uint8)
+        big2 = torch.empty_like(big)
+        outs = [torch.empty(M, N, device=DEV, dtype=torch.bfloat16) for _ in range(4)]
+        bad = 0
+        with config.lib_option("gemm_4h_plain", 1):
+            for rep in range(6):
+                with torch.cuda.stream(side):
+                    for _ in range(rep + 1):
+                        big2.copy_(big, non_blocking=True)
+                for y in outs:
+                    y.fill_(float("nan"))
+                    o.gemm(a, w, y, **kw)
+                torch.cuda.synchronize()
+                bad += sum(int(not torch.equal(y, ref)) for y in outs)
+        assert bad == 0, f"{bad} of 24 launches (N = {N}) differ from gemm4_kernel's output"

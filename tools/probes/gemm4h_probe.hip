@@ -1,9 +1,10 @@
-// Bring-up / tuning probe of the split-half one-wave-per-SIMD GEMM experiment (tools/probes/gemm4h_experiment.hip) against the library's
-// gemm4_kernel (mage_gemm): bitwise comparison of the outputs and interleaved HIP-event timing on the decoder's K = 512 shapes.
+// Bring-up / tuning probe of the split-half one-wave-per-SIMD GEMM (mage_amd/csrc/gemm4h.hip; this file compiles its own copy, so the MAGE4H_*
+// tuning flags work) against the library's gemm4_kernel (mage_gemm with option gemm_no_4h = 1): bitwise comparison of the outputs and interleaved HIP-event timing on the decoder's K = 512 shapes.
 // build (from the repo root; the library must be built first):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DMAGE4H_ABL=n] tools/probes/gemm4h_probe.hip -Lmage_amd/lib -lmage_hip -Wl,-rpath,'$ORIGIN/../../mage_amd/lib' -o tools/probes/gemm4h_probe.bin
 // MAGE4H_ABL: 1 = K loop only (no outputs: the comparison is skipped), 2 = epilogue ops without global stores (likewise)
-#include "gemm4h_experiment.hip"
+#define mage_gemm4h_try mage_gemm4h_try_probe      // this file's own copy of the kernel (tuning builds), beside the library's
+#include "../../mage_amd/csrc/gemm4h.hip"
 #include <cstring>
 #include <vector>
 
@@ -62,7 +63,10 @@ int main(int argc, char** argv) {
         mage_gemm_desc d0 = d, d1 = d;
         d0.Y = Y0;
         d1.Y = Y1;
+        mage_set_option("gemm_no_4h", 1);           // the library's dispatch: gemm4_kernel
         if (mage_gemm(&d0, nullptr) != MAGE_OK) { printf("mage_gemm: %s\n", mage_last_error()); return 1; }
+        mage_set_option("gemm_no_4h", 0);
+        mage_set_option("gemm_4h_plain", 1);
         const int r = mage_gemm4h_try(&d1, nullptr, 256);
         if (r != 1) { printf("%s: gemm4h not eligible (%d) %s\n", sh.name, r, mage_last_error()); continue; }
         if (hipDeviceSynchronize() != hipSuccess) { printf("sync failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
