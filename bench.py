@@ -361,7 +361,62 @@ def cfg4_probe(m4, dev, B=32, L=32):
                         "flop_per_frame": F8_ENC_FLOP_PER_FRAME}
     m4.set_precision(saved[0])
     m4.ar_mode, m4.use_graph = saved[1], saved[2]
+    # the cfg4 TRAINING step (main_mage.py:142-154 on the HIP path: MAGE.forward with the randomness branch, backward, FlatAdam), bf16, and the
+    # share of it that is the frozen f8 encoder tokenising the batch's B*L frames (mage_model.py:579; exact-fp32 chains)
+    try:
+        # (MAGE.forward's video prior collapses the clip with four stride-2 Conv3d blocks, mage_model.py:496-501,592-594: at most 16 frames, the
+        # reference's own configs train on 10: the step is timed on the first 16 frames of the cfg4 batch)
+        Lt = min(L, 16)
+        out["train_step"] = cfg4_train_probe(dev, B, Lt, {k: (v[:, :Lt].contiguous() if k == "images" else v) for k, v in batch.items()})
+    except Exception as e:                          # the generation figures above stay
+        out["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
+
+
+def cfg4_train_probe(dev, B, L, batch):
+    import gc
+    from mage_amd.optim import FlatAdam
+    from mage_amd.utils import synth
+    from mage_amd.utils.util import instantiate_from_config
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.manual_seed(4)
+    tm = instantiate_from_config(synth.cater_model_config(frames_length=L))
+    synth.fill_state_dict(tm, 0)
+    tm = tm.to(dev).set_precision("bf16").train()
+    opt = FlatAdam(tm.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6)
+    tb = {k: v for k, v in batch.items() if k != "video_noise"}
+
+    def one():
+        opt.zero_grad()
+        loss, _ = tm(tb)
+        loss.backward()
+        opt.step()
+        return loss
+    l0 = one().item()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        last = one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    with torch.no_grad():
+        tm.first_stage_encode(tb["images"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tm.first_stage_encode(tb["images"])
+        torch.cuda.synchronize()
+        ms_enc = (time.perf_counter() - t0) * 1e3
+    res = {"ms_per_step": round(ms, 2), "frames_per_s_trained": round(B * L / ms * 1e3, 1), "steps_timed": n, "batch": B, "frames": L, "dtype": "bf16",
+           "encode_ms": round(ms_enc, 2), "encode_share": round(ms_enc / ms, 3), "loss_first_last": [round(l0, 4), round(last.item(), 4)],
+           "trainable_parameters": sum(p.numel() for p in tm.parameters() if p.requires_grad),
+           "note": "secondary: the reference's training loop body at cfg4 (randomness branch: Conv3d video prior, KL term), 1 GPU; encode = the frozen f8 "
+                   "VQ-VAE tokenising the step's B*L frames on exact-fp32 chains"}
+    del tm, opt
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
 
 
 def latency_b1(model2, dev, L, m4=None):

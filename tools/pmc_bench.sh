@@ -19,6 +19,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in agg.items():
         out[k][c + "_KB_avg"] = sum(v) / len(v)
         out[k]["launches"] = len(v)
+        # a symbol that serves two shapes (out_proj K = 512 and c_proj K = 2048 share the x + Linear(.) producer): the two clusters of its launches
+        m = sum(v) / len(v)
+        lo, hi = [x for x in v if x < m], [x for x in v if x >= m]
+        if lo and hi and min(hi) > 1.3 * max(lo):
+            out[k][c + "_KB_clusters"] = [[len(lo), sum(lo) / len(lo)], [len(hi), sum(hi) / len(hi)]]
 res = {}
 for k, v in out.items():
     f, w = v.get("FETCH_SIZE_KB_avg", 0.0), v.get("WRITE_SIZE_KB_avg", 0.0)
@@ -26,6 +31,10 @@ for k, v in out.items():
     # (16 B/lane global_load and buffer_load..lds alike) -> doubled; WRITE_SIZE taken as is (KB -> bytes x1024)
     res[k] = {"launches": v["launches"], "fetch_bytes_raw": f * 1024, "fetch_bytes_corrected": 2 * f * 1024, "write_bytes": w * 1024,
               "hbm_bytes_per_launch": (2 * f + w) * 1024}
+    if "FETCH_SIZE_KB_clusters" in v:
+        res[k]["fetch_bytes_corrected_clusters"] = [[n, 2 * x * 1024] for n, x in v["FETCH_SIZE_KB_clusters"]]
+    if "WRITE_SIZE_KB_clusters" in v:
+        res[k]["write_bytes_clusters"] = [[n, x * 1024] for n, x in v["WRITE_SIZE_KB_clusters"]]
 json.dump(res, open("$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG.json", "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]:
     print(f"{k[:60]:60s} n={v['launches']:4d} fetch(x2) {v['fetch_bytes_corrected']/1e6:9.1f} MB write {v['write_bytes']/1e6:9.1f} MB")
