@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256) void gemm_tn4_kernel(const Tn4Args g) {
 
 }  // namespace
 
-int mage_gemm4h_try(const mage_gemm_desc* d, hipStream_t s, int n_cu);      // gemm4h.hip
+int mage_gemm4h_try(const mage_gemm_desc* d, hipStream_t s, int n_cu);      // gemm4h.hip (applies its own tile-count rule)
 
 // 1 = launched, 0 = not eligible (the caller falls through to the 8-wave kernels), < 0 = error.
 // Eligible: bf16 plain GEMMs (no gather, rows not regrouped) with the epilogues y = act(acc + b) (b optional), its LayerNorm-consuming form, or
@@ -778,11 +778,13 @@ int mage_gemm4_try(const mage_gemm_desc* d, hipStream_t s) {
     const int n_cu = n_cu_dev[dev];
     // at least four tiles per CU: with two (the incremental loop's c_fc at 16 k rows) the prologue's un-overlapped slab pair and the single
     // tile boundary cost more than the K loop gains (47.5 vs 41 us per launch there): those sizes stay on the lockstep kernel
-    if ((long)(d->M / 256) * (d->N / 256) < 4L * n_cu) return 0;
+    const long ntiles = (long)(d->M / 256) * (d->N / 256);
+    const bool few_tiles = ntiles < 4L * n_cu;          // gemm4_kernel itself stays above it; its split-half form also runs below (see mage_gemm4h_try)
     const int ldw = d->ldw ? d->ldw : d->K;
     if (((long)d->M + d->a_off) * d->lda * 2 + 16384 >= (1L << 32) || (long)d->N * ldw * 2 + 16384 >= (1L << 32)) return 0;     // 32-bit lane offsets
     if (!dual && !gbwd)
         if (const int r = mage_gemm4h_try(d, s, n_cu)) return r;         // K = 512, 16-bit rows out: the split-half form (gemm4h.hip)
+    if (few_tiles) return 0;
     if (dual) return launch4<MAGE_ACT_QUICKGELU, EK_BIAS, LN_DUAL, false>(d, s, n_cu);
     if (gbwd) return launch4<MAGE_ACT_NONE, EK_BIAS, LN_GELUBWD, false>(d, s, n_cu);
     if (hf) {

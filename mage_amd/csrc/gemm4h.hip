@@ -502,13 +502,20 @@ int launch4h(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
 }  // namespace
 
 // Called by mage_gemm4_try (gemm4.hip) once a product has passed gemm4_kernel's eligibility checks (M, N multiples of 256, plain rows, 32-bit
-// lane offsets, at least 4 tiles per CU): 1 = launched, 0 = not this kernel's form.  Its form: K = 512 (one epilogue piece per K slab), 16-bit
+// lane offsets; NOT its tile-count rule): 1 = launched, 0 = not this kernel's form.  Its form: K = 512 (one epilogue piece per K slab), 16-bit
 // rows out, the epilogues act(acc + bias) and its LayerNorm-consuming form -- the decoder's QKV and c_fc in the 16-bit modes.
 // Options (mage_set_option): gemm_no_4h = 1: gemm4_kernel runs instead (tests compare the two bitwise); gemm_4h_plain = 1: also the forms
 // without QuickGELU (default: only the QuickGELU forms come here -- the others gain 0..5 %, inside the box-to-box spread).
 int mage_gemm4h_try(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     if (mage_options().gemm_no_4h) return 0;
-    if (d->act != MAGE_ACT_QUICKGELU && !mage_options().gemm_4h_plain) return 0;
+    // Which products (measured, profiles/r06_gemm4h_small_m.txt; one MI355X):
+    //   >= 4 tiles per CU (the full-loop sizes): the QuickGELU forms (c_fc: +6-9 %); the others gain 0-5 % there and stay on gemm4_kernel
+    //   3/4 .. 4 tiles per CU (the incremental loop's step at 8 k - 32 k rows, where gemm4_kernel loses to the 8-wave kernels: a tile's exposed
+    //     epilogue is not amortised): every form -- c_fc +9 % at 16 k rows, +23 % at 8 k; QKV +16 % / +32 %
+    //   below 3/4 tile per CU (<= 4 k rows): -20 % against the lockstep kernel: not taken
+    const long ntiles = (long)(d->M / 256) * (d->N / 256);
+    if (ntiles * 4 < 3L * n_cu) return 0;
+    if (ntiles >= 4L * n_cu && d->act != MAGE_ACT_QUICKGELU && !mage_options().gemm_4h_plain) return 0;
     if (d->K != 512 || d->y_dtype != d->dtype || d->y2 || (d->act != MAGE_ACT_NONE && d->act != MAGE_ACT_QUICKGELU)) return 0;
     if (d->ln_stats && (((uintptr_t)d->ln_stats) & 15)) return 0;
     const bool hf = d->dtype == MAGE_F16;

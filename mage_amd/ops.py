@@ -344,11 +344,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, M: int, N: int, K
                 and (bias is not None or (N <= 4096 and ln_stats is None)) and (ln_stats is None) == (ln_colsum is None)
                 and (act in (ACT_NONE, ACT_QUICKGELU) if y2 is None else (ln in (3, 4) and y.dtype == torch.bfloat16 and ldy2 % 8 == 0
                                                                           and bool(lo["gemm4_train_forms"])))
-                and lda % 8 == 0 and ldy % 8 == 0 and (M // 256) * (N // 256) >= 4 * n_cu and not lo["gemm_no_4w"]):
-            key = f"gemm4_kernel<{act_k}, 0, {ln}, false, {hf}>"
-            # its split-half form (mage_gemm4h_try in csrc/gemm4h.hip): K = 512, 16-bit rows out, by default the QuickGELU forms (c_fc)
-            if (K == 512 and y.dtype == a.dtype and y2 is None and ln in (0, 2) and not lo["gemm_no_4h"]
-                    and (act == ACT_QUICKGELU or lo["gemm_4h_plain"]) and (ln_stats is None or ln_stats.data_ptr() % 16 == 0)):
+                and lda % 8 == 0 and ldy % 8 == 0 and not lo["gemm_no_4w"]):
+            nt4 = (M // 256) * (N // 256)
+            if nt4 >= 4 * n_cu:
+                key = f"gemm4_kernel<{act_k}, 0, {ln}, false, {hf}>"
+            # its split-half form (mage_gemm4h_try in csrc/gemm4h.hip): K = 512, 16-bit rows out; at >= 4 tiles per CU the QuickGELU forms
+            # (c_fc), from 3/4 tile per CU up to there (the incremental loop's step) every form
+            if (K == 512 and y.dtype == a.dtype and y2 is None and ln in (0, 2) and not lo["gemm_no_4h"] and nt4 * 4 >= 3 * n_cu
+                    and (nt4 < 4 * n_cu or act == ACT_QUICKGELU or lo["gemm_4h_plain"]) and (ln_stats is None or ln_stats.data_ptr() % 16 == 0)):
                 key = f"gemm4h_kernel<{act_k}, {ln}, {hf}>"
         if PROFILE.wants(key):
             ev = PROFILE.begin()

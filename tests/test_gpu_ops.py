@@ -1078,7 +1078,8 @@ def test_gemm_one_wave_per_simd_training_forms_equal_the_8phase_kernel():
 
 @pytest.mark.parametrize("ht", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,act,ln", [(65536, 2048, 2, True), (65792, 2048, 2, True), (262144, 512, 2, False), (65536, 1536, 0, True),
-                                        (33024, 1536, 0, True), (65536, 1024, 0, False)])
+                                        (33024, 1536, 0, True), (65536, 1024, 0, False),
+                                        (16384, 2048, 2, True), (16384, 1536, 0, True), (8192, 2048, 2, True), (8192, 1536, 0, True)])      # the incremental step
 def test_gemm_split_half_kernel_equals_gemm4_and_the_8phase_kernel(M, N, act, ln, ht):
     """csrc/gemm4h.hip (round 6: the wave's 128 x 128 block as two 64-row halves, the finished half's epilogue between the other half's MFMAs, rows
     stored straight from the swapped-role accumulator layout) against gemm4_kernel and the 8-phase kernel on the same product: bit-identical

@@ -28,7 +28,21 @@ int main(int argc, char** argv) {
                             {"plain N2048 bias", 262144, 2048, 512, MAGE_ACT_NONE, false},
                             {"plain N512 bias+gelu", 262144, 512, 512, MAGE_ACT_QUICKGELU, false},
                             {"c_fc M=65792 (257 row tiles)", 65792, 2048, 512, MAGE_ACT_QUICKGELU, true},
-                            {"qkv  M=33024 (129 row tiles)", 33024, 1536, 512, MAGE_ACT_NONE, true}};
+                            {"qkv  M=33024 (129 row tiles)", 33024, 1536, 512, MAGE_ACT_NONE, true},
+                            {"c_fc M=16384 (incremental step, cfg2)", 16384, 2048, 512, MAGE_ACT_QUICKGELU, true},
+                            {"qkv  M=16384 (incremental step, cfg2)", 16384, 1536, 512, MAGE_ACT_NONE, true},
+                            {"c_fc M=8192 (incremental step, cfg4)", 8192, 2048, 512, MAGE_ACT_QUICKGELU, true},
+                            {"qkv  M=8192 (incremental step, cfg4)", 8192, 1536, 512, MAGE_ACT_NONE, true},
+                            {"c_fc M=4096", 4096, 2048, 512, MAGE_ACT_QUICKGELU, true},
+                            {"qkv  M=4096", 4096, 1536, 512, MAGE_ACT_NONE, true},
+                            {"c_fc M=2048", 2048, 2048, 512, MAGE_ACT_QUICKGELU, true},
+                            {"qkv  M=2048", 2048, 1536, 512, MAGE_ACT_NONE, true},
+                            {"c_fc M=1280", 1280, 2048, 512, MAGE_ACT_QUICKGELU, true},
+                            {"qkv  M=1280", 1280, 1536, 512, MAGE_ACT_NONE, true},
+                            {"c_fc M=24576", 24576, 2048, 512, MAGE_ACT_QUICKGELU, true},
+                            {"qkv  M=49152", 49152, 1536, 512, MAGE_ACT_NONE, true},
+                            {"c_fc M=32768", 32768, 2048, 512, MAGE_ACT_QUICKGELU, true},
+                            {"qkv  M=32768", 32768, 1536, 512, MAGE_ACT_NONE, true}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -90,13 +104,13 @@ int main(int argc, char** argv) {
         for (int rd = 0; rd < rounds; ++rd) {
             float ms;
             hipEventRecord(e0);
-            for (int i = 0; i < 4; ++i) mage_gemm(&d0, nullptr);
+            for (int i = 0; i < 8; ++i) mage_gemm(&d0, nullptr);
                 hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
-            t4 += ms / 4;
+            t4 += ms / 8;
             hipEventRecord(e0);
-            for (int i = 0; i < 4; ++i) mage_gemm4h_try(&d1, nullptr, 256);
+            for (int i = 0; i < 8; ++i) mage_gemm4h_try(&d1, nullptr, 256);
             hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
-            th += ms / 4;
+            th += ms / 8;
         }
         const double fl = 2.0 * M * N * K;
         printf("%-30s gemm4 %8.1f us %7.1f TFLOP/s | gemm4h(ABL=%d) %8.1f us %7.1f TFLOP/s  (%+.1f %%)\n", sh.name, t4 / rounds * 1e3, fl / (t4 / rounds) / 1e9,
