@@ -328,7 +328,7 @@ def cfg4_probe(m4, dev, B=32, L=32):
     for prec in ("bf16", "f16"):
         m4.set_precision(prec)
         row = {}
-        for mode, n in (("full", 1), ("incremental", 3)):
+        for mode, n in (("full", 3), ("incremental", 3)):
             m4.ar_mode = mode
             ms = timed(lambda: m4.autoregressive_generate(batch), n)
             toks[(prec, mode)] = m4.last_tokens.clone()

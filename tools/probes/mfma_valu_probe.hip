@@ -40,6 +40,14 @@ template <int KIND, int N> __device__ __forceinline__ void filler(float (&r)[8],
     if constexpr (KIND == 8) asm volatile("ds_write_b64 %0, %1" ::"v"(la), "v"(*(const unsigned long long*)&ld));
     if constexpr (KIND == 9) { if constexpr ((N & 15) == 0) asm volatile("ds_write_b64 %0, %1" ::"v"(la), "v"(*(const unsigned long long*)&ld)); }
     if constexpr (KIND == 10) { if constexpr ((N & 15) == 0) asm volatile("ds_write_b128 %0, %1" ::"v"(la), "v"(ld)); }
+    // 16-bit forms: are the f16 transcendentals cheaper than the f32 ones, and what do packed f16 ops cost beside MFMAs?
+    if constexpr (KIND == 12) asm volatile("v_exp_f16 %0, %0" : "+v"(r[e]));
+    if constexpr (KIND == 13) asm volatile("v_rcp_f16 %0, %0" : "+v"(r[e]));
+    if constexpr (KIND == 14) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(r[e]) : "v"(seed));
+    if constexpr (KIND == 15) asm volatile("v_pk_fma_f16 %0, %0, %1, %0" : "+v"(r[e]) : "v"(seed));
+    if constexpr (KIND == 16) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(r[e]), "v"(r[(e + 1) & 7]));
+    if constexpr (KIND == 17) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(r[e]) : "v"(pk));
+    if constexpr (KIND == 18) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(r[e]) : "v"(seed));
     if constexpr (KIND == 11) { if constexpr ((N & 15) == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(la), "v"(ld[0])); }
 }
 // KIND: 0 v_fma_f32 (VOP3), 1 v_mul_f32 (VOP2), 2 v_exp_f32, 3 v_accvgpr_read (of the other half of the file), 4 v_cvt_pk_bf16_f32,
@@ -112,5 +120,12 @@ int main(int argc, char** argv) {
     sweep<9>("ds_write_b64 1 per 16 fillers", d, n_cu);
     sweep<10>("ds_write_b128 1 per 16", d, n_cu);
     sweep<11>("ds_write_b32 1 per 16", d, n_cu);
+    sweep<12>("v_exp_f16", d, n_cu);
+    sweep<13>("v_rcp_f16", d, n_cu);
+    sweep<14>("v_pk_mul_f16", d, n_cu);
+    sweep<15>("v_pk_fma_f16", d, n_cu);
+    sweep<16>("v_cvt_pk_f16_f32", d, n_cu);
+    sweep<17>("v_cvt_f32_f16", d, n_cu);
+    sweep<18>("v_pk_add_f16", d, n_cu);
     return 0;
 }
