@@ -1153,3 +1153,28 @@ def test_gemm_split_half_kernel_race_screen_under_memory_load():
                 torch.cuda.synchronize()
                 bad += sum(int(not torch.equal(y, ref)) for y in outs)
         assert bad == 0, f"{bad} of 24 launches (N = {N}) differ from gemm4_kernel's output"
+
+
+@pytest.mark.parametrize("M,N,act", [(65536, 2048, 2), (16384, 1536, 0)])
+def test_gemm_split_half_kernel_row_offsets(M, N, act):
+    """a_off / y_off (rows of A skipped, rows of Y skipped: plain rows otherwise) go through gemm4h_kernel's base pointers: same bits as the 8-phase
+    kernel, nothing written outside the addressed rows."""
+    o = ops()
+    K, a_off, y_off = 512, 37, 53
+    a = rnd(M + a_off + 8, K, seed=61).bfloat16().to(DEV)
+    w, b = rnd(N, K, seed=62, scale=K ** -0.5).bfloat16().to(DEV), rnd(N, seed=63, scale=0.1).to(DEV)
+    st = torch.stack([0.05 * rnd(M, seed=64), 1.0 + 0.2 * rnd(M, seed=65).abs()], 1).contiguous().to(DEV)
+    cs = (0.3 * rnd(N, seed=66)).to(DEV)
+    kw = dict(M=M, N=N, K=K, lda=K, ldy=N, bias=b, ln_stats=st, ln_colsum=cs, act=act, a_off=a_off, y_off=y_off, a_img_stride=M, y_img_stride=M)
+    outs = []
+    for opt in (dict(gemm_no_4w=1), dict(gemm_4h_plain=1)):
+        import contextlib
+        with contextlib.ExitStack() as es:
+            for k_, v_ in opt.items():
+                es.enter_context(config.lib_option(k_, v_))
+            y = torch.full((M + y_off + 8, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            o.gemm(a, w, y, **kw)
+            outs.append(y)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[1][:y_off] == 7.0).all() and (outs[1][M + y_off:] == 7.0).all() and not (outs[1][y_off:M + y_off] == 7.0).all()
