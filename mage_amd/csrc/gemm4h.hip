@@ -46,11 +46,11 @@ struct Gemm4hArgs {
 };
 
 #ifndef MAGE4H_ABL
-#define MAGE4H_ABL 0      // tuning builds, bit flags: 1 = no epilogue (K loop only), 2 = epilogue ops but no global stores
+#define MAGE4H_ABL 0      // tuning builds (tools/probes/gemm4h_probe.hip), bit flags: 1 = no epilogue (K loop only), 2 = epilogue ops but no global stores
 #endif
 #ifndef MAGE4H_OPMASK
-#define MAGE4H_OPMASK 31  // tuning builds, which op classes of a piece are emitted: 1 = accumulator reads, 2 = arithmetic, 4 = the constants' LDS reads,
-                          // 8 = the staging writes, 16 = the row reads (timing only: the outputs are garbage unless all are on)
+#define MAGE4H_OPMASK 7   // tuning builds, which op classes of a piece are emitted: 1 = accumulator reads, 2 = arithmetic, 4 = the constants' LDS reads
+                          // (timing only: the outputs are garbage unless all are on)
 #endif
 #ifndef MAGE4H_R0
 #define MAGE4H_R0 2       // first slot of the fragment reads in each half step
@@ -309,8 +309,8 @@ __global__ __launch_bounds__(256) void gemm4h_kernel(const Gemm4hArgs g) {
     for (int m = 0; m < 4; ++m) rd_x(0, 0, 0, m);
 
     // One step.  H = the accumulating half, S = the slab (0..7), EPI = the other half leaves meanwhile, CONSTS = this pass requests the epilogue
-    // constants of its tile (half-0 passes), prev_stores = the previous step (the last step of the previous pass) ended with two stores
-    // (wave-uniform, read by S == 0 only), cpar = parity of this pass's tile (selects the constants' set), tm / tn = this pass's tile.
+    // constants of its tile (half-0 passes), prev_stores = the previous pass was an epilogue pass, i.e. its last step left row stores behind its
+    // last W piece (wave-uniform, read by S == 0 only), cpar = parity of this pass's tile (selects the constants' set), tm / tn = this pass's tile.
     auto step = [&](auto H_, auto S_, auto EPI_, auto CONSTS_, bool prev_stores, int cpar, int tm, int tn) __attribute__((always_inline)) {
         constexpr int H = decltype(H_)::value, S = decltype(S_)::value;
         constexpr bool EPI = decltype(EPI_)::value && !(MAGE4H_ABL & 1), CONSTS = decltype(CONSTS_)::value && !(MAGE4H_ABL & 1);
