@@ -1183,6 +1183,10 @@ int gn_launch(const char* who, const float* x, int64_t sample_stride_rows, int64
         hipLaunchKernelGGL((gn_apply_kernel<unsigned short>), grid, dim3(256), 0, s, x, (long)sample_stride_rows, (long)row_off,
                            rows_per_sample, C, groups, stats, gamma, beta, residual, act, (unsigned short*)y,
                            (long)y_sample_stride_rows, (long)y_row_off, total);
+    else if (y_dtype == MAGE_F16)                      // the f16 mode on the latent (MAGE+) path: the GroupNorm + SiLU head's rows (round 6)
+        hipLaunchKernelGGL((gn_apply_kernel<f16_t>), grid, dim3(256), 0, s, x, (long)sample_stride_rows, (long)row_off,
+                           rows_per_sample, C, groups, stats, gamma, beta, residual, act, (f16_t*)y,
+                           (long)y_sample_stride_rows, (long)y_row_off, total);
     else {
         mage_set_error("%s: bad y_dtype %d", who, y_dtype);
         return MAGE_EINVAL;

@@ -998,10 +998,6 @@ class MAGE(nn.Module):
     def set_precision(self, precision: str) -> "MAGE":
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
-        if precision == "f16" and not self.use_cids:
-            # the latent path's fp32-operand embedding Linear and its GroupNorm + SiLU + Conv3d head have bf16 and fp32 / split outputs only
-            raise ValueError("precision 'f16' covers the VQ-token path (use_cids=True); the latent first-stage path (use_cids=False, MAGE+) runs "
-                             "'bf16', 'f16x3' or 'fp32'")
         self.precision = precision
         self.generate_model.compute_dtype, self.generate_model.split_kind = PRECISIONS[precision]
         # the once-per-clip prologue: exact-fp32 MFMA chains only in 'fp32' mode, f16x3 split operands otherwise (_lin_fp32)
@@ -1174,8 +1170,11 @@ class MAGE(nn.Module):
         R, Cc = self.image_resolution, self.vision_width
         rows = lat.numel() // ld
         E = d["emb_lin.w"].shape[1]
-        emb = ops.gemm(lat, d["emb_lin.w"], torch.empty(rows, Cc, device=lat.device, dtype=dt), M=rows, N=Cc, K=E, lda=ld, ldy=Cc,
-                       bias=d["emb_lin.b"])                                                   # K = 4: fp32 MFMA path
+        # K = 4: fp32 MFMA path; it writes fp32 or bf16 rows -- the f16 mode takes fp32 rows through one cast pass
+        emb = ops.gemm(lat, d["emb_lin.w"], torch.empty(rows, Cc, device=lat.device, dtype=F32 if dt == F16 else dt), M=rows, N=Cc, K=E, lda=ld,
+                       ldy=Cc, bias=d["emb_lin.b"])
+        if dt == F16:
+            emb = ops.cast(emb, torch.empty(rows, Cc, device=lat.device, dtype=F16))
         return VectorQuantizedVAE._conv(emb, _wdt(d, "conv", dt), torch.empty_like(emb), n_img=rows // (R * R), H=R, W=R, cin=Cc,
                                         cout=Cc, k=3, rowadd=d["hwpos"], rowadd_div=1, rowadd_mod=R * R)
 
