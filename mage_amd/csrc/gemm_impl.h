@@ -1369,10 +1369,13 @@ int launch_tile(const mage_gemm_desc* d, hipStream_t s, int n_cu) {
     // Only the residual kind by default: its tile ends in a 512 KB read + write burst per CU that the stagger spreads (out_proj
     // 0.307 -> 0.276 ms, c_proj 0.567 -> 0.542 ms).  The bias kinds (QKV, c_fc) have no drain stall to hide (round-2 tile probe); an
     // interleaved A/B with and without it is inside +-0.5 %, so they skip the idle start.  MAGE_GEMM_STAGGER applies to every kind.
-    const bool kind_wants = st_env || EK == EK_RES_INIT;
+    // Round 6 (tools/producer_probe.py, profiles/r06_producer_stagger.txt, 8 interleaved rounds): out_proj (K = 512) 189.6 us with the default
+    // 8 groups over 60 % against 197.2 without; c_proj (K = 2048: the burst is a quarter of the tile period) 500.3 with it, 484.9 WITHOUT: the
+    // idle start only pays for short K loops, so it is applied up to 16 slabs (K <= 1024 16-bit elements).
+    const int es = d->dtype == MAGE_F32 ? 4 : 2;
+    const long nk = ((long)d->K * es + 127) / 128 * (SPL ? 3 : 1);
+    const bool kind_wants = st_env || (EK == EK_RES_INIT && nk <= 16);
     if (kind_wants && st_groups > 1 && a.ntiles >= n_cu && tiles_per_wg >= 6) {
-        const int es = d->dtype == MAGE_F32 ? 4 : 2;
-        const long nk = ((long)d->K * es + 127) / 128 * (SPL ? 3 : 1);
         const long out_b = (long)TL::BM * TL::BNT * (d->y_dtype == MAGE_F32 ? 4 : 2);
         const long res_b = d->residual ? (long)TL::BM * TL::BNT * (d->res_dtype == MAGE_F32 ? 4 : 2) : 0;
         const long period = nk * 3400 * MT / 8 + (long)((out_b + res_b) / 10.6);
