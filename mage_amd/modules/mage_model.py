@@ -1218,7 +1218,10 @@ class MAGE(nn.Module):
         # (weights_frozen: no parameter changes during one inference call -- the derived caches validate once, not at each of their ~40 fetches)
         with torch.cuda.device(images.device), weights_frozen():
             ug = self._graph_auto(batch) if self.use_graph is None else bool(self.use_graph)
-            if ug and int(getattr(self, "streams", 1)) == 1 and not torch.cuda.is_current_stream_capturing():
+            # (clip groups on several streams are captured too when `graph_multistream` is set: fork / join edges inside ONE graph -- the probe of
+            # tools/inc_streams_graph_probe.py; off by default: measured slower than one stream at every size, DESIGN finding 94)
+            if (ug and (int(getattr(self, "streams", 1)) == 1 or getattr(self, "graph_multistream", False))
+                    and not torch.cuda.is_current_stream_capturing()):
                 out = self._generate_graphed(batch)
             else:
                 self.last_call_mode = "eager"
@@ -1237,7 +1240,7 @@ class MAGE(nn.Module):
     def _graph_fingerprint(self):
         """Everything besides shapes, precision, AR mode and weights that selects kernels: a captured graph replays only under the same."""
         fs = self.first_stage_model
-        return (bool(getattr(self, "frame_table", True)), self.generate_model._stream_bf16(), bool(getattr(self.ma_encoder, "mage_plus", False)),
+        return (int(getattr(self, "streams", 1)), bool(getattr(self, "frame_table", True)), self.generate_model._stream_bf16(), bool(getattr(self.ma_encoder, "mage_plus", False)),
                 getattr(self.ma_encoder, "split_kind", 0), getattr(self.text_encoder, "split_kind", 0),
                 tuple(str(getattr(fs, a, None)) for a in ("decode_dtype", "encode_split", "decode_split")),
                 config.get(), tuple(sorted(config.lib_options().items())))
