@@ -27,6 +27,7 @@ int main(int argc, char** argv) {
                             {"c_fc N2048 ln+gelu", 262144, 2048, 512, MAGE_ACT_QUICKGELU, true},
                             {"plain N2048 bias", 262144, 2048, 512, MAGE_ACT_NONE, false},
                             {"plain N512 bias+gelu", 262144, 512, 512, MAGE_ACT_QUICKGELU, false},
+                            {"plain N512 bias (out_proj's product without residual / sums)", 262144, 512, 512, MAGE_ACT_NONE, false},
                             {"c_fc M=65792 (257 row tiles)", 65792, 2048, 512, MAGE_ACT_QUICKGELU, true},
                             {"qkv  M=33024 (129 row tiles)", 33024, 1536, 512, MAGE_ACT_NONE, true},
                             {"c_fc M=16384 (incremental step, cfg2)", 16384, 2048, 512, MAGE_ACT_QUICKGELU, true},
