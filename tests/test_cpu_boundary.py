@@ -149,6 +149,14 @@ def test_config_is_read_once_and_library_options_round_trip(monkeypatch):
     with pytest.raises(Exception):
         with config.lib_option("no_such_option", 1):
             pass
+    # values are validated by the library (round 6): switches take 0 | 1, counts and percentages have ranges; the Python mirror stays in step
+    for name, bad in (("gemm_no_4h", 2), ("gemm_no_4w", -1), ("gemm_stagger_groups", 65), ("gemm_stagger_percent", 401), ("gemm_small_m", -5)):
+        with pytest.raises(Exception, match="out of range"):
+            config.set_lib_option(name, bad)
+        assert config.lib_flag(name) == opts[name]
+    with config.lib_option("gemm_4h_plain", 1):
+        assert config.lib_options()["gemm_4h_plain"] == 1
+    assert config.lib_options() == opts
     # no module of the package besides config.py (and _lib.py's library path) reads the environment
     import pathlib
     root = pathlib.Path(config.__file__).parent
